@@ -1,0 +1,31 @@
+"""Live differential test: unmodified reference (through its own hooks) vs. the oracle.
+
+Runs only where /root/reference exists (the build container); skipped on the GPU box."""
+
+import os
+
+import pytest
+
+pytestmark = pytest.mark.skipif(not os.path.isdir("/root/reference/bithtm"),
+                                reason="reference checkout not present")
+
+
+@pytest.fixture(scope="module")
+def ref():
+    from oracle.ref_hooks import import_reference
+    return import_reference()
+
+
+def test_lockstep_small(ref):
+    import refdiff
+    stats, _, _ = refdiff.run_lockstep(ref, seed=31, input_dim=200, column_dim=1024, cell_dim=8, patterns=50,
+                                       density=0.1, noise=0.02, steps=330, store_every=30)
+    assert stats["segments"] > 1000
+
+
+def test_lockstep_learning_off_and_jumps(ref):
+    import refdiff
+    stats, _, _ = refdiff.run_lockstep(ref, seed=32, input_dim=160, column_dim=1024, cell_dim=16, patterns=30,
+                                       density=0.1, noise=0.02, steps=200, store_every=25, jump=0.2,
+                                       learning_schedule=lambda t: (t % 17) != 3)
+    assert stats["segments"] > 500
