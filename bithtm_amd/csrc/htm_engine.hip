@@ -1,0 +1,1406 @@
+// MI355X (gfx950) bitHTM timestep engine: HIP kernels + the C ABI of include/bithtm_hip.h.
+//
+// One handle = all device state of one SpatialPooler + TemporalMemory pair.  A timestep is a
+// fixed sequence of kernel launches on one stream with NO host synchronisation: every
+// data-dependent size (segments, matching segments, winners, work items) lives in a device
+// counter block and kernels grid-stride over those counters.
+//
+// Semantics follow the reference lines cited next to each kernel (paths relative to the
+// reference checkout) under the deterministic policies of DESIGN.md.  Compile with
+// -ffp-contract=off: several kernels must round exactly like the NumPy expressions they replace.
+//
+// Internal cell encoding: enc = column * 32 + cell ("one 32-bit word per column" bitmaps);
+// the ABI converts to / from the reference's flat id column * cell_dim + cell.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <algorithm>
+#include <map>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "../../include/bithtm_hip.h"
+#include "htm_fexp.h"
+#include "htm_rng.h"
+
+typedef unsigned long long u64;
+
+#define SEL_PASSES 6
+#define SEL_BINS 2048
+#define CAND_CAP 256          // growth candidates staged per wave
+#define MAX_SLOTS 512
+#define EPS32 1e-8f           // `epsilon=1e-8` against float32 arrays (weak Python scalar)
+
+__constant__ int c_sel_shift[SEL_PASSES] = {53, 42, 31, 20, 9, 0};
+__constant__ int c_sel_bits[SEL_PASSES] = {11, 11, 11, 11, 11, 9};
+
+// ------------------------------------------------------------------------------------------
+// device-resident scalars
+struct Counters {
+    uint32_t step;            // timestep index (key of the random draws)
+    int32_t S;                // allocated segment ids
+    int32_t n_match[2];       // matching segments of the scan with parity p
+    int32_t n_win[2];         // winner cells of step parity p
+    int32_t has_winner[2];    // winner list of parity p is valid (winner_cell is not None)
+    int32_t has_distal;       // a scan has run (distal_state is not None)
+    int32_t n_active_cells;
+    int32_t n_work;           // learning / punish work items of this step
+    int32_t n_un;             // winners needing a new segment
+    int32_t n_recycled, n_new, S_old;
+    int32_t error;            // sticky capacity flags
+    u64 sel_prefix;           // radix-select state
+    uint32_t sel_krem;
+    uint32_t sel_ticket[SEL_PASSES];
+};
+
+struct Dev {
+    int I, W, W4, Ipad, C, K, k, E, Scap, work_cap;
+    double sp_thr, sp_don, sp_doff;
+    float coef, mom, dinc;
+    double lrn_act, lrn_inact, pun_act, pun_inact;
+    int lrn_prune, pun_prune;
+    float perm_init, perm_thr;
+    int act_thr, match_thr, sample;
+    uint32_t seed;
+    // Spatial Pooler
+    double *perm;             // [C][Ipad] float64 permanences (projections.py:16)
+    uint32_t *mask;           // [C][W]    bit-packed `permanence >= threshold` (projections.py:19)
+    float *duty;              // [C]
+    int *overlap;             // [C]
+    double *boosted;          // [C]
+    u64 *key;                 // [C] bits of boosted (non-negative doubles order like uint64)
+    uint32_t *hist;           // [SEL_PASSES][SEL_BINS]
+    uint32_t *sel_blk;        // [ceil(C/1024)] packed (greater, equal) counts
+    int *active_cols;         // [k] ascending
+    uint32_t *input_stage;    // [W] host-fed input
+    // Temporal Memory
+    uint32_t *act[2];         // [C] active-cell words, parity double buffer
+    uint32_t *pred[2];        // [C] predicted-cell words
+    uint32_t *win;            // [C] winner-cell words of the current step
+    int *winners[2];          // [k*32] winner cells (enc), ascending
+    uint8_t *bursting;        // [k]
+    uint32_t *colcnt;         // [k] popc(winner) | popc(unaccounted) << 16
+    uint32_t *unacc_word;     // [k]
+    int *unacc_list;          // [k*32] winners without a matching segment, ascending
+    int *seg_cell;            // [Scap] owning cell (enc)
+    int *seg_nsyn;            // [Scap] valid synapses; rows are packed: slots [0, nsyn) are valid
+    int *presyn;              // [Scap][E] presynaptic cell (enc)
+    float *sperm;             // [Scap][E] float32 permanence
+    int *segcount;            // [C*32] segments per cell
+    uint32_t *cellmax;        // [C*32] float bits of max jittered potential per cell (0 = none)
+    int *seg_pot;             // [Scap]
+    int *match_seg[2];        // [Scap]
+    uint32_t *match_info[2];  // potential | activation << 12 | active << 31
+    float *match_jit[2];
+    uint32_t *work;           // [work_cap] segment | mode << 31 (0 = learn + grow, 1 = punish)
+    int *recyc_cnt;           // [ceil(Scap/1024)] recyclable segments per 1024-segment block
+    int *recyc_off;
+    int *recyc_list;          // [k*32]
+    Counters *ctr;
+};
+
+// ------------------------------------------------------------------------------------------
+// small device helpers
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ u64 lanemask_lt() { return (1ull << lane_id()) - 1ull; }
+
+template <int BS>
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *s_wave, uint32_t &total) {
+    const int lane = lane_id(), wv = threadIdx.x >> 6;
+    uint32_t x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t y = __shfl_up(x, o);
+        if (lane >= o) x += y;
+    }
+    if (lane == 63) s_wave[wv] = x;
+    __syncthreads();
+    uint32_t woff = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < BS / 64; ++i) {
+        uint32_t t = s_wave[i];
+        if (i < wv) woff += t;
+        tot += t;
+    }
+    __syncthreads();
+    total = tot;
+    return woff + x - v;
+}
+
+// all lanes of the wave must call; returns the slot for lanes with pred, -1 otherwise
+__device__ __forceinline__ int wave_append(int *counter, bool pred) {
+    u64 m = __ballot(pred);
+    if (m == 0) return -1;
+    int leader = __ffsll((long long)m) - 1;
+    int base = 0;
+    if (lane_id() == leader) base = atomicAdd(counter, __popcll(m));
+    base = __shfl(base, leader);
+    return pred ? base + __popcll(m & lanemask_lt()) : -1;
+}
+
+__device__ __forceinline__ uint32_t cell_mask(int K) { return K >= 32 ? 0xFFFFFFFFu : ((1u << K) - 1u); }
+__device__ __forceinline__ uint32_t enc_to_flat(int enc, int K) { return (uint32_t)((enc >> 5) * K + (enc & 31)); }
+
+// ------------------------------------------------------------------------------------------
+// Spatial Pooler
+
+// projections.py:19 for whole rows (after htm_sp_set_permanence)
+__global__ __launch_bounds__(256) void k_sp_build_mask(Dev d, int row_begin, int row_count) {
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    const int lane = lane_id();
+    const int chunks = d.Ipad >> 6;                       // 64 elements per ballot
+    for (long long t = wave; t < (long long)row_count * chunks; t += nwaves) {
+        int row = row_begin + (int)(t / chunks), ch = (int)(t % chunks);
+        int i = ch * 64 + lane;
+        bool conn = (i < d.I) && (d.perm[(size_t)row * d.Ipad + i] >= d.sp_thr);
+        u64 m = __ballot(conn);
+        if (lane == 0) *(u64 *)&d.mask[(size_t)row * d.W + ch * 2] = m;
+    }
+}
+
+// DenseProjection.process (projections.py:18-21) + ExponentialBoosting.process
+// (regularizations.py:15-17).  G lanes share one row (G = power of two, W4 16-byte chunks per row).
+__global__ __launch_bounds__(256) void k_sp_overlap(Dev d, const uint32_t *__restrict__ bank, int n_inputs, int G) {
+    const int gtid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nthreads = gridDim.x * blockDim.x;
+    for (int i = gtid; i < SEL_PASSES * SEL_BINS; i += nthreads) d.hist[i] = 0;
+    if (gtid < SEL_PASSES) d.ctr->sel_ticket[gtid] = 0;
+    if (gtid == 0) {
+        d.ctr->sel_prefix = 0;
+        d.ctr->sel_krem = (uint32_t)d.k;
+    }
+    const uint4 *in4 = (const uint4 *)(bank + (size_t)(d.ctr->step % (uint32_t)n_inputs) * d.W);
+    const uint4 *mask4 = (const uint4 *)d.mask;
+    const int lane = lane_id();
+    const int rpw = 64 / G, sub = lane / G, l = lane % G;
+    const int wave = gtid >> 6, nwaves = nthreads >> 6;
+    for (int row0 = wave * rpw; row0 < d.C; row0 += nwaves * rpw) {
+        const int row = row0 + sub;
+        int cnt = 0;
+        if (row < d.C) {
+            for (int j = l; j < d.W4; j += G) {
+                uint4 m = mask4[(size_t)row * d.W4 + j];
+                uint4 x = in4[j];
+                cnt += __popc(m.x & x.x) + __popc(m.y & x.y) + __popc(m.z & x.z) + __popc(m.w & x.w);
+            }
+        }
+        for (int o = G >> 1; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+        if (l == 0 && row < d.C) {
+            d.overlap[row] = cnt;
+            float f = htm_exp_f32(d.coef * d.duty[row]);         // float32 product, documented exp
+            double b = (double)f * (double)cnt;                  // exact (24-bit x <= 16-bit)
+            d.boosted[row] = b;
+            d.key[row] = (u64)__double_as_longlong(b);
+        }
+    }
+}
+
+// GlobalInhibition.process (regularizations.py:28-29) as an exact radix select of the k-th
+// largest key, one 11-bit digit per launch; the last block to arrive folds the histogram.
+__global__ __launch_bounds__(256) void k_sel_pass(Dev d, int pass) {
+    __shared__ uint32_t h[SEL_BINS];
+    __shared__ uint32_t s_chunk[256];
+    __shared__ int s_last;
+    const int tid = threadIdx.x;
+    const int shift = c_sel_shift[pass], bits = c_sel_bits[pass], nb = 1 << bits;
+    const u64 prefix = d.ctr->sel_prefix;
+    const u64 himask = pass == 0 ? 0ull : (~0ull << (shift + bits));
+    for (int i = tid; i < nb; i += 256) h[i] = 0;
+    __syncthreads();
+    for (int c = blockIdx.x * 256 + tid; c < d.C; c += gridDim.x * 256) {
+        u64 key = d.key[c];
+        if (((key ^ prefix) & himask) == 0) atomicAdd(&h[(uint32_t)(key >> shift) & (nb - 1)], 1u);
+    }
+    __syncthreads();
+    uint32_t *gh = d.hist + pass * SEL_BINS;
+    for (int i = tid; i < nb; i += 256)
+        if (h[i]) atomicAdd(&gh[i], h[i]);
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) s_last = (atomicAdd(&d.ctr->sel_ticket[pass], 1u) == gridDim.x - 1);
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    for (int i = tid; i < nb; i += 256) h[i] = __hip_atomic_load(&gh[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int per = nb / 256;                 // 8 or 2 bins per thread, thread t owns [t*per, (t+1)*per)
+    uint32_t cs = 0;
+    for (int j = 0; j < per; ++j) cs += h[tid * per + j];
+    s_chunk[tid] = cs;
+    __syncthreads();
+    // suffix sums over chunks (bins above mine): Hillis-Steele on the reversed array
+    uint32_t x = cs;
+    for (int o = 1; o < 256; o <<= 1) {
+        uint32_t y = (tid + o < 256) ? s_chunk[tid + o] : 0;
+        __syncthreads();
+        x += y;
+        s_chunk[tid] = x;
+        __syncthreads();
+    }
+    uint32_t above = x - cs;                  // keys in bins above my chunk
+    const uint32_t krem = d.ctr->sel_krem;
+    if (above < krem && krem <= above + cs) {
+        for (int b = (tid + 1) * per - 1; b >= tid * per; --b) {
+            uint32_t hb = h[b];
+            if (above + hb >= krem) {
+                d.ctr->sel_prefix = prefix | ((u64)b << shift);
+                d.ctr->sel_krem = krem - above;
+                break;
+            }
+            above += hb;
+        }
+    }
+}
+
+// per 1024-column block: how many keys are above / equal to the k-th largest
+__global__ __launch_bounds__(256) void k_sp_count(Dev d) {
+    __shared__ uint32_t s_wave[4];
+    const u64 T = d.ctr->sel_prefix;
+    uint32_t v = 0;
+    for (int q = 0; q < 4; ++q) {
+        int c = blockIdx.x * 1024 + threadIdx.x * 4 + q;
+        if (c < d.C) {
+            u64 key = d.key[c];
+            v += (key > T) ? 1u : ((key == T) ? 0x10000u : 0u);
+        }
+    }
+    uint32_t total;
+    block_excl_scan<256>(v, s_wave, total);
+    if (threadIdx.x == 0) d.sel_blk[blockIdx.x] = total;
+}
+
+// Emit the winners in ascending column order (ties: lower index first), update the duty cycle
+// (regularizations.py:19-21, float32, two separately rounded operations) and clear the dense
+// per-column words the Temporal Memory fills this step.
+__global__ __launch_bounds__(256) void k_sp_emit(Dev d, int p) {
+    __shared__ uint32_t s_wave[4];
+    __shared__ uint32_t s_gt, s_eq;
+    const int tid = threadIdx.x;
+    if (tid == 0) { s_gt = 0; s_eq = 0; }
+    __syncthreads();
+    uint32_t g = 0, e = 0;
+    for (int i = tid; i < (int)blockIdx.x; i += 256) {
+        uint32_t v = d.sel_blk[i];
+        g += v & 0xFFFFu;
+        e += v >> 16;
+    }
+    for (int o = 32; o > 0; o >>= 1) { g += __shfl_xor(g, o); e += __shfl_xor(e, o); }
+    if (lane_id() == 0) { atomicAdd(&s_gt, g); atomicAdd(&s_eq, e); }
+    __syncthreads();
+    const uint32_t gt_before = s_gt, eq_before = s_eq;
+    const u64 T = d.ctr->sel_prefix;
+    const uint32_t r = d.ctr->sel_krem;            // how many of the keys == T are selected
+    uint32_t flag[4];
+    uint32_t v = 0;
+    for (int q = 0; q < 4; ++q) {
+        int c = blockIdx.x * 1024 + tid * 4 + q;
+        flag[q] = 0;
+        if (c < d.C) {
+            u64 key = d.key[c];
+            flag[q] = (key > T) ? 1u : ((key == T) ? 0x10000u : 0u);
+        }
+        v += flag[q];
+    }
+    uint32_t total;
+    uint32_t ex = block_excl_scan<256>(v, s_wave, total);
+    uint32_t g_run = gt_before + (ex & 0xFFFFu), e_run = eq_before + (ex >> 16);
+    for (int q = 0; q < 4; ++q) {
+        int c = blockIdx.x * 1024 + tid * 4 + q;
+        if (c >= d.C) break;
+        bool sel = (flag[q] & 1u) || ((flag[q] >> 16) && e_run < r);
+        if (sel) d.active_cols[g_run + min(e_run, r)] = c;
+        float dc = d.duty[c] * d.mom;
+        if (sel) dc = dc + d.dinc;
+        d.duty[c] = dc;
+        g_run += flag[q] & 1u;
+        e_run += flag[q] >> 16;
+        if (d.act[0]) {                           // Temporal Memory present
+            d.act[p][c] = 0;
+            d.pred[p][c] = 0;
+            d.win[c] = 0;
+        }
+    }
+}
+
+// DenseProjection.update (projections.py:23-24) on the k winner rows, fused with the rebuild
+// of those rows' connected mask.  One block per winner row.
+__global__ __launch_bounds__(256) void k_sp_learn(Dev d, const uint32_t *__restrict__ bank, int n_inputs) {
+    const uint32_t *in = bank + (size_t)(d.ctr->step % (uint32_t)n_inputs) * d.W;
+    const int row = d.active_cols[blockIdx.x];
+    double *prow = d.perm + (size_t)row * d.Ipad;
+    uint32_t *mrow = d.mask + (size_t)row * d.W;
+    for (int i0 = 0; i0 < d.Ipad; i0 += 256) {
+        int i = i0 + threadIdx.x;
+        bool conn = false;
+        if (i < d.I) {
+            bool on = (in[i >> 5] >> (i & 31)) & 1u;
+            double v = prow[i] + (on ? d.sp_don : d.sp_doff);
+            prow[i] = v;
+            conn = v >= d.sp_thr;
+        }
+        u64 m = __ballot(conn);
+        if (lane_id() == 0 && i < d.Ipad) *(u64 *)&mrow[i >> 5] = m;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Temporal Memory
+
+// stand-alone TM: take the active columns from the caller, clear the per-step words
+__global__ __launch_bounds__(256) void k_tm_load_active(Dev d, int p, const int *cols, int n) {
+    for (int c = blockIdx.x * 256 + threadIdx.x; c < d.C; c += gridDim.x * 256) {
+        d.act[p][c] = 0;
+        d.pred[p][c] = 0;
+        d.win[c] = 0;
+        if (c < n) d.active_cols[c] = cols[c];
+    }
+}
+
+// TemporalMemory.process up to the winner cells (networks.py:95-104) for one active column per
+// half-wave: bursting, best-matching cell (networks.py:73-82), least-used cell (:84-89).
+__global__ __launch_bounds__(256) void k_tm_activate(Dev d, int p, int n_active, int want_winner) {
+    const int lane = lane_id(), half = lane >> 5, j = lane & 31;
+    const int idx = (blockIdx.x * 256 + threadIdx.x) >> 5;
+    const bool col_ok = idx < n_active;
+    const bool valid = col_ok && j < d.K;
+    const int a = col_ok ? d.active_cols[idx] : 0;
+    const uint32_t pw = col_ok ? d.pred[p ^ 1][a] : 0;       // prev_state.cell_prediction row
+    const bool burst = pw == 0;
+    const uint32_t act = burst ? cell_mask(d.K) : pw;        // networks.py:115
+    const int has_distal = d.ctr->has_distal;
+    float cm = -1.0f;
+    if (valid && has_distal) cm = __uint_as_float(d.cellmax[a * 32 + j]);
+    uint32_t winner = pw, unacc = 0;
+    if (want_winner) {
+        float colmax = cm;
+        for (int o = 16; o > 0; o >>= 1) colmax = fmaxf(colmax, __shfl_xor(colmax, o));
+        const bool col_matching = has_distal && colmax >= (float)d.match_thr;      // networks.py:80
+        const bool best = valid && has_distal && fabsf(cm - colmax) < EPS32;       // :81
+        float jit = 3.0e38f;
+        if (valid) {
+            uint32_t base = htm_stream_base(d.seed, HTM_STREAM_LEAST_USED, d.ctr->step);
+            jit = htm_jitter((float)d.segcount[a * 32 + j], htm_draw24(base, (uint32_t)(a * d.K + j), 0u));   // :86-87
+        }
+        float mn = jit;
+        for (int o = 16; o > 0; o >>= 1) mn = fminf(mn, __shfl_xor(mn, o));
+        const bool least = valid && fabsf(jit - mn) < EPS32;                       // :88
+        const bool wbit = col_matching ? best : least;
+        const u64 bw = __ballot(wbit);
+        const uint32_t pick = (uint32_t)(bw >> (half * 32));
+        if (burst) winner = pick;                                                  // :102
+        const u64 bm = __ballot(valid && has_distal && !(cm < EPS32));             // cell has a matching segment
+        unacc = has_distal ? (winner & ~(uint32_t)(bm >> (half * 32))) : 0u;       // projections.py:271
+    }
+    if (col_ok && j == 0) {
+        d.act[p][a] = act;
+        d.win[a] = want_winner ? winner : 0u;
+        d.bursting[idx] = burst ? 1 : 0;
+        d.colcnt[idx] = (uint32_t)__popc(winner) | ((uint32_t)__popc(unacc) << 16);
+        d.unacc_word[idx] = unacc;
+    }
+}
+
+// ordered lists of winner cells (networks.py:103-104) and of winners that need a new segment
+// (projections.py:271-273); single block
+__global__ __launch_bounds__(1024) void k_tm_activate_scan(Dev d, int p, int n_active, int want_winner, int learning) {
+    __shared__ uint32_t s_wave[16];
+    uint32_t carry_w = 0, carry_u = 0, n_cells = 0;
+    for (int base = 0; base < n_active; base += 1024) {
+        const int idx = base + threadIdx.x;
+        uint32_t v = 0, ww = 0, uw = 0;
+        int a = 0;
+        if (idx < n_active) {
+            a = d.active_cols[idx];
+            ww = d.win[a];
+            uw = d.unacc_word[idx];
+            v = d.colcnt[idx];
+            n_cells += __popc(d.act[p][a]);
+        }
+        if (!want_winner) v = 0;
+        uint32_t total;
+        uint32_t ex = block_excl_scan<1024>(v, s_wave, total);
+        if (idx < n_active && want_winner) {
+            int pw = carry_w + (ex & 0xFFFFu), pu = carry_u + (ex >> 16);
+            while (ww) { int b = __ffs(ww) - 1; ww &= ww - 1; d.winners[p][pw++] = a * 32 + b; }
+            while (uw) { int b = __ffs(uw) - 1; uw &= uw - 1; d.unacc_list[pu++] = a * 32 + b; }
+        }
+        carry_w += total & 0xFFFFu;
+        carry_u += total >> 16;
+    }
+    // block-wide sum of n_cells
+    __shared__ uint32_t s_cells;
+    if (threadIdx.x == 0) s_cells = 0;
+    __syncthreads();
+    for (int o = 32; o > 0; o >>= 1) n_cells += __shfl_xor(n_cells, o);
+    if (lane_id() == 0) atomicAdd(&s_cells, n_cells);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        Counters *c = d.ctr;
+        c->n_win[p] = want_winner ? (int)carry_w : 0;
+        c->has_winner[p] = want_winner;
+        c->n_un = (learning && c->has_distal) ? (int)carry_u : 0;
+        c->n_work = 0;
+        c->n_active_cells = (int)s_cells;
+    }
+}
+
+// PredictiveProjection.update: which previous matching segments learn, which are punished
+// (projections.py:264-269; punishment mask built at networks.py:107-108,111)
+__global__ __launch_bounds__(256) void k_tm_classify(Dev d, int p) {
+    Counters *c = d.ctr;
+    const int q = p ^ 1;
+    const int n = c->n_match[q];
+    const int nth = gridDim.x * 256;
+    for (int i0 = blockIdx.x * 256 + (threadIdx.x & ~63); i0 < n; i0 += nth) {
+        const int i = i0 + lane_id();
+        bool learn = false, punish = false;
+        int seg = 0;
+        if (i < n) {
+            seg = d.match_seg[q][i];
+            const uint32_t info = d.match_info[q][i];
+            const int cell = d.seg_cell[seg], col = cell >> 5, bit = cell & 31;
+            const bool is_winner = (d.win[col] >> bit) & 1u;
+            const bool unpred = !((d.pred[q][col] >> bit) & 1u);                         // :266
+            const bool best = fabsf(d.match_jit[q][i] - __uint_as_float(d.cellmax[cell])) < EPS32;   // :267
+            learn = is_winner && ((info >> 31) || (unpred && best));                     // :268
+            punish = d.act[p][col] == 0;                                                 // :269
+        }
+        const int n_l = __popcll(__ballot(learn)), n_p = __popcll(__ballot(punish));
+        if (n_l + n_p == 0) continue;
+        int base = 0;
+        if (lane_id() == 0) base = atomicAdd(&c->n_work, n_l + n_p);
+        base = __shfl(base, 0);
+        const u64 ml = __ballot(learn), mp = __ballot(punish);
+        if (learn) {
+            int pos = base + __popcll(ml & lanemask_lt());
+            if (pos < d.work_cap) d.work[pos] = (uint32_t)seg; else atomicOr(&c->error, 4);
+        }
+        if (punish) {
+            int pos = base + n_l + __popcll(mp & lanemask_lt());
+            if (pos < d.work_cap) d.work[pos] = (uint32_t)seg | 0x80000000u; else atomicOr(&c->error, 4);
+        }
+    }
+}
+
+// SparseProjection.add_output, planning half (projections.py:79-95): how many of the needed
+// segments are recycled (lowest ids with fewer than matching_threshold synapses) and how many
+// are appended.  Single block.
+__global__ __launch_bounds__(1024) void k_tm_alloc_plan(Dev d) {
+    __shared__ uint32_t s_wave[16];
+    Counters *c = d.ctr;
+    const int S = c->S, n_un = c->n_un;
+    const int nb = (S + 1023) >> 10;
+    uint32_t carry = 0;
+    if (n_un > 0) {
+        for (int base = 0; base < nb; base += 1024) {
+            int b = base + threadIdx.x;
+            uint32_t v = b < nb ? (uint32_t)d.recyc_cnt[b] : 0u;
+            uint32_t total;
+            uint32_t ex = block_excl_scan<1024>(v, s_wave, total);
+            if (b < nb) d.recyc_off[b] = (int)(carry + ex);
+            carry += total;
+            if (carry >= (uint32_t)n_un) {       // later blocks are never needed
+                for (int b2 = base + 1024 + threadIdx.x; b2 < nb; b2 += 1024) d.recyc_off[b2] = 0x7FFFFFFF;
+                break;
+            }
+        }
+    }
+    if (threadIdx.x == 0) {
+        int n_r = min(n_un, (int)carry), n_new = n_un - n_r;
+        if (S + n_new > d.Scap) {
+            atomicOr(&c->error, 1);
+            n_new = max(d.Scap - S, 0);
+        }
+        c->n_recycled = n_r;
+        c->n_new = n_new;
+        c->S_old = S;
+        c->S = S + n_new;
+    }
+}
+
+// ids of the recycled segments, ascending (projections.py:80-81)
+__global__ __launch_bounds__(256) void k_tm_recyc_emit(Dev d) {
+    __shared__ uint32_t s_wave[4];
+    Counters *c = d.ctr;
+    const int n_r = c->n_recycled, S = c->S_old, b = blockIdx.x;
+    if (n_r == 0 || b * 1024 >= S) return;
+    const int off = d.recyc_off[b];
+    if (off >= n_r || d.recyc_cnt[b] == 0) return;
+    uint32_t fl[4], v = 0;
+    for (int q = 0; q < 4; ++q) {
+        int s = b * 1024 + threadIdx.x * 4 + q;
+        fl[q] = (s < S && d.seg_nsyn[s] < d.match_thr) ? 1u : 0u;
+        v += fl[q];
+    }
+    uint32_t total;
+    uint32_t ex = block_excl_scan<256>(v, s_wave, total);
+    int rank = off + (int)ex;
+    for (int q = 0; q < 4; ++q) {
+        if (fl[q]) {
+            if (rank < n_r) d.recyc_list[rank] = b * 1024 + threadIdx.x * 4 + q;
+            ++rank;
+        }
+    }
+}
+
+// bind recycled / fresh segments to the winners that need one (projections.py:275-281);
+// rows are packed, so clearing a recycled row (projections.py:82-85) is nsyn = 0
+__global__ __launch_bounds__(256) void k_tm_new_segments(Dev d) {
+    Counters *c = d.ctr;
+    const int n_r = c->n_recycled, n = n_r + c->n_new, S_old = c->S_old;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const int cell = d.unacc_list[i];
+        int seg;
+        if (i < n_r) {
+            seg = d.recyc_list[i];
+            atomicSub(&d.segcount[d.seg_cell[seg]], 1);
+        } else {
+            seg = S_old + (i - n_r);
+            d.seg_pot[seg] = 0;
+        }
+        d.seg_nsyn[seg] = 0;
+        d.seg_cell[seg] = cell;
+        atomicAdd(&d.segcount[cell], 1);
+        int pos = atomicAdd(&c->n_work, 1);
+        if (pos < d.work_cap) d.work[pos] = (uint32_t)seg; else atomicOr(&c->error, 4);
+    }
+}
+
+// SparseProjection.update_permanence (projections.py:97-109) and add_edge (:111-161) for one
+// work item per wave.  Permanences: float64 sum, float32 store, prune on the float64 value; the
+// surviving synapses are re-packed to the front of the row.  Growth: the n_add previous winner
+// cells with the smallest keyed priority that the segment does not have yet.
+template <int EPL>
+__global__ __launch_bounds__(256) void k_tm_learn(Dev d, int p) {
+    __shared__ int s_keep[4][EPL * 64];
+    __shared__ u64 s_cand[4][CAND_CAP];
+    Counters *c = d.ctr;
+    const int wv = threadIdx.x >> 6, lane = lane_id();
+    const int n_work = min(c->n_work, d.work_cap);
+    const uint32_t *act_prev = d.act[p ^ 1];
+    const int *winners = d.winners[p ^ 1];
+    const int n_w = c->has_winner[p ^ 1] ? c->n_win[p ^ 1] : -1;       // -1: winner_input is None
+    const uint32_t base2 = htm_stream_base(d.seed, HTM_STREAM_GROWTH, c->step);
+    for (int item = blockIdx.x * 4 + wv; item < n_work; item += gridDim.x * 4) {
+        const uint32_t w = d.work[item];
+        const int seg = (int)(w & 0x7FFFFFFFu), mode = (int)(w >> 31);
+        const double dA = mode ? d.pun_act : d.lrn_act, dI = mode ? d.pun_inact : d.lrn_inact;
+        const bool prune = mode ? d.pun_prune : d.lrn_prune;
+        const int n = d.seg_nsyn[seg];
+        int *prow = d.presyn + (size_t)seg * d.E;
+        float *mrow = d.sperm + (size_t)seg * d.E;
+        int n_keep = 0, n_active = 0;
+#pragma unroll
+        for (int jj = 0; jj < EPL; ++jj) {
+            const int idx = jj * 64 + lane;
+            const bool valid = idx < n;
+            int ps = 0;
+            float pm = 0.f;
+            if (valid) { ps = prow[idx]; pm = mrow[idx]; }
+            const bool a = valid && ((act_prev[ps >> 5] >> (ps & 31)) & 1u);
+            const double p64 = (double)pm + (a ? dA : dI);               // :102-103
+            const bool keep = valid && !(prune && p64 < 0.0);            // :105-108
+            const u64 mk = __ballot(keep);
+            if (keep) {
+                const int pos = n_keep + __popcll(mk & lanemask_lt());
+                prow[pos] = ps;
+                mrow[pos] = (float)p64;                                   // :104
+                s_keep[wv][pos] = ps;
+            }
+            n_keep += __popcll(mk);
+            n_active += __popcll(__ballot(keep && a));                    // :114
+        }
+        __builtin_amdgcn_wave_barrier();
+        int n_total = n_keep;
+        if (mode == 0 && n_w > 0) {
+            const int n_add = min(max(d.sample - n_active, 0), min(d.sample, n_w));     // :115
+            if (n_add > 0) {
+                // threshold T with n_add <= |{absent winners with priority < T}| <= CAND_CAP
+                uint32_t lo = 0, hi = 1u << 24, T = 1u << 24;
+                if (n_w > CAND_CAP) {
+                    u64 est = ((u64)(2 * n_add + 16) << 24) / (u64)max(n_w - n_active, 1);
+                    T = (uint32_t)min(est, (u64)(1u << 24));
+                }
+                int found = 0;
+                for (int iter = 0; iter < 64; ++iter) {
+                    found = 0;
+                    for (int b0 = 0; b0 < n_w; b0 += 64) {
+                        const int i = b0 + lane;
+                        bool take = false;
+                        uint32_t pr = 0;
+                        if (i < n_w) {
+                            const int cell = winners[i];
+                            pr = htm_draw24(base2, (uint32_t)seg, enc_to_flat(cell, d.K));     // :120
+                            if (pr < T) {
+                                take = true;                                                   // :121-123
+                                for (int qq = 0; qq < n_keep; ++qq)
+                                    if (s_keep[wv][qq] == cell) { take = false; break; }
+                            }
+                        }
+                        const u64 mt = __ballot(take);
+                        if (take) {
+                            const int pos = found + __popcll(mt & lanemask_lt());
+                            if (pos < CAND_CAP) s_cand[wv][pos] = ((u64)pr << 32) | (uint32_t)i;
+                        }
+                        found += __popcll(mt);
+                    }
+                    if (found >= n_add && found <= CAND_CAP) break;
+                    if (found < n_add) {
+                        if (T == (1u << 24)) break;               // fewer absent winners than n_add: take all
+                        lo = T;
+                        T = (hi == (1u << 24)) ? (uint32_t)min((u64)T * 4u + 16u, (u64)hi) : (lo + hi + 1) / 2;
+                    } else {
+                        hi = T;
+                        if (hi - lo <= 1) { atomicOr(&c->error, 4); break; }
+                        T = (lo + hi) / 2;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                const int n_c = min(found, CAND_CAP), take_n = min(n_add, n_c);        // :125-127
+                for (int e = lane; e < n_c; e += 64) {
+                    const u64 key = s_cand[wv][e];
+                    int rank = 0;
+                    for (int f = 0; f < n_c; ++f) rank += s_cand[wv][f] < key;
+                    if (rank < take_n) {
+                        const int slot = n_keep + rank;
+                        if (slot < d.E) {
+                            prow[slot] = winners[(uint32_t)key];
+                            mrow[slot] = d.perm_init;                                   // :149,158
+                        } else {
+                            atomicOr(&c->error, 2);
+                        }
+                    }
+                }
+                n_total = min(n_keep + take_n, d.E);                                    // :161
+            }
+        }
+        if (lane == 0) d.seg_nsyn[seg] = n_total;
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// forget the previous scan's per-cell maxima (sparse clear) before the new scan writes
+__global__ __launch_bounds__(256) void k_tm_prescan(Dev d, int p) {
+    Counters *c = d.ctr;
+    const int q = p ^ 1;
+    const int n = c->has_distal ? c->n_match[q] : 0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
+        d.cellmax[d.seg_cell[d.match_seg[q][i]]] = 0u;
+    if (blockIdx.x == 0 && threadIdx.x == 0) c->n_match[p] = 0;
+}
+
+// PredictiveProjection.process (projections.py:245-255): per segment, potential = active
+// presynaptic cells; matching segments additionally count connected active synapses;
+// per-cell prediction and max jittered potential (:229-239).  16 lanes per segment, 16-byte
+// loads of the packed row; a block owns 1024 consecutive segment ids and also counts the
+// recyclable ones among them for the next step's add_output.
+__global__ __launch_bounds__(256) void k_tm_scan(Dev d, int p) {
+    __shared__ int s_recyc;
+    Counters *c = d.ctr;
+    const int S = c->S, b = blockIdx.x;
+    if (b * 1024 >= S) return;
+    if (threadIdx.x == 0) s_recyc = 0;
+    __syncthreads();
+    const uint32_t *act = d.act[p];
+    const uint32_t base3 = htm_stream_base(d.seed, HTM_STREAM_SEGMENT_JITTER, c->step);
+    const int g = threadIdx.x >> 4, l = threadIdx.x & 15;
+    for (int it = 0; it < 64; ++it) {
+        const int seg = b * 1024 + it * 16 + g;
+        const bool ok = seg < S;
+        const int n = ok ? d.seg_nsyn[seg] : 0;
+        const int *prow = d.presyn + (size_t)seg * d.E;
+        uint32_t bits = 0;
+        for (int i = l * 4, ch = 0; i < n; i += 64, ++ch) {
+            const int4 ps = *(const int4 *)(prow + i);
+            const int e[4] = {ps.x, ps.y, ps.z, ps.w};
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq)
+                if (i + qq < n) bits |= ((act[e[qq] >> 5] >> (e[qq] & 31)) & 1u) << (ch * 4 + qq);
+        }
+        int pot = __popc(bits);
+        for (int o = 8; o > 0; o >>= 1) pot += __shfl_xor(pot, o);
+        const bool matching = ok && pot >= d.match_thr;                          // :247
+        int conn = 0;
+        if (matching) {
+            const float *mrow = d.sperm + (size_t)seg * d.E;
+            for (int i = l * 4, ch = 0; i < n; i += 64, ++ch) {
+                const float4 pm = *(const float4 *)(mrow + i);
+                const float e[4] = {pm.x, pm.y, pm.z, pm.w};
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq)
+                    conn += ((bits >> (ch * 4 + qq)) & 1u) && (e[qq] >= d.perm_thr);     // :171-172
+            }
+        }
+        for (int o = 8; o > 0; o >>= 1) conn += __shfl_xor(conn, o);
+        const bool lead = l == 0 && ok;
+        const int slot = wave_append(&c->n_match[p], lead && matching);
+        if (lead) {
+            d.seg_pot[seg] = pot;
+            if (n < d.match_thr) atomicAdd(&s_recyc, 1);
+            if (matching) {
+                const bool active = conn >= d.act_thr;                            // :250
+                const int cell = d.seg_cell[seg];
+                const float jit = htm_jitter((float)pot, htm_draw24(base3, (uint32_t)seg, 0u));   // :234-235
+                atomicMax(&d.cellmax[cell], __float_as_uint(jit));               // :237
+                if (active) atomicOr(&d.pred[p][cell >> 5], 1u << (cell & 31));   // :251, networks.py:122
+                d.match_seg[p][slot] = seg;
+                d.match_info[p][slot] = (uint32_t)pot | ((uint32_t)conn << 12) | (active ? 0x80000000u : 0u);
+                d.match_jit[p][slot] = jit;
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) d.recyc_cnt[b] = s_recyc;
+}
+
+// recount recyclable segments after a state import
+__global__ __launch_bounds__(256) void k_tm_recount(Dev d) {
+    __shared__ int s_recyc;
+    const int S = d.ctr->S, b = blockIdx.x;
+    if (b * 1024 >= S) return;
+    if (threadIdx.x == 0) s_recyc = 0;
+    __syncthreads();
+    int v = 0;
+    for (int q = 0; q < 4; ++q) {
+        int s = b * 1024 + threadIdx.x * 4 + q;
+        v += (s < S && d.seg_nsyn[s] < d.match_thr) ? 1 : 0;
+    }
+    if (v) atomicAdd(&s_recyc, v);
+    __syncthreads();
+    if (threadIdx.x == 0) d.recyc_cnt[b] = s_recyc;
+}
+
+__global__ void k_finalize(Dev d, int tm_ran) {
+    Counters *c = d.ctr;
+    c->step += 1;
+    if (tm_ran) c->has_distal = 1;
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+
+static thread_local std::string g_create_error;
+
+struct htm_handle {
+    htm_config cfg;
+    Dev d;
+    int device;
+    hipStream_t stream;
+    bool own_stream;
+    long long step_host;
+    std::string err;
+    std::vector<void *> allocs;
+    int *d_cols_stage;                    // stand-alone TM: active columns
+    int G;                                // lanes per SP row
+    int sp_blocks, sel_blocks, c1024_blocks, s1024_blocks;
+    // graphs keyed by (parity, learning, bank, n_inputs)
+    std::map<std::tuple<int, int, const void *, int>, hipGraphExec_t> graphs;
+    // profiling
+    bool profile;
+    std::vector<std::string> prof_names;
+    std::vector<std::vector<std::pair<hipEvent_t, hipEvent_t>>> prof_events;
+    std::vector<double> prof_ms;
+    std::vector<long long> prof_n;
+};
+
+#define HIPCHK(h, call)                                                                          \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess) {                                                                  \
+            (h)->err = std::string(#call) + ": " + hipGetErrorString(e_);                        \
+            return HTM_ERR_HIP;                                                                  \
+        }                                                                                        \
+    } while (0)
+
+template <typename T>
+static int dalloc(htm_handle *h, T **p, size_t count) {
+    void *q = nullptr;
+    size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+    hipError_t e = hipMalloc(&q, bytes);
+    if (e != hipSuccess) {
+        h->err = "hipMalloc(" + std::to_string(bytes) + " bytes): " + hipGetErrorString(e);
+        return HTM_ERR_HIP;
+    }
+    e = hipMemsetAsync(q, 0, bytes, h->stream);
+    if (e != hipSuccess) { h->err = std::string("hipMemsetAsync: ") + hipGetErrorString(e); return HTM_ERR_HIP; }
+    h->allocs.push_back(q);
+    *p = (T *)q;
+    return 0;
+}
+
+static int prof_slot(htm_handle *h, const char *name) {
+    for (size_t i = 0; i < h->prof_names.size(); ++i)
+        if (h->prof_names[i] == name) return (int)i;
+    h->prof_names.push_back(name);
+    h->prof_events.emplace_back();
+    h->prof_ms.push_back(0.0);
+    h->prof_n.push_back(0);
+    return (int)h->prof_names.size() - 1;
+}
+
+#define LAUNCH(h, name, kernel, grid, block, ...)                                                 \
+    do {                                                                                         \
+        hipEvent_t e0_ = nullptr, e1_ = nullptr;                                                 \
+        if ((h)->profile) {                                                                      \
+            hipEventCreate(&e0_);                                                                \
+            hipEventCreate(&e1_);                                                                \
+            hipEventRecord(e0_, (h)->stream);                                                    \
+        }                                                                                        \
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, (h)->stream, __VA_ARGS__);        \
+        if ((h)->profile) {                                                                      \
+            hipEventRecord(e1_, (h)->stream);                                                    \
+            (h)->prof_events[prof_slot(h, name)].push_back({e0_, e1_});                          \
+        }                                                                                        \
+    } while (0)
+
+static int enqueue_sp(htm_handle *h, const uint32_t *bank, int n_inputs, int learning, int p) {
+    Dev &d = h->d;
+    LAUNCH(h, "sp_overlap", k_sp_overlap, h->sp_blocks, 256, d, bank, n_inputs, h->G);
+    for (int pass = 0; pass < SEL_PASSES; ++pass) LAUNCH(h, "sp_select", k_sel_pass, h->sel_blocks, 256, d, pass);
+    LAUNCH(h, "sp_count", k_sp_count, h->c1024_blocks, 256, d);
+    LAUNCH(h, "sp_emit", k_sp_emit, h->c1024_blocks, 256, d, p);
+    if (learning) LAUNCH(h, "sp_learn", k_sp_learn, d.k, 256, d, bank, n_inputs);
+    return 0;
+}
+
+static void launch_learn(htm_handle *h, int p) {
+    Dev &d = h->d;
+    const int blocks = 512;
+    switch (d.E / 64) {
+        case 1: LAUNCH(h, "tm_learn", k_tm_learn<1>, blocks, 256, d, p); break;
+        case 2: LAUNCH(h, "tm_learn", k_tm_learn<2>, blocks, 256, d, p); break;
+        case 3: case 4: LAUNCH(h, "tm_learn", k_tm_learn<4>, blocks, 256, d, p); break;
+        default: LAUNCH(h, "tm_learn", k_tm_learn<8>, blocks, 256, d, p); break;
+    }
+}
+
+static int enqueue_tm(htm_handle *h, int n_active, int learning, int want_winner, int p) {
+    Dev &d = h->d;
+    if (learning) want_winner = 1;
+    LAUNCH(h, "tm_activate", k_tm_activate, (n_active * 32 + 255) / 256, 256, d, p, n_active, want_winner);
+    LAUNCH(h, "tm_activate_scan", k_tm_activate_scan, 1, 1024, d, p, n_active, want_winner, learning);
+    if (learning) {
+        LAUNCH(h, "tm_classify", k_tm_classify, 64, 256, d, p);
+        LAUNCH(h, "tm_alloc_plan", k_tm_alloc_plan, 1, 1024, d);
+        LAUNCH(h, "tm_recyc_emit", k_tm_recyc_emit, h->s1024_blocks, 256, d);
+        LAUNCH(h, "tm_new_segments", k_tm_new_segments, 16, 256, d);
+        launch_learn(h, p);
+    }
+    LAUNCH(h, "tm_prescan", k_tm_prescan, 32, 256, d, p);
+    LAUNCH(h, "tm_scan", k_tm_scan, h->s1024_blocks, 256, d, p);
+    return 0;
+}
+
+static int enqueue_step(htm_handle *h, const uint32_t *bank, int n_inputs, int learning) {
+    const int p = (int)(h->step_host & 1);
+    if (h->cfg.enable_sp) enqueue_sp(h, bank, n_inputs, learning, p);
+    if (h->cfg.enable_tm) enqueue_tm(h, h->d.k, learning, 1, p);
+    LAUNCH(h, "finalize", k_finalize, 1, 1, h->d, h->cfg.enable_tm);
+    h->step_host += 1;
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { h->err = std::string("kernel launch: ") + hipGetErrorString(e); return HTM_ERR_HIP; }
+    return 0;
+}
+
+extern "C" int htm_abi_version(void) { return BITHTM_ABI_VERSION; }
+
+extern "C" const char *htm_last_error(const htm_handle *h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+extern "C" void htm_destroy(htm_handle *h) {
+    if (!h) return;
+    hipSetDevice(h->device);
+    hipStreamSynchronize(h->stream);
+    for (auto &kv : h->graphs) hipGraphExecDestroy(kv.second);
+    for (auto &v : h->prof_events)
+        for (auto &pr : v) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+    for (void *p : h->allocs) hipFree(p);
+    if (h->own_stream) hipStreamDestroy(h->stream);
+    delete h;
+}
+
+static int fail_create(htm_handle *h, const std::string &msg, int code) {
+    g_create_error = msg;
+    if (h) { h->err = msg; htm_destroy(h); }
+    return code;
+}
+
+extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
+    if (!cfg || !out) return fail_create(nullptr, "htm_create: null argument", HTM_ERR_ARGUMENT);
+    if (cfg->struct_bytes != sizeof(htm_config)) return fail_create(nullptr, "htm_create: htm_config size mismatch (ABI)", HTM_ERR_ARGUMENT);
+    if (cfg->column_dim < 1 || cfg->active_columns < 1 || cfg->active_columns > cfg->column_dim)
+        return fail_create(nullptr, "htm_create: need 1 <= active_columns <= column_dim", HTM_ERR_ARGUMENT);
+    if (cfg->enable_sp && cfg->input_dim < 1) return fail_create(nullptr, "htm_create: input_dim < 1", HTM_ERR_ARGUMENT);
+    if (cfg->enable_tm) {
+        if (cfg->cell_dim < 1 || cfg->cell_dim > 32) return fail_create(nullptr, "htm_create: cell_dim must be in 1..32", HTM_ERR_ARGUMENT);
+        if (cfg->segment_slots < 64 || cfg->segment_slots > MAX_SLOTS || cfg->segment_slots % 64)
+            return fail_create(nullptr, "htm_create: segment_slots must be a multiple of 64 in 64..512", HTM_ERR_ARGUMENT);
+        if (cfg->segment_capacity < 1) return fail_create(nullptr, "htm_create: segment_capacity < 1", HTM_ERR_ARGUMENT);
+        if (cfg->segment_sampling_synapses < 1 || cfg->segment_sampling_synapses > 64)
+            return fail_create(nullptr, "htm_create: segment_sampling_synapses must be in 1..64", HTM_ERR_ARGUMENT);
+        if (cfg->segment_activation_threshold < cfg->segment_matching_threshold)      // projections.py:211
+            return fail_create(nullptr, "htm_create: activation threshold < matching threshold", HTM_ERR_ARGUMENT);
+        if ((long long)cfg->column_dim * 32 > 0x7FFFFFFFLL) return fail_create(nullptr, "htm_create: column_dim too large", HTM_ERR_ARGUMENT);
+    }
+    if (!cfg->enable_sp && !cfg->enable_tm) return fail_create(nullptr, "htm_create: nothing enabled", HTM_ERR_ARGUMENT);
+
+    htm_handle *h = new htm_handle();
+    h->cfg = *cfg;
+    h->device = cfg->device;
+    h->profile = false;
+    h->step_host = 0;
+    h->d_cols_stage = nullptr;
+    hipError_t e = hipSetDevice(cfg->device);
+    if (e != hipSuccess) return fail_create(h, std::string("hipSetDevice: ") + hipGetErrorString(e), HTM_ERR_HIP);
+    if (cfg->stream) {
+        h->stream = (hipStream_t)cfg->stream;
+        h->own_stream = false;
+    } else {
+        e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) return fail_create(h, std::string("hipStreamCreate: ") + hipGetErrorString(e), HTM_ERR_HIP);
+        h->own_stream = true;
+    }
+    Dev &d = h->d;
+    memset(&d, 0, sizeof(d));
+    d.I = cfg->enable_sp ? cfg->input_dim : 0;
+    d.W = ((d.I + 127) / 128) * 4;
+    d.W4 = d.W / 4;
+    d.Ipad = d.W * 32;
+    d.C = cfg->column_dim;
+    d.K = cfg->enable_tm ? cfg->cell_dim : 0;
+    d.k = cfg->active_columns;
+    d.E = cfg->enable_tm ? cfg->segment_slots : 64;
+    d.Scap = cfg->enable_tm ? cfg->segment_capacity : 0;
+    d.work_cap = d.Scap + d.k * 32;
+    d.sp_thr = cfg->sp_permanence_threshold; d.sp_don = cfg->sp_delta_on; d.sp_doff = cfg->sp_delta_off;
+    d.coef = cfg->boost_coefficient; d.mom = cfg->duty_momentum; d.dinc = cfg->duty_increment;
+    d.lrn_act = cfg->tm_learn_active; d.lrn_inact = cfg->tm_learn_inactive;
+    d.pun_act = cfg->tm_punish_active; d.pun_inact = cfg->tm_punish_inactive;
+    d.lrn_prune = cfg->tm_learn_prune; d.pun_prune = cfg->tm_punish_prune;
+    d.perm_init = cfg->tm_permanence_initial; d.perm_thr = cfg->tm_permanence_threshold;
+    d.act_thr = cfg->segment_activation_threshold; d.match_thr = cfg->segment_matching_threshold;
+    d.sample = cfg->segment_sampling_synapses;
+    d.seed = cfg->seed;
+
+    int rc = 0;
+    const size_t C = d.C, k = d.k;
+    rc |= dalloc(h, &d.ctr, 1);
+    rc |= dalloc(h, &d.active_cols, k);
+    if (cfg->enable_sp) {
+        rc |= dalloc(h, &d.perm, C * d.Ipad);
+        rc |= dalloc(h, &d.mask, C * d.W);
+        rc |= dalloc(h, &d.duty, C);
+        rc |= dalloc(h, &d.overlap, C);
+        rc |= dalloc(h, &d.boosted, C);
+        rc |= dalloc(h, &d.key, C);
+        rc |= dalloc(h, &d.hist, (size_t)SEL_PASSES * SEL_BINS);
+        rc |= dalloc(h, &d.sel_blk, (C + 1023) / 1024);
+        rc |= dalloc(h, &d.input_stage, (size_t)d.W);
+    }
+    if (cfg->enable_tm) {
+        const size_t S = d.Scap, E = d.E;
+        for (int q = 0; q < 2; ++q) {
+            rc |= dalloc(h, &d.act[q], C);
+            rc |= dalloc(h, &d.pred[q], C);
+            rc |= dalloc(h, &d.winners[q], k * 32);
+            rc |= dalloc(h, &d.match_seg[q], S);
+            rc |= dalloc(h, &d.match_info[q], S);
+            rc |= dalloc(h, &d.match_jit[q], S);
+        }
+        rc |= dalloc(h, &d.win, C);
+        rc |= dalloc(h, &d.bursting, k);
+        rc |= dalloc(h, &d.colcnt, k);
+        rc |= dalloc(h, &d.unacc_word, k);
+        rc |= dalloc(h, &d.unacc_list, k * 32);
+        rc |= dalloc(h, &d.seg_cell, S);
+        rc |= dalloc(h, &d.seg_nsyn, S);
+        rc |= dalloc(h, &d.presyn, S * E);
+        rc |= dalloc(h, &d.sperm, S * E);
+        rc |= dalloc(h, &d.segcount, C * 32);
+        rc |= dalloc(h, &d.cellmax, C * 32);
+        rc |= dalloc(h, &d.seg_pot, S);
+        rc |= dalloc(h, &d.work, (size_t)d.work_cap);
+        rc |= dalloc(h, &d.recyc_cnt, (S + 1023) / 1024);
+        rc |= dalloc(h, &d.recyc_off, (S + 1023) / 1024);
+        rc |= dalloc(h, &d.recyc_list, k * 32);
+        rc |= dalloc(h, &h->d_cols_stage, k);
+    }
+    if (rc) return fail_create(h, h->err, HTM_ERR_HIP);
+    // lanes per SP row: the smallest power of two >= W4, at most 64
+    h->G = 1;
+    while (h->G < d.W4 && h->G < 64) h->G <<= 1;
+    const int rows_per_block = 4 * (64 / h->G);
+    h->sp_blocks = std::max(1, std::min((d.C + rows_per_block - 1) / rows_per_block, 4096));
+    h->sel_blocks = std::max(1, std::min((d.C + 255) / 256, 256));
+    h->c1024_blocks = (d.C + 1023) / 1024;
+    h->s1024_blocks = std::max(1, (d.Scap + 1023) / 1024);
+    e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) return fail_create(h, std::string("hipStreamSynchronize: ") + hipGetErrorString(e), HTM_ERR_HIP);
+    *out = h;
+    return HTM_OK;
+}
+
+extern "C" int htm_sync(htm_handle *h) {
+    if (!h) return HTM_ERR_ARGUMENT;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return HTM_OK;
+}
+
+static int check_rows(htm_handle *h, const void *rows, int row_begin, int row_count) {
+    if (!h) return HTM_ERR_ARGUMENT;
+    if (!h->cfg.enable_sp) { h->err = "handle has no Spatial Pooler"; return HTM_ERR_STATE; }
+    if (!rows || row_begin < 0 || row_count < 0 || row_begin + (long long)row_count > h->d.C) {
+        h->err = "permanence rows out of range";
+        return HTM_ERR_ARGUMENT;
+    }
+    return 0;
+}
+
+extern "C" int htm_sp_set_permanence(htm_handle *h, const double *rows, int32_t row_begin, int32_t row_count) {
+    int rc = check_rows(h, rows, row_begin, row_count);
+    if (rc) return rc;
+    if (row_count == 0) return HTM_OK;
+    Dev &d = h->d;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemcpy2DAsync(d.perm + (size_t)row_begin * d.Ipad, (size_t)d.Ipad * 8, rows, (size_t)d.I * 8,
+                               (size_t)d.I * 8, (size_t)row_count, hipMemcpyHostToDevice, h->stream));
+    const long long waves = (long long)row_count * (d.Ipad / 64);
+    const int blocks = (int)std::min<long long>((waves + 3) / 4, 8192);
+    hipLaunchKernelGGL(k_sp_build_mask, dim3(blocks), dim3(256), 0, h->stream, d, row_begin, row_count);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return HTM_OK;
+}
+
+extern "C" int htm_sp_get_permanence(htm_handle *h, double *rows, int32_t row_begin, int32_t row_count) {
+    int rc = check_rows(h, rows, row_begin, row_count);
+    if (rc) return rc;
+    if (row_count == 0) return HTM_OK;
+    Dev &d = h->d;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemcpy2DAsync(rows, (size_t)d.I * 8, d.perm + (size_t)row_begin * d.Ipad, (size_t)d.Ipad * 8,
+                               (size_t)d.I * 8, (size_t)row_count, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return HTM_OK;
+}
+
+static int stage_input(htm_handle *h, const uint32_t *packed_input) {
+    Dev &d = h->d;
+    const int words = (d.I + 31) / 32;
+    HIPCHK(h, hipMemcpyAsync(d.input_stage, packed_input, (size_t)words * 4, hipMemcpyHostToDevice, h->stream));
+    return 0;
+}
+
+extern "C" int htm_step(htm_handle *h, const uint32_t *packed_input, int32_t learning) {
+    if (!h || !packed_input) return HTM_ERR_ARGUMENT;
+    if (!h->cfg.enable_sp || !h->cfg.enable_tm) { h->err = "htm_step needs a handle with SP and TM"; return HTM_ERR_STATE; }
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc = stage_input(h, packed_input);
+    if (rc) return rc;
+    return enqueue_step(h, h->d.input_stage, 1, learning ? 1 : 0);
+}
+
+extern "C" int htm_sp_step(htm_handle *h, const uint32_t *packed_input, int32_t learning) {
+    if (!h || !packed_input) return HTM_ERR_ARGUMENT;
+    if (!h->cfg.enable_sp) { h->err = "handle has no Spatial Pooler"; return HTM_ERR_STATE; }
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc = stage_input(h, packed_input);
+    if (rc) return rc;
+    const int p = (int)(h->step_host & 1);
+    enqueue_sp(h, h->d.input_stage, 1, learning ? 1 : 0, p);
+    LAUNCH(h, "finalize", k_finalize, 1, 1, h->d, 0);
+    h->step_host += 1;
+    return HTM_OK;
+}
+
+extern "C" int htm_tm_step(htm_handle *h, const int32_t *active_column, int32_t n, int32_t learning, int32_t return_winner_cell) {
+    if (!h || (!active_column && n > 0)) return HTM_ERR_ARGUMENT;
+    if (!h->cfg.enable_tm) { h->err = "handle has no Temporal Memory"; return HTM_ERR_STATE; }
+    Dev &d = h->d;
+    if (n < 0 || n > d.k) { h->err = "htm_tm_step: more active columns than active_columns"; return HTM_ERR_ARGUMENT; }
+    std::vector<int> cols(active_column, active_column + n);
+    std::sort(cols.begin(), cols.end());
+    for (int i = 0; i < n; ++i)
+        if (cols[i] < 0 || cols[i] >= d.C || (i && cols[i] == cols[i - 1])) { h->err = "htm_tm_step: bad active column list"; return HTM_ERR_ARGUMENT; }
+    HIPCHK(h, hipSetDevice(h->device));
+    if (n) HIPCHK(h, hipMemcpyAsync(h->d_cols_stage, cols.data(), (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));      // cols is a local
+    const int p = (int)(h->step_host & 1);
+    LAUNCH(h, "tm_load_active", k_tm_load_active, std::min((d.C + 255) / 256, 1024), 256, d, p, h->d_cols_stage, n);
+    enqueue_tm(h, n, learning ? 1 : 0, return_winner_cell ? 1 : 0, p);
+    LAUNCH(h, "finalize", k_finalize, 1, 1, d, 1);
+    h->step_host += 1;
+    return HTM_OK;
+}
+
+extern "C" int htm_run(htm_handle *h, const uint32_t *device_inputs, int32_t n_inputs, int32_t n_steps, int32_t learning, int32_t use_graph) {
+    if (!h || !device_inputs || n_inputs < 1 || n_steps < 0) return HTM_ERR_ARGUMENT;
+    if (!h->cfg.enable_sp || !h->cfg.enable_tm) { h->err = "htm_run needs a handle with SP and TM"; return HTM_ERR_STATE; }
+    HIPCHK(h, hipSetDevice(h->device));
+    learning = learning ? 1 : 0;
+    if (!use_graph || h->profile) {
+        for (int t = 0; t < n_steps; ++t) {
+            int rc = enqueue_step(h, device_inputs, n_inputs, learning);
+            if (rc) return rc;
+        }
+        return HTM_OK;
+    }
+    for (int t = 0; t < n_steps; ++t) {
+        const int p = (int)(h->step_host & 1);
+        auto key = std::make_tuple(p, learning, (const void *)device_inputs, n_inputs);
+        auto it = h->graphs.find(key);
+        if (it == h->graphs.end()) {
+            hipGraph_t graph;
+            HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+            const long long keep = h->step_host;
+            int rc = enqueue_step(h, device_inputs, n_inputs, learning);
+            h->step_host = keep;
+            hipError_t e = hipStreamEndCapture(h->stream, &graph);
+            if (rc) return rc;
+            if (e != hipSuccess) { h->err = std::string("hipStreamEndCapture: ") + hipGetErrorString(e); return HTM_ERR_HIP; }
+            hipGraphExec_t exec;
+            HIPCHK(h, hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+            hipGraphDestroy(graph);
+            it = h->graphs.emplace(key, exec).first;
+        }
+        HIPCHK(h, hipGraphLaunch(it->second, h->stream));
+        h->step_host += 1;
+    }
+    return HTM_OK;
+}
+
+extern "C" int htm_bank_upload(htm_handle *h, const uint32_t *host_inputs, int32_t n_inputs, uint32_t **device_bank) {
+    if (!h || !host_inputs || n_inputs < 1 || !device_bank) return HTM_ERR_ARGUMENT;
+    if (!h->cfg.enable_sp) { h->err = "handle has no Spatial Pooler"; return HTM_ERR_STATE; }
+    Dev &d = h->d;
+    HIPCHK(h, hipSetDevice(h->device));
+    uint32_t *bank = nullptr;
+    int rc = dalloc(h, &bank, (size_t)n_inputs * d.W);
+    if (rc) return rc;
+    const size_t words = (size_t)(d.I + 31) / 32;
+    HIPCHK(h, hipMemcpy2DAsync(bank, (size_t)d.W * 4, host_inputs, words * 4, words * 4, (size_t)n_inputs,
+                               hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    *device_bank = bank;
+    return HTM_OK;
+}
+
+static int read_counters(htm_handle *h, Counters *out) {
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(out, h->d.ctr, sizeof(Counters), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int htm_get_info(htm_handle *h, htm_info *out) {
+    if (!h || !out) return HTM_ERR_ARGUMENT;
+    Counters c;
+    int rc = read_counters(h, &c);
+    if (rc) return rc;
+    const int q = (int)((h->step_host + 1) & 1);          // parity of the last completed step
+    out->step_index = h->step_host;
+    out->segments = c.S;
+    out->matching_segments = c.has_distal ? c.n_match[q] : 0;
+    out->winner_cells = c.n_win[q];
+    out->active_cells = c.n_active_cells;
+    out->has_distal_state = c.has_distal;
+    out->has_winner_cells = h->step_host > 0 ? c.has_winner[q] : 0;
+    out->capacity_error = c.error;
+    out->words_per_row = h->d.W;
+    if (c.error) {
+        h->err = std::string("capacity exhausted:") + ((c.error & 1) ? " segment pool (segment_capacity)" : "") +
+                 ((c.error & 2) ? " synapse slots (segment_slots)" : "") + ((c.error & 4) ? " work list / growth staging" : "");
+    }
+    return HTM_OK;
+}
+
+// conversions between the internal cell encoding (col*32+cell) and the ABI's flat ids
+static inline int enc_flat(int enc, int K) { return (enc >> 5) * K + (enc & 31); }
+static inline int flat_enc(int flat, int K) { return (flat / K) * 32 + (flat % K); }
+
+extern "C" int64_t htm_read(htm_handle *h, int32_t field, void *dst, int64_t count) {
+    if (!h || !dst) return HTM_ERR_ARGUMENT;
+    Counters c;
+    int rc = read_counters(h, &c);
+    if (rc) return rc;
+    Dev &d = h->d;
+    const int q = (int)((h->step_host + 1) & 1);
+    const bool sp = h->cfg.enable_sp, tm = h->cfg.enable_tm;
+    const int64_t C = d.C, K = d.K, S = c.S, E = d.E, M = c.has_distal ? c.n_match[q] : 0;
+    auto need = [&](bool ok, int64_t n) -> int64_t {
+        if (!ok) { h->err = "htm_read: field not available on this handle"; return HTM_ERR_STATE; }
+        if (count < n) { h->err = "htm_read: buffer too small"; return HTM_ERR_ARGUMENT; }
+        return n;
+    };
+    auto copy = [&](const void *src, int64_t n, size_t elem) -> int64_t {
+        if (n > 0 && hipMemcpy(dst, src, (size_t)n * elem, hipMemcpyDeviceToHost) != hipSuccess) { h->err = "htm_read: hipMemcpy failed"; return HTM_ERR_HIP; }
+        return n;
+    };
+    int64_t n;
+    switch (field) {
+        case HTM_F_ACTIVE_COLUMN: if ((n = need(true, d.k)) < 0) return n; return copy(d.active_cols, n, 4);
+        case HTM_F_OVERLAPS: if ((n = need(sp, C)) < 0) return n; return copy(d.overlap, n, 4);
+        case HTM_F_BOOSTED: if ((n = need(sp, C)) < 0) return n; return copy(d.boosted, n, 8);
+        case HTM_F_DUTY_CYCLE: if ((n = need(sp, C)) < 0) return n; return copy(d.duty, n, 4);
+        case HTM_F_CELL_ACTIVATION: if ((n = need(tm, C)) < 0) return n; return copy(d.act[q], n, 4);
+        case HTM_F_CELL_PREDICTION: if ((n = need(tm, C)) < 0) return n; return copy(d.pred[q], n, 4);
+        case HTM_F_WINNER_WORDS: if ((n = need(tm, C)) < 0) return n; return copy(d.win, n, 4);
+        case HTM_F_BURSTING: if ((n = need(tm, d.k)) < 0) return n; return copy(d.bursting, n, 1);
+        case HTM_F_SEG_NSYN: if ((n = need(tm, S)) < 0) return n; return copy(d.seg_nsyn, n, 4);
+        case HTM_F_SEG_POTENTIAL: if ((n = need(tm, S)) < 0) return n; return copy(d.seg_pot, n, 4);
+        case HTM_F_MATCH_SEGMENT: if ((n = need(tm, M)) < 0) return n; return copy(d.match_seg[q], n, 4);
+        case HTM_F_MATCH_INFO: if ((n = need(tm, M)) < 0) return n; return copy(d.match_info[q], n, 4);
+        case HTM_F_MATCH_JITTER: if ((n = need(tm, M)) < 0) return n; return copy(d.match_jit[q], n, 4);
+        case HTM_F_WINNER_CELL:
+        case HTM_F_SEG_CELL: {
+            const bool w = field == HTM_F_WINNER_CELL;
+            if ((n = need(tm, w ? c.n_win[q] : S)) < 0) return n;
+            if ((rc = (int)copy(w ? d.winners[q] : d.seg_cell, n, 4)) < 0) return rc;
+            int *v = (int *)dst;
+            for (int64_t i = 0; i < n; ++i) v[i] = enc_flat(v[i], (int)K);
+            return n;
+        }
+        case HTM_F_SEG_PRESYN:
+        case HTM_F_SEG_PERM: {
+            if ((n = need(tm, S * E)) < 0) return n;
+            std::vector<int> nsyn((size_t)S);
+            if (S && hipMemcpy(nsyn.data(), d.seg_nsyn, (size_t)S * 4, hipMemcpyDeviceToHost) != hipSuccess) { h->err = "htm_read: hipMemcpy failed"; return HTM_ERR_HIP; }
+            if ((rc = (int)copy(field == HTM_F_SEG_PRESYN ? (const void *)d.presyn : (const void *)d.sperm, n, 4)) < 0) return rc;
+            for (int64_t s = 0; s < S; ++s)
+                for (int64_t e = 0; e < E; ++e) {
+                    const bool valid = e < nsyn[(size_t)s];
+                    if (field == HTM_F_SEG_PRESYN) { int *v = (int *)dst + s * E + e; *v = valid ? enc_flat(*v, (int)K) : -1; }
+                    else if (!valid) ((float *)dst)[s * E + e] = -1.0f;
+                }
+            return n;
+        }
+        case HTM_F_SEGCOUNT:
+        case HTM_F_CELL_MAX_JITTER: {
+            if ((n = need(tm, C * K)) < 0) return n;
+            std::vector<uint32_t> tmp((size_t)C * 32);
+            const void *src = field == HTM_F_SEGCOUNT ? (const void *)d.segcount : (const void *)d.cellmax;
+            if (hipMemcpy(tmp.data(), src, tmp.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) { h->err = "htm_read: hipMemcpy failed"; return HTM_ERR_HIP; }
+            uint32_t *v = (uint32_t *)dst;
+            for (int64_t col = 0; col < C; ++col)
+                for (int64_t j = 0; j < K; ++j) v[col * K + j] = tmp[(size_t)col * 32 + j];
+            return n;
+        }
+        default: h->err = "htm_read: unknown field"; return HTM_ERR_ARGUMENT;
+    }
+}
+
+extern "C" int htm_write(htm_handle *h, int32_t field, const void *src, int64_t count) {
+    if (!h || (!src && count > 0) || count < 0) return HTM_ERR_ARGUMENT;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    Dev &d = h->d;
+    const bool sp = h->cfg.enable_sp, tm = h->cfg.enable_tm;
+    const int64_t C = d.C, K = d.K, E = d.E;
+    const int q = (int)((h->step_host + 1) & 1);      // becomes "previous step" for the next one
+    auto put = [&](void *dstp, const void *s, int64_t n, size_t elem, int64_t cap) -> int {
+        if (n > cap) { h->err = "htm_write: too many elements"; return HTM_ERR_ARGUMENT; }
+        if (n > 0 && hipMemcpy(dstp, s, (size_t)n * elem, hipMemcpyHostToDevice) != hipSuccess) { h->err = "htm_write: hipMemcpy failed"; return HTM_ERR_HIP; }
+        return HTM_OK;
+    };
+    if (((field >= HTM_F_CELL_ACTIVATION) && !tm) || ((field >= HTM_F_OVERLAPS && field <= HTM_F_DUTY_CYCLE) && !sp)) {
+        h->err = "htm_write: field not available on this handle";
+        return HTM_ERR_STATE;
+    }
+    switch (field) {
+        case HTM_F_DUTY_CYCLE: return put(d.duty, src, count, 4, C);
+        case HTM_F_CELL_ACTIVATION: return put(d.act[q], src, count, 4, C);
+        case HTM_F_CELL_PREDICTION: return put(d.pred[q], src, count, 4, C);
+        case HTM_F_SEG_NSYN: return put(d.seg_nsyn, src, count, 4, d.Scap);
+        case HTM_F_SEG_POTENTIAL: return put(d.seg_pot, src, count, 4, d.Scap);
+        case HTM_F_MATCH_SEGMENT: return put(d.match_seg[q], src, count, 4, d.Scap);
+        case HTM_F_MATCH_INFO: return put(d.match_info[q], src, count, 4, d.Scap);
+        case HTM_F_MATCH_JITTER: return put(d.match_jit[q], src, count, 4, d.Scap);
+        case HTM_F_SEG_PERM: return put(d.sperm, src, count, 4, (int64_t)d.Scap * E);
+        case HTM_F_WINNER_CELL:
+        case HTM_F_SEG_CELL:
+        case HTM_F_SEG_PRESYN: {
+            std::vector<int> v((const int *)src, (const int *)src + count);
+            for (auto &x : v) x = x < 0 ? 0 : flat_enc(x, (int)K);
+            if (field == HTM_F_WINNER_CELL) return put(d.winners[q], v.data(), count, 4, (int64_t)d.k * 32);
+            if (field == HTM_F_SEG_CELL) return put(d.seg_cell, v.data(), count, 4, d.Scap);
+            return put(d.presyn, v.data(), count, 4, (int64_t)d.Scap * E);
+        }
+        case HTM_F_SEGCOUNT:
+        case HTM_F_CELL_MAX_JITTER: {
+            if (count != C * K) { h->err = "htm_write: need column_dim * cell_dim elements"; return HTM_ERR_ARGUMENT; }
+            std::vector<uint32_t> tmp((size_t)C * 32, 0u);
+            const uint32_t *v = (const uint32_t *)src;
+            for (int64_t col = 0; col < C; ++col)
+                for (int64_t j = 0; j < K; ++j) tmp[(size_t)col * 32 + j] = v[col * K + j];
+            return put(field == HTM_F_SEGCOUNT ? (void *)d.segcount : (void *)d.cellmax, tmp.data(), (int64_t)tmp.size(), 4, (int64_t)tmp.size());
+        }
+        default: h->err = "htm_write: field is not writable"; return HTM_ERR_ARGUMENT;
+    }
+}
+
+extern "C" int htm_import_begin(htm_handle *h, int64_t step_index) {
+    if (!h || step_index < 0) return HTM_ERR_ARGUMENT;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->step_host = step_index;
+    return HTM_OK;
+}
+
+extern "C" int htm_import_commit(htm_handle *h, int32_t segments, int32_t matching_segments, int32_t winner_cells,
+                                 int32_t has_distal_state, int32_t has_winner_cells) {
+    if (!h) return HTM_ERR_ARGUMENT;
+    Dev &d = h->d;
+    if (segments < 0 || segments > d.Scap || matching_segments < 0 || matching_segments > segments ||
+        winner_cells < 0 || winner_cells > d.k * 32) { h->err = "htm_import_commit: bad scalars"; return HTM_ERR_ARGUMENT; }
+    Counters c;
+    int rc = read_counters(h, &c);
+    if (rc) return rc;
+    const int q = (int)((h->step_host + 1) & 1);
+    c.step = (uint32_t)h->step_host;
+    c.S = segments;
+    c.n_match[q] = matching_segments;
+    c.n_win[q] = winner_cells;
+    c.has_winner[q] = has_winner_cells ? 1 : 0;
+    c.has_distal = has_distal_state ? 1 : 0;
+    c.error = 0;
+    HIPCHK(h, hipMemcpy(d.ctr, &c, sizeof(c), hipMemcpyHostToDevice));
+    if (h->cfg.enable_tm) {
+        hipLaunchKernelGGL(k_tm_recount, dim3(h->s1024_blocks), dim3(256), 0, h->stream, d);
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+    return HTM_OK;
+}
+
+extern "C" int htm_profile(htm_handle *h, int32_t enable) {
+    if (!h) return HTM_ERR_ARGUMENT;
+    h->profile = enable != 0;
+    return HTM_OK;
+}
+
+extern "C" int htm_profile_read(htm_handle *h, int32_t max_kernels, const char **names, double *total_ms, int64_t *launches) {
+    if (!h) return HTM_ERR_ARGUMENT;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (size_t i = 0; i < h->prof_names.size(); ++i) {
+        for (auto &pr : h->prof_events[i]) {
+            float ms = 0.f;
+            hipEventElapsedTime(&ms, pr.first, pr.second);
+            h->prof_ms[i] += ms;
+            h->prof_n[i] += 1;
+            hipEventDestroy(pr.first);
+            hipEventDestroy(pr.second);
+        }
+        h->prof_events[i].clear();
+    }
+    int n = (int)std::min<size_t>(h->prof_names.size(), (size_t)std::max(max_kernels, 0));
+    for (int i = 0; i < n; ++i) {
+        if (names) names[i] = h->prof_names[i].c_str();
+        if (total_ms) total_ms[i] = h->prof_ms[i];
+        if (launches) launches[i] = h->prof_n[i];
+    }
+    for (size_t i = 0; i < h->prof_names.size(); ++i) { h->prof_ms[i] = 0; h->prof_n[i] = 0; }
+    return n;
+}

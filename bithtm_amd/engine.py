@@ -1,0 +1,286 @@
+"""One device engine = one handle of the C ABI (include/bithtm_hip.h): all device state of one
+SpatialPooler and / or TemporalMemory.  Host logic only; every computation is a HIP kernel."""
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+class HtmError(RuntimeError):
+    pass
+
+
+class CapacityError(HtmError):
+    """The fixed-capacity segment pool or a segment's synapse slots are exhausted."""
+
+
+def pack_bits(bits, words):
+    """bool[I] -> uint32[words], bit i of the input = bit (i & 31) of word (i >> 5)."""
+    bits = np.asarray(bits)
+    if bits.dtype != np.bool_:
+        bits = bits.astype(np.bool_)
+    packed = np.packbits(bits, bitorder="little")
+    out = np.zeros(words * 4, dtype=np.uint8)
+    out[:len(packed)] = packed
+    return out.view(np.uint32)
+
+
+def words_to_bool(words, cell_dim):
+    """uint32[C] -> bool[C, K]."""
+    return ((words[:, None] >> np.arange(cell_dim, dtype=np.uint32)) & 1).astype(np.bool_)
+
+
+def bool_to_words(mat):
+    mat = np.asarray(mat, dtype=np.bool_)
+    return (mat.astype(np.uint32) << np.arange(mat.shape[1], dtype=np.uint32)).sum(axis=1).astype(np.uint32)
+
+
+class Engine:
+    def __init__(self, input_dim, column_dim, cell_dim, active_columns, proximal=None, boosting=None,
+                 distal=None, seed=0, device=0, stream=None):
+        self.lib = L.load()
+        self.input_dim = int(input_dim) if proximal is not None else 0
+        self.column_dim = int(column_dim)
+        self.cell_dim = int(cell_dim) if distal is not None else 0
+        self.active_columns = int(active_columns)
+        self.has_sp = proximal is not None
+        self.has_tm = distal is not None
+        cfg = L.HtmConfig()
+        cfg.struct_bytes = C.sizeof(L.HtmConfig)
+        cfg.device = device
+        cfg.input_dim, cfg.column_dim, cfg.cell_dim = self.input_dim, self.column_dim, self.cell_dim
+        cfg.active_columns = self.active_columns
+        cfg.enable_sp, cfg.enable_tm = int(self.has_sp), int(self.has_tm)
+        if self.has_sp:
+            inc, dec = proximal.permanence_increment, proximal.permanence_decrement
+            cfg.sp_permanence_threshold = proximal.permanence_threshold
+            cfg.sp_delta_on = 1.0 * (inc + dec) - dec                 # projections.py:24
+            cfg.sp_delta_off = 0.0 * (inc + dec) - dec
+            density = boosting.active_outputs / boosting.output_dim     # regularizations.py:9
+            cfg.boost_coefficient = np.float32(-(boosting.intensity / density))   # :16
+            cfg.duty_momentum = np.float32(boosting.momentum)                     # :20
+            cfg.duty_increment = np.float32(1.0 - boosting.momentum)              # :21
+        if self.has_tm:
+            a, b = distal.permanence_increment, -distal.permanence_decrement      # projections.py:287
+            pa, pb = -distal.permanence_punishment, 0.0                           # :292
+            cfg.tm_learn_active, cfg.tm_learn_inactive = 1.0 * (a - b) + b, 0.0 * (a - b) + b   # :102
+            cfg.tm_punish_active, cfg.tm_punish_inactive = 1.0 * (pa - pb) + pb, 0.0 * (pa - pb) + pb
+            cfg.tm_learn_prune, cfg.tm_punish_prune = int(min(a, b) < 0), int(min(pa, pb) < 0)   # :105
+            cfg.tm_permanence_initial = np.float32(distal.permanence_initial)
+            cfg.tm_permanence_threshold = np.float32(distal.permanence_threshold)
+            cfg.segment_activation_threshold = distal.segment_activation_threshold
+            cfg.segment_matching_threshold = distal.segment_matching_threshold
+            cfg.segment_sampling_synapses = distal.segment_sampling_synapses
+            cap = distal.segment_capacity
+            cfg.segment_capacity = int(cap) if cap is not None else max(4096, 512 * self.active_columns)
+            cfg.segment_slots = int(distal.segment_slots)
+        cfg.seed = int(seed) & 0xFFFFFFFF
+        cfg.stream = stream
+        self.segment_capacity, self.segment_slots = cfg.segment_capacity, cfg.segment_slots
+        self.seed = cfg.seed
+        handle = C.c_void_p()
+        rc = self.lib.htm_create(C.byref(cfg), C.byref(handle))
+        if rc != 0:
+            raise HtmError(f"htm_create failed ({rc}): {self.lib.htm_last_error(None).decode()}")
+        self.h = handle
+        self.steps = 0
+        self._banks = []
+        if self.has_sp:
+            self.set_permanence(proximal._permanence)
+            self.words = self.info().words_per_row
+
+    def __del__(self):
+        h, self.h = getattr(self, "h", None), None
+        if h:
+            self.lib.htm_destroy(h)
+
+    # ---- plumbing
+    def _check(self, rc, what):
+        if rc < 0:
+            raise HtmError(f"{what} failed ({rc}): {self.lib.htm_last_error(self.h).decode()}")
+        return rc
+
+    def info(self):
+        out = L.HtmInfo()
+        self._check(self.lib.htm_get_info(self.h, C.byref(out)), "htm_get_info")
+        return out
+
+    def check_capacity(self):
+        info = self.info()
+        if info.capacity_error:
+            raise CapacityError(self.lib.htm_last_error(self.h).decode())
+        return info
+
+    def sync(self):
+        self._check(self.lib.htm_sync(self.h), "htm_sync")
+
+    def read(self, field, dtype, count):
+        out = np.empty(int(count), dtype=dtype)
+        n = self._check(self.lib.htm_read(self.h, field, out.ctypes.data_as(C.c_void_p), out.size), "htm_read")
+        return out[:n]
+
+    def write(self, field, array, dtype):
+        a = np.ascontiguousarray(array, dtype=dtype)
+        self._check(self.lib.htm_write(self.h, field, a.ctypes.data_as(C.c_void_p), a.size), "htm_write")
+
+    # ---- SP state
+    def set_permanence(self, perm, row_begin=0):
+        perm = np.ascontiguousarray(perm, dtype=np.float64)
+        assert perm.ndim == 2 and perm.shape[1] == self.input_dim
+        self._check(self.lib.htm_sp_set_permanence(self.h, perm.ctypes.data_as(C.c_void_p), row_begin, perm.shape[0]),
+                    "htm_sp_set_permanence")
+
+    def get_permanence(self, row_begin=0, row_count=None):
+        row_count = self.column_dim - row_begin if row_count is None else row_count
+        out = np.empty((row_count, self.input_dim), dtype=np.float64)
+        self._check(self.lib.htm_sp_get_permanence(self.h, out.ctypes.data_as(C.c_void_p), row_begin, row_count),
+                    "htm_sp_get_permanence")
+        return out
+
+    def read_duty_cycle(self):
+        return self.read(L.F_DUTY_CYCLE, np.float32, self.column_dim)
+
+    # ---- stepping
+    def step(self, input_bits, learning=True):
+        packed = pack_bits(input_bits, self.words)
+        self._check(self.lib.htm_step(self.h, packed.ctypes.data_as(C.c_void_p), int(bool(learning))), "htm_step")
+        self.steps += 1
+
+    def sp_step(self, input_bits, learning=True):
+        packed = pack_bits(input_bits, self.words)
+        self._check(self.lib.htm_sp_step(self.h, packed.ctypes.data_as(C.c_void_p), int(bool(learning))), "htm_sp_step")
+        self.steps += 1
+
+    def tm_step(self, active_column, learning=True, return_winner_cell=True):
+        cols = np.ascontiguousarray(active_column, dtype=np.int32)
+        self._check(self.lib.htm_tm_step(self.h, cols.ctypes.data_as(C.c_void_p), cols.size, int(bool(learning)),
+                                         int(bool(return_winner_cell))), "htm_tm_step")
+        self.steps += 1
+
+    def upload_bank(self, inputs):
+        """bool[n, I] -> device address of the packed bank htm_run reads."""
+        inputs = np.asarray(inputs, dtype=np.bool_)
+        n = inputs.shape[0]
+        words = (self.input_dim + 31) // 32
+        packed = np.zeros((n, words * 4), dtype=np.uint8)
+        pb = np.packbits(inputs, axis=1, bitorder="little")
+        packed[:, :pb.shape[1]] = pb
+        ptr = C.c_void_p()
+        self._check(self.lib.htm_bank_upload(self.h, packed.ctypes.data_as(C.c_void_p), n, C.byref(ptr)), "htm_bank_upload")
+        return ptr.value
+
+    def run(self, device_bank, n_inputs, n_steps, learning=True, use_graph=True):
+        self._check(self.lib.htm_run(self.h, C.c_void_p(device_bank), int(n_inputs), int(n_steps), int(bool(learning)),
+                                     int(bool(use_graph))), "htm_run")
+        self.steps += n_steps
+
+    def profile(self, enable):
+        self._check(self.lib.htm_profile(self.h, int(bool(enable))), "htm_profile")
+
+    def profile_read(self, max_kernels=64):
+        names = (C.c_char_p * max_kernels)()
+        ms = (C.c_double * max_kernels)()
+        cnt = (C.c_int64 * max_kernels)()
+        n = self._check(self.lib.htm_profile_read(self.h, max_kernels, names, ms, cnt), "htm_profile_read")
+        return {names[i].decode(): (ms[i], cnt[i]) for i in range(n)}
+
+    # ---- State fields (host views of the last completed step)
+    def read_sp_fields(self):
+        return dict(
+            active_column=self.read(L.F_ACTIVE_COLUMN, np.int32, self.active_columns).astype(np.int64),
+            overlaps=self.read(L.F_OVERLAPS, np.int32, self.column_dim).astype(np.int64),
+            boosted_overlaps=self.read(L.F_BOOSTED, np.float64, self.column_dim))
+
+    def read_store(self):
+        info = self.info()
+        S, E = info.segments, self.segment_slots
+        return dict(
+            S=S, slots=E,
+            seg_cell=self.read(L.F_SEG_CELL, np.int32, S), seg_nsyn=self.read(L.F_SEG_NSYN, np.int32, S),
+            presyn=self.read(L.F_SEG_PRESYN, np.int32, S * E).reshape(S, E),
+            perm=self.read(L.F_SEG_PERM, np.float32, S * E).reshape(S, E),
+            segcount=self.read(L.F_SEGCOUNT, np.int32, self.column_dim * self.cell_dim))
+
+    def read_distal(self):
+        """PredictiveProjection.State (projections.py:195-203) of the last step, segment ids
+        ascending as np.where (projections.py:247) yields them."""
+        info = self.info()
+        if not info.has_distal_state:
+            return None
+        S, M, N = info.segments, info.matching_segments, self.column_dim * self.cell_dim
+        seg = self.read(L.F_MATCH_SEGMENT, np.int32, M).astype(np.int64)
+        minfo = self.read(L.F_MATCH_INFO, np.uint32, M)
+        jit = self.read(L.F_MATCH_JITTER, np.float32, M)
+        order = np.argsort(seg, kind="stable")
+        seg, minfo, jit = seg[order], minfo[order], jit[order]
+        active = (minfo >> 31).astype(np.bool_)
+        seg_cell = self.read(L.F_SEG_CELL, np.int32, S)
+        prediction = np.bincount(seg_cell[seg], weights=active, minlength=N).astype(np.float64)
+        return dict(
+            prediction=prediction,
+            segment_potential=self.read(L.F_SEG_POTENTIAL, np.int32, S).astype(np.int64),
+            matching_segment=seg, matching_segment_activation=((minfo >> 12) & 0xFFF).astype(np.int64),
+            matching_segment_active=active, max_jittered_potential=self.read(L.F_CELL_MAX_JITTER, np.float32, N),
+            matching_segment_jittered_potential=jit)
+
+    # ---- state hand-off in the oracle's dictionary layout (oracle/htm_oracle.py export_state)
+    def export_tm_state(self):
+        info = self.check_capacity()
+        K = self.cell_dim
+        st = self.read_store()
+        out = dict(
+            S=np.int64(st["S"]), slots=np.int64(st["slots"]), step_index=np.int64(info.step_index),
+            seg_cell=st["seg_cell"], seg_nsyn=st["seg_nsyn"], presyn=st["presyn"], perm=st["perm"], segcount=st["segcount"],
+            prev_prediction=words_to_bool(self.read(L.F_CELL_PREDICTION, np.uint32, self.column_dim), K),
+            prev_activation=words_to_bool(self.read(L.F_CELL_ACTIVATION, np.uint32, self.column_dim), K),
+            prev_winner=self.read(L.F_WINNER_CELL, np.int32, info.winner_cells).astype(np.int64),
+            has_prev_winner=np.bool_(info.has_winner_cells), has_distal=np.bool_(info.has_distal_state))
+        d = self.read_distal()
+        if d is not None:
+            out.update(d)
+        return out
+
+    def import_tm_state(self, st):
+        K, S, E = self.cell_dim, int(st["S"]), self.segment_slots
+        if S > self.segment_capacity:
+            raise CapacityError(f"state has {S} segments, pool holds {self.segment_capacity}")
+        self._check(self.lib.htm_import_begin(self.h, int(st["step_index"])), "htm_import_begin")
+        presyn = np.asarray(st["presyn"], dtype=np.int32).reshape(S, -1)
+        perm = np.asarray(st["perm"], dtype=np.float32).reshape(S, -1)
+        nsyn = (presyn >= 0).sum(axis=1).astype(np.int32)
+        if nsyn.max(initial=0) > E:
+            raise CapacityError(f"a segment has {nsyn.max()} synapses, segment_slots is {E}")
+        # rows are packed on the device: valid synapses first
+        order = np.argsort(presyn < 0, axis=1, kind="stable")[:, :E] if presyn.shape[1] else np.zeros((S, 0), np.int64)
+        p_presyn = np.full((S, E), -1, dtype=np.int32)
+        p_perm = np.full((S, E), -1.0, dtype=np.float32)
+        w = min(E, presyn.shape[1])
+        p_presyn[:, :w] = np.take_along_axis(presyn, order, axis=1)[:, :w]
+        p_perm[:, :w] = np.take_along_axis(perm, order, axis=1)[:, :w]
+        self.write(L.F_SEG_CELL, st["seg_cell"], np.int32)
+        self.write(L.F_SEG_NSYN, nsyn, np.int32)
+        self.write(L.F_SEG_PRESYN, p_presyn, np.int32)
+        self.write(L.F_SEG_PERM, p_perm, np.float32)
+        self.write(L.F_SEGCOUNT, st["segcount"], np.int32)
+        self.write(L.F_CELL_PREDICTION, bool_to_words(np.asarray(st["prev_prediction"]).reshape(self.column_dim, K)), np.uint32)
+        self.write(L.F_CELL_ACTIVATION, bool_to_words(np.asarray(st["prev_activation"]).reshape(self.column_dim, K)), np.uint32)
+        winners = np.asarray(st["prev_winner"], dtype=np.int32)
+        self.write(L.F_WINNER_CELL, winners, np.int32)
+        M = 0
+        has_distal = bool(st["has_distal"])
+        if has_distal:
+            seg = np.asarray(st["matching_segment"], dtype=np.int32)
+            M = len(seg)
+            pot = np.asarray(st["segment_potential"], dtype=np.int64)
+            minfo = (pot[seg].astype(np.uint32) | (np.asarray(st["matching_segment_activation"]).astype(np.uint32) << 12)
+                     | (np.asarray(st["matching_segment_active"]).astype(np.uint32) << 31))
+            self.write(L.F_SEG_POTENTIAL, pot, np.int32)
+            self.write(L.F_MATCH_SEGMENT, seg, np.int32)
+            self.write(L.F_MATCH_INFO, minfo, np.uint32)
+            self.write(L.F_MATCH_JITTER, st["matching_segment_jittered_potential"], np.float32)
+            self.write(L.F_CELL_MAX_JITTER, np.asarray(st["max_jittered_potential"], dtype=np.float32).view(np.uint32), np.uint32)
+        self._check(self.lib.htm_import_commit(self.h, S, M, len(winners), int(has_distal), int(bool(st["has_prev_winner"]))),
+                    "htm_import_commit")
+        self.steps = int(st["step_index"])

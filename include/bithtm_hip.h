@@ -1,0 +1,182 @@
+/*
+ * bithtm_hip.h -- C ABI of the MI355X-native bitHTM timestep engine (libbithtm_hip.so).
+ *
+ * The reference (cokwa/bitHTM) is pure Python/NumPy and has no FFI of its own; its drop-in
+ * boundary is the Python class surface bithtm/networks.py:7-149.  This header is the
+ * boundary a binding for that surface uses: one handle owns all device state of one
+ * SpatialPooler + TemporalMemory pair, one call enqueues one timestep, results are read
+ * back lazily.  Plain pointers and sizes only; no C++ or torch types cross it.
+ *
+ * Every entry point names the reference interface it replaces (file:line relative to the
+ * reference checkout).  All functions return 0 on success or a negative htm_status; after
+ * a failure htm_last_error() describes it.  A handle is not thread-safe; different
+ * handles are independent.  Host buffers are borrowed for the duration of the call only.
+ *
+ * Cell ids crossing this ABI are the reference's flat ids  col * cell_dim + cell
+ * (networks.py:67-71).  Bitmaps are one uint32 word per column, bit j = cell j.
+ */
+#ifndef BITHTM_HIP_H
+#define BITHTM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BITHTM_ABI_VERSION 1
+
+typedef struct htm_handle htm_handle;
+
+typedef enum htm_status {
+    HTM_OK = 0,
+    HTM_ERR_ARGUMENT = -1,      /* bad pointer / size / field id / config */
+    HTM_ERR_HIP = -2,           /* a HIP runtime call failed */
+    HTM_ERR_CAPACITY = -3,      /* segment pool or synapse slots exhausted (reported, never silent) */
+    HTM_ERR_STATE = -4          /* call not valid in the handle's current state */
+} htm_status;
+
+/* Scalars the reference forms implicitly, with the dtype each one ends up in
+ * (projections.py:7-11,24,102,205-210; regularizations.py:5-9,16,20-21).  The Python binding
+ * computes them with the same Python expressions so they are bit-identical. */
+typedef struct htm_config {
+    uint32_t struct_bytes;              /* sizeof(htm_config), checked */
+    int32_t device;                     /* HIP device ordinal */
+    int32_t input_dim;                  /* SpatialPooler.input_dim   (networks.py:18) */
+    int32_t column_dim;                 /* column_dim                (networks.py:19,52) */
+    int32_t cell_dim;                   /* TemporalMemory.cell_dim   (networks.py:53), 1..32 */
+    int32_t active_columns;             /* k                         (networks.py:20,137) */
+    int32_t enable_sp;                  /* 0: handle is a stand-alone TemporalMemory */
+    int32_t enable_tm;                  /* 0: handle is a stand-alone SpatialPooler */
+    /* DenseProjection (projections.py:6-24) */
+    double sp_permanence_threshold;     /* permanence >= threshold  <=> connected (:19) */
+    double sp_delta_on;                 /* 1.0*(inc+dec)-dec         (:24) */
+    double sp_delta_off;                /* 0.0*(inc+dec)-dec         (:24) */
+    /* ExponentialBoosting (regularizations.py:4-21) */
+    float boost_coefficient;            /* float32(-(intensity/density))  (:16) */
+    float duty_momentum;                /* float32(momentum)              (:20) */
+    float duty_increment;               /* float32(1.0 - momentum)        (:21) */
+    /* PredictiveProjection / SparseProjection (projections.py:97-109,205-293) */
+    double tm_learn_active;             /* 1.0*(a-b)+b with a=+increment, b=-decrement (:102,:287) */
+    double tm_learn_inactive;           /* 0.0*(a-b)+b */
+    double tm_punish_active;            /* same with a=-punishment, b=0.0             (:292) */
+    double tm_punish_inactive;
+    int32_t tm_learn_prune;             /* min(a,b) < 0 (:105) */
+    int32_t tm_punish_prune;
+    float tm_permanence_initial;        /* float32(permanence_initial)   (:158) */
+    float tm_permanence_threshold;      /* float32(permanence_threshold) (:171) */
+    int32_t segment_activation_threshold;   /* (:221) */
+    int32_t segment_matching_threshold;     /* (:222) */
+    int32_t segment_sampling_synapses;      /* (:223), 1..64 */
+    /* fixed-capacity pool replacing DynamicArray2D growth (utils.py:79-135) */
+    int32_t segment_capacity;           /* max segments; overflow => HTM_ERR_CAPACITY */
+    int32_t segment_slots;              /* synapse slots per segment, multiple of 64, <= 512 */
+    uint32_t seed;                      /* keyed random draws, see bithtm_amd/csrc/htm_rng.h */
+    void *stream;                       /* hipStream_t to enqueue on, or NULL for a private stream */
+} htm_config;
+
+typedef struct htm_info {
+    int64_t step_index;                 /* timesteps processed */
+    int32_t segments;                   /* S: allocated segment ids (len(segment_bundle)) */
+    int32_t matching_segments;          /* len(distal_state.matching_segment) of the last step */
+    int32_t winner_cells;               /* len(winner_cell[0]) of the last step */
+    int32_t active_cells;               /* len(active_cell[0]) of the last step */
+    int32_t has_distal_state;           /* last_state.distal_state is not None */
+    int32_t has_winner_cells;           /* last_state.winner_cell is not None */
+    int32_t capacity_error;             /* sticky: 1 = segment pool, 2 = synapse slots, 4 = work list */
+    int32_t words_per_row;              /* packed input words per SP row (input_dim padded to 128 bits) */
+} htm_info;
+
+/* Device arrays readable with htm_read / writable with htm_write. Element type and count
+ * (C = column_dim, k = active_columns, N = C * cell_dim, S = htm_info.segments,
+ * E = segment_slots, M = htm_info.matching_segments, Wn = htm_info.winner_cells). */
+typedef enum htm_field {
+    HTM_F_ACTIVE_COLUMN = 1,   /* int32[k]   State.active_column, ascending (networks.py:29) */
+    HTM_F_OVERLAPS = 2,        /* int32[C]   State.overlaps (networks.py:27) */
+    HTM_F_BOOSTED = 3,         /* double[C]  State.boosted_overlaps (networks.py:28) */
+    HTM_F_DUTY_CYCLE = 4,      /* float[C]   ExponentialBoosting.duty_cycle (regularizations.py:13) */
+    HTM_F_CELL_ACTIVATION = 5, /* uint32[C]  State.cell_activation, packed (networks.py:118-119) */
+    HTM_F_CELL_PREDICTION = 6, /* uint32[C]  State.cell_prediction, packed (networks.py:122) */
+    HTM_F_WINNER_WORDS = 7,    /* uint32[C]  winner cells, packed (networks.py:102) */
+    HTM_F_BURSTING = 8,        /* uint8[k]   State.active_column_bursting (networks.py:97) */
+    HTM_F_WINNER_CELL = 9,     /* int32[Wn]  flat winner cell ids, ascending (networks.py:103-104) */
+    HTM_F_SEG_CELL = 10,       /* int32[S]   segment_bundle (projections.py:226) */
+    HTM_F_SEG_NSYN = 11,       /* int32[S]   output_edges (projections.py:42) */
+    HTM_F_SEG_PRESYN = 12,     /* int32[S*E] presynaptic flat cell id per slot, -1 = free */
+    HTM_F_SEG_PERM = 13,       /* float[S*E] output_permanence (projections.py:44), -1.0 = free */
+    HTM_F_SEGCOUNT = 14,       /* int32[N]   bundle_segments (projections.py:227) */
+    HTM_F_SEG_POTENTIAL = 15,  /* int32[S]   State.segment_potential (projections.py:246) */
+    HTM_F_MATCH_SEGMENT = 16,  /* int32[M]   State.matching_segment, UNORDERED (projections.py:247) */
+    HTM_F_MATCH_INFO = 17,     /* uint32[M]  potential | activation<<12 | active<<31, same order */
+    HTM_F_MATCH_JITTER = 18,   /* float[M]   matching_segment_jittered_potential, same order */
+    HTM_F_CELL_MAX_JITTER = 19 /* float[N]   State.max_jittered_potential (projections.py:236-238) */
+} htm_field;
+
+/* Construction: HierarchicalTemporalMemory.__init__ / SpatialPooler.__init__ /
+ * TemporalMemory.__init__ (networks.py:14-24,48-57,132-144).  SP permanences start at zero;
+ * upload the matrix drawn as in projections.py:16 with htm_sp_set_permanence. */
+int htm_create(const htm_config *config, htm_handle **out);
+void htm_destroy(htm_handle *h);
+const char *htm_last_error(const htm_handle *h);     /* h may be NULL: error of the last failed htm_create */
+int htm_abi_version(void);
+
+/* DenseProjection.permanence (projections.py:16): rows [row_begin, row_begin+row_count) of the
+ * float64 [column_dim, input_dim] matrix, row-major, no padding. set rebuilds the connected mask. */
+int htm_sp_set_permanence(htm_handle *h, const double *rows, int32_t row_begin, int32_t row_count);
+int htm_sp_get_permanence(htm_handle *h, double *rows, int32_t row_begin, int32_t row_count);
+
+/* One timestep, enqueued asynchronously.  packed_input: input bit i is bit (i & 31) of word
+ * (i >> 5); ceil(input_dim / 32) host words.
+ *   htm_step     HierarchicalTemporalMemory.process(input, learning)   (networks.py:146-149)
+ *   htm_sp_step  SpatialPooler.process(input, learning)                (networks.py:26-35)
+ *   htm_tm_step  TemporalMemory.process(sp_state, learning=, return_winner_cell=)
+ *                (networks.py:91-128) for a stand-alone TM: active_column is a host array of n
+ *                distinct column ids (any order; processed in ascending order). */
+int htm_step(htm_handle *h, const uint32_t *packed_input, int32_t learning);
+int htm_sp_step(htm_handle *h, const uint32_t *packed_input, int32_t learning);
+int htm_tm_step(htm_handle *h, const int32_t *active_column, int32_t n, int32_t learning,
+                int32_t return_winner_cell);
+
+/* n_steps timesteps of htm_step over a bank of n_inputs packed inputs that is ALREADY IN
+ * DEVICE MEMORY (words_per_row words each, see htm_info); step t reads input
+ * (step_index % n_inputs).  Nothing is copied or synchronised: this is the loop
+ * example.py:48-53 runs, with the input bank resident in HBM.  use_graph != 0 replays a
+ * captured hipGraph per step instead of issuing the launches one by one. */
+int htm_run(htm_handle *h, const uint32_t *device_inputs, int32_t n_inputs, int32_t n_steps,
+            int32_t learning, int32_t use_graph);
+
+/* Convenience for callers without their own device allocator: copy n_inputs packed inputs
+ * (ceil(input_dim/32) host words each, as for htm_step) into a handle-owned device bank laid out
+ * as htm_run expects, and return its device address.  Freed by htm_destroy. */
+int htm_bank_upload(htm_handle *h, const uint32_t *host_inputs, int32_t n_inputs, uint32_t **device_bank);
+
+int htm_sync(htm_handle *h);
+int htm_get_info(htm_handle *h, htm_info *out);      /* synchronises */
+
+/* Lazy read-back of State fields / state export (synchronises); count = number of ELEMENTS
+ * the caller's buffer holds; it must be >= the field's current element count. Returns the
+ * number of elements written (>= 0) or a negative status. */
+int64_t htm_read(htm_handle *h, int32_t field, void *dst, int64_t count);
+
+/* State import (checkpoint / hand-off from another implementation), in three steps:
+ *   htm_import_begin(h, step_index)   the state being imported is "after step_index steps"
+ *   htm_write(h, field, src, count)   the arrays of htm_read, same element types
+ *   htm_import_commit(...)            the scalars that go with them; rebuilds derived state
+ * SP permanences are imported with htm_sp_set_permanence. */
+int htm_import_begin(htm_handle *h, int64_t step_index);
+int htm_write(htm_handle *h, int32_t field, const void *src, int64_t count);
+int htm_import_commit(htm_handle *h, int32_t segments, int32_t matching_segments, int32_t winner_cells,
+                      int32_t has_distal_state, int32_t has_winner_cells);
+
+/* Per-kernel device time of the most recent htm_run: names[i] / total_ms[i] / launches[i] for
+ * up to max_kernels kernels (HIP events on the handle's stream).  Only collected when
+ * htm_profile(h, 1) was called before the run (profiled runs are slower). */
+int htm_profile(htm_handle *h, int32_t enable);
+int htm_profile_read(htm_handle *h, int32_t max_kernels, const char **names, double *total_ms,
+                     int64_t *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BITHTM_HIP_H */
