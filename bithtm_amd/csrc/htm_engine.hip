@@ -28,21 +28,24 @@
 
 typedef unsigned long long u64;
 
-#define SEL_PASSES 6
-#define SEL_BINS 2048
+#define SEL_MAX_PASSES 6
+#define SEL_DIGIT 12
+#define SEL_BINS 4096         // 1 << SEL_DIGIT
+#define SCAN_SEGS 64          // segments per block of the segment scan
 #define CAND_CAP 256          // growth candidates staged per wave
 #define MAX_SLOTS 512
 #define EPS32 1e-8f           // `epsilon=1e-8` against float32 arrays (weak Python scalar)
 
-__constant__ int c_sel_shift[SEL_PASSES] = {53, 42, 31, 20, 9, 0};
-__constant__ int c_sel_bits[SEL_PASSES] = {11, 11, 11, 11, 11, 9};
+// radix-select digit p covers key bits [shift, shift + bits): 12 bits from the top, the last one 4
+__host__ __device__ __forceinline__ int sel_shift(int pass) { return pass < 5 ? 52 - SEL_DIGIT * pass : 0; }
+__host__ __device__ __forceinline__ int sel_bits(int pass) { return pass < 5 ? SEL_DIGIT : 4; }
 
 // ------------------------------------------------------------------------------------------
 // device-resident scalars
 struct Counters {
-    uint32_t step;            // timestep index (key of the random draws)
+    uint32_t step[2];         // timestep index (key of the random draws); step t reads step[t & 1]
+                              // and its last kernel writes step[(t + 1) & 1] = t + 1
     int32_t S;                // allocated segment ids
-    int32_t n_match[2];       // matching segments of the scan with parity p
     int32_t n_win[2];         // winner cells of step parity p
     int32_t has_winner[2];    // winner list of parity p is valid (winner_cell is not None)
     int32_t has_distal;       // a scan has run (distal_state is not None)
@@ -51,13 +54,14 @@ struct Counters {
     int32_t n_un;             // winners needing a new segment
     int32_t n_recycled, n_new, S_old;
     int32_t error;            // sticky capacity flags
-    u64 sel_prefix;           // radix-select state
+    u64 sel_prefix;           // k-th largest key and how many of the keys equal to it are winners
     uint32_t sel_krem;
-    uint32_t sel_ticket[SEL_PASSES];
+    u64 sel_pass_prefix[SEL_MAX_PASSES + 1];    // radix-select state entering pass p
+    uint32_t sel_pass_krem[SEL_MAX_PASSES + 1];
 };
 
 struct Dev {
-    int I, W, W4, Ipad, C, K, k, E, Scap, work_cap;
+    int I, W, W4, Ipad, C, K, k, E, Scap, work_cap, sel_passes;
     double sp_thr, sp_don, sp_doff;
     float coef, mom, dinc;
     double lrn_act, lrn_inact, pun_act, pun_inact;
@@ -72,7 +76,7 @@ struct Dev {
     int *overlap;             // [C]
     double *boosted;          // [C]
     u64 *key;                 // [C] bits of boosted (non-negative doubles order like uint64)
-    uint32_t *hist;           // [SEL_PASSES][SEL_BINS]
+    uint32_t *hist;           // [SEL_MAX_PASSES][SEL_BINS]
     uint32_t *sel_blk;        // [ceil(C/1024)] packed (greater, equal) counts
     int *active_cols;         // [k] ascending
     uint32_t *input_stage;    // [W] host-fed input
@@ -91,14 +95,11 @@ struct Dev {
     float *sperm;             // [Scap][E] float32 permanence
     int *segcount;            // [C*32] segments per cell
     uint32_t *cellmax;        // [C*32] float bits of max jittered potential per cell (0 = none)
-    int *seg_pot;             // [Scap]
-    int *match_seg[2];        // [Scap]
-    uint32_t *match_info[2];  // potential | activation << 12 | active << 31
-    float *match_jit[2];
+    uint32_t *seg_info;       // [Scap] last scan: potential | activation << 12 | matching << 30 | active << 31
+    float *seg_jit;           // [Scap] jittered potential of the matching segments
     uint32_t *work;           // [work_cap] segment | mode << 31 (0 = learn + grow, 1 = punish)
     int *recyc_cnt;           // [ceil(Scap/1024)] recyclable segments per 1024-segment block
-    int *recyc_off;
-    int *recyc_list;          // [k*32]
+    int *recyc_need;          // [2*k*32] (block, first rank) pairs of the blocks add_output draws from
     Counters *ctr;
 };
 
@@ -141,6 +142,20 @@ __device__ __forceinline__ int wave_append(int *counter, bool pred) {
     return pred ? base + __popcll(m & lanemask_lt()) : -1;
 }
 
+// h[digit] += 1 for every lane with `active`, one LDS atomic per distinct digit in the wave (keys
+// of neighbouring columns mostly share their leading digits: per-lane atomics would serialise).
+// All lanes of the wave must call.
+__device__ __forceinline__ void hist_add(uint32_t *h, uint32_t digit, bool active) {
+    u64 todo = __ballot(active);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const uint32_t dl = __shfl(digit, leader);
+        const u64 same = __ballot(active && digit == dl) & todo;
+        if (lane_id() == leader) atomicAdd(&h[dl], (uint32_t)__popcll(same));
+        todo &= ~same;
+    }
+}
+
 __device__ __forceinline__ uint32_t cell_mask(int K) { return K >= 32 ? 0xFFFFFFFFu : ((1u << K) - 1u); }
 __device__ __forceinline__ uint32_t enc_to_flat(int enc, int K) { return (uint32_t)((enc >> 5) * K + (enc & 31)); }
 
@@ -164,123 +179,220 @@ __global__ __launch_bounds__(256) void k_sp_build_mask(Dev d, int row_begin, int
 
 // DenseProjection.process (projections.py:18-21) + ExponentialBoosting.process
 // (regularizations.py:15-17).  G lanes share one row (G = power of two, W4 16-byte chunks per row).
-__global__ __launch_bounds__(256) void k_sp_overlap(Dev d, const uint32_t *__restrict__ bank, int n_inputs, int G) {
+__global__ __launch_bounds__(1024) void k_sp_overlap(Dev d, const uint32_t *__restrict__ bank, int n_inputs, int G, int p) {
+    __shared__ uint32_t h[SEL_BINS];               // histogram of the top key digit (select pass 0)
     const int gtid = blockIdx.x * blockDim.x + threadIdx.x;
     const int nthreads = gridDim.x * blockDim.x;
-    for (int i = gtid; i < SEL_PASSES * SEL_BINS; i += nthreads) d.hist[i] = 0;
-    if (gtid < SEL_PASSES) d.ctr->sel_ticket[gtid] = 0;
+    for (int i = gtid; i < (d.sel_passes - 1) * SEL_BINS; i += nthreads) d.hist[SEL_BINS + i] = 0;
+    for (int i = threadIdx.x; i < SEL_BINS; i += 1024) h[i] = 0;
     if (gtid == 0) {
-        d.ctr->sel_prefix = 0;
-        d.ctr->sel_krem = (uint32_t)d.k;
+        d.ctr->sel_pass_prefix[0] = 0;
+        d.ctr->sel_pass_krem[0] = (uint32_t)d.k;
     }
-    const uint4 *in4 = (const uint4 *)(bank + (size_t)(d.ctr->step % (uint32_t)n_inputs) * d.W);
+    __syncthreads();
+    const uint4 *in4 = (const uint4 *)(bank + (size_t)(d.ctr->step[p] % (uint32_t)n_inputs) * d.W);
     const uint4 *mask4 = (const uint4 *)d.mask;
     const int lane = lane_id();
     const int rpw = 64 / G, sub = lane / G, l = lane % G;
     const int wave = gtid >> 6, nwaves = nthreads >> 6;
-    for (int row0 = wave * rpw; row0 < d.C; row0 += nwaves * rpw) {
-        const int row = row0 + sub;
-        int cnt = 0;
-        if (row < d.C) {
-            for (int j = l; j < d.W4; j += G) {
-                uint4 m = mask4[(size_t)row * d.W4 + j];
-                uint4 x = in4[j];
-                cnt += __popc(m.x & x.x) + __popc(m.y & x.y) + __popc(m.z & x.z) + __popc(m.w & x.w);
+    constexpr int U = 4;                           // row groups in flight per wave
+    for (int row0 = wave * rpw * U; row0 < d.C; row0 += nwaves * rpw * U) {
+        int cnt[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) cnt[u] = 0;
+        for (int j = l; j < d.W4; j += G) {
+            const uint4 x = in4[j];
+            uint4 m[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int row = row0 + u * rpw + sub;
+                m[u] = row < d.C ? mask4[(size_t)row * d.W4 + j] : make_uint4(0, 0, 0, 0);
             }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                cnt[u] += __popc(m[u].x & x.x) + __popc(m[u].y & x.y) + __popc(m[u].z & x.z) + __popc(m[u].w & x.w);
         }
-        for (int o = G >> 1; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
-        if (l == 0 && row < d.C) {
-            d.overlap[row] = cnt;
-            float f = htm_exp_f32(d.coef * d.duty[row]);         // float32 product, documented exp
-            double b = (double)f * (double)cnt;                  // exact (24-bit x <= 16-bit)
-            d.boosted[row] = b;
-            d.key[row] = (u64)__double_as_longlong(b);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            int cn = cnt[u];
+            for (int o = G >> 1; o > 0; o >>= 1) cn += __shfl_xor(cn, o);
+            const int row = row0 + u * rpw + sub;
+            const bool owner = l == 0 && row < d.C;
+            u64 key = 0;
+            if (owner) {
+                d.overlap[row] = cn;
+                const float f = htm_exp_f32(d.coef * d.duty[row]);     // float32 product, documented exp
+                const double bo = (double)f * (double)cn;              // exact (24-bit x <= 16-bit)
+                d.boosted[row] = bo;
+                key = (u64)__double_as_longlong(bo);
+                d.key[row] = key;
+            }
+            hist_add(h, (uint32_t)(key >> sel_shift(0)), owner);
         }
     }
+    __syncthreads();
+    for (int i = threadIdx.x; i < SEL_BINS; i += 1024)
+        if (h[i]) atomicAdd(&d.hist[i], h[i]);
 }
 
 // GlobalInhibition.process (regularizations.py:28-29) as an exact radix select of the k-th
-// largest key, one 11-bit digit per launch; the last block to arrive folds the histogram.
-__global__ __launch_bounds__(256) void k_sel_pass(Dev d, int pass) {
-    __shared__ uint32_t h[SEL_BINS];
-    __shared__ uint32_t s_chunk[256];
-    __shared__ int s_last;
-    const int tid = threadIdx.x;
-    const int shift = c_sel_shift[pass], bits = c_sel_bits[pass], nb = 1 << bits;
-    const u64 prefix = d.ctr->sel_prefix;
-    const u64 himask = pass == 0 ? 0ull : (~0ull << (shift + bits));
-    for (int i = tid; i < nb; i += 256) h[i] = 0;
-    __syncthreads();
-    for (int c = blockIdx.x * 256 + tid; c < d.C; c += gridDim.x * 256) {
-        u64 key = d.key[c];
-        if (((key ^ prefix) & himask) == 0) atomicAdd(&h[(uint32_t)(key >> shift) & (nb - 1)], 1u);
-    }
-    __syncthreads();
-    uint32_t *gh = d.hist + pass * SEL_BINS;
-    for (int i = tid; i < nb; i += 256)
-        if (h[i]) atomicAdd(&gh[i], h[i]);
-    __threadfence();
-    __syncthreads();
-    if (tid == 0) s_last = (atomicAdd(&d.ctr->sel_ticket[pass], 1u) == gridDim.x - 1);
-    __syncthreads();
-    if (!s_last) return;
-    __threadfence();
-    for (int i = tid; i < nb; i += 256) h[i] = __hip_atomic_load(&gh[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    const int per = nb / 256;                 // 8 or 2 bins per thread, thread t owns [t*per, (t+1)*per)
+// largest key, one 12-bit digit per launch.  There is no intra-kernel hand-off: every block of
+// pass p re-derives the bucket chosen by pass p-1 from that pass's (complete) histogram.
+//
+// sel_resolve: given the state entering pass `prev` and its histogram, the state entering
+// pass prev+1.  Called by all BS threads of the block; h is SEL_BINS words of LDS scratch.
+template <int BS>
+__device__ __forceinline__ void sel_resolve(const Dev &d, int prev, uint32_t *h, uint32_t *s_wave,
+                                            u64 *out_prefix, uint32_t *out_krem, u64 *s_res_prefix, uint32_t *s_res_krem) {
+    const int tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
+    const int shift = sel_shift(prev), nb = 1 << sel_bits(prev);
+    const u64 prefix = d.ctr->sel_pass_prefix[prev];
+    const uint32_t krem = d.ctr->sel_pass_krem[prev];
+    const uint32_t *gh = d.hist + prev * SEL_BINS;
+    constexpr int PER = SEL_BINS / BS;            // bins per thread, thread t owns [t*PER, (t+1)*PER)
     uint32_t cs = 0;
-    for (int j = 0; j < per; ++j) cs += h[tid * per + j];
-    s_chunk[tid] = cs;
-    __syncthreads();
-    // suffix sums over chunks (bins above mine): Hillis-Steele on the reversed array
-    uint32_t x = cs;
-    for (int o = 1; o < 256; o <<= 1) {
-        uint32_t y = (tid + o < 256) ? s_chunk[tid + o] : 0;
-        __syncthreads();
-        x += y;
-        s_chunk[tid] = x;
-        __syncthreads();
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int b = tid * PER + j;
+        const uint32_t v = b < nb ? gh[b] : 0u;
+        h[b] = v;
+        cs += v;
     }
-    uint32_t above = x - cs;                  // keys in bins above my chunk
-    const uint32_t krem = d.ctr->sel_krem;
-    if (above < krem && krem <= above + cs) {
-        for (int b = (tid + 1) * per - 1; b >= tid * per; --b) {
-            uint32_t hb = h[b];
+    uint32_t x = cs;                              // inclusive suffix sum inside the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t y = __shfl_down(x, o);
+        if (lane + o < 64) x += y;
+    }
+    if (lane == 0) s_wave[wv] = x;                // wave total
+    __syncthreads();
+    uint32_t above = x - cs;                      // keys in bins above my chunk, inside my wave ...
+    for (int w = wv + 1; w < BS / 64; ++w) above += s_wave[w];      // ... plus the higher waves
+    if (above < krem && krem <= above + cs) {     // exactly one thread
+        for (int b = min((tid + 1) * PER, nb) - 1; b >= tid * PER; --b) {
+            const uint32_t hb = h[b];
             if (above + hb >= krem) {
-                d.ctr->sel_prefix = prefix | ((u64)b << shift);
-                d.ctr->sel_krem = krem - above;
+                *s_res_prefix = prefix | ((u64)b << shift);
+                *s_res_krem = krem - above;
                 break;
             }
             above += hb;
         }
     }
+    __syncthreads();
+    *out_prefix = *s_res_prefix;
+    *out_krem = *s_res_krem;
 }
 
-// per 1024-column block: how many keys are above / equal to the k-th largest
+__global__ __launch_bounds__(1024) void k_sel_pass(Dev d, int pass) {
+    __shared__ uint32_t h[SEL_BINS];
+    __shared__ uint32_t s_wave[16];
+    __shared__ u64 s_prefix;
+    __shared__ uint32_t s_krem;
+    const int tid = threadIdx.x;
+    u64 prefix;
+    uint32_t krem;
+    sel_resolve<1024>(d, pass - 1, h, s_wave, &prefix, &krem, &s_prefix, &s_krem);
+    if (blockIdx.x == 0 && tid == 0) {
+        d.ctr->sel_pass_prefix[pass] = prefix;
+        d.ctr->sel_pass_krem[pass] = krem;
+    }
+    __syncthreads();
+    const int shift = sel_shift(pass), bits = sel_bits(pass), nb = 1 << bits;
+    const u64 himask = ~0ull << (shift + bits);
+    for (int i = tid; i < nb; i += 1024) h[i] = 0;
+    __syncthreads();
+    for (int c0 = blockIdx.x * 1024 + (tid & ~63); c0 < d.C; c0 += gridDim.x * 1024) {
+        const int c = c0 + lane_id();
+        const u64 key = c < d.C ? d.key[c] : 0;
+        hist_add(h, (uint32_t)(key >> shift) & (nb - 1), c < d.C && ((key ^ prefix) & himask) == 0);
+    }
+    __syncthreads();
+    uint32_t *gh = d.hist + pass * SEL_BINS;
+    for (int i = tid; i < nb; i += 1024)
+        if (h[i]) atomicAdd(&gh[i], h[i]);
+}
+
+// per 256-column block: how many keys are above / equal to the k-th largest
 __global__ __launch_bounds__(256) void k_sp_count(Dev d) {
     __shared__ uint32_t s_wave[4];
-    const u64 T = d.ctr->sel_prefix;
+    __shared__ uint32_t h[SEL_BINS];
+    __shared__ u64 s_prefix;
+    __shared__ uint32_t s_krem;
+    u64 T;
+    uint32_t r;
+    sel_resolve<256>(d, d.sel_passes - 1, h, s_wave, &T, &r, &s_prefix, &s_krem);
+    __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        d.ctr->sel_prefix = T;                  // skipped low digits are zero in every key
+        d.ctr->sel_krem = r;
+    }
+    if (d.sel_passes > 1)                       // pass-0 histogram is consumed: clear it for the next step
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < SEL_BINS; i += gridDim.x * 256) d.hist[i] = 0;
+    const int c = blockIdx.x * 256 + threadIdx.x;
     uint32_t v = 0;
-    for (int q = 0; q < 4; ++q) {
-        int c = blockIdx.x * 1024 + threadIdx.x * 4 + q;
-        if (c < d.C) {
-            u64 key = d.key[c];
-            v += (key > T) ? 1u : ((key == T) ? 0x10000u : 0u);
-        }
+    if (c < d.C) {
+        u64 key = d.key[c];
+        v = (key > T) ? 1u : ((key == T) ? 0x10000u : 0u);
     }
     uint32_t total;
     block_excl_scan<256>(v, s_wave, total);
     if (threadIdx.x == 0) d.sel_blk[blockIdx.x] = total;
 }
 
+// TemporalMemory.process up to the winner cells (networks.py:95-104) for ONE active column,
+// executed by a half-wave (lane j = cell j): bursting, best-matching cell (networks.py:73-82),
+// least-used cell (:84-89).  idx = position of column a in the ascending active list.
+__device__ __forceinline__ void tm_activate_column(const Dev &d, int p, int want_winner, bool col_ok, int a, int idx) {
+    const int lane = lane_id(), half = lane >> 5, j = lane & 31;
+    const bool valid = col_ok && j < d.K;
+    const uint32_t pw = col_ok ? d.pred[p ^ 1][a] : 0;       // prev_state.cell_prediction row
+    const bool burst = pw == 0;
+    const uint32_t act = burst ? cell_mask(d.K) : pw;        // networks.py:115
+    const int has_distal = d.ctr->has_distal;
+    float cm = -1.0f;
+    if (valid && has_distal) cm = __uint_as_float(d.cellmax[a * 32 + j]);
+    uint32_t winner = pw, unacc = 0;
+    if (want_winner) {
+        float colmax = cm;
+        for (int o = 16; o > 0; o >>= 1) colmax = fmaxf(colmax, __shfl_xor(colmax, o));
+        const bool col_matching = has_distal && colmax >= (float)d.match_thr;      // networks.py:80
+        const bool best = valid && has_distal && fabsf(cm - colmax) < EPS32;       // :81
+        float jit = 3.0e38f;
+        if (valid) {
+            uint32_t base = htm_stream_base(d.seed, HTM_STREAM_LEAST_USED, d.ctr->step[p]);
+            jit = htm_jitter((float)d.segcount[a * 32 + j], htm_draw24(base, (uint32_t)(a * d.K + j), 0u));   // :86-87
+        }
+        float mn = jit;
+        for (int o = 16; o > 0; o >>= 1) mn = fminf(mn, __shfl_xor(mn, o));
+        const bool least = valid && fabsf(jit - mn) < EPS32;                       // :88
+        const bool wbit = col_matching ? best : least;
+        const u64 bw = __ballot(wbit);
+        const uint32_t pick = (uint32_t)(bw >> (half * 32));
+        if (burst) winner = pick;                                                  // :102
+        const u64 bm = __ballot(valid && has_distal && !(cm < EPS32));             // cell has a matching segment
+        unacc = has_distal ? (winner & ~(uint32_t)(bm >> (half * 32))) : 0u;       // projections.py:271
+    }
+    if (col_ok && j == 0) {
+        d.act[p][a] = act;
+        d.win[a] = want_winner ? winner : 0u;
+        d.bursting[idx] = burst ? 1 : 0;
+        d.colcnt[idx] = (uint32_t)__popc(winner) | ((uint32_t)__popc(unacc) << 16);
+        d.unacc_word[idx] = unacc;
+    }
+}
+
 // Emit the winners in ascending column order (ties: lower index first), update the duty cycle
-// (regularizations.py:19-21, float32, two separately rounded operations) and clear the dense
-// per-column words the Temporal Memory fills this step.
-__global__ __launch_bounds__(256) void k_sp_emit(Dev d, int p) {
+// (regularizations.py:19-21, float32, two separately rounded operations), clear the dense
+// per-column words of the non-winners, and run the Temporal Memory's per-column activation for
+// the winners of this block.  One block per 256 columns.
+__global__ __launch_bounds__(256) void k_sp_emit(Dev d, int p, int want_winner) {
     __shared__ uint32_t s_wave[4];
     __shared__ uint32_t s_gt, s_eq;
+    __shared__ int s_col[256];
+    __shared__ int s_n;
     const int tid = threadIdx.x;
-    if (tid == 0) { s_gt = 0; s_eq = 0; }
+    if (tid == 0) { s_gt = 0; s_eq = 0; s_n = 0; }
     __syncthreads();
     uint32_t g = 0, e = 0;
     for (int i = tid; i < (int)blockIdx.x; i += 256) {
@@ -294,42 +406,47 @@ __global__ __launch_bounds__(256) void k_sp_emit(Dev d, int p) {
     const uint32_t gt_before = s_gt, eq_before = s_eq;
     const u64 T = d.ctr->sel_prefix;
     const uint32_t r = d.ctr->sel_krem;            // how many of the keys == T are selected
-    uint32_t flag[4];
-    uint32_t v = 0;
-    for (int q = 0; q < 4; ++q) {
-        int c = blockIdx.x * 1024 + tid * 4 + q;
-        flag[q] = 0;
-        if (c < d.C) {
-            u64 key = d.key[c];
-            flag[q] = (key > T) ? 1u : ((key == T) ? 0x10000u : 0u);
-        }
-        v += flag[q];
+    const int c = blockIdx.x * 256 + tid;
+    uint32_t flag = 0;
+    if (c < d.C) {
+        u64 key = d.key[c];
+        flag = (key > T) ? 1u : ((key == T) ? 0x10000u : 0u);
     }
     uint32_t total;
-    uint32_t ex = block_excl_scan<256>(v, s_wave, total);
-    uint32_t g_run = gt_before + (ex & 0xFFFFu), e_run = eq_before + (ex >> 16);
-    for (int q = 0; q < 4; ++q) {
-        int c = blockIdx.x * 1024 + tid * 4 + q;
-        if (c >= d.C) break;
-        bool sel = (flag[q] & 1u) || ((flag[q] >> 16) && e_run < r);
-        if (sel) d.active_cols[g_run + min(e_run, r)] = c;
+    const uint32_t ex = block_excl_scan<256>(flag, s_wave, total);
+    const uint32_t g_run = gt_before + (ex & 0xFFFFu), e_run = eq_before + (ex >> 16);
+    const int first_pos = (int)(gt_before + min(eq_before, r));
+    if (c < d.C) {
+        const bool sel = (flag & 1u) || ((flag >> 16) && e_run < r);
         float dc = d.duty[c] * d.mom;
         if (sel) dc = dc + d.dinc;
         d.duty[c] = dc;
-        g_run += flag[q] & 1u;
-        e_run += flag[q] >> 16;
-        if (d.act[0]) {                           // Temporal Memory present
-            d.act[p][c] = 0;
-            d.pred[p][c] = 0;
-            d.win[c] = 0;
+        if (sel) {
+            const int pos = (int)(g_run + min(e_run, r));
+            d.active_cols[pos] = c;
+            s_col[pos - first_pos] = c;
+            atomicAdd(&s_n, 1);
         }
+        if (d.act[0]) {                            // Temporal Memory present
+            d.pred[p][c] = 0;
+            if (!sel) { d.act[p][c] = 0; d.win[c] = 0; }
+        }
+    }
+    if (blockIdx.x == 0 && tid == 0 && !d.act[0]) d.ctr->step[p ^ 1] = d.ctr->step[p] + 1;   // SP-only handle
+    if (!d.act[0]) return;
+    __syncthreads();
+    const int n_sel = s_n;
+    for (int i0 = 0; i0 < n_sel; i0 += 8) {        // 8 half-waves
+        const int i = i0 + (tid >> 5);
+        const bool ok = i < n_sel;
+        tm_activate_column(d, p, want_winner, ok, ok ? s_col[i] : 0, first_pos + i);
     }
 }
 
 // DenseProjection.update (projections.py:23-24) on the k winner rows, fused with the rebuild
 // of those rows' connected mask.  One block per winner row.
-__global__ __launch_bounds__(256) void k_sp_learn(Dev d, const uint32_t *__restrict__ bank, int n_inputs) {
-    const uint32_t *in = bank + (size_t)(d.ctr->step % (uint32_t)n_inputs) * d.W;
+__global__ __launch_bounds__(256) void k_sp_learn(Dev d, const uint32_t *__restrict__ bank, int n_inputs, int p) {
+    const uint32_t *in = bank + (size_t)(d.ctr->step[p] % (uint32_t)n_inputs) * d.W;
     const int row = d.active_cols[blockIdx.x];
     double *prow = d.perm + (size_t)row * d.Ipad;
     uint32_t *mrow = d.mask + (size_t)row * d.W;
@@ -360,54 +477,77 @@ __global__ __launch_bounds__(256) void k_tm_load_active(Dev d, int p, const int 
     }
 }
 
-// TemporalMemory.process up to the winner cells (networks.py:95-104) for one active column per
-// half-wave: bursting, best-matching cell (networks.py:73-82), least-used cell (:84-89).
+// stand-alone TM: per-column activation, one active column per half-wave
 __global__ __launch_bounds__(256) void k_tm_activate(Dev d, int p, int n_active, int want_winner) {
-    const int lane = lane_id(), half = lane >> 5, j = lane & 31;
     const int idx = (blockIdx.x * 256 + threadIdx.x) >> 5;
-    const bool col_ok = idx < n_active;
-    const bool valid = col_ok && j < d.K;
-    const int a = col_ok ? d.active_cols[idx] : 0;
-    const uint32_t pw = col_ok ? d.pred[p ^ 1][a] : 0;       // prev_state.cell_prediction row
-    const bool burst = pw == 0;
-    const uint32_t act = burst ? cell_mask(d.K) : pw;        // networks.py:115
-    const int has_distal = d.ctr->has_distal;
-    float cm = -1.0f;
-    if (valid && has_distal) cm = __uint_as_float(d.cellmax[a * 32 + j]);
-    uint32_t winner = pw, unacc = 0;
-    if (want_winner) {
-        float colmax = cm;
-        for (int o = 16; o > 0; o >>= 1) colmax = fmaxf(colmax, __shfl_xor(colmax, o));
-        const bool col_matching = has_distal && colmax >= (float)d.match_thr;      // networks.py:80
-        const bool best = valid && has_distal && fabsf(cm - colmax) < EPS32;       // :81
-        float jit = 3.0e38f;
-        if (valid) {
-            uint32_t base = htm_stream_base(d.seed, HTM_STREAM_LEAST_USED, d.ctr->step);
-            jit = htm_jitter((float)d.segcount[a * 32 + j], htm_draw24(base, (uint32_t)(a * d.K + j), 0u));   // :86-87
-        }
-        float mn = jit;
-        for (int o = 16; o > 0; o >>= 1) mn = fminf(mn, __shfl_xor(mn, o));
-        const bool least = valid && fabsf(jit - mn) < EPS32;                       // :88
-        const bool wbit = col_matching ? best : least;
-        const u64 bw = __ballot(wbit);
-        const uint32_t pick = (uint32_t)(bw >> (half * 32));
-        if (burst) winner = pick;                                                  // :102
-        const u64 bm = __ballot(valid && has_distal && !(cm < EPS32));             // cell has a matching segment
-        unacc = has_distal ? (winner & ~(uint32_t)(bm >> (half * 32))) : 0u;       // projections.py:271
-    }
-    if (col_ok && j == 0) {
-        d.act[p][a] = act;
-        d.win[a] = want_winner ? winner : 0u;
-        d.bursting[idx] = burst ? 1 : 0;
-        d.colcnt[idx] = (uint32_t)__popc(winner) | ((uint32_t)__popc(unacc) << 16);
-        d.unacc_word[idx] = unacc;
-    }
+    const bool ok = idx < n_active;
+    tm_activate_column(d, p, want_winner, ok, ok ? d.active_cols[idx] : 0, idx);
 }
 
-// ordered lists of winner cells (networks.py:103-104) and of winners that need a new segment
-// (projections.py:271-273); single block
-__global__ __launch_bounds__(1024) void k_tm_activate_scan(Dev d, int p, int n_active, int want_winner, int learning) {
+// bind segment `seg` to winner cell `cell` (projections.py:275-281) and queue it for learning at
+// work-list slot `pos`; rows are packed, so clearing a recycled row (projections.py:82-85) is nsyn = 0
+__device__ __forceinline__ void tm_bind_segment(const Dev &d, int seg, int cell, bool recycled, int pos) {
+    if (recycled) atomicSub(&d.segcount[d.seg_cell[seg]], 1);
+    d.seg_nsyn[seg] = 0;
+    d.seg_cell[seg] = cell;
+    atomicAdd(&d.segcount[cell], 1);
+    if (pos < d.work_cap) d.work[pos] = (uint32_t)seg; else atomicOr(&d.ctr->error, 4);
+}
+
+// The middle of TemporalMemory.process / PredictiveProjection.update, one launch:
+//   block 0      ordered lists of winner cells (networks.py:103-104) and of winners that need a new
+//                segment (projections.py:271-273); SparseProjection.add_output (projections.py:79-95):
+//                recycle the lowest-id segments with fewer than matching_threshold synapses, append
+//                the rest; bind them to the winners in ascending cell order (:275-281)
+//   blocks 1..   which previous matching segments learn, which are punished (projections.py:264-269;
+//                punishment mask built at networks.py:107-108,111)
+__global__ __launch_bounds__(1024) void k_tm_mid(Dev d, int p, int n_active, int want_winner, int learning) {
+    Counters *c = d.ctr;
+    __shared__ int s_cnt, s_base;
+    if (blockIdx.x > 0) {
+        if (!learning || !c->has_distal) return;
+        const int q = p ^ 1;
+        const int n = c->S;          // ids at or above the S of the last scan still hold info == 0
+        const int stride = (gridDim.x - 1) * 1024;
+        for (int i0 = (blockIdx.x - 1) * 1024; i0 < n; i0 += stride) {
+            const int seg = i0 + threadIdx.x;
+            bool learn = false, punish = false;
+            const uint32_t info = seg < n ? d.seg_info[seg] : 0u;
+            if (info & 0x40000000u) {
+                const int cell = d.seg_cell[seg], col = cell >> 5, bit = cell & 31;
+                const bool is_winner = (d.win[col] >> bit) & 1u;
+                const bool unpred = !((d.pred[q][col] >> bit) & 1u);                         // :266
+                const bool best = fabsf(d.seg_jit[seg] - __uint_as_float(d.cellmax[cell])) < EPS32;   // :267
+                learn = is_winner && ((info >> 31) || (unpred && best));                     // :268
+                punish = d.act[p][col] == 0;                                                 // :269
+            }
+            if (threadIdx.x == 0) s_cnt = 0;
+            __syncthreads();
+            const u64 ml = __ballot(learn), mp = __ballot(punish);
+            const int n_l = __popcll(ml), n_p = __popcll(mp);
+            int woff = 0;
+            if (lane_id() == 0 && n_l + n_p) woff = atomicAdd(&s_cnt, n_l + n_p);
+            woff = __shfl(woff, 0);
+            __syncthreads();
+            if (threadIdx.x == 0 && s_cnt) s_base = atomicAdd(&c->n_work, s_cnt);     // one reservation per block
+            __syncthreads();
+            const int base = s_base + woff;
+            if (learn) {
+                const int pos = base + __popcll(ml & lanemask_lt());
+                if (pos < d.work_cap) d.work[pos] = (uint32_t)seg; else atomicOr(&c->error, 4);
+            }
+            if (punish) {
+                const int pos = base + n_l + __popcll(mp & lanemask_lt());
+                if (pos < d.work_cap) d.work[pos] = (uint32_t)seg | 0x80000000u; else atomicOr(&c->error, 4);
+            }
+        }
+        return;
+    }
+    // ---- block 0
     __shared__ uint32_t s_wave[16];
+    __shared__ uint32_t s_cells;
+    __shared__ int s_nneed;
+    if (threadIdx.x == 0) { s_cells = 0; s_nneed = 0; }
     uint32_t carry_w = 0, carry_u = 0, n_cells = 0;
     for (int base = 0; base < n_active; base += 1024) {
         const int idx = base + threadIdx.x;
@@ -431,142 +571,58 @@ __global__ __launch_bounds__(1024) void k_tm_activate_scan(Dev d, int p, int n_a
         carry_w += total & 0xFFFFu;
         carry_u += total >> 16;
     }
-    // block-wide sum of n_cells
-    __shared__ uint32_t s_cells;
-    if (threadIdx.x == 0) s_cells = 0;
-    __syncthreads();
     for (int o = 32; o > 0; o >>= 1) n_cells += __shfl_xor(n_cells, o);
     if (lane_id() == 0) atomicAdd(&s_cells, n_cells);
     __syncthreads();
+    const int n_un = (learning && c->has_distal) ? (int)carry_u : 0;
     if (threadIdx.x == 0) {
-        Counters *c = d.ctr;
         c->n_win[p] = want_winner ? (int)carry_w : 0;
         c->has_winner[p] = want_winner;
-        c->n_un = (learning && c->has_distal) ? (int)carry_u : 0;
-        c->n_work = 0;
+        c->n_un = n_un;
         c->n_active_cells = (int)s_cells;
     }
-}
-
-// PredictiveProjection.update: which previous matching segments learn, which are punished
-// (projections.py:264-269; punishment mask built at networks.py:107-108,111)
-__global__ __launch_bounds__(256) void k_tm_classify(Dev d, int p) {
-    Counters *c = d.ctr;
-    const int q = p ^ 1;
-    const int n = c->n_match[q];
-    const int nth = gridDim.x * 256;
-    for (int i0 = blockIdx.x * 256 + (threadIdx.x & ~63); i0 < n; i0 += nth) {
-        const int i = i0 + lane_id();
-        bool learn = false, punish = false;
-        int seg = 0;
-        if (i < n) {
-            seg = d.match_seg[q][i];
-            const uint32_t info = d.match_info[q][i];
-            const int cell = d.seg_cell[seg], col = cell >> 5, bit = cell & 31;
-            const bool is_winner = (d.win[col] >> bit) & 1u;
-            const bool unpred = !((d.pred[q][col] >> bit) & 1u);                         // :266
-            const bool best = fabsf(d.match_jit[q][i] - __uint_as_float(d.cellmax[cell])) < EPS32;   // :267
-            learn = is_winner && ((info >> 31) || (unpred && best));                     // :268
-            punish = d.act[p][col] == 0;                                                 // :269
+    if (n_un == 0) return;
+    const int S = c->S, nb = (S + 1023) >> 10;
+    uint32_t carry = 0;                       // recyclable segments seen so far
+    for (int base = 0; base < nb; base += 1024) {
+        const int b = base + threadIdx.x;
+        const uint32_t v = b < nb ? (uint32_t)d.recyc_cnt[b] : 0u;
+        uint32_t total;
+        const uint32_t ex = block_excl_scan<1024>(v, s_wave, total);
+        if (v > 0 && carry + ex < (uint32_t)n_un) {
+            const int slot = atomicAdd(&s_nneed, 1);
+            d.recyc_need[2 * slot] = b;
+            d.recyc_need[2 * slot + 1] = (int)(carry + ex);
         }
-        const int n_l = __popcll(__ballot(learn)), n_p = __popcll(__ballot(punish));
-        if (n_l + n_p == 0) continue;
-        int base = 0;
-        if (lane_id() == 0) base = atomicAdd(&c->n_work, n_l + n_p);
-        base = __shfl(base, 0);
-        const u64 ml = __ballot(learn), mp = __ballot(punish);
-        if (learn) {
-            int pos = base + __popcll(ml & lanemask_lt());
-            if (pos < d.work_cap) d.work[pos] = (uint32_t)seg; else atomicOr(&c->error, 4);
-        }
-        if (punish) {
-            int pos = base + n_l + __popcll(mp & lanemask_lt());
-            if (pos < d.work_cap) d.work[pos] = (uint32_t)seg | 0x80000000u; else atomicOr(&c->error, 4);
-        }
+        carry += total;
+        if (carry >= (uint32_t)n_un) break;
     }
-}
-
-// SparseProjection.add_output, planning half (projections.py:79-95): how many of the needed
-// segments are recycled (lowest ids with fewer than matching_threshold synapses) and how many
-// are appended.  Single block.
-__global__ __launch_bounds__(1024) void k_tm_alloc_plan(Dev d) {
-    __shared__ uint32_t s_wave[16];
-    Counters *c = d.ctr;
-    const int S = c->S, n_un = c->n_un;
-    const int nb = (S + 1023) >> 10;
-    uint32_t carry = 0;
-    if (n_un > 0) {
-        for (int base = 0; base < nb; base += 1024) {
-            int b = base + threadIdx.x;
-            uint32_t v = b < nb ? (uint32_t)d.recyc_cnt[b] : 0u;
-            uint32_t total;
-            uint32_t ex = block_excl_scan<1024>(v, s_wave, total);
-            if (b < nb) d.recyc_off[b] = (int)(carry + ex);
-            carry += total;
-            if (carry >= (uint32_t)n_un) {       // later blocks are never needed
-                for (int b2 = base + 1024 + threadIdx.x; b2 < nb; b2 += 1024) d.recyc_off[b2] = 0x7FFFFFFF;
-                break;
-            }
-        }
+    __syncthreads();
+    const int n_r = min(n_un, (int)carry);
+    int n_new = n_un - n_r;
+    if (S + n_new > d.Scap) {
+        if (threadIdx.x == 0) atomicOr(&c->error, 1);
+        n_new = max(d.Scap - S, 0);
     }
+    if (threadIdx.x == 0) s_base = atomicAdd(&c->n_work, n_r + n_new);      // one reservation for all binds
+    __syncthreads();
+    const int wbase = s_base;
+    const int n_need = s_nneed;
+    for (int i = 0; i < n_need; ++i) {          // each needed 1024-block: rank its recyclable segments
+        const int b = d.recyc_need[2 * i], off = d.recyc_need[2 * i + 1];
+        const int seg = b * 1024 + threadIdx.x;
+        const uint32_t fl = (seg < S && d.seg_nsyn[seg] < d.match_thr) ? 1u : 0u;
+        uint32_t total;
+        const uint32_t ex = block_excl_scan<1024>(fl, s_wave, total);
+        const int rank = off + (int)ex;
+        if (fl && rank < n_r) tm_bind_segment(d, seg, d.unacc_list[rank], true, wbase + rank);
+    }
+    for (int i = threadIdx.x; i < n_new; i += 1024) tm_bind_segment(d, S + i, d.unacc_list[n_r + i], false, wbase + n_r + i);
     if (threadIdx.x == 0) {
-        int n_r = min(n_un, (int)carry), n_new = n_un - n_r;
-        if (S + n_new > d.Scap) {
-            atomicOr(&c->error, 1);
-            n_new = max(d.Scap - S, 0);
-        }
         c->n_recycled = n_r;
         c->n_new = n_new;
         c->S_old = S;
         c->S = S + n_new;
-    }
-}
-
-// ids of the recycled segments, ascending (projections.py:80-81)
-__global__ __launch_bounds__(256) void k_tm_recyc_emit(Dev d) {
-    __shared__ uint32_t s_wave[4];
-    Counters *c = d.ctr;
-    const int n_r = c->n_recycled, S = c->S_old, b = blockIdx.x;
-    if (n_r == 0 || b * 1024 >= S) return;
-    const int off = d.recyc_off[b];
-    if (off >= n_r || d.recyc_cnt[b] == 0) return;
-    uint32_t fl[4], v = 0;
-    for (int q = 0; q < 4; ++q) {
-        int s = b * 1024 + threadIdx.x * 4 + q;
-        fl[q] = (s < S && d.seg_nsyn[s] < d.match_thr) ? 1u : 0u;
-        v += fl[q];
-    }
-    uint32_t total;
-    uint32_t ex = block_excl_scan<256>(v, s_wave, total);
-    int rank = off + (int)ex;
-    for (int q = 0; q < 4; ++q) {
-        if (fl[q]) {
-            if (rank < n_r) d.recyc_list[rank] = b * 1024 + threadIdx.x * 4 + q;
-            ++rank;
-        }
-    }
-}
-
-// bind recycled / fresh segments to the winners that need one (projections.py:275-281);
-// rows are packed, so clearing a recycled row (projections.py:82-85) is nsyn = 0
-__global__ __launch_bounds__(256) void k_tm_new_segments(Dev d) {
-    Counters *c = d.ctr;
-    const int n_r = c->n_recycled, n = n_r + c->n_new, S_old = c->S_old;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        const int cell = d.unacc_list[i];
-        int seg;
-        if (i < n_r) {
-            seg = d.recyc_list[i];
-            atomicSub(&d.segcount[d.seg_cell[seg]], 1);
-        } else {
-            seg = S_old + (i - n_r);
-            d.seg_pot[seg] = 0;
-        }
-        d.seg_nsyn[seg] = 0;
-        d.seg_cell[seg] = cell;
-        atomicAdd(&d.segcount[cell], 1);
-        int pos = atomicAdd(&c->n_work, 1);
-        if (pos < d.work_cap) d.work[pos] = (uint32_t)seg; else atomicOr(&c->error, 4);
     }
 }
 
@@ -579,12 +635,20 @@ __global__ __launch_bounds__(256) void k_tm_learn(Dev d, int p) {
     __shared__ int s_keep[4][EPL * 64];
     __shared__ u64 s_cand[4][CAND_CAP];
     Counters *c = d.ctr;
+    {   // forget the previous scan's per-cell maxima (sparse clear; every reader ran in an earlier
+        // launch) and reset what the coming scan accumulates
+        const int n = c->has_distal ? c->S : 0;
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
+            if (d.seg_info[i] & 0x40000000u) d.cellmax[d.seg_cell[i]] = 0u;
+        const int nb = (c->S + 1023) >> 10;
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < nb; i += gridDim.x * 256) d.recyc_cnt[i] = 0;
+    }
     const int wv = threadIdx.x >> 6, lane = lane_id();
     const int n_work = min(c->n_work, d.work_cap);
     const uint32_t *act_prev = d.act[p ^ 1];
     const int *winners = d.winners[p ^ 1];
     const int n_w = c->has_winner[p ^ 1] ? c->n_win[p ^ 1] : -1;       // -1: winner_input is None
-    const uint32_t base2 = htm_stream_base(d.seed, HTM_STREAM_GROWTH, c->step);
+    const uint32_t base2 = htm_stream_base(d.seed, HTM_STREAM_GROWTH, c->step[p]);
     for (int item = blockIdx.x * 4 + wv; item < n_work; item += gridDim.x * 4) {
         const uint32_t w = d.work[item];
         const int seg = (int)(w & 0x7FFFFFFFu), mode = (int)(w >> 31);
@@ -683,78 +747,104 @@ __global__ __launch_bounds__(256) void k_tm_learn(Dev d, int p) {
     }
 }
 
-// forget the previous scan's per-cell maxima (sparse clear) before the new scan writes
-__global__ __launch_bounds__(256) void k_tm_prescan(Dev d, int p) {
-    Counters *c = d.ctr;
-    const int q = p ^ 1;
-    const int n = c->has_distal ? c->n_match[q] : 0;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
-        d.cellmax[d.seg_cell[d.match_seg[q][i]]] = 0u;
-    if (blockIdx.x == 0 && threadIdx.x == 0) c->n_match[p] = 0;
-}
-
 // PredictiveProjection.process (projections.py:245-255): per segment, potential = active
 // presynaptic cells; matching segments additionally count connected active synapses;
 // per-cell prediction and max jittered potential (:229-239).  16 lanes per segment, 16-byte
-// loads of the packed row; a block owns 1024 consecutive segment ids and also counts the
-// recyclable ones among them for the next step's add_output.
+// loads of the packed row, four segments in flight per lane group; a block owns SCAN_SEGS
+// consecutive segment ids and also counts the recyclable ones among them (per 1024 ids) for the
+// next step's add_output.  The last duty of a timestep: publish the next step index.
 __global__ __launch_bounds__(256) void k_tm_scan(Dev d, int p) {
     __shared__ int s_recyc;
     Counters *c = d.ctr;
-    const int S = c->S, b = blockIdx.x;
-    if (b * 1024 >= S) return;
-    if (threadIdx.x == 0) s_recyc = 0;
-    __syncthreads();
+    const int S = c->S;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        c->step[p ^ 1] = c->step[p] + 1;
+        c->has_distal = 1;
+        c->n_work = 0;
+    }
     const uint32_t *act = d.act[p];
-    const uint32_t base3 = htm_stream_base(d.seed, HTM_STREAM_SEGMENT_JITTER, c->step);
+    const uint32_t base3 = htm_stream_base(d.seed, HTM_STREAM_SEGMENT_JITTER, c->step[p]);
     const int g = threadIdx.x >> 4, l = threadIdx.x & 15;
-    for (int it = 0; it < 64; ++it) {
-        const int seg = b * 1024 + it * 16 + g;
-        const bool ok = seg < S;
-        const int n = ok ? d.seg_nsyn[seg] : 0;
-        const int *prow = d.presyn + (size_t)seg * d.E;
-        uint32_t bits = 0;
-        for (int i = l * 4, ch = 0; i < n; i += 64, ++ch) {
-            const int4 ps = *(const int4 *)(prow + i);
-            const int e[4] = {ps.x, ps.y, ps.z, ps.w};
+    constexpr int U = SCAN_SEGS / 16;
+    for (int b = blockIdx.x; b * SCAN_SEGS < S; b += gridDim.x) {
+        if (threadIdx.x == 0) s_recyc = 0;
+        __syncthreads();
+        int seg[U], n[U], pot[U], conn[U];
+        uint32_t bits[U];
+        int4 ps[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            seg[u] = b * SCAN_SEGS + u * 16 + g;
+            n[u] = seg[u] < S ? d.seg_nsyn[seg[u]] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            ps[u] = make_int4(0, 0, 0, 0);
+            if (l * 4 < n[u]) ps[u] = *(const int4 *)(d.presyn + (size_t)seg[u] * d.E + l * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e[4] = {ps[u].x, ps[u].y, ps[u].z, ps[u].w};
+            uint32_t bb = 0;
 #pragma unroll
             for (int qq = 0; qq < 4; ++qq)
-                if (i + qq < n) bits |= ((act[e[qq] >> 5] >> (e[qq] & 31)) & 1u) << (ch * 4 + qq);
+                if (l * 4 + qq < n[u]) bb |= ((act[e[qq] >> 5] >> (e[qq] & 31)) & 1u) << qq;
+            bits[u] = bb;
         }
-        int pot = __popc(bits);
-        for (int o = 8; o > 0; o >>= 1) pot += __shfl_xor(pot, o);
-        const bool matching = ok && pot >= d.match_thr;                          // :247
-        int conn = 0;
-        if (matching) {
-            const float *mrow = d.sperm + (size_t)seg * d.E;
-            for (int i = l * 4, ch = 0; i < n; i += 64, ++ch) {
-                const float4 pm = *(const float4 *)(mrow + i);
-                const float e[4] = {pm.x, pm.y, pm.z, pm.w};
 #pragma unroll
-                for (int qq = 0; qq < 4; ++qq)
-                    conn += ((bits >> (ch * 4 + qq)) & 1u) && (e[qq] >= d.perm_thr);     // :171-172
+        for (int u = 0; u < U; ++u) {
+            if (n[u] > 64) {                         // rare: rows longer than one 64-slot chunk
+                const int *prow = d.presyn + (size_t)seg[u] * d.E;
+                for (int i = 64 + l * 4, ch = 1; i < n[u]; i += 64, ++ch) {
+                    const int4 pv = *(const int4 *)(prow + i);
+                    const int e[4] = {pv.x, pv.y, pv.z, pv.w};
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq)
+                        if (i + qq < n[u]) bits[u] |= ((act[e[qq] >> 5] >> (e[qq] & 31)) & 1u) << (ch * 4 + qq);
+                }
             }
+            int v = __popc(bits[u]);
+            for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o);
+            pot[u] = v;
         }
-        for (int o = 8; o > 0; o >>= 1) conn += __shfl_xor(conn, o);
-        const bool lead = l == 0 && ok;
-        const int slot = wave_append(&c->n_match[p], lead && matching);
-        if (lead) {
-            d.seg_pot[seg] = pot;
-            if (n < d.match_thr) atomicAdd(&s_recyc, 1);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool matching = pot[u] >= d.match_thr;                             // :247
+            int cn = 0;
             if (matching) {
-                const bool active = conn >= d.act_thr;                            // :250
-                const int cell = d.seg_cell[seg];
-                const float jit = htm_jitter((float)pot, htm_draw24(base3, (uint32_t)seg, 0u));   // :234-235
-                atomicMax(&d.cellmax[cell], __float_as_uint(jit));               // :237
-                if (active) atomicOr(&d.pred[p][cell >> 5], 1u << (cell & 31));   // :251, networks.py:122
-                d.match_seg[p][slot] = seg;
-                d.match_info[p][slot] = (uint32_t)pot | ((uint32_t)conn << 12) | (active ? 0x80000000u : 0u);
-                d.match_jit[p][slot] = jit;
+                const float *mrow = d.sperm + (size_t)seg[u] * d.E;
+                for (int i = l * 4, ch = 0; i < n[u]; i += 64, ++ch) {
+                    const float4 pm = *(const float4 *)(mrow + i);
+                    const float e[4] = {pm.x, pm.y, pm.z, pm.w};
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq)
+                        cn += ((bits[u] >> (ch * 4 + qq)) & 1u) && (e[qq] >= d.perm_thr);   // :171-172
+                }
+            }
+            for (int o = 8; o > 0; o >>= 1) cn += __shfl_xor(cn, o);
+            conn[u] = cn;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (l == 0 && seg[u] < S) {
+                const bool matching = pot[u] >= d.match_thr;
+                uint32_t info = (uint32_t)pot[u];
+                if (n[u] < d.match_thr) atomicAdd(&s_recyc, 1);
+                if (matching) {
+                    const bool active = conn[u] >= d.act_thr;                         // :250
+                    const int cell = d.seg_cell[seg[u]];
+                    const float jit = htm_jitter((float)pot[u], htm_draw24(base3, (uint32_t)seg[u], 0u));   // :234-235
+                    atomicMax(&d.cellmax[cell], __float_as_uint(jit));               // :237
+                    if (active) atomicOr(&d.pred[p][cell >> 5], 1u << (cell & 31));   // :251, networks.py:122
+                    info |= ((uint32_t)conn[u] << 12) | 0x40000000u | (active ? 0x80000000u : 0u);
+                    d.seg_jit[seg[u]] = jit;
+                }
+                d.seg_info[seg[u]] = info;
             }
         }
+        __syncthreads();
+        if (threadIdx.x == 0 && s_recyc) atomicAdd(&d.recyc_cnt[(b * SCAN_SEGS) >> 10], s_recyc);
     }
-    __syncthreads();
-    if (threadIdx.x == 0) d.recyc_cnt[b] = s_recyc;
 }
 
 // recount recyclable segments after a state import
@@ -774,12 +864,6 @@ __global__ __launch_bounds__(256) void k_tm_recount(Dev d) {
     if (threadIdx.x == 0) d.recyc_cnt[b] = s_recyc;
 }
 
-__global__ void k_finalize(Dev d, int tm_ran) {
-    Counters *c = d.ctr;
-    c->step += 1;
-    if (tm_ran) c->has_distal = 1;
-}
-
 // ------------------------------------------------------------------------------------------
 // host side
 
@@ -791,14 +875,20 @@ struct htm_handle {
     int device;
     hipStream_t stream;
     bool own_stream;
+    hipStream_t side;                     // forked branch: SP permanence update runs beside the TM chain
+    hipEvent_t ev_fork, ev_join;
     long long step_host;
     std::string err;
     std::vector<void *> allocs;
     int *d_cols_stage;                    // stand-alone TM: active columns
     int G;                                // lanes per SP row
-    int sp_blocks, sel_blocks, c1024_blocks, s1024_blocks;
+    int sp_blocks, sel_blocks, c256_blocks, s1024_blocks, scan_blocks;
     // graphs keyed by (parity, learning, bank, n_inputs)
     std::map<std::tuple<int, int, const void *, int>, hipGraphExec_t> graphs;
+    // state import staging (htm_write of the MATCH_* / SEG_POTENTIAL fields, applied at commit)
+    std::vector<int> imp_pot, imp_match_seg;
+    std::vector<uint32_t> imp_match_info;
+    std::vector<float> imp_match_jit;
     // profiling
     bool profile;
     std::vector<std::string> prof_names;
@@ -842,30 +932,21 @@ static int prof_slot(htm_handle *h, const char *name) {
     return (int)h->prof_names.size() - 1;
 }
 
-#define LAUNCH(h, name, kernel, grid, block, ...)                                                 \
+#define LAUNCH_ON(h, strm, name, kernel, grid, block, ...)                                        \
     do {                                                                                         \
         hipEvent_t e0_ = nullptr, e1_ = nullptr;                                                 \
         if ((h)->profile) {                                                                      \
             hipEventCreate(&e0_);                                                                \
             hipEventCreate(&e1_);                                                                \
-            hipEventRecord(e0_, (h)->stream);                                                    \
+            hipEventRecord(e0_, strm);                                                           \
         }                                                                                        \
-        hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, (h)->stream, __VA_ARGS__);        \
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, strm, __VA_ARGS__);               \
         if ((h)->profile) {                                                                      \
-            hipEventRecord(e1_, (h)->stream);                                                    \
+            hipEventRecord(e1_, strm);                                                           \
             (h)->prof_events[prof_slot(h, name)].push_back({e0_, e1_});                          \
         }                                                                                        \
     } while (0)
-
-static int enqueue_sp(htm_handle *h, const uint32_t *bank, int n_inputs, int learning, int p) {
-    Dev &d = h->d;
-    LAUNCH(h, "sp_overlap", k_sp_overlap, h->sp_blocks, 256, d, bank, n_inputs, h->G);
-    for (int pass = 0; pass < SEL_PASSES; ++pass) LAUNCH(h, "sp_select", k_sel_pass, h->sel_blocks, 256, d, pass);
-    LAUNCH(h, "sp_count", k_sp_count, h->c1024_blocks, 256, d);
-    LAUNCH(h, "sp_emit", k_sp_emit, h->c1024_blocks, 256, d, p);
-    if (learning) LAUNCH(h, "sp_learn", k_sp_learn, d.k, 256, d, bank, n_inputs);
-    return 0;
-}
+#define LAUNCH(h, name, kernel, grid, block, ...) LAUNCH_ON(h, (h)->stream, name, kernel, grid, block, __VA_ARGS__)
 
 static void launch_learn(htm_handle *h, int p) {
     Dev &d = h->d;
@@ -878,28 +959,34 @@ static void launch_learn(htm_handle *h, int p) {
     }
 }
 
-static int enqueue_tm(htm_handle *h, int n_active, int learning, int want_winner, int p) {
+// SpatialPooler.process: overlap + boost (+ select digit 0), select digits 1.., count, emit
+// (+ the TM's per-column activation when the handle has a Temporal Memory)
+static void enqueue_sp(htm_handle *h, const uint32_t *bank, int n_inputs, int learning, int p, int want_winner) {
     Dev &d = h->d;
-    if (learning) want_winner = 1;
-    LAUNCH(h, "tm_activate", k_tm_activate, (n_active * 32 + 255) / 256, 256, d, p, n_active, want_winner);
-    LAUNCH(h, "tm_activate_scan", k_tm_activate_scan, 1, 1024, d, p, n_active, want_winner, learning);
-    if (learning) {
-        LAUNCH(h, "tm_classify", k_tm_classify, 64, 256, d, p);
-        LAUNCH(h, "tm_alloc_plan", k_tm_alloc_plan, 1, 1024, d);
-        LAUNCH(h, "tm_recyc_emit", k_tm_recyc_emit, h->s1024_blocks, 256, d);
-        LAUNCH(h, "tm_new_segments", k_tm_new_segments, 16, 256, d);
-        launch_learn(h, p);
-    }
-    LAUNCH(h, "tm_prescan", k_tm_prescan, 32, 256, d, p);
-    LAUNCH(h, "tm_scan", k_tm_scan, h->s1024_blocks, 256, d, p);
-    return 0;
+    LAUNCH(h, "sp_overlap", k_sp_overlap, h->sp_blocks, 1024, d, bank, n_inputs, h->G, p);
+    for (int pass = 1; pass < d.sel_passes; ++pass) LAUNCH(h, "sp_select", k_sel_pass, h->sel_blocks, 1024, d, pass);
+    LAUNCH(h, "sp_count", k_sp_count, h->c256_blocks, 256, d);
+    LAUNCH(h, "sp_emit", k_sp_emit, h->c256_blocks, 256, d, p, want_winner);
+    // (a forked graph branch for this independent update was measured at +17..29 us per step on
+    // this runtime, against 2.3 us for one more kernel in the chain: tools/launch_overhead.hip)
+    if (learning) LAUNCH(h, "sp_learn", k_sp_learn, d.k, 256, d, bank, n_inputs, p);
+}
+
+static void join_sp(htm_handle *, int) {}
+
+// TemporalMemory.process after the per-column activation
+static void enqueue_tm(htm_handle *h, int n_active, int learning, int want_winner, int p) {
+    Dev &d = h->d;
+    LAUNCH(h, "tm_mid", k_tm_mid, learning ? 33 : 1, 1024, d, p, n_active, want_winner, learning);
+    launch_learn(h, p);
+    LAUNCH(h, "tm_scan", k_tm_scan, h->scan_blocks, 256, d, p);
 }
 
 static int enqueue_step(htm_handle *h, const uint32_t *bank, int n_inputs, int learning) {
     const int p = (int)(h->step_host & 1);
-    if (h->cfg.enable_sp) enqueue_sp(h, bank, n_inputs, learning, p);
-    if (h->cfg.enable_tm) enqueue_tm(h, h->d.k, learning, 1, p);
-    LAUNCH(h, "finalize", k_finalize, 1, 1, h->d, h->cfg.enable_tm);
+    enqueue_sp(h, bank, n_inputs, learning, p, 1);
+    enqueue_tm(h, h->d.k, learning, 1, p);
+    join_sp(h, learning);
     h->step_host += 1;
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { h->err = std::string("kernel launch: ") + hipGetErrorString(e); return HTM_ERR_HIP; }
@@ -918,6 +1005,9 @@ extern "C" void htm_destroy(htm_handle *h) {
     for (auto &v : h->prof_events)
         for (auto &pr : v) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     for (void *p : h->allocs) hipFree(p);
+    if (h->side) hipStreamDestroy(h->side);
+    if (h->ev_fork) hipEventDestroy(h->ev_fork);
+    if (h->ev_join) hipEventDestroy(h->ev_join);
     if (h->own_stream) hipStreamDestroy(h->stream);
     delete h;
 }
@@ -953,6 +1043,8 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
     h->profile = false;
     h->step_host = 0;
     h->d_cols_stage = nullptr;
+    h->side = nullptr;
+    h->ev_fork = h->ev_join = nullptr;
     hipError_t e = hipSetDevice(cfg->device);
     if (e != hipSuccess) return fail_create(h, std::string("hipSetDevice: ") + hipGetErrorString(e), HTM_ERR_HIP);
     if (cfg->stream) {
@@ -963,6 +1055,10 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
         if (e != hipSuccess) return fail_create(h, std::string("hipStreamCreate: ") + hipGetErrorString(e), HTM_ERR_HIP);
         h->own_stream = true;
     }
+    if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess)
+        return fail_create(h, "htm_create: cannot create the side stream / events", HTM_ERR_HIP);
     Dev &d = h->d;
     memset(&d, 0, sizeof(d));
     d.I = cfg->enable_sp ? cfg->input_dim : 0;
@@ -996,8 +1092,8 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
         rc |= dalloc(h, &d.overlap, C);
         rc |= dalloc(h, &d.boosted, C);
         rc |= dalloc(h, &d.key, C);
-        rc |= dalloc(h, &d.hist, (size_t)SEL_PASSES * SEL_BINS);
-        rc |= dalloc(h, &d.sel_blk, (C + 1023) / 1024);
+        rc |= dalloc(h, &d.hist, (size_t)SEL_MAX_PASSES * SEL_BINS);
+        rc |= dalloc(h, &d.sel_blk, (C + 255) / 256);
         rc |= dalloc(h, &d.input_stage, (size_t)d.W);
     }
     if (cfg->enable_tm) {
@@ -1006,9 +1102,6 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
             rc |= dalloc(h, &d.act[q], C);
             rc |= dalloc(h, &d.pred[q], C);
             rc |= dalloc(h, &d.winners[q], k * 32);
-            rc |= dalloc(h, &d.match_seg[q], S);
-            rc |= dalloc(h, &d.match_info[q], S);
-            rc |= dalloc(h, &d.match_jit[q], S);
         }
         rc |= dalloc(h, &d.win, C);
         rc |= dalloc(h, &d.bursting, k);
@@ -1021,22 +1114,34 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
         rc |= dalloc(h, &d.sperm, S * E);
         rc |= dalloc(h, &d.segcount, C * 32);
         rc |= dalloc(h, &d.cellmax, C * 32);
-        rc |= dalloc(h, &d.seg_pot, S);
+        rc |= dalloc(h, &d.seg_info, S);
+        rc |= dalloc(h, &d.seg_jit, S);
         rc |= dalloc(h, &d.work, (size_t)d.work_cap);
         rc |= dalloc(h, &d.recyc_cnt, (S + 1023) / 1024);
-        rc |= dalloc(h, &d.recyc_off, (S + 1023) / 1024);
-        rc |= dalloc(h, &d.recyc_list, k * 32);
+        rc |= dalloc(h, &d.recyc_need, 2 * k * 32);
         rc |= dalloc(h, &h->d_cols_stage, k);
     }
     if (rc) return fail_create(h, h->err, HTM_ERR_HIP);
     // lanes per SP row: the smallest power of two >= W4, at most 64
     h->G = 1;
     while (h->G < d.W4 && h->G < 64) h->G <<= 1;
-    const int rows_per_block = 4 * (64 / h->G);
-    h->sp_blocks = std::max(1, std::min((d.C + rows_per_block - 1) / rows_per_block, 4096));
-    h->sel_blocks = std::max(1, std::min((d.C + 255) / 256, 256));
-    h->c1024_blocks = (d.C + 1023) / 1024;
+    // few fat blocks for the kernels that flush a histogram: every block adds into the same few
+    // hot bins and same-address global atomics are slow (~88 per us per address)
+    const int rows_per_block = 16 * 4 * (64 / h->G);   // 16 waves x 4 row groups in flight
+    h->sp_blocks = std::max(1, std::min((d.C + rows_per_block - 1) / rows_per_block, 128));
+    h->sel_blocks = std::max(1, std::min((d.C + 1023) / 1024, 64));
+    h->c256_blocks = (d.C + 255) / 256;
     h->s1024_blocks = std::max(1, (d.Scap + 1023) / 1024);
+    h->scan_blocks = std::max(1, std::min((d.Scap + SCAN_SEGS - 1) / SCAN_SEGS, 2048));
+    // boosted = float32 factor x integer overlap <= input_dim has at most 24 + bit_length(I)
+    // significant bits, so the low 53 - 24 - bit_length(I) bits of every key are zero and the
+    // radix passes that would only see them are skipped.
+    {
+        int B = 0;
+        while ((1ll << B) <= (long long)d.I) ++B;
+        const int informative = std::min(64, 64 - (29 - B));
+        d.sel_passes = std::max(1, std::min(SEL_MAX_PASSES, (informative + SEL_DIGIT - 1) / SEL_DIGIT));
+    }
     e = hipStreamSynchronize(h->stream);
     if (e != hipSuccess) return fail_create(h, std::string("hipStreamSynchronize: ") + hipGetErrorString(e), HTM_ERR_HIP);
     *out = h;
@@ -1110,8 +1215,8 @@ extern "C" int htm_sp_step(htm_handle *h, const uint32_t *packed_input, int32_t 
     int rc = stage_input(h, packed_input);
     if (rc) return rc;
     const int p = (int)(h->step_host & 1);
-    enqueue_sp(h, h->d.input_stage, 1, learning ? 1 : 0, p);
-    LAUNCH(h, "finalize", k_finalize, 1, 1, h->d, 0);
+    enqueue_sp(h, h->d.input_stage, 1, learning ? 1 : 0, p, 0);
+    join_sp(h, learning ? 1 : 0);
     h->step_host += 1;
     return HTM_OK;
 }
@@ -1129,9 +1234,10 @@ extern "C" int htm_tm_step(htm_handle *h, const int32_t *active_column, int32_t 
     if (n) HIPCHK(h, hipMemcpyAsync(h->d_cols_stage, cols.data(), (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));      // cols is a local
     const int p = (int)(h->step_host & 1);
+    const int want = (learning || return_winner_cell) ? 1 : 0;
     LAUNCH(h, "tm_load_active", k_tm_load_active, std::min((d.C + 255) / 256, 1024), 256, d, p, h->d_cols_stage, n);
-    enqueue_tm(h, n, learning ? 1 : 0, return_winner_cell ? 1 : 0, p);
-    LAUNCH(h, "finalize", k_finalize, 1, 1, d, 1);
+    LAUNCH(h, "tm_activate", k_tm_activate, std::max(1, (n * 32 + 255) / 256), 256, d, p, n, want);
+    enqueue_tm(h, n, learning ? 1 : 0, want, p);
     h->step_host += 1;
     return HTM_OK;
 }
@@ -1203,7 +1309,12 @@ extern "C" int htm_get_info(htm_handle *h, htm_info *out) {
     const int q = (int)((h->step_host + 1) & 1);          // parity of the last completed step
     out->step_index = h->step_host;
     out->segments = c.S;
-    out->matching_segments = c.has_distal ? c.n_match[q] : 0;
+    out->matching_segments = 0;
+    if (c.has_distal && c.S > 0) {
+        std::vector<uint32_t> info((size_t)c.S);
+        HIPCHK(h, hipMemcpy(info.data(), h->d.seg_info, info.size() * 4, hipMemcpyDeviceToHost));
+        for (uint32_t v : info) out->matching_segments += (v >> 30) & 1u;
+    }
     out->winner_cells = c.n_win[q];
     out->active_cells = c.n_active_cells;
     out->has_distal_state = c.has_distal;
@@ -1229,7 +1340,7 @@ extern "C" int64_t htm_read(htm_handle *h, int32_t field, void *dst, int64_t cou
     Dev &d = h->d;
     const int q = (int)((h->step_host + 1) & 1);
     const bool sp = h->cfg.enable_sp, tm = h->cfg.enable_tm;
-    const int64_t C = d.C, K = d.K, S = c.S, E = d.E, M = c.has_distal ? c.n_match[q] : 0;
+    const int64_t C = d.C, K = d.K, S = c.S, E = d.E;
     auto need = [&](bool ok, int64_t n) -> int64_t {
         if (!ok) { h->err = "htm_read: field not available on this handle"; return HTM_ERR_STATE; }
         if (count < n) { h->err = "htm_read: buffer too small"; return HTM_ERR_ARGUMENT; }
@@ -1250,10 +1361,37 @@ extern "C" int64_t htm_read(htm_handle *h, int32_t field, void *dst, int64_t cou
         case HTM_F_WINNER_WORDS: if ((n = need(tm, C)) < 0) return n; return copy(d.win, n, 4);
         case HTM_F_BURSTING: if ((n = need(tm, d.k)) < 0) return n; return copy(d.bursting, n, 1);
         case HTM_F_SEG_NSYN: if ((n = need(tm, S)) < 0) return n; return copy(d.seg_nsyn, n, 4);
-        case HTM_F_SEG_POTENTIAL: if ((n = need(tm, S)) < 0) return n; return copy(d.seg_pot, n, 4);
-        case HTM_F_MATCH_SEGMENT: if ((n = need(tm, M)) < 0) return n; return copy(d.match_seg[q], n, 4);
-        case HTM_F_MATCH_INFO: if ((n = need(tm, M)) < 0) return n; return copy(d.match_info[q], n, 4);
-        case HTM_F_MATCH_JITTER: if ((n = need(tm, M)) < 0) return n; return copy(d.match_jit[q], n, 4);
+        case HTM_F_SEG_POTENTIAL:
+        case HTM_F_MATCH_SEGMENT:
+        case HTM_F_MATCH_INFO:
+        case HTM_F_MATCH_JITTER: {
+            // the device keeps one info word per segment; the matching-segment lists of
+            // PredictiveProjection.State (ascending ids, projections.py:247) are its non-zero part
+            if (!tm) { h->err = "htm_read: field not available on this handle"; return HTM_ERR_STATE; }
+            std::vector<uint32_t> info((size_t)S);
+            std::vector<float> jit((size_t)S);
+            if (S && (hipMemcpy(info.data(), d.seg_info, (size_t)S * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+                      hipMemcpy(jit.data(), d.seg_jit, (size_t)S * 4, hipMemcpyDeviceToHost) != hipSuccess)) { h->err = "htm_read: hipMemcpy failed"; return HTM_ERR_HIP; }
+            if (!c.has_distal) std::fill(info.begin(), info.end(), 0u);
+            int64_t m = 0;
+            if (field == HTM_F_SEG_POTENTIAL) {
+                if ((n = need(true, S)) < 0) return n;
+                for (int64_t i = 0; i < S; ++i) ((int *)dst)[i] = (int)(info[(size_t)i] & 0xFFFu);
+                return S;
+            }
+            for (int64_t i = 0; i < S; ++i) m += (info[(size_t)i] >> 30) & 1u;
+            if ((n = need(true, m)) < 0) return n;
+            m = 0;
+            for (int64_t i = 0; i < S; ++i) {
+                const uint32_t v = info[(size_t)i];
+                if (!((v >> 30) & 1u)) continue;
+                if (field == HTM_F_MATCH_SEGMENT) ((int *)dst)[m] = (int)i;
+                else if (field == HTM_F_MATCH_INFO) ((uint32_t *)dst)[m] = v & ~0x40000000u;
+                else ((float *)dst)[m] = jit[(size_t)i];
+                ++m;
+            }
+            return m;
+        }
         case HTM_F_WINNER_CELL:
         case HTM_F_SEG_CELL: {
             const bool w = field == HTM_F_WINNER_CELL;
@@ -1314,10 +1452,10 @@ extern "C" int htm_write(htm_handle *h, int32_t field, const void *src, int64_t 
         case HTM_F_CELL_ACTIVATION: return put(d.act[q], src, count, 4, C);
         case HTM_F_CELL_PREDICTION: return put(d.pred[q], src, count, 4, C);
         case HTM_F_SEG_NSYN: return put(d.seg_nsyn, src, count, 4, d.Scap);
-        case HTM_F_SEG_POTENTIAL: return put(d.seg_pot, src, count, 4, d.Scap);
-        case HTM_F_MATCH_SEGMENT: return put(d.match_seg[q], src, count, 4, d.Scap);
-        case HTM_F_MATCH_INFO: return put(d.match_info[q], src, count, 4, d.Scap);
-        case HTM_F_MATCH_JITTER: return put(d.match_jit[q], src, count, 4, d.Scap);
+        case HTM_F_SEG_POTENTIAL: h->imp_pot.assign((const int *)src, (const int *)src + count); return HTM_OK;
+        case HTM_F_MATCH_SEGMENT: h->imp_match_seg.assign((const int *)src, (const int *)src + count); return HTM_OK;
+        case HTM_F_MATCH_INFO: h->imp_match_info.assign((const uint32_t *)src, (const uint32_t *)src + count); return HTM_OK;
+        case HTM_F_MATCH_JITTER: h->imp_match_jit.assign((const float *)src, (const float *)src + count); return HTM_OK;
         case HTM_F_SEG_PERM: return put(d.sperm, src, count, 4, (int64_t)d.Scap * E);
         case HTM_F_WINNER_CELL:
         case HTM_F_SEG_CELL:
@@ -1359,9 +1497,33 @@ extern "C" int htm_import_commit(htm_handle *h, int32_t segments, int32_t matchi
     int rc = read_counters(h, &c);
     if (rc) return rc;
     const int q = (int)((h->step_host + 1) & 1);
-    c.step = (uint32_t)h->step_host;
+    c.step[h->step_host & 1] = (uint32_t)h->step_host;
+    c.n_work = 0;
     c.S = segments;
-    c.n_match[q] = matching_segments;
+    {   // dense per-segment info from the staged PredictiveProjection.State lists
+        const size_t M = (size_t)matching_segments;
+        if (has_distal_state && (h->imp_pot.size() != (size_t)segments || h->imp_match_seg.size() != M ||
+                                 h->imp_match_info.size() != M || h->imp_match_jit.size() != M)) {
+            h->err = "htm_import_commit: SEG_POTENTIAL / MATCH_* fields missing or of the wrong length";
+            return HTM_ERR_ARGUMENT;
+        }
+        std::vector<uint32_t> info((size_t)segments, 0u);
+        std::vector<float> jit((size_t)segments, 0.f);
+        if (has_distal_state) {
+            for (size_t i = 0; i < (size_t)segments; ++i) info[i] = (uint32_t)h->imp_pot[i] & 0xFFFu;
+            for (size_t i = 0; i < M; ++i) {
+                const int sgm = h->imp_match_seg[i];
+                if (sgm < 0 || sgm >= segments) { h->err = "htm_import_commit: matching segment id out of range"; return HTM_ERR_ARGUMENT; }
+                info[(size_t)sgm] = (h->imp_match_info[i] & ~0x40000000u) | 0x40000000u;
+                jit[(size_t)sgm] = h->imp_match_jit[i];
+            }
+        }
+        if (segments) {
+            HIPCHK(h, hipMemcpy(d.seg_info, info.data(), info.size() * 4, hipMemcpyHostToDevice));
+            HIPCHK(h, hipMemcpy(d.seg_jit, jit.data(), jit.size() * 4, hipMemcpyHostToDevice));
+        }
+        h->imp_pot.clear(); h->imp_match_seg.clear(); h->imp_match_info.clear(); h->imp_match_jit.clear();
+    }
     c.n_win[q] = winner_cells;
     c.has_winner[q] = has_winner_cells ? 1 : 0;
     c.has_distal = has_distal_state ? 1 : 0;
