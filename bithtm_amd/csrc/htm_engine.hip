@@ -61,7 +61,7 @@ struct Counters {
 };
 
 struct Dev {
-    int I, W, W4, Ipad, C, K, k, E, Scap, work_cap, sel_passes;
+    int I, W, W4, Ipad, C, K, k, E, Scap, work_cap, sel_passes, colwords;
     double sp_thr, sp_don, sp_doff;
     float coef, mom, dinc;
     double lrn_act, lrn_inact, pun_act, pun_inact;
@@ -84,6 +84,7 @@ struct Dev {
     uint32_t *act[2];         // [C] active-cell words, parity double buffer
     uint32_t *pred[2];        // [C] predicted-cell words
     uint32_t *win;            // [C] winner-cell words of the current step
+    uint32_t *colbits;        // [ceil(C/64)*2] bitmap of this step's active columns
     int *winners[2];          // [k*32] winner cells (enc), ascending
     uint8_t *bursting;        // [k]
     uint32_t *colcnt;         // [k] popc(winner) | popc(unaccounted) << 16
@@ -416,8 +417,13 @@ __global__ __launch_bounds__(256) void k_sp_emit(Dev d, int p, int want_winner) 
     const uint32_t ex = block_excl_scan<256>(flag, s_wave, total);
     const uint32_t g_run = gt_before + (ex & 0xFFFFu), e_run = eq_before + (ex >> 16);
     const int first_pos = (int)(gt_before + min(eq_before, r));
+    const bool sel_any = c < d.C && ((flag & 1u) || ((flag >> 16) && e_run < r));
+    if (d.act[0]) {
+        const u64 mcol = __ballot(sel_any);
+        if (lane_id() == 0) *(u64 *)&d.colbits[(blockIdx.x * 256 + (tid & ~63)) >> 5] = mcol;
+    }
     if (c < d.C) {
-        const bool sel = (flag & 1u) || ((flag >> 16) && e_run < r);
+        const bool sel = sel_any;
         float dc = d.duty[c] * d.mom;
         if (sel) dc = dc + d.dinc;
         d.duty[c] = dc;
@@ -474,6 +480,7 @@ __global__ __launch_bounds__(256) void k_tm_load_active(Dev d, int p, const int 
         d.pred[p][c] = 0;
         d.win[c] = 0;
         if (c < n) d.active_cols[c] = cols[c];
+        if (c < d.colwords) d.colbits[c] = 0;
     }
 }
 
@@ -481,7 +488,9 @@ __global__ __launch_bounds__(256) void k_tm_load_active(Dev d, int p, const int 
 __global__ __launch_bounds__(256) void k_tm_activate(Dev d, int p, int n_active, int want_winner) {
     const int idx = (blockIdx.x * 256 + threadIdx.x) >> 5;
     const bool ok = idx < n_active;
-    tm_activate_column(d, p, want_winner, ok, ok ? d.active_cols[idx] : 0, idx);
+    const int a = ok ? d.active_cols[idx] : 0;
+    if (ok && (threadIdx.x & 31) == 0) atomicOr(&d.colbits[a >> 5], 1u << (a & 31));
+    tm_activate_column(d, p, want_winner, ok, a, idx);
 }
 
 // bind segment `seg` to winner cell `cell` (projections.py:275-281) and queue it for learning at
@@ -501,14 +510,37 @@ __device__ __forceinline__ void tm_bind_segment(const Dev &d, int seg, int cell,
 //                the rest; bind them to the winners in ascending cell order (:275-281)
 //   blocks 1..   which previous matching segments learn, which are punished (projections.py:264-269;
 //                punishment mask built at networks.py:107-108,111)
-__global__ __launch_bounds__(1024) void k_tm_mid(Dev d, int p, int n_active, int want_winner, int learning) {
+//   last n_sp_rows blocks   DenseProjection.update (projections.py:23-24) on one winner row each,
+//                fused with the rebuild of that row's connected mask: independent of the TM work and
+//                bandwidth-bound, it rides along with the latency-bound block 0
+__global__ __launch_bounds__(1024) void k_tm_mid(Dev d, int p, int n_active, int want_winner, int learning,
+                                                 const uint32_t *__restrict__ bank, int n_inputs, int n_cls, int n_sp_rows) {
     Counters *c = d.ctr;
     __shared__ int s_cnt, s_base;
+    if ((int)blockIdx.x > n_cls) {
+        const uint32_t *in = bank + (size_t)(c->step[p] % (uint32_t)n_inputs) * d.W;
+        const int row = d.active_cols[blockIdx.x - 1 - n_cls];
+        double *prow = d.perm + (size_t)row * d.Ipad;
+        uint32_t *mrow = d.mask + (size_t)row * d.W;
+        for (int i0 = 0; i0 < d.Ipad; i0 += 1024) {
+            const int i = i0 + threadIdx.x;
+            bool conn = false;
+            if (i < d.I) {
+                const bool on = (in[i >> 5] >> (i & 31)) & 1u;
+                const double v = prow[i] + (on ? d.sp_don : d.sp_doff);
+                prow[i] = v;
+                conn = v >= d.sp_thr;
+            }
+            const u64 m = __ballot(conn);
+            if (lane_id() == 0 && i < d.Ipad) *(u64 *)&mrow[i >> 5] = m;
+        }
+        return;
+    }
     if (blockIdx.x > 0) {
         if (!learning || !c->has_distal) return;
         const int q = p ^ 1;
         const int n = c->S;          // ids at or above the S of the last scan still hold info == 0
-        const int stride = (gridDim.x - 1) * 1024;
+        const int stride = n_cls * 1024;
         for (int i0 = (blockIdx.x - 1) * 1024; i0 < n; i0 += stride) {
             const int seg = i0 + threadIdx.x;
             bool learn = false, punish = false;
@@ -753,7 +785,20 @@ __global__ __launch_bounds__(256) void k_tm_learn(Dev d, int p) {
 // loads of the packed row, four segments in flight per lane group; a block owns SCAN_SEGS
 // consecutive segment ids and also counts the recyclable ones among them (per 1024 ids) for the
 // next step's add_output.  The last duty of a timestep: publish the next step index.
-__global__ __launch_bounds__(256) void k_tm_scan(Dev d, int p) {
+// use_lds: the bitmap of active columns is staged in LDS and consulted first, so that only the
+// ~2 % of synapses whose presynaptic column is active touch the per-column cell words in L2.
+extern __shared__ __attribute__((aligned(16))) uint32_t s_colbits[];
+// Branch-free: lanes whose column is inactive read act[0] instead (one shared cache line), so all
+// LDS reads and then all global reads of a lane can be in flight together.
+__device__ __forceinline__ uint32_t scan_cell_active(const uint32_t *act, int enc, bool valid, bool use_lds) {
+    const int col = enc >> 5;
+    uint32_t maybe = valid ? 1u : 0u;
+    if (use_lds) maybe &= (s_colbits[col >> 5] >> (col & 31));
+    const uint32_t aw = act[maybe ? col : 0];
+    return maybe & (aw >> (enc & 31));
+}
+
+__global__ __launch_bounds__(256) void k_tm_scan(Dev d, int p, int use_lds) {
     __shared__ int s_recyc;
     Counters *c = d.ctr;
     const int S = c->S;
@@ -766,21 +811,31 @@ __global__ __launch_bounds__(256) void k_tm_scan(Dev d, int p) {
     const uint32_t base3 = htm_stream_base(d.seed, HTM_STREAM_SEGMENT_JITTER, c->step[p]);
     const int g = threadIdx.x >> 4, l = threadIdx.x & 15;
     constexpr int U = SCAN_SEGS / 16;
+    bool staged = false;
     for (int b = blockIdx.x; b * SCAN_SEGS < S; b += gridDim.x) {
-        if (threadIdx.x == 0) s_recyc = 0;
-        __syncthreads();
         int seg[U], n[U], pot[U], conn[U];
         uint32_t bits[U];
         int4 ps[U];
+        // the synapse count and the first 64-slot chunk of each row are fetched together (the
+        // chunk is masked by the count afterwards): one memory round trip instead of two
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            seg[u] = b * SCAN_SEGS + u * 16 + g;
-            n[u] = seg[u] < S ? d.seg_nsyn[seg[u]] : 0;
+            seg[u] = min(b * SCAN_SEGS + u * 16 + g, S - 1);
+            n[u] = d.seg_nsyn[seg[u]];
+            ps[u] = *(const int4 *)(d.presyn + (size_t)seg[u] * d.E + l * 4);
         }
+        if (!staged) {                               // overlap the bitmap staging with those loads
+            if (use_lds)
+                for (int i = threadIdx.x; i < d.colwords; i += 256) s_colbits[i] = d.colbits[i];
+            staged = true;
+        }
+        if (threadIdx.x == 0) s_recyc = 0;
+        __syncthreads();
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            ps[u] = make_int4(0, 0, 0, 0);
-            if (l * 4 < n[u]) ps[u] = *(const int4 *)(d.presyn + (size_t)seg[u] * d.E + l * 4);
+            const bool ok = b * SCAN_SEGS + u * 16 + g < S;
+            if (!ok) n[u] = 0;
+            seg[u] = ok ? seg[u] : S;
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -788,7 +843,7 @@ __global__ __launch_bounds__(256) void k_tm_scan(Dev d, int p) {
             uint32_t bb = 0;
 #pragma unroll
             for (int qq = 0; qq < 4; ++qq)
-                if (l * 4 + qq < n[u]) bb |= ((act[e[qq] >> 5] >> (e[qq] & 31)) & 1u) << qq;
+                bb |= scan_cell_active(act, e[qq], l * 4 + qq < n[u], use_lds) << qq;
             bits[u] = bb;
         }
 #pragma unroll
@@ -800,7 +855,7 @@ __global__ __launch_bounds__(256) void k_tm_scan(Dev d, int p) {
                     const int e[4] = {pv.x, pv.y, pv.z, pv.w};
 #pragma unroll
                     for (int qq = 0; qq < 4; ++qq)
-                        if (i + qq < n[u]) bits[u] |= ((act[e[qq] >> 5] >> (e[qq] & 31)) & 1u) << (ch * 4 + qq);
+                        bits[u] |= scan_cell_active(act, e[qq], i + qq < n[u], use_lds) << (ch * 4 + qq);
                 }
             }
             int v = __popc(bits[u]);
@@ -932,7 +987,7 @@ static int prof_slot(htm_handle *h, const char *name) {
     return (int)h->prof_names.size() - 1;
 }
 
-#define LAUNCH_ON(h, strm, name, kernel, grid, block, ...)                                        \
+#define LAUNCH_ON(h, strm, shmem, name, kernel, grid, block, ...)                                 \
     do {                                                                                         \
         hipEvent_t e0_ = nullptr, e1_ = nullptr;                                                 \
         if ((h)->profile) {                                                                      \
@@ -940,13 +995,13 @@ static int prof_slot(htm_handle *h, const char *name) {
             hipEventCreate(&e1_);                                                                \
             hipEventRecord(e0_, strm);                                                           \
         }                                                                                        \
-        hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, strm, __VA_ARGS__);               \
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), shmem, strm, __VA_ARGS__);           \
         if ((h)->profile) {                                                                      \
             hipEventRecord(e1_, strm);                                                           \
             (h)->prof_events[prof_slot(h, name)].push_back({e0_, e1_});                          \
         }                                                                                        \
     } while (0)
-#define LAUNCH(h, name, kernel, grid, block, ...) LAUNCH_ON(h, (h)->stream, name, kernel, grid, block, __VA_ARGS__)
+#define LAUNCH(h, name, kernel, grid, block, ...) LAUNCH_ON(h, (h)->stream, 0, name, kernel, grid, block, __VA_ARGS__)
 
 static void launch_learn(htm_handle *h, int p) {
     Dev &d = h->d;
@@ -969,23 +1024,28 @@ static void enqueue_sp(htm_handle *h, const uint32_t *bank, int n_inputs, int le
     LAUNCH(h, "sp_emit", k_sp_emit, h->c256_blocks, 256, d, p, want_winner);
     // (a forked graph branch for this independent update was measured at +17..29 us per step on
     // this runtime, against 2.3 us for one more kernel in the chain: tools/launch_overhead.hip)
-    if (learning) LAUNCH(h, "sp_learn", k_sp_learn, d.k, 256, d, bank, n_inputs, p);
+    if (learning && !h->cfg.enable_tm) LAUNCH(h, "sp_learn", k_sp_learn, d.k, 256, d, bank, n_inputs, p);
 }
 
 static void join_sp(htm_handle *, int) {}
 
 // TemporalMemory.process after the per-column activation
-static void enqueue_tm(htm_handle *h, int n_active, int learning, int want_winner, int p) {
+static void enqueue_tm(htm_handle *h, int n_active, int learning, int want_winner, int p,
+                       const uint32_t *bank, int n_inputs) {
     Dev &d = h->d;
-    LAUNCH(h, "tm_mid", k_tm_mid, learning ? 33 : 1, 1024, d, p, n_active, want_winner, learning);
+    const int n_cls = learning ? 32 : 0;
+    const int n_sp_rows = (learning && h->cfg.enable_sp) ? d.k : 0;      // SP permanence update rides along
+    LAUNCH(h, "tm_mid", k_tm_mid, 1 + n_cls + n_sp_rows, 1024, d, p, n_active, want_winner, learning, bank, n_inputs,
+           n_cls, n_sp_rows);
     launch_learn(h, p);
-    LAUNCH(h, "tm_scan", k_tm_scan, h->scan_blocks, 256, d, p);
+    const int use_lds = (size_t)d.colwords * 4 <= 64 * 1024;
+    LAUNCH_ON(h, h->stream, use_lds ? (size_t)d.colwords * 4 : 0, "tm_scan", k_tm_scan, h->scan_blocks, 256, d, p, use_lds);
 }
 
 static int enqueue_step(htm_handle *h, const uint32_t *bank, int n_inputs, int learning) {
     const int p = (int)(h->step_host & 1);
     enqueue_sp(h, bank, n_inputs, learning, p, 1);
-    enqueue_tm(h, h->d.k, learning, 1, p);
+    enqueue_tm(h, h->d.k, learning, 1, p, bank, n_inputs);
     join_sp(h, learning);
     h->step_host += 1;
     hipError_t e = hipGetLastError();
@@ -1104,6 +1164,8 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
             rc |= dalloc(h, &d.winners[q], k * 32);
         }
         rc |= dalloc(h, &d.win, C);
+        d.colwords = (int)((C + 63) / 64) * 2;
+        rc |= dalloc(h, &d.colbits, (size_t)d.colwords);
         rc |= dalloc(h, &d.bursting, k);
         rc |= dalloc(h, &d.colcnt, k);
         rc |= dalloc(h, &d.unacc_word, k);
@@ -1237,7 +1299,7 @@ extern "C" int htm_tm_step(htm_handle *h, const int32_t *active_column, int32_t 
     const int want = (learning || return_winner_cell) ? 1 : 0;
     LAUNCH(h, "tm_load_active", k_tm_load_active, std::min((d.C + 255) / 256, 1024), 256, d, p, h->d_cols_stage, n);
     LAUNCH(h, "tm_activate", k_tm_activate, std::max(1, (n * 32 + 255) / 256), 256, d, p, n, want);
-    enqueue_tm(h, n, learning ? 1 : 0, want, p);
+    enqueue_tm(h, n, learning ? 1 : 0, want, p, nullptr, 1);
     h->step_host += 1;
     return HTM_OK;
 }

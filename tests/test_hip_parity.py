@@ -60,3 +60,64 @@ def test_harness_counters_match_reference():
         correct = int(prev_col_pred[sp_state.active_column].sum())
         got.append((burst, correct, int(prev_col_pred.sum() - correct)))
     assert np.array_equal(np.array(got, dtype=np.int32), z["counters"])
+
+
+def test_full_size_65536x32_state_handoff_and_parity():
+    """BASELINE.json configs[2] (65 536 columns x 32 cells, 1024 inputs, 2 % density): run the
+    GPU through a learned phase with the batched entry point (hipGraph replay), hand the whole
+    state to the oracle, then step both in lock-step and compare every output bit for bit.
+    Also checks size-independent properties of the full-size state."""
+    import bench
+    from hip_impl import step_outputs
+    from oracle import HTMOracle
+    w = dict(bench.WORKLOAD)
+    noisy, perm = bench.make_inputs(w)
+    htm = bench.build_htm(w, perm, 0)
+    eng = htm.engine
+    C, I, K = w["column_dim"], w["input_dim"], w["cell_dim"]
+    htm.run(noisy, 260, learning=True, use_graph=True)          # > 5 passes over the 50 patterns
+    info = eng.check_capacity()
+    assert info.step_index == 260 and info.segments > 50000
+    # properties: k winners, sorted, unique; segcount is the histogram of seg_cell; rows packed
+    sp = eng.read_sp_fields()
+    assert len(sp["active_column"]) == htm.active_columns and np.all(np.diff(sp["active_column"]) > 0)
+    thr = np.sort(sp["boosted_overlaps"])[-htm.active_columns]
+    assert sp["boosted_overlaps"][sp["active_column"]].min() >= thr
+    st = eng.read_store()
+    assert np.array_equal(np.bincount(st["seg_cell"], minlength=C * K), st["segcount"])
+    valid = st["presyn"] >= 0
+    assert np.array_equal(valid.sum(axis=1), st["seg_nsyn"])
+    assert np.all(valid[:, :-1] >= valid[:, 1:])                 # valid slots first
+    assert (st["perm"][valid] >= 0).all() and (st["presyn"][valid] < C * K).all()
+    # hand-off: GPU -> oracle, then 6 lock-step timesteps
+    ora = HTMOracle(I, C, K, seed=0, permanence=eng.get_permanence())
+    ora.spatial_pooler.duty_cycle = eng.read_duty_cycle().copy()
+    ora.temporal_memory.import_state(eng.export_tm_state())
+    for t in range(6):
+        x = noisy[(260 + t) % len(noisy)]
+        o_sp, o_tm = ora.step(x)
+        h_sp, h_tm = htm.process(x)
+        got = step_outputs(h_sp, h_tm, K)
+        od = o_tm.distal_state
+        want = dict(active_column=o_sp.active_column, overlaps=o_sp.overlaps, boosted=o_sp.boosted_overlaps,
+                    bursting=o_tm.active_column_bursting[:, 0],
+                    act_bits=np.packbits(o_tm.cell_activation.reshape(-1), bitorder="little"),
+                    pred_bits=np.packbits(o_tm.cell_prediction.reshape(-1), bitorder="little"),
+                    winner=o_tm.winner_cell[0] * K + o_tm.winner_cell[1], matching=od.matching_segment,
+                    match_pot=od.segment_potential[od.matching_segment], match_act=od.matching_segment_activation,
+                    match_active=od.matching_segment_active, S=len(od.segment_potential))
+        for key in gr.FIELDS:
+            a, b = np.asarray(got[key]), np.asarray(want[key])
+            if key == "boosted":
+                a, b = a.view(np.int64), b.view(np.int64)
+            assert a.shape == b.shape and np.array_equal(a, b), f"full-size step {t}: {key}"
+    # oracle -> GPU: import the oracle's state into a fresh engine and continue identically
+    htm2 = bench.build_htm(w, ora.spatial_pooler.permanence, 0)
+    htm2.engine.write(4, ora.spatial_pooler.duty_cycle, np.float32)          # HTM_F_DUTY_CYCLE
+    htm2.engine.import_tm_state(ora.temporal_memory.export_state())
+    x = noisy[(266) % len(noisy)]
+    a_sp, a_tm = htm.process(x)
+    b_sp, b_tm = htm2.process(x)
+    for key in gr.FIELDS:
+        u, v = np.asarray(step_outputs(a_sp, a_tm, K)[key]), np.asarray(step_outputs(b_sp, b_tm, K)[key])
+        assert u.shape == v.shape and np.array_equal(u, v), f"import round trip: {key}"
