@@ -23,7 +23,8 @@ class HtmConfig(C.Structure):
         ("segment_activation_threshold", C.c_int32), ("segment_matching_threshold", C.c_int32),
         ("segment_sampling_synapses", C.c_int32),
         ("segment_capacity", C.c_int32), ("segment_slots", C.c_int32),
-        ("seed", C.c_uint32), ("stream", C.c_void_p),
+        ("seed", C.c_uint32), ("shard_rank", C.c_int32), ("shard_world", C.c_int32), ("use_caller_stream", C.c_int32),
+        ("stream", C.c_void_p),
     ]
 
 
@@ -32,6 +33,8 @@ class HtmInfo(C.Structure):
         ("step_index", C.c_int64), ("segments", C.c_int32), ("matching_segments", C.c_int32),
         ("winner_cells", C.c_int32), ("active_cells", C.c_int32), ("has_distal_state", C.c_int32),
         ("has_winner_cells", C.c_int32), ("capacity_error", C.c_int32), ("words_per_row", C.c_int32),
+        ("new_segment_requests", C.c_int32), ("recycled_segments", C.c_int32), ("appended_segments", C.c_int32),
+        ("work_items", C.c_int32),
     ]
 
 
@@ -52,6 +55,9 @@ EXPORTS = {
     "htm_tm_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
     "htm_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "htm_bank_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]),
+    "htm_shard_record_bytes": (C.c_int64, [C.c_void_p]),
+    "htm_shard_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
+    "htm_shard_finish": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     "htm_sync": (C.c_int, [C.c_void_p]),
     "htm_get_info": (C.c_int, [C.c_void_p, C.POINTER(HtmInfo)]),
     "htm_read": (C.c_int64, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]),

@@ -32,6 +32,7 @@ typedef unsigned long long u64;
 #define SEL_DIGIT 12
 #define SEL_BINS 4096         // 1 << SEL_DIGIT
 #define SCAN_SEGS 64          // segments per block of the segment scan
+#define DEAD_CAP 256          // newly dead segment ids one rank can report per exchange
 #define CAND_CAP 256          // growth candidates staged per wave
 #define MAX_SLOTS 512
 #define EPS32 1e-8f           // `epsilon=1e-8` against float32 arrays (weak Python scalar)
@@ -51,6 +52,7 @@ struct Counters {
     int32_t has_distal;       // a scan has run (distal_state is not None)
     int32_t n_active_cells;
     int32_t n_work;           // learning / punish work items of this step
+    int32_t n_work_last;      // ... of the last completed step (telemetry)
     int32_t n_un;             // winners needing a new segment
     int32_t n_recycled, n_new, S_old;
     int32_t error;            // sticky capacity flags
@@ -62,6 +64,7 @@ struct Counters {
 
 struct Dev {
     int I, W, W4, Ipad, C, K, k, E, Scap, work_cap, sel_passes, colwords;
+    int world, c0, c1;        // this rank owns columns [c0, c1) (world == 1: everything)
     double sp_thr, sp_don, sp_doff;
     float coef, mom, dinc;
     double lrn_act, lrn_inact, pun_act, pun_inact;
@@ -101,6 +104,10 @@ struct Dev {
     uint32_t *work;           // [work_cap] segment | mode << 31 (0 = learn + grow, 1 = punish)
     int *recyc_cnt;           // [ceil(Scap/1024)] recyclable segments per 1024-segment block
     int *recyc_need;          // [2*k*32] (block, first rank) pairs of the blocks add_output draws from
+    // column sharding (world > 1): speculative per-column words of ALL columns after the exchange,
+    // and the ids of owned segments that fell below the matching threshold while learning
+    uint32_t *spec_act, *spec_win, *spec_unacc, *spec_burst;      // [C] [C] [C] [ceil(C/32)]
+    int *dead_list;           // [1 + DEAD_CAP]: count, ids
     Counters *ctr;
 };
 
@@ -180,24 +187,29 @@ __global__ __launch_bounds__(256) void k_sp_build_mask(Dev d, int row_begin, int
 
 // DenseProjection.process (projections.py:18-21) + ExponentialBoosting.process
 // (regularizations.py:15-17).  G lanes share one row (G = power of two, W4 16-byte chunks per row).
+// Sharded handles run it on their own rows only and leave the histogram to k_shard_unpack, which
+// sees the keys of all columns.
 __global__ __launch_bounds__(1024) void k_sp_overlap(Dev d, const uint32_t *__restrict__ bank, int n_inputs, int G, int p) {
     __shared__ uint32_t h[SEL_BINS];               // histogram of the top key digit (select pass 0)
     const int gtid = blockIdx.x * blockDim.x + threadIdx.x;
     const int nthreads = gridDim.x * blockDim.x;
-    for (int i = gtid; i < (d.sel_passes - 1) * SEL_BINS; i += nthreads) d.hist[SEL_BINS + i] = 0;
-    for (int i = threadIdx.x; i < SEL_BINS; i += 1024) h[i] = 0;
-    if (gtid == 0) {
-        d.ctr->sel_pass_prefix[0] = 0;
-        d.ctr->sel_pass_krem[0] = (uint32_t)d.k;
+    const bool do_hist = d.world == 1;
+    if (do_hist) {
+        for (int i = gtid; i < (d.sel_passes - 1) * SEL_BINS; i += nthreads) d.hist[SEL_BINS + i] = 0;
+        for (int i = threadIdx.x; i < SEL_BINS; i += 1024) h[i] = 0;
+        if (gtid == 0) {
+            d.ctr->sel_pass_prefix[0] = 0;
+            d.ctr->sel_pass_krem[0] = (uint32_t)d.k;
+        }
+        __syncthreads();
     }
-    __syncthreads();
     const uint4 *in4 = (const uint4 *)(bank + (size_t)(d.ctr->step[p] % (uint32_t)n_inputs) * d.W);
     const uint4 *mask4 = (const uint4 *)d.mask;
     const int lane = lane_id();
     const int rpw = 64 / G, sub = lane / G, l = lane % G;
     const int wave = gtid >> 6, nwaves = nthreads >> 6;
     constexpr int U = 4;                           // row groups in flight per wave
-    for (int row0 = wave * rpw * U; row0 < d.C; row0 += nwaves * rpw * U) {
+    for (int row0 = d.c0 + wave * rpw * U; row0 < d.c1; row0 += nwaves * rpw * U) {
         int cnt[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) cnt[u] = 0;
@@ -207,7 +219,7 @@ __global__ __launch_bounds__(1024) void k_sp_overlap(Dev d, const uint32_t *__re
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int row = row0 + u * rpw + sub;
-                m[u] = row < d.C ? mask4[(size_t)row * d.W4 + j] : make_uint4(0, 0, 0, 0);
+                m[u] = row < d.c1 ? mask4[(size_t)row * d.W4 + j] : make_uint4(0, 0, 0, 0);
             }
 #pragma unroll
             for (int u = 0; u < U; ++u)
@@ -218,7 +230,7 @@ __global__ __launch_bounds__(1024) void k_sp_overlap(Dev d, const uint32_t *__re
             int cn = cnt[u];
             for (int o = G >> 1; o > 0; o >>= 1) cn += __shfl_xor(cn, o);
             const int row = row0 + u * rpw + sub;
-            const bool owner = l == 0 && row < d.C;
+            const bool owner = l == 0 && row < d.c1;
             u64 key = 0;
             if (owner) {
                 d.overlap[row] = cn;
@@ -228,9 +240,10 @@ __global__ __launch_bounds__(1024) void k_sp_overlap(Dev d, const uint32_t *__re
                 key = (u64)__double_as_longlong(bo);
                 d.key[row] = key;
             }
-            hist_add(h, (uint32_t)(key >> sel_shift(0)), owner);
+            if (do_hist) hist_add(h, (uint32_t)(key >> sel_shift(0)), owner);
         }
     }
+    if (!do_hist) return;
     __syncthreads();
     for (int i = threadIdx.x; i < SEL_BINS; i += 1024)
         if (h[i]) atomicAdd(&d.hist[i], h[i]);
@@ -344,7 +357,9 @@ __global__ __launch_bounds__(256) void k_sp_count(Dev d) {
 // TemporalMemory.process up to the winner cells (networks.py:95-104) for ONE active column,
 // executed by a half-wave (lane j = cell j): bursting, best-matching cell (networks.py:73-82),
 // least-used cell (:84-89).  idx = position of column a in the ascending active list.
-__device__ __forceinline__ void tm_activate_column(const Dev &d, int p, int want_winner, bool col_ok, int a, int idx) {
+struct ColumnWords { uint32_t act, winner, unacc; bool burst; };
+
+__device__ __forceinline__ ColumnWords tm_column_words(const Dev &d, int p, int want_winner, bool col_ok, int a) {
     const int lane = lane_id(), half = lane >> 5, j = lane & 31;
     const bool valid = col_ok && j < d.K;
     const uint32_t pw = col_ok ? d.pred[p ^ 1][a] : 0;       // prev_state.cell_prediction row
@@ -374,12 +389,130 @@ __device__ __forceinline__ void tm_activate_column(const Dev &d, int p, int want
         const u64 bm = __ballot(valid && has_distal && !(cm < EPS32));             // cell has a matching segment
         unacc = has_distal ? (winner & ~(uint32_t)(bm >> (half * 32))) : 0u;       // projections.py:271
     }
-    if (col_ok && j == 0) {
-        d.act[p][a] = act;
-        d.win[a] = want_winner ? winner : 0u;
-        d.bursting[idx] = burst ? 1 : 0;
-        d.colcnt[idx] = (uint32_t)__popc(winner) | ((uint32_t)__popc(unacc) << 16);
-        d.unacc_word[idx] = unacc;
+    return ColumnWords{act, want_winner ? winner : 0u, unacc, burst};
+}
+
+// store the words of active column a, the idx-th of the ascending active list
+__device__ __forceinline__ void tm_store_column(const Dev &d, int p, bool col_ok, int a, int idx, const ColumnWords &w) {
+    if (col_ok && (lane_id() & 31) == 0) {
+        d.act[p][a] = w.act;
+        d.win[a] = w.winner;
+        d.bursting[idx] = w.burst ? 1 : 0;
+        d.colcnt[idx] = (uint32_t)__popc(w.winner) | ((uint32_t)__popc(w.unacc) << 16);
+        d.unacc_word[idx] = w.unacc;
+    }
+}
+
+__device__ __forceinline__ void tm_activate_column(const Dev &d, int p, int want_winner, bool col_ok, int a, int idx) {
+    if (d.world == 1) {
+        tm_store_column(d, p, col_ok, a, idx, tm_column_words(d, p, want_winner, col_ok, a));
+    } else {          // the owner computed the words before the exchange
+        ColumnWords w{0, 0, 0, false};
+        if (col_ok) {
+            w.act = d.spec_act[a];
+            w.winner = want_winner ? d.spec_win[a] : 0u;
+            w.unacc = want_winner ? d.spec_unacc[a] : 0u;
+            w.burst = (d.spec_burst[a >> 5] >> (a & 31)) & 1u;
+        }
+        tm_store_column(d, p, col_ok, a, idx, w);
+    }
+}
+
+// ---- column sharding: the two kernels around the exchange ---------------------------------
+// wire format of one rank's record (oracle/sharded.py record_nbytes):
+//   [boosted f64 x Cl][act u32 x Cl][win u32 x Cl][unacc u32 x Cl][bursting bits u32 x ceil(Cl/32)]
+//   [n_dead u32][dead ids u32 x DEAD_CAP], padded to 16 bytes
+__host__ __device__ __forceinline__ size_t shard_record_bytes(int cl) {
+    size_t n = (size_t)cl * 20 + 4 * (size_t)((cl + 31) / 32) + 4 + 4 * DEAD_CAP;
+    return (n + 15) / 16 * 16;
+}
+
+// before the exchange: what each OWN column would look like if it became active (this only
+// needs the rank's own previous predictions, segment maxima and segment counts), its boosted
+// overlap, and the segments that died during the previous step's learning
+__global__ __launch_bounds__(256) void k_shard_pack(Dev d, int p, unsigned char *send) {
+    const int cl = d.c1 - d.c0;
+    double *r_boost = (double *)send;
+    uint32_t *r_act = (uint32_t *)(send + (size_t)cl * 8);
+    uint32_t *r_win = r_act + cl, *r_unacc = r_win + cl, *r_burst = r_unacc + cl;
+    uint32_t *r_dead = r_burst + (cl + 31) / 32;
+    const int i = (blockIdx.x * 256 + threadIdx.x) >> 5;           // local column, one per half-wave
+    const bool ok = i < cl;
+    const int a = d.c0 + (ok ? i : 0);
+    const ColumnWords w = tm_column_words(d, p, 1, ok, a);
+    // bursting bits: one 32-bit word per 32 columns = 16 consecutive waves' halves; use atomics
+    if (ok && (lane_id() & 31) == 0) {
+        r_boost[i] = d.boosted[a];
+        r_act[i] = w.act;
+        r_win[i] = w.winner;
+        r_unacc[i] = w.unacc;
+        if (w.burst) atomicOr(&r_burst[i >> 5], 1u << (i & 31));
+    }
+    if (blockIdx.x == 0) {
+        const int n = min(d.dead_list[0], DEAD_CAP);
+        if (threadIdx.x == 0) r_dead[0] = (uint32_t)n;
+        for (int j = threadIdx.x; j < n; j += 256) r_dead[1 + j] = (uint32_t)d.dead_list[1 + j];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_shard_pack_clear(Dev d, unsigned char *send) {
+    const int cl = d.c1 - d.c0;
+    uint32_t *r_burst = (uint32_t *)(send + (size_t)cl * 20);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < (cl + 31) / 32; i += gridDim.x * 256) r_burst[i] = 0;
+}
+
+// after the exchange: the keys and speculative words of ALL columns in global column order, the
+// histogram of the top key digit (what k_sp_overlap does on an unsharded handle), and the deaths
+// the other ranks reported (only "fewer synapses than the matching threshold" matters here:
+// projections.py:80)
+__global__ __launch_bounds__(1024) void k_shard_unpack(Dev d, const unsigned char *recv, int rank) {
+    __shared__ uint32_t h[SEL_BINS];
+    const int gtid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nthreads = gridDim.x * blockDim.x;
+    const int cl = d.c1 - d.c0;
+    const size_t rb = shard_record_bytes(cl);
+    for (int i = gtid; i < (d.sel_passes - 1) * SEL_BINS; i += nthreads) d.hist[SEL_BINS + i] = 0;
+    for (int i = threadIdx.x; i < SEL_BINS; i += 1024) h[i] = 0;
+    if (gtid == 0) {
+        d.ctr->sel_pass_prefix[0] = 0;
+        d.ctr->sel_pass_krem[0] = (uint32_t)d.k;
+        d.dead_list[0] = 0;                        // reported; start collecting this step's
+    }
+    __syncthreads();
+    for (int c0 = blockIdx.x * 1024 + (threadIdx.x & ~63); c0 < d.C; c0 += gridDim.x * 1024) {
+        const int c = c0 + lane_id();
+        u64 key = 0;
+        if (c < d.C) {
+            const int r = c / cl, i = c - r * cl;
+            const unsigned char *rec = recv + (size_t)r * rb;
+            const double bo = ((const double *)rec)[i];
+            const uint32_t *r_act = (const uint32_t *)(rec + (size_t)cl * 8);
+            key = (u64)__double_as_longlong(bo);
+            d.boosted[c] = bo;
+            d.key[c] = key;
+            d.spec_act[c] = r_act[i];
+            d.spec_win[c] = r_act[cl + i];
+            d.spec_unacc[c] = r_act[2 * cl + i];
+            if ((c & 31) == 0) {                   // cl is a multiple of 32: words do not straddle ranks
+                d.spec_burst[c >> 5] = r_act[3 * cl + (i >> 5)];
+            }
+        }
+        hist_add(h, (uint32_t)(key >> sel_shift(0)), c < d.C);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < SEL_BINS; i += 1024)
+        if (h[i]) atomicAdd(&d.hist[i], h[i]);
+    if (blockIdx.x == 0) {
+        for (int r = 0; r < d.world; ++r) {
+            if (r == rank) continue;
+            const uint32_t *r_dead = (const uint32_t *)(recv + (size_t)r * rb + (size_t)cl * 20) + (cl + 31) / 32;
+            const int n = min((int)r_dead[0], DEAD_CAP);
+            for (int j = threadIdx.x; j < n; j += 1024) {
+                const int seg = (int)r_dead[1 + j];
+                d.seg_nsyn[seg] = 0;
+                atomicAdd(&d.recyc_cnt[seg >> 10], 1);
+            }
+        }
     }
 }
 
@@ -424,9 +557,11 @@ __global__ __launch_bounds__(256) void k_sp_emit(Dev d, int p, int want_winner) 
     }
     if (c < d.C) {
         const bool sel = sel_any;
-        float dc = d.duty[c] * d.mom;
-        if (sel) dc = dc + d.dinc;
-        d.duty[c] = dc;
+        if (c >= d.c0 && c < d.c1) {
+            float dc = d.duty[c] * d.mom;
+            if (sel) dc = dc + d.dinc;
+            d.duty[c] = dc;
+        }
         if (sel) {
             const int pos = (int)(g_run + min(e_run, r));
             d.active_cols[pos] = c;
@@ -495,12 +630,26 @@ __global__ __launch_bounds__(256) void k_tm_activate(Dev d, int p, int n_active,
 
 // bind segment `seg` to winner cell `cell` (projections.py:275-281) and queue it for learning at
 // work-list slot `pos`; rows are packed, so clearing a recycled row (projections.py:82-85) is nsyn = 0
-__device__ __forceinline__ void tm_bind_segment(const Dev &d, int seg, int cell, bool recycled, int pos) {
-    if (recycled) atomicSub(&d.segcount[d.seg_cell[seg]], 1);
-    d.seg_nsyn[seg] = 0;
+// Sharded: every rank records the new owner (segment ids are global), but only the owner of a
+// cell keeps that cell's segment count, and only the new owner queues the segment; the others
+// note how many synapses it will grow (projections.py:114-127 on an empty row: min(sampling,
+// previous winners)), which is all they ever need to know about it.
+__device__ __forceinline__ bool col_is_local(const Dev &d, int cell) { const int col = cell >> 5; return col >= d.c0 && col < d.c1; }
+
+__device__ __forceinline__ void tm_bind_segment(const Dev &d, int seg, int cell, bool recycled, int pos, int grown) {
+    if (recycled) {
+        const int old = d.seg_cell[seg];
+        if (col_is_local(d, old)) atomicSub(&d.segcount[old], 1);
+    }
     d.seg_cell[seg] = cell;
-    atomicAdd(&d.segcount[cell], 1);
-    if (pos < d.work_cap) d.work[pos] = (uint32_t)seg; else atomicOr(&d.ctr->error, 4);
+    if (col_is_local(d, cell)) {
+        d.seg_nsyn[seg] = 0;
+        atomicAdd(&d.segcount[cell], 1);
+        if (pos < 0) pos = atomicAdd(&d.ctr->n_work, 1);
+        if (pos < d.work_cap) d.work[pos] = (uint32_t)seg; else atomicOr(&d.ctr->error, 4);
+    } else {
+        d.seg_nsyn[seg] = grown;
+    }
 }
 
 // The middle of TemporalMemory.process / PredictiveProjection.update, one launch:
@@ -520,6 +669,7 @@ __global__ __launch_bounds__(1024) void k_tm_mid(Dev d, int p, int n_active, int
     if ((int)blockIdx.x > n_cls) {
         const uint32_t *in = bank + (size_t)(c->step[p] % (uint32_t)n_inputs) * d.W;
         const int row = d.active_cols[blockIdx.x - 1 - n_cls];
+        if (row < d.c0 || row >= d.c1) return;      // another rank's column
         double *prow = d.perm + (size_t)row * d.Ipad;
         uint32_t *mrow = d.mask + (size_t)row * d.W;
         for (int i0 = 0; i0 < d.Ipad; i0 += 1024) {
@@ -636,9 +786,12 @@ __global__ __launch_bounds__(1024) void k_tm_mid(Dev d, int p, int n_active, int
         if (threadIdx.x == 0) atomicOr(&c->error, 1);
         n_new = max(d.Scap - S, 0);
     }
-    if (threadIdx.x == 0) s_base = atomicAdd(&c->n_work, n_r + n_new);      // one reservation for all binds
+    const bool whole = d.world == 1;            // sharded: only the binds to own cells are queued
+    if (threadIdx.x == 0 && whole) s_base = atomicAdd(&c->n_work, n_r + n_new);      // one reservation for all binds
     __syncthreads();
     const int wbase = s_base;
+    const int n_w = c->has_winner[p ^ 1] ? c->n_win[p ^ 1] : -1;
+    const int grown = n_w > 0 ? min(d.sample, n_w) : 0;
     const int n_need = s_nneed;
     for (int i = 0; i < n_need; ++i) {          // each needed 1024-block: rank its recyclable segments
         const int b = d.recyc_need[2 * i], off = d.recyc_need[2 * i + 1];
@@ -647,9 +800,10 @@ __global__ __launch_bounds__(1024) void k_tm_mid(Dev d, int p, int n_active, int
         uint32_t total;
         const uint32_t ex = block_excl_scan<1024>(fl, s_wave, total);
         const int rank = off + (int)ex;
-        if (fl && rank < n_r) tm_bind_segment(d, seg, d.unacc_list[rank], true, wbase + rank);
+        if (fl && rank < n_r) tm_bind_segment(d, seg, d.unacc_list[rank], true, whole ? wbase + rank : -1, grown);
     }
-    for (int i = threadIdx.x; i < n_new; i += 1024) tm_bind_segment(d, S + i, d.unacc_list[n_r + i], false, wbase + n_r + i);
+    for (int i = threadIdx.x; i < n_new; i += 1024)
+        tm_bind_segment(d, S + i, d.unacc_list[n_r + i], false, whole ? wbase + n_r + i : -1, grown);
     if (threadIdx.x == 0) {
         c->n_recycled = n_r;
         c->n_new = n_new;
@@ -774,7 +928,13 @@ __global__ __launch_bounds__(256) void k_tm_learn(Dev d, int p) {
                 n_total = min(n_keep + take_n, d.E);                                    // :161
             }
         }
-        if (lane == 0) d.seg_nsyn[seg] = n_total;
+        if (lane == 0) {
+            d.seg_nsyn[seg] = n_total;
+            if (d.world > 1 && n >= d.match_thr && n_total < d.match_thr) {       // tell the other ranks
+                const int slot = atomicAdd(&d.dead_list[0], 1);
+                if (slot < DEAD_CAP) d.dead_list[1 + slot] = seg; else atomicOr(&c->error, 8);
+            }
+        }
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -805,6 +965,7 @@ __global__ __launch_bounds__(256) void k_tm_scan(Dev d, int p, int use_lds) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         c->step[p ^ 1] = c->step[p] + 1;
         c->has_distal = 1;
+        c->n_work_last = c->n_work;
         c->n_work = 0;
     }
     const uint32_t *act = d.act[p];
@@ -818,11 +979,15 @@ __global__ __launch_bounds__(256) void k_tm_scan(Dev d, int p, int use_lds) {
         int4 ps[U];
         // the synapse count and the first 64-slot chunk of each row are fetched together (the
         // chunk is masked by the count afterwards): one memory round trip instead of two
+        bool mine[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             seg[u] = min(b * SCAN_SEGS + u * 16 + g, S - 1);
             n[u] = d.seg_nsyn[seg[u]];
-            ps[u] = *(const int4 *)(d.presyn + (size_t)seg[u] * d.E + l * 4);
+            mine[u] = true;
+            if (d.world > 1) mine[u] = col_is_local(d, d.seg_cell[seg[u]]);       // rows of other ranks are not here
+            ps[u] = make_int4(0, 0, 0, 0);
+            if (mine[u]) ps[u] = *(const int4 *)(d.presyn + (size_t)seg[u] * d.E + l * 4);
         }
         if (!staged) {                               // overlap the bitmap staging with those loads
             if (use_lds)
@@ -831,10 +996,12 @@ __global__ __launch_bounds__(256) void k_tm_scan(Dev d, int p, int use_lds) {
         }
         if (threadIdx.x == 0) s_recyc = 0;
         __syncthreads();
+        int n_true[U];                                // for the recyclable count (all ranks, all segments)
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const bool ok = b * SCAN_SEGS + u * 16 + g < S;
-            if (!ok) n[u] = 0;
+            n_true[u] = ok ? n[u] : 0x7FFFFFFF;
+            if (!ok || !mine[u]) n[u] = 0;
             seg[u] = ok ? seg[u] : S;
         }
 #pragma unroll
@@ -882,9 +1049,10 @@ __global__ __launch_bounds__(256) void k_tm_scan(Dev d, int p, int use_lds) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (l == 0 && seg[u] < S) {
+                if (n_true[u] < d.match_thr) atomicAdd(&s_recyc, 1);
+                if (!mine[u]) continue;
                 const bool matching = pot[u] >= d.match_thr;
                 uint32_t info = (uint32_t)pot[u];
-                if (n[u] < d.match_thr) atomicAdd(&s_recyc, 1);
                 if (matching) {
                     const bool active = conn[u] >= d.act_thr;                         // :250
                     const int cell = d.seg_cell[seg[u]];
@@ -936,6 +1104,10 @@ struct htm_handle {
     std::string err;
     std::vector<void *> allocs;
     int *d_cols_stage;                    // stand-alone TM: active columns
+    int rank, world;                      // column sharding
+    const uint32_t *shard_bank;           // input of the step between htm_shard_begin and _finish
+    int shard_n_inputs;
+    bool shard_open;
     int G;                                // lanes per SP row
     int sp_blocks, sel_blocks, c256_blocks, s1024_blocks, scan_blocks;
     // graphs keyed by (parity, learning, bank, n_inputs)
@@ -1096,6 +1268,12 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
         if ((long long)cfg->column_dim * 32 > 0x7FFFFFFFLL) return fail_create(nullptr, "htm_create: column_dim too large", HTM_ERR_ARGUMENT);
     }
     if (!cfg->enable_sp && !cfg->enable_tm) return fail_create(nullptr, "htm_create: nothing enabled", HTM_ERR_ARGUMENT);
+    const int world = cfg->shard_world > 1 ? cfg->shard_world : 1;
+    if (world > 1) {
+        if (!cfg->enable_sp || !cfg->enable_tm) return fail_create(nullptr, "htm_create: a sharded handle needs SP and TM", HTM_ERR_ARGUMENT);
+        if (cfg->shard_rank < 0 || cfg->shard_rank >= world) return fail_create(nullptr, "htm_create: shard_rank out of range", HTM_ERR_ARGUMENT);
+        if (cfg->column_dim % (world * 64)) return fail_create(nullptr, "htm_create: column_dim must be a multiple of 64 * shard_world", HTM_ERR_ARGUMENT);
+    }
 
     htm_handle *h = new htm_handle();
     h->cfg = *cfg;
@@ -1103,12 +1281,17 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
     h->profile = false;
     h->step_host = 0;
     h->d_cols_stage = nullptr;
+    h->rank = world > 1 ? cfg->shard_rank : 0;
+    h->world = world;
+    h->shard_bank = nullptr;
+    h->shard_n_inputs = 1;
+    h->shard_open = false;
     h->side = nullptr;
     h->ev_fork = h->ev_join = nullptr;
     hipError_t e = hipSetDevice(cfg->device);
     if (e != hipSuccess) return fail_create(h, std::string("hipSetDevice: ") + hipGetErrorString(e), HTM_ERR_HIP);
-    if (cfg->stream) {
-        h->stream = (hipStream_t)cfg->stream;
+    if (cfg->use_caller_stream) {
+        h->stream = (hipStream_t)cfg->stream;          // NULL = the default stream
         h->own_stream = false;
     } else {
         e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
@@ -1126,6 +1309,9 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
     d.W4 = d.W / 4;
     d.Ipad = d.W * 32;
     d.C = cfg->column_dim;
+    d.world = world;
+    d.c0 = h->rank * (d.C / world);
+    d.c1 = d.c0 + d.C / world;
     d.K = cfg->enable_tm ? cfg->cell_dim : 0;
     d.k = cfg->active_columns;
     d.E = cfg->enable_tm ? cfg->segment_slots : 64;
@@ -1181,6 +1367,13 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
         rc |= dalloc(h, &d.work, (size_t)d.work_cap);
         rc |= dalloc(h, &d.recyc_cnt, (S + 1023) / 1024);
         rc |= dalloc(h, &d.recyc_need, 2 * k * 32);
+        rc |= dalloc(h, &d.dead_list, (size_t)1 + DEAD_CAP);
+        if (world > 1) {
+            rc |= dalloc(h, &d.spec_act, C);
+            rc |= dalloc(h, &d.spec_win, C);
+            rc |= dalloc(h, &d.spec_unacc, C);
+            rc |= dalloc(h, &d.spec_burst, (C + 31) / 32);
+        }
         rc |= dalloc(h, &h->d_cols_stage, k);
     }
     if (rc) return fail_create(h, h->err, HTM_ERR_HIP);
@@ -1190,7 +1383,7 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
     // few fat blocks for the kernels that flush a histogram: every block adds into the same few
     // hot bins and same-address global atomics are slow (~88 per us per address)
     const int rows_per_block = 16 * 4 * (64 / h->G);   // 16 waves x 4 row groups in flight
-    h->sp_blocks = std::max(1, std::min((d.C + rows_per_block - 1) / rows_per_block, 128));
+    h->sp_blocks = std::max(1, std::min((d.c1 - d.c0 + rows_per_block - 1) / rows_per_block, 128));
     h->sel_blocks = std::max(1, std::min((d.C + 1023) / 1024, 64));
     h->c256_blocks = (d.C + 255) / 256;
     h->s1024_blocks = std::max(1, (d.Scap + 1023) / 1024);
@@ -1264,6 +1457,7 @@ static int stage_input(htm_handle *h, const uint32_t *packed_input) {
 extern "C" int htm_step(htm_handle *h, const uint32_t *packed_input, int32_t learning) {
     if (!h || !packed_input) return HTM_ERR_ARGUMENT;
     if (!h->cfg.enable_sp || !h->cfg.enable_tm) { h->err = "htm_step needs a handle with SP and TM"; return HTM_ERR_STATE; }
+    if (h->world > 1) { h->err = "sharded handle: use htm_shard_begin / htm_shard_finish"; return HTM_ERR_STATE; }
     HIPCHK(h, hipSetDevice(h->device));
     int rc = stage_input(h, packed_input);
     if (rc) return rc;
@@ -1307,6 +1501,7 @@ extern "C" int htm_tm_step(htm_handle *h, const int32_t *active_column, int32_t 
 extern "C" int htm_run(htm_handle *h, const uint32_t *device_inputs, int32_t n_inputs, int32_t n_steps, int32_t learning, int32_t use_graph) {
     if (!h || !device_inputs || n_inputs < 1 || n_steps < 0) return HTM_ERR_ARGUMENT;
     if (!h->cfg.enable_sp || !h->cfg.enable_tm) { h->err = "htm_run needs a handle with SP and TM"; return HTM_ERR_STATE; }
+    if (h->world > 1) { h->err = "sharded handle: use htm_shard_begin / htm_shard_finish"; return HTM_ERR_STATE; }
     HIPCHK(h, hipSetDevice(h->device));
     learning = learning ? 1 : 0;
     if (!use_graph || h->profile) {
@@ -1337,6 +1532,57 @@ extern "C" int htm_run(htm_handle *h, const uint32_t *device_inputs, int32_t n_i
         HIPCHK(h, hipGraphLaunch(it->second, h->stream));
         h->step_host += 1;
     }
+    return HTM_OK;
+}
+
+extern "C" int64_t htm_shard_record_bytes(htm_handle *h) {
+    if (!h) return HTM_ERR_ARGUMENT;
+    return (int64_t)shard_record_bytes(h->d.c1 - h->d.c0);
+}
+
+extern "C" int htm_shard_begin(htm_handle *h, const uint32_t *device_inputs, int32_t n_inputs, const uint32_t *packed_input,
+                               int32_t learning, void *send_device) {
+    if (!h || !send_device || (!device_inputs == !packed_input)) return HTM_ERR_ARGUMENT;
+    if (h->world < 2) { h->err = "htm_shard_begin: handle is not sharded"; return HTM_ERR_STATE; }
+    if (h->shard_open) { h->err = "htm_shard_begin: previous step not finished"; return HTM_ERR_STATE; }
+    HIPCHK(h, hipSetDevice(h->device));
+    if (packed_input) {
+        int rc = stage_input(h, packed_input);
+        if (rc) return rc;
+        h->shard_bank = h->d.input_stage;
+        h->shard_n_inputs = 1;
+    } else {
+        if (n_inputs < 1) return HTM_ERR_ARGUMENT;
+        h->shard_bank = device_inputs;
+        h->shard_n_inputs = n_inputs;
+    }
+    Dev &d = h->d;
+    const int p = (int)(h->step_host & 1);
+    const int cl = d.c1 - d.c0;
+    LAUNCH(h, "sp_overlap", k_sp_overlap, h->sp_blocks, 1024, d, h->shard_bank, h->shard_n_inputs, h->G, p);
+    LAUNCH(h, "shard_pack_clear", k_shard_pack_clear, 1, 256, d, (unsigned char *)send_device);
+    LAUNCH(h, "shard_pack", k_shard_pack, (cl * 32 + 255) / 256, 256, d, p, (unsigned char *)send_device);
+    h->shard_open = true;
+    (void)learning;
+    return HTM_OK;
+}
+
+extern "C" int htm_shard_finish(htm_handle *h, const void *recv_device, int32_t learning) {
+    if (!h || !recv_device) return HTM_ERR_ARGUMENT;
+    if (h->world < 2 || !h->shard_open) { h->err = "htm_shard_finish: no step in progress"; return HTM_ERR_STATE; }
+    HIPCHK(h, hipSetDevice(h->device));
+    Dev &d = h->d;
+    const int p = (int)(h->step_host & 1);
+    learning = learning ? 1 : 0;
+    LAUNCH(h, "shard_unpack", k_shard_unpack, h->sel_blocks, 1024, d, (const unsigned char *)recv_device, h->rank);
+    for (int pass = 1; pass < d.sel_passes; ++pass) LAUNCH(h, "sp_select", k_sel_pass, h->sel_blocks, 1024, d, pass);
+    LAUNCH(h, "sp_count", k_sp_count, h->c256_blocks, 256, d);
+    LAUNCH(h, "sp_emit", k_sp_emit, h->c256_blocks, 256, d, p, 1);
+    enqueue_tm(h, d.k, learning, 1, p, h->shard_bank, h->shard_n_inputs);
+    h->step_host += 1;
+    h->shard_open = false;
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { h->err = std::string("kernel launch: ") + hipGetErrorString(e); return HTM_ERR_HIP; }
     return HTM_OK;
 }
 
@@ -1383,9 +1629,14 @@ extern "C" int htm_get_info(htm_handle *h, htm_info *out) {
     out->has_winner_cells = h->step_host > 0 ? c.has_winner[q] : 0;
     out->capacity_error = c.error;
     out->words_per_row = h->d.W;
+    out->new_segment_requests = c.n_un;
+    out->recycled_segments = c.n_un ? c.n_recycled : 0;
+    out->appended_segments = c.n_un ? c.n_new : 0;
+    out->work_items = c.n_work_last;
     if (c.error) {
         h->err = std::string("capacity exhausted:") + ((c.error & 1) ? " segment pool (segment_capacity)" : "") +
-                 ((c.error & 2) ? " synapse slots (segment_slots)" : "") + ((c.error & 4) ? " work list / growth staging" : "");
+                 ((c.error & 2) ? " synapse slots (segment_slots)" : "") + ((c.error & 4) ? " work list / growth staging" : "") +
+                 ((c.error & 8) ? " dead-segment report (DEAD_CAP)" : "");
     }
     return HTM_OK;
 }

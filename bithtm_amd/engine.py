@@ -39,7 +39,7 @@ def bool_to_words(mat):
 
 class Engine:
     def __init__(self, input_dim, column_dim, cell_dim, active_columns, proximal=None, boosting=None,
-                 distal=None, seed=0, device=0, stream=None):
+                 distal=None, seed=0, device=0, stream=None, shard_rank=0, shard_world=1):
         self.lib = L.load()
         self.input_dim = int(input_dim) if proximal is not None else 0
         self.column_dim = int(column_dim)
@@ -77,7 +77,12 @@ class Engine:
             cfg.segment_capacity = int(cap) if cap is not None else max(4096, 512 * self.active_columns)
             cfg.segment_slots = int(distal.segment_slots)
         cfg.seed = int(seed) & 0xFFFFFFFF
-        cfg.stream = stream
+        cfg.shard_rank, cfg.shard_world = int(shard_rank), int(shard_world)
+        cfg.use_caller_stream = int(stream is not None)
+        cfg.stream = stream if stream else None
+        self.shard_rank, self.shard_world = int(shard_rank), max(int(shard_world), 1)
+        per = self.column_dim // self.shard_world
+        self.column_range = (self.shard_rank * per, (self.shard_rank + 1) * per)
         self.segment_capacity, self.segment_slots = cfg.segment_capacity, cfg.segment_slots
         self.seed = cfg.seed
         handle = C.c_void_p()
@@ -88,7 +93,8 @@ class Engine:
         self.steps = 0
         self._banks = []
         if self.has_sp:
-            self.set_permanence(proximal._permanence)
+            c0, c1 = self.column_range          # a sharded handle only ever reads its own rows
+            self.set_permanence(proximal._permanence[c0:c1], row_begin=c0)
             self.words = self.info().words_per_row
 
     def __del__(self):
@@ -175,6 +181,22 @@ class Engine:
         self._check(self.lib.htm_run(self.h, C.c_void_p(device_bank), int(n_inputs), int(n_steps), int(bool(learning)),
                                      int(bool(use_graph))), "htm_run")
         self.steps += n_steps
+
+    # ---- column-sharded stepping (shard_world > 1): begin -> all-gather by the caller -> finish
+    def shard_record_bytes(self):
+        return int(self._check(self.lib.htm_shard_record_bytes(self.h), "htm_shard_record_bytes"))
+
+    def shard_begin(self, send_ptr, input_bits=None, device_bank=None, n_inputs=1, learning=True):
+        if input_bits is not None:
+            packed = pack_bits(input_bits, self.words)
+            rc = self.lib.htm_shard_begin(self.h, None, 1, packed.ctypes.data_as(C.c_void_p), int(bool(learning)), C.c_void_p(send_ptr))
+        else:
+            rc = self.lib.htm_shard_begin(self.h, C.c_void_p(device_bank), int(n_inputs), None, int(bool(learning)), C.c_void_p(send_ptr))
+        self._check(rc, "htm_shard_begin")
+
+    def shard_finish(self, recv_ptr, learning=True):
+        self._check(self.lib.htm_shard_finish(self.h, C.c_void_p(recv_ptr), int(bool(learning))), "htm_shard_finish")
+        self.steps += 1
 
     def profile(self, enable):
         self._check(self.lib.htm_profile(self.h, int(bool(enable))), "htm_profile")

@@ -73,7 +73,11 @@ typedef struct htm_config {
     int32_t segment_capacity;           /* max segments; overflow => HTM_ERR_CAPACITY */
     int32_t segment_slots;              /* synapse slots per segment, multiple of 64, <= 512 */
     uint32_t seed;                      /* keyed random draws, see bithtm_amd/csrc/htm_rng.h */
-    void *stream;                       /* hipStream_t to enqueue on, or NULL for a private stream */
+    int32_t shard_rank;                 /* column sharding: this handle owns columns               */
+    int32_t shard_world;                /*   [rank, rank+1) * column_dim / world; 0 or 1 = unsharded */
+    int32_t use_caller_stream;          /* 1: enqueue on `stream` (NULL then means the default stream, e.g.
+                                           torch's current stream); 0: create a private stream */
+    void *stream;                       /* hipStream_t, see use_caller_stream */
 } htm_config;
 
 typedef struct htm_info {
@@ -84,8 +88,13 @@ typedef struct htm_info {
     int32_t active_cells;               /* len(active_cell[0]) of the last step */
     int32_t has_distal_state;           /* last_state.distal_state is not None */
     int32_t has_winner_cells;           /* last_state.winner_cell is not None */
-    int32_t capacity_error;             /* sticky: 1 = segment pool, 2 = synapse slots, 4 = work list */
+    int32_t capacity_error;             /* sticky: 1 = segment pool, 2 = synapse slots, 4 = work list,
+                                           8 = dead-segment report of a sharded handle */
     int32_t words_per_row;              /* packed input words per SP row (input_dim padded to 128 bits) */
+    int32_t new_segment_requests;       /* last step: winners without a matching segment (projections.py:271) */
+    int32_t recycled_segments;          /* last step: of those, served by recycling (projections.py:80-85) */
+    int32_t appended_segments;          /* last step: served by fresh ids (projections.py:90-94) */
+    int32_t work_items;                 /* last step: segments that learned or were punished */
 } htm_info;
 
 /* Device arrays readable with htm_read / writable with htm_write. Element type and count
@@ -150,6 +159,24 @@ int htm_run(htm_handle *h, const uint32_t *device_inputs, int32_t n_inputs, int3
  * (ceil(input_dim/32) host words each, as for htm_step) into a handle-owned device bank laid out
  * as htm_run expects, and return its device address.  Freed by htm_destroy. */
 int htm_bank_upload(htm_handle *h, const uint32_t *host_inputs, int32_t n_inputs, uint32_t **device_bank);
+
+/* Column-sharded timestep (one handle per GPU, shard_world > 1; DESIGN.md "Multi-GPU").  The
+ * reference has no counterpart: it is HierarchicalTemporalMemory.process (networks.py:146-149)
+ * split around the one exchange the sharding needs.
+ *   htm_shard_begin   the rank's own part that precedes the exchange; writes this rank's record
+ *                     (htm_shard_record_bytes bytes) to send_device.  The input is either a
+ *                     device bank as for htm_run (packed_input == NULL) or one host input as for
+ *                     htm_step (device_inputs == NULL).
+ *   (caller)          all-gather of the records in rank order into recv_device
+ *                     (world * record bytes) on the same stream, e.g. RCCL ncclAllGather
+ *   htm_shard_finish  global top-k, segment allocation and this rank's share of the learning and
+ *                     of the segment scan.
+ * With identical inputs on all ranks the union of the ranks' results equals the unsharded result
+ * bit for bit. */
+int64_t htm_shard_record_bytes(htm_handle *h);
+int htm_shard_begin(htm_handle *h, const uint32_t *device_inputs, int32_t n_inputs, const uint32_t *packed_input,
+                    int32_t learning, void *send_device);
+int htm_shard_finish(htm_handle *h, const void *recv_device, int32_t learning);
 
 int htm_sync(htm_handle *h);
 int htm_get_info(htm_handle *h, htm_info *out);      /* synchronises */

@@ -1,0 +1,257 @@
+"""Column-sharded form of the oracle timestep.  TEST INFRASTRUCTURE ONLY.
+
+This file pins the multi-GPU protocol the HIP engine implements ("Multi-GPU"):
+rank r of R owns the contiguous columns [c0, c1) -- their Spatial Pooler rows and duty cycles,
+their cells, and every distal segment whose owning cell is one of those cells.  All arrays keep
+the global index space ("replicated address space"): segment ids, cell ids and column ids mean
+the same thing on every rank; a rank simply never touches rows it does not own.
+
+One exchange per timestep (an all-gather of fixed-size per-rank records):
+
+    boosted[C_local]      float64 boosted overlaps of the rank's columns
+    act/win/unacc[C_local] the cell words each local column WOULD have if it became active
+                          (computable before the global top-k: they depend only on the
+                          rank's own previous predictions / segment maxima / segment counts)
+    dead[]                ids of owned segments that dropped below the matching threshold
+                          during the previous step's learning (needed by the global
+                          lowest-id-first recycling rule, projections.py:80-81)
+
+After the gather every rank performs the identical global top-k and the identical segment-id
+allocation, so no further communication is needed and the R-way result equals the 1-way result
+bit for bit.  `all_gather` is injected: torch.distributed (gloo) in tests/test_sharded_gloo.py.
+"""
+
+from types import SimpleNamespace
+
+import numpy as np
+
+from .fexp import exp_f32
+from .htm_oracle import (EPS32, SPParams, TMParams, TemporalMemoryOracle, sp_derived, stable_topk)
+from .keyed_rng import draw_unit, STREAM_LEAST_USED, STREAM_SEGMENT_JITTER
+
+
+def shard_range(rank, world, column_dim):
+    """Contiguous, equal column shards (column_dim must divide evenly)."""
+    if column_dim % world:
+        raise ValueError("column_dim must be a multiple of the number of shards")
+    per = column_dim // world
+    return rank * per, (rank + 1) * per
+
+
+class ShardedHTMOracle:
+    def __init__(self, rank, world, input_dim, column_dim, cell_dim, active_columns=None, seed=0,
+                 sp_params=None, tm_params=None, permanence=None):
+        if active_columns is None:
+            active_columns = round(column_dim * 0.02)
+        self.rank, self.world = rank, world
+        self.input_dim, self.column_dim, self.cell_dim, self.k = input_dim, column_dim, cell_dim, active_columns
+        self.c0, self.c1 = shard_range(rank, world, column_dim)
+        self.spp = sp_params or SPParams()
+        self.d_sp = sp_derived(self.spp, column_dim, active_columns)
+        assert permanence is not None and permanence.shape == (column_dim, input_dim)
+        self.permanence = np.array(permanence[self.c0:self.c1], dtype=np.float64)      # own rows only
+        self.duty = np.zeros(self.c1 - self.c0, dtype=np.float32)
+        # the TM store keeps the global index space; rows of segments owned elsewhere stay untouched
+        self.tm = TemporalMemoryOracle(column_dim, cell_dim, tm_params, seed)
+        self.dead_out = np.zeros(0, dtype=np.int64)       # reported with the next exchange
+
+    # ---- ownership
+    def owns_cell(self, flat):
+        col = np.asarray(flat) // self.cell_dim
+        return (col >= self.c0) & (col < self.c1)
+
+    # ---- phase A: everything that needs only this rank's own state
+    def local_record(self, input_bits):
+        tm, K = self.tm, self.cell_dim
+        connected = self.permanence >= self.spp.permanence_threshold
+        overlaps = (connected & input_bits).sum(axis=1)
+        boosted = exp_f32(self.d_sp.coef32 * self.duty).astype(np.float64) * overlaps
+        cols = np.arange(self.c0, self.c1)
+        predicted = tm.prev_prediction[cols]
+        bursting = ~predicted.any(axis=1)
+        flat = cols[:, None] * K + np.arange(K)
+        if tm.prev_distal is None:
+            column_matching = np.zeros(len(cols), dtype=np.bool_)
+            best = np.zeros((len(cols), K), dtype=np.bool_)
+            has_match = np.zeros((len(cols), K), dtype=np.bool_)
+        else:
+            cell_max = tm.prev_distal.max_jittered_potential.reshape(self.column_dim, K)[cols]
+            column_max = cell_max.max(axis=1, keepdims=True)
+            column_matching = (column_max >= tm.params.segment_matching_threshold)[:, 0]
+            best = np.abs(cell_max - column_max) < EPS32
+            has_match = ~(cell_max < EPS32)
+        count = tm.segcount.reshape(self.column_dim, K)[cols].astype(np.float32)
+        u = draw_unit(tm.seed, STREAM_LEAST_USED, tm.step_index, flat)
+        jittered = (count.astype(np.float64) + u).astype(np.float32)
+        least = np.abs(jittered - jittered.min(axis=1, keepdims=True)) < EPS32
+        winner = predicted | (bursting[:, None] & np.where(column_matching[:, None], best, least))
+        act = predicted | bursting[:, None]
+        unacc = winner & ~has_match if tm.prev_distal is not None else np.zeros_like(winner)
+        rec = SimpleNamespace(overlaps=overlaps, boosted=boosted, act=act, win=winner, unacc=unacc,
+                              bursting=bursting, dead=self.dead_out.copy())
+        return rec
+
+    # ---- phase B: identical global decisions + this rank's share of the work
+    def finish_step(self, input_bits, records, learning=True):
+        tm, K, C = self.tm, self.cell_dim, self.column_dim
+        p, d = tm.params, tm.d
+        t = tm.step_index
+        boosted = np.concatenate([r.boosted for r in records])
+        act_spec = np.concatenate([r.act for r in records])
+        win_spec = np.concatenate([r.win for r in records])
+        unacc_spec = np.concatenate([r.unacc for r in records])
+        burst_spec = np.concatenate([r.bursting for r in records])
+        active = stable_topk(boosted, self.k)                                  # identical everywhere
+        # dead segments reported by the other ranks: only the "< threshold" fact matters here
+        for r, rec in enumerate(records):
+            if r != self.rank and len(rec.dead):
+                tm.seg_nsyn[rec.dead] = 0
+        # SP learning and duty cycle on the own rows
+        mine = active[(active >= self.c0) & (active < self.c1)] - self.c0
+        if learning:
+            self.permanence[mine] += np.where(input_bits, self.d_sp.delta_on, self.d_sp.delta_off)
+        self.duty *= self.d_sp.momentum32
+        self.duty[mine] += self.d_sp.increment32
+
+        flat = active[:, None] * K + np.arange(K)
+        winner_flat = flat[win_spec[active]]
+        activation = np.zeros((C, K), dtype=np.bool_)
+        activation[active] = act_spec[active]
+        dead_out = []
+        if learning and tm.prev_distal is not None:
+            dd = tm.prev_distal
+            m = dd.matching_segment                                            # owned segments only
+            mcell = tm.seg_cell[m]
+            is_winner = np.zeros(tm.N, dtype=np.bool_)
+            is_winner[winner_flat] = True
+            unpredicted = dd.prediction[mcell] < 1e-8
+            best = np.abs(dd.matching_segment_jittered_potential - dd.max_jittered_potential[mcell]) < EPS32
+            learning_seg = m[is_winner[mcell] & (dd.matching_segment_active | (unpredicted & best))]
+            column_active = np.zeros(C, dtype=np.bool_)
+            column_active[active] = True
+            punished = m[~column_active[mcell // K]]
+            # allocation: every rank takes the same decision (projections.py:79-95, 271-281)
+            unaccounted = flat[unacc_spec[active]]
+            n_w = -1 if tm.prev_winner is None else len(tm.prev_winner)
+            if len(unaccounted):
+                recycled = np.flatnonzero(tm.seg_nsyn[:tm.S] < p.segment_matching_threshold)[:len(unaccounted)]
+                n_r = len(recycled)
+                n_new = len(unaccounted) - n_r
+                fresh = np.arange(tm.S, tm.S + n_new)
+                tm._ensure_rows(tm.S + n_new)
+                old_cells = tm.seg_cell[recycled]
+                own_old = self.owns_cell(old_cells)
+                np.subtract.at(tm.segcount, old_cells[own_old], 1)
+                ids = np.concatenate([recycled, fresh]).astype(np.int64)
+                tm.seg_cell[ids] = unaccounted
+                own_new = self.owns_cell(unaccounted)
+                tm.segcount[unaccounted[own_new]] += 1
+                tm.presyn[ids[own_new]] = -1
+                tm.perm[ids[own_new]] = -1.0
+                tm.seg_nsyn[ids] = 0
+                # segments bound elsewhere: remember only whether they end up below the threshold
+                grown = min(p.segment_sampling_synapses, n_w) if n_w > 0 else 0
+                tm.seg_nsyn[ids[~own_new]] = grown
+                tm.S += n_new
+                learning_seg = np.concatenate([learning_seg, ids[own_new]])
+            act_pad = tm._padded(tm.prev_activation)
+            before = tm.seg_nsyn[learning_seg].copy()
+            tm._update_permanence(learning_seg, act_pad, d.learn_active, d.learn_inactive, d.learn_prune)
+            if tm.prev_winner is not None:
+                tm._grow(learning_seg.astype(np.int64), act_pad, tm.prev_winner, t)
+            thr = p.segment_matching_threshold
+            dead_out.append(learning_seg[(before >= thr) & (tm.seg_nsyn[learning_seg] < thr)])
+            before = tm.seg_nsyn[punished].copy()
+            tm._update_permanence(punished, act_pad, d.punish_active, d.punish_inactive, d.punish_prune)
+            dead_out.append(punished[(before >= thr) & (tm.seg_nsyn[punished] < thr)])
+        self.dead_out = np.concatenate(dead_out).astype(np.int64) if dead_out else np.zeros(0, dtype=np.int64)
+
+        distal = self._scan_owned(activation, t)
+        prediction = distal.prediction.reshape(C, K) > 1e-8
+        tm.prev_prediction, tm.prev_activation = prediction, activation
+        tm.prev_winner = winner_flat
+        tm.prev_distal = distal
+        tm.step_index += 1
+        return SimpleNamespace(active_column=active, boosted_overlaps=boosted, winner_flat=winner_flat,
+                               cell_activation=activation, cell_prediction=prediction,     # own columns only
+                               bursting=burst_spec[active], distal_state=distal)
+
+    def _scan_owned(self, activation, step):
+        """PredictiveProjection.process restricted to the segments this rank owns."""
+        tm, p = self.tm, self.tm.params
+        act_pad = tm._padded(activation)
+        segs = np.arange(tm.S)
+        owned = self.owns_cell(tm.seg_cell[:tm.S])
+        _, _, idx = tm._targets(segs)
+        hit = act_pad[idx] & owned[:, None]
+        potential = hit.sum(axis=1).astype(np.int64)
+        matching = np.flatnonzero(potential >= p.segment_matching_threshold) if p.segment_matching_threshold > 0 \
+            else np.flatnonzero(owned)
+        connected = (tm.perm[matching] >= tm.d.threshold32) & hit[matching]
+        activation_count = connected.sum(axis=1).astype(np.int64)
+        active = activation_count >= p.segment_activation_threshold
+        cells = tm.seg_cell[matching]
+        prediction = np.bincount(cells, weights=active, minlength=tm.N).astype(np.float64)
+        u = draw_unit(tm.seed, STREAM_SEGMENT_JITTER, step, matching)
+        jittered = (potential[matching].astype(np.float32).astype(np.float64) + u).astype(np.float32)
+        cell_max = np.zeros(tm.N, dtype=np.float32)
+        np.maximum.at(cell_max, cells, jittered)
+        return SimpleNamespace(prediction=prediction, segment_potential=potential, matching_segment=matching,
+                               matching_segment_activation=activation_count, matching_segment_active=active,
+                               max_jittered_potential=cell_max, matching_segment_jittered_potential=jittered)
+
+    def step(self, input_bits, all_gather, learning=True):
+        """all_gather(record) -> [record of rank 0, ..., record of rank R-1]."""
+        input_bits = np.asarray(input_bits, dtype=np.bool_)
+        rec = self.local_record(input_bits)
+        return self.finish_step(input_bits, all_gather(rec), learning=learning), rec
+
+
+# ---- fixed-size wire format of one rank's record (what the HIP engine puts in its send buffer)
+
+DEAD_CAP = 256
+
+
+def burst_words(c_local):
+    return (c_local + 31) // 32
+
+
+def record_nbytes(c_local):
+    """[boosted f64 x C_local][act u32 x C_local][win u32 x C_local][unacc u32 x C_local]
+    [bursting bits u32 x ceil(C_local/32)][n_dead u32][dead ids u32 x DEAD_CAP][pad to 16 bytes]"""
+    n = c_local * (8 + 4 + 4 + 4) + 4 * burst_words(c_local) + 4 + 4 * DEAD_CAP
+    return (n + 15) // 16 * 16
+
+
+def pack_record(rec, cell_dim):
+    c_local = len(rec.boosted)
+    buf = np.zeros(record_nbytes(c_local), dtype=np.uint8)
+    weights = (np.uint32(1) << np.arange(cell_dim, dtype=np.uint32))
+    o = 0
+    buf[o:o + 8 * c_local] = rec.boosted.astype(np.float64).view(np.uint8); o += 8 * c_local
+    for mat in (rec.act, rec.win, rec.unacc):
+        buf[o:o + 4 * c_local] = (mat.astype(np.uint32) * weights).sum(axis=1).astype(np.uint32).view(np.uint8)
+        o += 4 * c_local
+    bw = burst_words(c_local)
+    bits = np.zeros(bw * 32, dtype=np.bool_)
+    bits[:c_local] = rec.bursting
+    buf[o:o + 4 * bw] = np.packbits(bits, bitorder="little"); o += 4 * bw
+    if len(rec.dead) > DEAD_CAP:
+        raise OverflowError("more newly dead segments than the exchange record holds")
+    buf[o:o + 4] = np.array([len(rec.dead)], dtype=np.uint32).view(np.uint8); o += 4
+    buf[o:o + 4 * len(rec.dead)] = rec.dead.astype(np.uint32).view(np.uint8)
+    return buf
+
+
+def unpack_record(buf, c_local, cell_dim):
+    o = 0
+    boosted = buf[o:o + 8 * c_local].view(np.float64).copy(); o += 8 * c_local
+    mats = []
+    for _ in range(3):
+        words = buf[o:o + 4 * c_local].view(np.uint32); o += 4 * c_local
+        mats.append(((words[:, None] >> np.arange(cell_dim, dtype=np.uint32)) & 1).astype(np.bool_))
+    bw = burst_words(c_local)
+    bursting = np.unpackbits(buf[o:o + 4 * bw], bitorder="little")[:c_local].astype(np.bool_); o += 4 * bw
+    n_dead = int(buf[o:o + 4].view(np.uint32)[0]); o += 4
+    dead = buf[o:o + 4 * n_dead].view(np.uint32).astype(np.int64)
+    return SimpleNamespace(boosted=boosted, act=mats[0], win=mats[1], unacc=mats[2], dead=dead, bursting=bursting)

@@ -1,0 +1,123 @@
+"""GPU: the column-sharded HIP path.  R shards run inside one process on the one GPU of the test
+box (the all-gather becomes device copies), and every rank's share of every result must equal the
+unsharded oracle bit for bit -- the same check tests/test_sharded_gloo.py makes on the CPU protocol."""
+
+import numpy as np
+import pytest
+
+from oracle import HTMOracle, SPParams, TMParams, canonical_synapses
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(world, I, C, K, P, density, noise, steps, jump, seed, spp=None, tmp=None, slots=128):
+    import torch
+    import bithtm_amd as B
+    from bithtm_amd.distributed import LocalGroup
+    from bithtm_amd.engine import words_to_bool
+    from bithtm_amd import _lib as L
+    np.random.seed(seed)
+    spp_, tmp_ = spp or SPParams(), tmp or TMParams()
+    perm = np.random.randn(C, I) * spp_.permanence_std + spp_.permanence_mean
+    k = round(C * 0.02)
+    ora = HTMOracle(I, C, K, active_columns=k, seed=seed, sp_params=spp, tm_params=tmp, permanence=perm)
+
+    def parts():
+        prox = B.DenseProjection.__new__(B.DenseProjection)
+        prox.input_dim, prox.output_dim = I, C
+        prox.permanence_threshold, prox.permanence_increment, prox.permanence_decrement = \
+            spp_.permanence_threshold, spp_.permanence_increment, spp_.permanence_decrement
+        prox._engine, prox._permanence = None, perm
+        return dict(proximal=prox,
+                    boosting=B.ExponentialBoosting(C, k, intensity=spp_.boost_intensity, momentum=spp_.boost_momentum),
+                    distal=B.PredictiveProjection(C * K, segment_slots=slots, **{f: getattr(tmp_, f) for f in tmp_.__dataclass_fields__}))
+    from bithtm_amd.distributed import ShardedHTM
+    group = LocalGroup.__new__(LocalGroup)
+    group.members = [ShardedHTM(I, C, K, rank=r, world=world, active_columns=k, seed=seed, all_gather=lambda a, b: None, **parts())
+                     for r in range(world)]
+    rng = np.random.RandomState(seed + 1)
+    bank = rng.rand(P, I) < density
+    thr = tmp_.segment_matching_threshold
+    dead_seen = 0
+    for t in range(steps):
+        idx = int(rng.randint(P)) if (jump > 0 and rng.rand() < jump) else t % P
+        x = bank[idx] ^ (rng.rand(I) < noise)
+        learning = (t % 23) != 5
+        o_sp, o_tm = ora.step(x, learning=learning)
+        group.process(x, learning=learning)
+        check_store = (t % 25 == 0) or t == steps - 1
+        otm = ora.temporal_memory
+        for m in group.members:
+            eng = m.engine
+            c0, c1 = m.column_range
+            info = eng.check_capacity()
+            tag = f"rank {m.rank}/{world} step {t}"
+            if info.segments != otm.S:
+                flags = eng.read(L.F_SEG_NSYN, np.int32, info.segments)
+                sc = eng.read(L.F_SEG_CELL, np.int32, info.segments)
+                n = min(info.segments, otm.S)
+                bad = np.flatnonzero((flags[:n] < thr) != (otm.seg_nsyn[:n] < thr))
+                raise AssertionError(
+                    f"{tag}: S {info.segments} vs {otm.S}; requests={info.new_segment_requests} recycled={info.recycled_segments} "
+                    f"appended={info.appended_segments}; oracle dead now={int((otm.seg_nsyn[:otm.S] < thr).sum())}; "
+                    f"flag mismatches at {bad[:10]} flags={flags[bad[:10]]} oracle={otm.seg_nsyn[bad[:10]]} "
+                    f"owners={(sc[bad[:10]] // K) // ((c1 - c0))} learning={learning}")
+            act_cols = eng.read(L.F_ACTIVE_COLUMN, np.int32, k)
+            assert np.array_equal(act_cols, o_sp.active_column), f"{tag}: active columns"
+            act = words_to_bool(eng.read(L.F_CELL_ACTIVATION, np.uint32, C), K)
+            assert np.array_equal(act, o_tm.cell_activation), f"{tag}: cell activation (replicated)"
+            pred = words_to_bool(eng.read(L.F_CELL_PREDICTION, np.uint32, C), K)
+            assert np.array_equal(pred[c0:c1], o_tm.cell_prediction[c0:c1]), f"{tag}: cell prediction (own)"
+            win = eng.read(L.F_WINNER_CELL, np.int32, info.winner_cells)
+            assert np.array_equal(win, o_tm.winner_cell[0] * K + o_tm.winner_cell[1]), f"{tag}: winner cells"
+            burst = eng.read(L.F_BURSTING, np.uint8, k).astype(bool)
+            assert np.array_equal(burst, o_tm.active_column_bursting[:, 0]), f"{tag}: bursting"
+            boosted = eng.read(L.F_BOOSTED, np.float64, C)
+            assert np.array_equal(boosted.view(np.int64), o_sp.boosted_overlaps.view(np.int64)), f"{tag}: boosted"
+            seg_cell = eng.read(L.F_SEG_CELL, np.int32, otm.S)
+            assert np.array_equal(seg_cell, otm.seg_cell[:otm.S]), f"{tag}: seg_cell"
+            owned = (seg_cell // K >= c0) & (seg_cell // K < c1)
+            nsyn = eng.read(L.F_SEG_NSYN, np.int32, otm.S)
+            assert np.array_equal(nsyn[owned], otm.seg_nsyn[:otm.S][owned]), f"{tag}: nsyn (own)"
+            od = o_tm.distal_state
+            mseg = eng.read(L.F_MATCH_SEGMENT, np.int32, otm.S)
+            mine = owned[od.matching_segment]
+            assert np.array_equal(mseg, od.matching_segment[mine]), f"{tag}: matching segments (own)"
+            minfo = eng.read(L.F_MATCH_INFO, np.uint32, otm.S)
+            assert np.array_equal((minfo >> 31).astype(bool), od.matching_segment_active[mine]), f"{tag}: active segments (own)"
+            dead_seen += int((otm.seg_nsyn[:otm.S] < thr).sum() > 0)
+            if check_store:
+                E = eng.segment_slots
+                presyn = eng.read(L.F_SEG_PRESYN, np.int32, otm.S * E).reshape(otm.S, E)
+                pm = eng.read(L.F_SEG_PERM, np.float32, otm.S * E).reshape(otm.S, E)
+                ids = np.flatnonzero(owned)
+                a = canonical_synapses(seg_cell[ids], presyn[ids], pm[ids])
+                b = canonical_synapses(otm.seg_cell[ids], otm.presyn[ids], otm.perm[ids])
+                for (ca, ia, pa), (cb, ib, pb) in zip(a, b):
+                    assert ca == cb and np.array_equal(ia, ib) and np.array_equal(pa.view(np.int32), pb.view(np.int32)), \
+                        f"{tag}: synapses of an owned segment"
+                segcount = eng.read(L.F_SEGCOUNT, np.int32, C * K)
+                assert np.array_equal(segcount[c0 * K:c1 * K], otm.segcount[c0 * K:c1 * K]), f"{tag}: segcount (own)"
+                assert np.array_equal(eng.get_permanence(c0, c1 - c0).view(np.int64),
+                                      ora.spatial_pooler.permanence[c0:c1].view(np.int64)), f"{tag}: SP permanence (own)"
+                assert np.array_equal(eng.read_duty_cycle()[c0:c1].view(np.int32),
+                                      ora.spatial_pooler.duty_cycle[c0:c1].view(np.int32)), f"{tag}: duty (own)"
+    return dead_seen
+
+
+def test_two_shards_default_parameters():
+    _run(2, I=256, C=2048, K=32, P=50, density=0.06, noise=0.01, steps=300, jump=0.0, seed=51)
+
+
+def test_four_shards_stress_parameters_with_recycling():
+    spp = SPParams(permanence_mean=0.01, permanence_std=0.08, permanence_threshold=0.02, permanence_increment=0.05,
+                   permanence_decrement=0.02, boost_intensity=0.5, boost_momentum=0.95)
+    tmp = TMParams(permanence_initial=0.3, permanence_threshold=0.45, permanence_increment=0.12, permanence_decrement=0.14,
+                   permanence_punishment=0.2, segment_activation_threshold=12, segment_matching_threshold=9,
+                   segment_sampling_synapses=20)
+    dead = _run(4, I=256, C=1024, K=4, P=40, density=0.12, noise=0.02, steps=320, jump=0.15, seed=13, spp=spp, tmp=tmp)
+    assert dead > 0        # dead segments existed, so cross-rank recycling was exercised
+
+
+def test_eight_shards_k16():
+    _run(8, I=512, C=4096, K=16, P=50, density=0.04, noise=0.005, steps=200, jump=0.0, seed=9)
