@@ -941,8 +941,8 @@ __global__ __launch_bounds__(256) void k_tm_learn(Dev d, int p) {
 
 // PredictiveProjection.process (projections.py:245-255): per segment, potential = active
 // presynaptic cells; matching segments additionally count connected active synapses;
-// per-cell prediction and max jittered potential (:229-239).  16 lanes per segment, 16-byte
-// loads of the packed row, four segments in flight per lane group; a block owns SCAN_SEGS
+// per-cell prediction and max jittered potential (:229-239).  8 lanes per segment, 16-byte
+// loads of the packed row, two segments in flight per lane group; a block owns SCAN_SEGS
 // consecutive segment ids and also counts the recyclable ones among them (per 1024 ids) for the
 // next step's add_output.  The last duty of a timestep: publish the next step index.
 // use_lds: the bitmap of active columns is staged in LDS and consulted first, so that only the
@@ -970,19 +970,22 @@ __global__ __launch_bounds__(256) void k_tm_scan(Dev d, int p, int use_lds) {
     }
     const uint32_t *act = d.act[p];
     const uint32_t base3 = htm_stream_base(d.seed, HTM_STREAM_SEGMENT_JITTER, c->step[p]);
-    const int g = threadIdx.x >> 4, l = threadIdx.x & 15;
-    constexpr int U = SCAN_SEGS / 16;
+    // 8 lanes per segment, 16 bytes per lane: one 128-byte chunk = 32 synapse slots.  Packed rows
+    // rarely exceed one chunk (growth tops a segment up to 32 active synapses), so a typical row
+    // costs exactly 128 bytes of presynaptic ids.
+    const int g = threadIdx.x >> 3, l = threadIdx.x & 7;
+    constexpr int U = SCAN_SEGS / 32;              // segments in flight per lane group
     bool staged = false;
     for (int b = blockIdx.x; b * SCAN_SEGS < S; b += gridDim.x) {
-        int seg[U], n[U], pot[U], conn[U];
-        uint32_t bits[U];
+        int seg[U], n[U], pot[U], conn[U], n_true[U];
+        u64 bits[U];
         int4 ps[U];
-        // the synapse count and the first 64-slot chunk of each row are fetched together (the
-        // chunk is masked by the count afterwards): one memory round trip instead of two
         bool mine[U];
+        // the synapse count and the first chunk of each row are fetched together (the chunk is
+        // masked by the count afterwards): one memory round trip instead of two
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            seg[u] = min(b * SCAN_SEGS + u * 16 + g, S - 1);
+            seg[u] = min(b * SCAN_SEGS + u * 32 + g, S - 1);
             n[u] = d.seg_nsyn[seg[u]];
             mine[u] = true;
             if (d.world > 1) mine[u] = col_is_local(d, d.seg_cell[seg[u]]);       // rows of other ranks are not here
@@ -996,37 +999,36 @@ __global__ __launch_bounds__(256) void k_tm_scan(Dev d, int p, int use_lds) {
         }
         if (threadIdx.x == 0) s_recyc = 0;
         __syncthreads();
-        int n_true[U];                                // for the recyclable count (all ranks, all segments)
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const bool ok = b * SCAN_SEGS + u * 16 + g < S;
-            n_true[u] = ok ? n[u] : 0x7FFFFFFF;
+            const bool ok = b * SCAN_SEGS + u * 32 + g < S;
+            n_true[u] = ok ? n[u] : 0x7FFFFFFF;      // for the recyclable count (all ranks, all segments)
             if (!ok || !mine[u]) n[u] = 0;
             seg[u] = ok ? seg[u] : S;
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int e[4] = {ps[u].x, ps[u].y, ps[u].z, ps[u].w};
-            uint32_t bb = 0;
+            u64 bb = 0;
 #pragma unroll
             for (int qq = 0; qq < 4; ++qq)
-                bb |= scan_cell_active(act, e[qq], l * 4 + qq < n[u], use_lds) << qq;
+                bb |= (u64)scan_cell_active(act, e[qq], l * 4 + qq < n[u], use_lds) << qq;
             bits[u] = bb;
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            if (n[u] > 64) {                         // rare: rows longer than one 64-slot chunk
+            if (n[u] > 32) {                         // further chunks of longer rows
                 const int *prow = d.presyn + (size_t)seg[u] * d.E;
-                for (int i = 64 + l * 4, ch = 1; i < n[u]; i += 64, ++ch) {
+                for (int i = 32 + l * 4, ch = 1; i < n[u]; i += 32, ++ch) {
                     const int4 pv = *(const int4 *)(prow + i);
                     const int e[4] = {pv.x, pv.y, pv.z, pv.w};
 #pragma unroll
                     for (int qq = 0; qq < 4; ++qq)
-                        bits[u] |= scan_cell_active(act, e[qq], i + qq < n[u], use_lds) << (ch * 4 + qq);
+                        bits[u] |= (u64)scan_cell_active(act, e[qq], i + qq < n[u], use_lds) << (ch * 4 + qq);
                 }
             }
-            int v = __popc(bits[u]);
-            for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o);
+            int v = __popcll(bits[u]);
+            for (int o = 4; o > 0; o >>= 1) v += __shfl_xor(v, o);
             pot[u] = v;
         }
 #pragma unroll
@@ -1035,15 +1037,15 @@ __global__ __launch_bounds__(256) void k_tm_scan(Dev d, int p, int use_lds) {
             int cn = 0;
             if (matching) {
                 const float *mrow = d.sperm + (size_t)seg[u] * d.E;
-                for (int i = l * 4, ch = 0; i < n[u]; i += 64, ++ch) {
+                for (int i = l * 4, ch = 0; i < n[u]; i += 32, ++ch) {
                     const float4 pm = *(const float4 *)(mrow + i);
                     const float e[4] = {pm.x, pm.y, pm.z, pm.w};
 #pragma unroll
                     for (int qq = 0; qq < 4; ++qq)
-                        cn += ((bits[u] >> (ch * 4 + qq)) & 1u) && (e[qq] >= d.perm_thr);   // :171-172
+                        cn += ((bits[u] >> (ch * 4 + qq)) & 1ull) && (e[qq] >= d.perm_thr);   // :171-172
                 }
             }
-            for (int o = 8; o > 0; o >>= 1) cn += __shfl_xor(cn, o);
+            for (int o = 4; o > 0; o >>= 1) cn += __shfl_xor(cn, o);
             conn[u] = cn;
         }
 #pragma unroll

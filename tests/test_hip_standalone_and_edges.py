@@ -1,0 +1,160 @@
+"""GPU: the stand-alone SpatialPooler / TemporalMemory classes (htm_sp_step / htm_tm_step), the
+learning / return_winner_cell switches, edge-case inputs and the loud failure modes."""
+
+import numpy as np
+import pytest
+
+from oracle import SpatialPoolerOracle, TemporalMemoryOracle, HTMOracle, canonical_synapses
+
+pytestmark = pytest.mark.gpu
+
+
+def test_standalone_spatial_pooler_matches_oracle():
+    import bithtm_amd as B
+    I, C, k = 777, 3000, 60                      # neither a multiple of 32 / 256
+    np.random.seed(1)
+    sp = B.SpatialPooler(I, C, k)
+    ora = SpatialPoolerOracle(I, C, k, permanence=sp.proximal_projection.permanence.copy())
+    rng = np.random.RandomState(2)
+    for t in range(120):
+        x = rng.rand(I) < 0.1
+        learning = t % 7 != 3
+        got = sp.process(x, learning=learning)
+        want = ora.step(x, learning=learning)
+        assert got.active_column.dtype == np.int64 and got.overlaps.dtype == np.int64 and got.boosted_overlaps.dtype == np.float64
+        assert np.array_equal(got.active_column, want.active_column), t
+        assert np.array_equal(got.overlaps, want.overlaps), t
+        assert np.array_equal(got.boosted_overlaps.view(np.int64), want.boosted_overlaps.view(np.int64)), t
+    assert np.array_equal(sp.proximal_projection.permanence.view(np.int64), ora.permanence.view(np.int64))
+    assert np.array_equal(sp.boosting.duty_cycle.view(np.int32), ora.duty_cycle.view(np.int32))
+
+
+def test_standalone_temporal_memory_matches_oracle_with_unsorted_columns():
+    """TemporalMemory.process(sp_state) fed by a foreign SP: any object with `.active_column`."""
+    import bithtm_amd as B
+    from types import SimpleNamespace
+    C, K, k = 1024, 16, 24
+    tm = B.TemporalMemory(C, K, seed=5)
+    ora = TemporalMemoryOracle(C, K, seed=5)
+    rng = np.random.RandomState(3)
+    seqs = [np.sort(rng.choice(C, k, replace=False)) for _ in range(12)]
+    assert tm.last_state.cell_prediction.shape == (C, K) and not tm.last_state.cell_prediction.any()
+    for t in range(150):
+        cols = seqs[t % 12]
+        learning = t % 11 != 4
+        rwc = not (t % 13 == 6 and not learning)
+        shuffled = cols[rng.permutation(k)]                       # reference order is arbitrary (argpartition)
+        got = tm.process(SimpleNamespace(active_column=shuffled), learning=learning, return_winner_cell=rwc)
+        want = ora.step(cols, learning=learning, return_winner_cell=rwc)
+        assert np.array_equal(got.cell_activation, want.cell_activation), t
+        assert np.array_equal(got.cell_prediction, want.cell_prediction), t
+        assert np.array_equal(got.active_column_bursting, want.active_column_bursting), t
+        assert np.array_equal(got.active_cell[0], want.active_cell[0]) and np.array_equal(got.active_cell[1], want.active_cell[1]), t
+        if learning or rwc:
+            assert np.array_equal(got.winner_cell[0], want.winner_cell[0]) and np.array_equal(got.winner_cell[1], want.winner_cell[1]), t
+        else:
+            assert got.winner_cell is None and want.winner_cell is None
+        d, od = got.distal_state, want.distal_state
+        assert np.array_equal(d.matching_segment, od.matching_segment), t
+        assert np.array_equal(d.segment_potential, od.segment_potential), t
+        assert np.array_equal(d.prediction, od.prediction), t
+        assert np.array_equal(d.max_jittered_potential.view(np.int32), od.max_jittered_potential.view(np.int32)), t
+        assert tm.last_state is got
+    st = tm._engine.read_store()
+    a = canonical_synapses(st["seg_cell"], st["presyn"], st["perm"])
+    b = canonical_synapses(ora.seg_cell[:ora.S], ora.presyn[:ora.S], ora.perm[:ora.S])
+    assert len(a) == len(b) and all(x[0] == y[0] and np.array_equal(x[1], y[1]) and np.array_equal(x[2].view(np.int32), y[2].view(np.int32)) for x, y in zip(a, b))
+    assert tm.flatten_cell((np.array([2, 3]), np.array([1, 5]))).tolist() == [2 * K + 1, 3 * K + 5]
+
+
+def test_sp_and_tm_objects_fuse_into_one_engine_and_compute_alias():
+    import bithtm_amd as B
+    np.random.seed(4)
+    sp = B.SpatialPooler(100, 512, 12)
+    tm = B.TemporalMemory(512, 8, seed=1)
+    perm = sp.proximal_projection.permanence.copy()
+    htm = B.HierarchicalTemporalMemory(100, 512, 8, active_columns=12, spatial_pooler=sp, temporal_memory=tm)
+    ora = HTMOracle(100, 512, 8, active_columns=12, seed=1, permanence=perm)
+    rng = np.random.RandomState(5)
+    for t in range(40):
+        x = rng.rand(100) < 0.2
+        s, m = htm.compute(x)
+        os_, om = ora.step(x)
+        assert np.array_equal(s.active_column, os_.active_column) and np.array_equal(m.cell_prediction, om.cell_prediction)
+    with pytest.raises(RuntimeError):
+        sp.process(rng.rand(100) < 0.2)             # fused: step through the HTM object
+
+
+def test_edge_inputs_all_zero_and_all_one():
+    import bithtm_amd as B
+    np.random.seed(6)
+    htm = B.HierarchicalTemporalMemory(64, 256, 4, active_columns=8)
+    ora = HTMOracle(64, 256, 4, active_columns=8, seed=0, permanence=htm.spatial_pooler.proximal_projection.permanence.copy())
+    for x in (np.zeros(64, bool), np.ones(64, bool), np.zeros(64, bool), np.arange(64) % 2 == 0):
+        for _ in range(3):
+            s, m = htm.process(x)
+            os_, om = ora.step(x)
+            assert np.array_equal(s.active_column, os_.active_column)          # all-ties case: lowest indices win
+            assert np.array_equal(s.overlaps, os_.overlaps)
+            assert np.array_equal(m.cell_activation, om.cell_activation) and np.array_equal(m.cell_prediction, om.cell_prediction)
+
+
+def test_states_stay_valid_after_later_steps_and_unread_states_cost_nothing():
+    import bithtm_amd as B
+    np.random.seed(7)
+    htm = B.HierarchicalTemporalMemory(128, 1024, 8)
+    rng = np.random.RandomState(8)
+    xs = [rng.rand(128) < 0.1 for _ in range(6)]
+    kept = [htm.process(x) for x in xs]                   # hold every State, read them only afterwards
+    np.random.seed(7)
+    htm2 = B.HierarchicalTemporalMemory(128, 1024, 8)
+    for (s, m), x in zip(kept, xs):
+        s2, m2 = htm2.process(x)
+        assert np.array_equal(s.active_column, s2.active_column) and np.array_equal(m.cell_prediction, m2.cell_prediction)
+        assert np.array_equal(m.winner_cell[0], m2.winner_cell[0])
+
+
+def test_capacity_overflow_is_reported_not_truncated():
+    import bithtm_amd as B
+    np.random.seed(9)
+    tm = B.TemporalMemory(1024, 8, distal_projection=B.PredictiveProjection(1024 * 8, segment_capacity=64, segment_slots=64))
+    htm = B.HierarchicalTemporalMemory(128, 1024, 8, temporal_memory=tm)
+    rng = np.random.RandomState(10)
+    with pytest.raises(B.CapacityError, match="segment pool"):
+        for _ in range(40):
+            htm.process(rng.rand(128) < 0.1)
+            htm.engine.check_capacity()
+
+
+def test_bad_arguments_fail_loudly():
+    import bithtm_amd as B
+    with pytest.raises(B.HtmError):
+        B.HierarchicalTemporalMemory(64, 256, 33)                      # cell_dim > 32
+    tm = B.TemporalMemory(256, 4)
+    from types import SimpleNamespace
+    with pytest.raises(B.HtmError):
+        tm.process(SimpleNamespace(active_column=np.array([1, 1, 2])))   # duplicate column
+    with pytest.raises(NotImplementedError):
+        tm.process(SimpleNamespace(active_column=np.array([1, 2])), prev_state=tm.get_empty_state())
+
+
+def test_batched_run_equals_step_by_step():
+    """htm.run (device-resident bank, hipGraph replay) == the same inputs through process()."""
+    import bithtm_amd as B
+    rng = np.random.RandomState(11)
+    bank = rng.rand(30, 200) < 0.08
+    outs = []
+    for mode in ("graph", "eager", "process"):
+        np.random.seed(12)
+        htm = B.HierarchicalTemporalMemory(200, 2048, 16)
+        if mode == "process":
+            for t in range(95):
+                htm.process(bank[t % 30])
+        else:
+            htm.run(bank, 95, use_graph=(mode == "graph"))
+        st = htm.engine.read_store()
+        outs.append((htm.engine.read_sp_fields()["active_column"], st["seg_cell"], st["seg_nsyn"], st["perm"],
+                     htm.temporal_memory.last_state.cell_prediction))
+    for o in outs[1:]:
+        for a, b in zip(outs[0], o):
+            assert np.array_equal(a, b)

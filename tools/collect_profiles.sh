@@ -1,0 +1,33 @@
+#!/bin/bash
+# Run on the GPU box (via gpurun) from the repo root: bench line, rocprofv3 kernel stats, PMC
+# passes (each counter in its own run, kernel-trace only), scan stress, PCIe-inclusive rate.
+# Everything lands in gpurun_out/profile_<tag>/; copy what should be judged into profiles/.
+set -u
+TAG=${1:-r01}
+OUT=$GRAFT_REPO_ROOT/gpurun_out/profile_$TAG
+mkdir -p $OUT
+cd $GRAFT_REPO_ROOT
+timeout -k 10 400 python bench.py > $OUT/bench.json 2> $OUT/bench.log; echo "bench exit=$?"
+timeout -k 10 300 python tools/pcie_rate.py > $OUT/pcie_rate.txt 2>&1
+timeout -k 10 600 python tools/scan_stress.py --segments 250000 1000000 4000000 --slots 64 > $OUT/scan_stress.jsonl 2> $OUT/scan_stress.log
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $GRAFT_REPO_ROOT/bench.py --steps 500 --warmup 500 --no-cpu-baseline --no-graph > $OUT/stats.log 2>&1; echo "stats exit=$?"
+for ctr in FETCH_SIZE WRITE_SIZE; do
+  timeout -k 10 300 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $OUT/pmc_$ctr -- python3 $GRAFT_REPO_ROOT/bench.py --steps 200 --warmup 600 --no-cpu-baseline --no-graph > $OUT/pmc_$ctr.log 2>&1; echo "$ctr exit=$?"
+done
+# keep the merged-back payload small: drop the per-dispatch traces of the PMC runs after summarising
+python3 - <<'PY'
+import csv, glob, os, collections, json
+out = os.environ.get("OUT") or glob.glob(os.path.join(os.environ["GRAFT_REPO_ROOT"], "gpurun_out", "profile_*"))[-1]
+summary = {}
+for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+    for f in glob.glob(os.path.join(out, f"pmc_{ctr}", "*", "*counter_collection.csv")):
+        d = collections.defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == ctr:
+                d[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
+        summary[ctr] = {k: {"launches": len(v), "mean_last150_KB": sum(v[-150:]) / len(v[-150:])} for k, v in d.items()}
+json.dump(summary, open(os.path.join(out, "pmc_summary.json"), "w"), indent=1)
+PY
+find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*counter_collection.csv" -delete
+ls -R $OUT | head -40
