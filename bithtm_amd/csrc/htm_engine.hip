@@ -520,26 +520,34 @@ __global__ __launch_bounds__(1024) void k_shard_unpack(Dev d, const unsigned cha
 // (regularizations.py:19-21, float32, two separately rounded operations), clear the dense
 // per-column words of the non-winners, and run the Temporal Memory's per-column activation for
 // the winners of this block.  One block per 256 columns.
-__global__ __launch_bounds__(256) void k_sp_emit(Dev d, int p, int want_winner) {
+// `fused` (grids of at most 1024 blocks, all co-resident): the per-block counts of k_sp_count are
+// computed here and exchanged through one tagged 32-bit word per block -- a block publishes
+// {epoch, equal, greater} with a write-through store and reads its predecessors' words with
+// L1-bypassing loads until their epoch matches (MI355X guide, Guideline 16, form R2: the data is
+// the flag).  A block's own counts do not depend on other blocks, so there is no serial chain.
+__global__ __launch_bounds__(256) void k_sp_emit(Dev d, int p, int want_winner, int fused) {
     __shared__ uint32_t s_wave[4];
     __shared__ uint32_t s_gt, s_eq;
     __shared__ int s_col[256];
     __shared__ int s_n;
+    __shared__ uint32_t h[SEL_BINS];
+    __shared__ u64 s_prefix;
+    __shared__ uint32_t s_krem;
     const int tid = threadIdx.x;
     if (tid == 0) { s_gt = 0; s_eq = 0; s_n = 0; }
-    __syncthreads();
-    uint32_t g = 0, e = 0;
-    for (int i = tid; i < (int)blockIdx.x; i += 256) {
-        uint32_t v = d.sel_blk[i];
-        g += v & 0xFFFFu;
-        e += v >> 16;
+    u64 T;
+    uint32_t r;                                     // how many of the keys == T are selected
+    if (fused) {
+        sel_resolve<256>(d, d.sel_passes - 1, h, s_wave, &T, &r, &s_prefix, &s_krem);
+        __syncthreads();
+        if (blockIdx.x == 0 && tid == 0) { d.ctr->sel_prefix = T; d.ctr->sel_krem = r; }
+        if (d.sel_passes > 1)                       // pass-0 histogram is consumed: clear it for the next step
+            for (int i = blockIdx.x * 256 + tid; i < SEL_BINS; i += gridDim.x * 256) d.hist[i] = 0;
+    } else {
+        T = d.ctr->sel_prefix;
+        r = d.ctr->sel_krem;
+        __syncthreads();
     }
-    for (int o = 32; o > 0; o >>= 1) { g += __shfl_xor(g, o); e += __shfl_xor(e, o); }
-    if (lane_id() == 0) { atomicAdd(&s_gt, g); atomicAdd(&s_eq, e); }
-    __syncthreads();
-    const uint32_t gt_before = s_gt, eq_before = s_eq;
-    const u64 T = d.ctr->sel_prefix;
-    const uint32_t r = d.ctr->sel_krem;            // how many of the keys == T are selected
     const int c = blockIdx.x * 256 + tid;
     uint32_t flag = 0;
     if (c < d.C) {
@@ -548,6 +556,35 @@ __global__ __launch_bounds__(256) void k_sp_emit(Dev d, int p, int want_winner) 
     }
     uint32_t total;
     const uint32_t ex = block_excl_scan<256>(flag, s_wave, total);
+    uint32_t g = 0, e = 0;
+    if (fused) {
+        const uint32_t epoch = (d.ctr->step[p] & 0x7FFu) + 1u;          // 1..2048, changes every step
+        if (tid == 0)
+            __hip_atomic_store(&d.sel_blk[blockIdx.x], (epoch << 20) | ((total >> 16) << 10) | (total & 0xFFFFu),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int i = tid; i < (int)blockIdx.x; i += 256) {
+            uint32_t v = 0;
+            int spins = 0;
+            do {
+                v = __hip_atomic_load(&d.sel_blk[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((v >> 20) == epoch) break;
+                __builtin_amdgcn_s_sleep(1);
+            } while (++spins < (1 << 22));
+            if ((v >> 20) != epoch) atomicOr(&d.ctr->error, 16);        // a predecessor never arrived
+            g += v & 0x3FFu;
+            e += (v >> 10) & 0x3FFu;
+        }
+    } else {
+        for (int i = tid; i < (int)blockIdx.x; i += 256) {
+            uint32_t v = d.sel_blk[i];
+            g += v & 0xFFFFu;
+            e += v >> 16;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) { g += __shfl_xor(g, o); e += __shfl_xor(e, o); }
+    if (lane_id() == 0) { atomicAdd(&s_gt, g); atomicAdd(&s_eq, e); }
+    __syncthreads();
+    const uint32_t gt_before = s_gt, eq_before = s_eq;
     const uint32_t g_run = gt_before + (ex & 0xFFFFu), e_run = eq_before + (ex >> 16);
     const int first_pos = (int)(gt_before + min(eq_before, r));
     const bool sel_any = c < d.C && ((flag & 1u) || ((flag >> 16) && e_run < r));
@@ -1120,6 +1157,8 @@ struct htm_handle {
     std::vector<float> imp_match_jit;
     // profiling
     bool profile;
+    hipEvent_t prof_last;                  // event closing the previous kernel of the profiled chain
+    std::vector<hipEvent_t> prof_all;      // every event created (destroyed in htm_profile_read)
     std::vector<std::string> prof_names;
     std::vector<std::vector<std::pair<hipEvent_t, hipEvent_t>>> prof_events;
     std::vector<double> prof_ms;
@@ -1161,18 +1200,18 @@ static int prof_slot(htm_handle *h, const char *name) {
     return (int)h->prof_names.size() - 1;
 }
 
+// Profiling: ONE event after every kernel (and one at the start of a run); a kernel's time is the
+// difference to the previous event, i.e. its execution plus its place in the dependent chain --
+// the same thing rocprofv3's back-to-back kernel timestamps measure.
 #define LAUNCH_ON(h, strm, shmem, name, kernel, grid, block, ...)                                 \
     do {                                                                                         \
-        hipEvent_t e0_ = nullptr, e1_ = nullptr;                                                 \
-        if ((h)->profile) {                                                                      \
-            hipEventCreate(&e0_);                                                                \
-            hipEventCreate(&e1_);                                                                \
-            hipEventRecord(e0_, strm);                                                           \
-        }                                                                                        \
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), shmem, strm, __VA_ARGS__);           \
         if ((h)->profile) {                                                                      \
+            hipEvent_t e1_ = nullptr;                                                            \
+            hipEventCreateWithFlags(&e1_, hipEventDisableSystemFence);                           \
             hipEventRecord(e1_, strm);                                                           \
-            (h)->prof_events[prof_slot(h, name)].push_back({e0_, e1_});                          \
+            (h)->prof_events[prof_slot(h, name)].push_back({(h)->prof_last, e1_});               \
+            (h)->prof_last = e1_;                                                                \
         }                                                                                        \
     } while (0)
 #define LAUNCH(h, name, kernel, grid, block, ...) LAUNCH_ON(h, (h)->stream, 0, name, kernel, grid, block, __VA_ARGS__)
@@ -1194,8 +1233,9 @@ static void enqueue_sp(htm_handle *h, const uint32_t *bank, int n_inputs, int le
     Dev &d = h->d;
     LAUNCH(h, "sp_overlap", k_sp_overlap, h->sp_blocks, 1024, d, bank, n_inputs, h->G, p);
     for (int pass = 1; pass < d.sel_passes; ++pass) LAUNCH(h, "sp_select", k_sel_pass, h->sel_blocks, 1024, d, pass);
-    LAUNCH(h, "sp_count", k_sp_count, h->c256_blocks, 256, d);
-    LAUNCH(h, "sp_emit", k_sp_emit, h->c256_blocks, 256, d, p, want_winner);
+    const int fused = h->c256_blocks <= 1024;      // all blocks co-resident: count inside emit
+    if (!fused) LAUNCH(h, "sp_count", k_sp_count, h->c256_blocks, 256, d);
+    LAUNCH(h, "sp_emit", k_sp_emit, h->c256_blocks, 256, d, p, want_winner, fused);
     // (a forked graph branch for this independent update was measured at +17..29 us per step on
     // this runtime, against 2.3 us for one more kernel in the chain: tools/launch_overhead.hip)
     if (learning && !h->cfg.enable_tm) LAUNCH(h, "sp_learn", k_sp_learn, d.k, 256, d, bank, n_inputs, p);
@@ -1237,7 +1277,8 @@ extern "C" void htm_destroy(htm_handle *h) {
     hipStreamSynchronize(h->stream);
     for (auto &kv : h->graphs) hipGraphExecDestroy(kv.second);
     for (auto &v : h->prof_events)
-        for (auto &pr : v) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+        for (auto &pr : v) hipEventDestroy(pr.second);
+    for (hipEvent_t e : h->prof_all) hipEventDestroy(e);
     for (void *p : h->allocs) hipFree(p);
     if (h->side) hipStreamDestroy(h->side);
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
@@ -1281,6 +1322,7 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
     h->cfg = *cfg;
     h->device = cfg->device;
     h->profile = false;
+    h->prof_last = nullptr;
     h->step_host = 0;
     h->d_cols_stage = nullptr;
     h->rank = world > 1 ? cfg->shard_rank : 0;
@@ -1578,8 +1620,9 @@ extern "C" int htm_shard_finish(htm_handle *h, const void *recv_device, int32_t 
     learning = learning ? 1 : 0;
     LAUNCH(h, "shard_unpack", k_shard_unpack, h->sel_blocks, 1024, d, (const unsigned char *)recv_device, h->rank);
     for (int pass = 1; pass < d.sel_passes; ++pass) LAUNCH(h, "sp_select", k_sel_pass, h->sel_blocks, 1024, d, pass);
-    LAUNCH(h, "sp_count", k_sp_count, h->c256_blocks, 256, d);
-    LAUNCH(h, "sp_emit", k_sp_emit, h->c256_blocks, 256, d, p, 1);
+    const int fused = h->c256_blocks <= 1024;
+    if (!fused) LAUNCH(h, "sp_count", k_sp_count, h->c256_blocks, 256, d);
+    LAUNCH(h, "sp_emit", k_sp_emit, h->c256_blocks, 256, d, p, 1, fused);
     enqueue_tm(h, d.k, learning, 1, p, h->shard_bank, h->shard_n_inputs);
     h->step_host += 1;
     h->shard_open = false;
@@ -1638,7 +1681,8 @@ extern "C" int htm_get_info(htm_handle *h, htm_info *out) {
     if (c.error) {
         h->err = std::string("capacity exhausted:") + ((c.error & 1) ? " segment pool (segment_capacity)" : "") +
                  ((c.error & 2) ? " synapse slots (segment_slots)" : "") + ((c.error & 4) ? " work list / growth staging" : "") +
-                 ((c.error & 8) ? " dead-segment report (DEAD_CAP)" : "");
+                 ((c.error & 8) ? " dead-segment report (DEAD_CAP)" : "") +
+                 ((c.error & 16) ? " (internal) block hand-off timed out in k_sp_emit" : "");
     }
     return HTM_OK;
 }
@@ -1854,6 +1898,13 @@ extern "C" int htm_import_commit(htm_handle *h, int32_t segments, int32_t matchi
 extern "C" int htm_profile(htm_handle *h, int32_t enable) {
     if (!h) return HTM_ERR_ARGUMENT;
     h->profile = enable != 0;
+    if (h->profile) {                      // opening event of the chain
+        HIPCHK(h, hipSetDevice(h->device));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        HIPCHK(h, hipEventCreateWithFlags(&h->prof_last, hipEventDisableSystemFence));
+        HIPCHK(h, hipEventRecord(h->prof_last, h->stream));
+        h->prof_all.push_back(h->prof_last);
+    }
     return HTM_OK;
 }
 
@@ -1867,11 +1918,12 @@ extern "C" int htm_profile_read(htm_handle *h, int32_t max_kernels, const char *
             hipEventElapsedTime(&ms, pr.first, pr.second);
             h->prof_ms[i] += ms;
             h->prof_n[i] += 1;
-            hipEventDestroy(pr.first);
-            hipEventDestroy(pr.second);
+            h->prof_all.push_back(pr.second);
         }
         h->prof_events[i].clear();
     }
+    for (hipEvent_t e : h->prof_all) hipEventDestroy(e);
+    h->prof_all.clear();
     int n = (int)std::min<size_t>(h->prof_names.size(), (size_t)std::max(max_kernels, 0));
     for (int i = 0; i < n; ++i) {
         if (names) names[i] = h->prof_names[i].c_str();
