@@ -117,11 +117,12 @@ def run_single(args):
     n_bank = noisy.shape[0]
     log(f"[bench] setup {time.perf_counter() - t_setup:.1f}s; warm-up {args.warmup} steps")
     use_graph = not args.no_graph
-    eng.run(bank, n_bank, args.warmup, learning=True, use_graph=use_graph)
+    pipeline = not args.no_pipeline
+    eng.run(bank, n_bank, args.warmup, learning=True, use_graph=use_graph, pipeline=pipeline)
     eng.sync()
     eng.check_capacity()
     t0 = time.perf_counter()
-    eng.run(bank, n_bank, args.steps, learning=True, use_graph=use_graph)
+    eng.run(bank, n_bank, args.steps, learning=True, use_graph=use_graph, pipeline=pipeline)
     eng.sync()
     dt = time.perf_counter() - t0
     info = eng.check_capacity()
@@ -161,7 +162,8 @@ def run_single(args):
         config=dict(workload="configs[2]: 65536 columns x 32 cells, SP + TM learning on, 1 MI355X",
                     input_dim=w["input_dim"], column_dim=w["column_dim"], cell_dim=w["cell_dim"], active_columns=k,
                     patterns=w["patterns"], input_density=w["density"], flip_noise=w["noise"],
-                    segments=int(info.segments), segment_slots=w["segment_slots"], hip_graph=use_graph),
+                    segments=int(info.segments), segment_slots=w["segment_slots"], hip_graph=use_graph,
+                    pipelined=pipeline),
         roofline=roofline, cpu_baseline=cpu,
         kernel_us_per_step={n: round(v, 2) for n, v in per_step_us.items()})
 
@@ -175,6 +177,7 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=40)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true", help="one role per launch (what the profiled replay always does)")
     args = ap.parse_args()
     if args.gpus > 1 or int(os.environ.get("WORLD_SIZE", "1")) > 1:
         from bench_sharded import run_sharded

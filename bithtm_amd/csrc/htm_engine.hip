@@ -31,7 +31,8 @@ typedef unsigned long long u64;
 #define SEL_MAX_PASSES 6
 #define SEL_DIGIT 12
 #define SEL_BINS 4096         // 1 << SEL_DIGIT
-#define SCAN_SEGS 64          // segments per block of the segment scan
+#define RB 512                // threads per block of the role kernels (overlap, select, learn, scan)
+#define SCAN_SEGS 64          // segments per 256-thread block iteration of the segment scan
 #define DEAD_CAP 256          // newly dead segment ids one rank can report per exchange
 #define CAND_CAP 256          // growth candidates staged per wave
 #define MAX_SLOTS 512
@@ -56,10 +57,12 @@ struct Counters {
     int32_t n_un;             // winners needing a new segment
     int32_t n_recycled, n_new, S_old;
     int32_t error;            // sticky capacity flags
-    u64 sel_prefix;           // k-th largest key and how many of the keys equal to it are winners
-    uint32_t sel_krem;
-    u64 sel_pass_prefix[SEL_MAX_PASSES + 1];    // radix-select state entering pass p
-    uint32_t sel_pass_krem[SEL_MAX_PASSES + 1];
+    // Spatial Pooler select state, double-buffered by the parity of the step it belongs to (the
+    // pipelined schedule computes step t+1's overlap / select digits while step t's TM runs)
+    u64 sel_prefix[2];        // k-th largest key and how many of the keys equal to it are winners
+    uint32_t sel_krem[2];
+    u64 sel_pass_prefix[2][SEL_MAX_PASSES + 1];    // radix-select state entering pass p
+    uint32_t sel_pass_krem[2][SEL_MAX_PASSES + 1];
 };
 
 struct Dev {
@@ -76,10 +79,10 @@ struct Dev {
     double *perm;             // [C][Ipad] float64 permanences (projections.py:16)
     uint32_t *mask;           // [C][W]    bit-packed `permanence >= threshold` (projections.py:19)
     float *duty;              // [C]
-    int *overlap;             // [C]
-    double *boosted;          // [C]
-    u64 *key;                 // [C] bits of boosted (non-negative doubles order like uint64)
-    uint32_t *hist;           // [SEL_MAX_PASSES][SEL_BINS]
+    int *overlap[2];          // [C]   parity double buffer, like the select state
+    double *boosted[2];       // [C]
+    u64 *key[2];              // [C] bits of boosted (non-negative doubles order like uint64)
+    uint32_t *hist;           // [2][SEL_MAX_PASSES][SEL_BINS]
     uint32_t *sel_blk;        // [ceil(C/1024)] packed (greater, equal) counts
     int *active_cols;         // [k] ascending
     uint32_t *input_stage;    // [W] host-fed input
@@ -91,6 +94,8 @@ struct Dev {
     int *winners[2];          // [k*32] winner cells (enc), ascending
     uint8_t *bursting;        // [k]
     uint32_t *colcnt;         // [k] popc(winner) | popc(unaccounted) << 16
+    uint32_t *winw_idx;       // [k] winner word of the idx-th active column (same as win[active_cols[idx]])
+    uint8_t *actcnt;          // [k] popc(active word) of the idx-th active column
     uint32_t *unacc_word;     // [k]
     int *unacc_list;          // [k*32] winners without a matching segment, ascending
     int *seg_cell;            // [Scap] owning cell (enc)
@@ -189,21 +194,25 @@ __global__ __launch_bounds__(256) void k_sp_build_mask(Dev d, int row_begin, int
 // (regularizations.py:15-17).  G lanes share one row (G = power of two, W4 16-byte chunks per row).
 // Sharded handles run it on their own rows only and leave the histogram to k_shard_unpack, which
 // sees the keys of all columns.
-__global__ __launch_bounds__(1024) void k_sp_overlap(Dev d, const uint32_t *__restrict__ bank, int n_inputs, int G, int p) {
-    __shared__ uint32_t h[SEL_BINS];               // histogram of the top key digit (select pass 0)
-    const int gtid = blockIdx.x * blockDim.x + threadIdx.x;
-    const int nthreads = gridDim.x * blockDim.x;
+// Roles are written against (blk, nblk) instead of blockIdx / gridDim so that two independent
+// roles can share one launch (pipelined schedule: step t's TM work beside step t+1's SP work).
+// sp = parity buffer of the SP step being computed; step_offset = that step minus the current one.
+__device__ __forceinline__ void role_overlap(const Dev &d, const uint32_t *__restrict__ bank, int n_inputs, int G,
+                                             int p, int sp, int step_offset, int blk, int nblk, uint32_t *h) {
+    const int gtid = blk * RB + threadIdx.x;
+    const int nthreads = nblk * RB;
     const bool do_hist = d.world == 1;
+    uint32_t *ghist = d.hist + sp * SEL_MAX_PASSES * SEL_BINS;
     if (do_hist) {
-        for (int i = gtid; i < (d.sel_passes - 1) * SEL_BINS; i += nthreads) d.hist[SEL_BINS + i] = 0;
-        for (int i = threadIdx.x; i < SEL_BINS; i += 1024) h[i] = 0;
+        for (int i = gtid; i < (d.sel_passes - 1) * SEL_BINS; i += nthreads) ghist[SEL_BINS + i] = 0;
+        for (int i = threadIdx.x; i < SEL_BINS; i += RB) h[i] = 0;
         if (gtid == 0) {
-            d.ctr->sel_pass_prefix[0] = 0;
-            d.ctr->sel_pass_krem[0] = (uint32_t)d.k;
+            d.ctr->sel_pass_prefix[sp][0] = 0;
+            d.ctr->sel_pass_krem[sp][0] = (uint32_t)d.k;
         }
         __syncthreads();
     }
-    const uint4 *in4 = (const uint4 *)(bank + (size_t)(d.ctr->step[p] % (uint32_t)n_inputs) * d.W);
+    const uint4 *in4 = (const uint4 *)(bank + (size_t)((d.ctr->step[p] + (uint32_t)step_offset) % (uint32_t)n_inputs) * d.W);
     const uint4 *mask4 = (const uint4 *)d.mask;
     const int lane = lane_id();
     const int rpw = 64 / G, sub = lane / G, l = lane % G;
@@ -233,20 +242,25 @@ __global__ __launch_bounds__(1024) void k_sp_overlap(Dev d, const uint32_t *__re
             const bool owner = l == 0 && row < d.c1;
             u64 key = 0;
             if (owner) {
-                d.overlap[row] = cn;
+                d.overlap[sp][row] = cn;
                 const float f = htm_exp_f32(d.coef * d.duty[row]);     // float32 product, documented exp
                 const double bo = (double)f * (double)cn;              // exact (24-bit x <= 16-bit)
-                d.boosted[row] = bo;
+                d.boosted[sp][row] = bo;
                 key = (u64)__double_as_longlong(bo);
-                d.key[row] = key;
+                d.key[sp][row] = key;
             }
             if (do_hist) hist_add(h, (uint32_t)(key >> sel_shift(0)), owner);
         }
     }
     if (!do_hist) return;
     __syncthreads();
-    for (int i = threadIdx.x; i < SEL_BINS; i += 1024)
-        if (h[i]) atomicAdd(&d.hist[i], h[i]);
+    for (int i = threadIdx.x; i < SEL_BINS; i += RB)
+        if (h[i]) atomicAdd(&ghist[i], h[i]);
+}
+
+__global__ __launch_bounds__(RB) void k_sp_overlap(Dev d, const uint32_t *__restrict__ bank, int n_inputs, int G, int p) {
+    __shared__ uint32_t h[SEL_BINS];               // histogram of the top key digit (select pass 0)
+    role_overlap(d, bank, n_inputs, G, p, p, 0, blockIdx.x, gridDim.x, h);
 }
 
 // GlobalInhibition.process (regularizations.py:28-29) as an exact radix select of the k-th
@@ -256,13 +270,13 @@ __global__ __launch_bounds__(1024) void k_sp_overlap(Dev d, const uint32_t *__re
 // sel_resolve: given the state entering pass `prev` and its histogram, the state entering
 // pass prev+1.  Called by all BS threads of the block; h is SEL_BINS words of LDS scratch.
 template <int BS>
-__device__ __forceinline__ void sel_resolve(const Dev &d, int prev, uint32_t *h, uint32_t *s_wave,
+__device__ __forceinline__ void sel_resolve(const Dev &d, int sp, int prev, uint32_t *h, uint32_t *s_wave,
                                             u64 *out_prefix, uint32_t *out_krem, u64 *s_res_prefix, uint32_t *s_res_krem) {
     const int tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
     const int shift = sel_shift(prev), nb = 1 << sel_bits(prev);
-    const u64 prefix = d.ctr->sel_pass_prefix[prev];
-    const uint32_t krem = d.ctr->sel_pass_krem[prev];
-    const uint32_t *gh = d.hist + prev * SEL_BINS;
+    const u64 prefix = d.ctr->sel_pass_prefix[sp][prev];
+    const uint32_t krem = d.ctr->sel_pass_krem[sp][prev];
+    const uint32_t *gh = d.hist + (sp * SEL_MAX_PASSES + prev) * SEL_BINS;
     constexpr int PER = SEL_BINS / BS;            // bins per thread, thread t owns [t*PER, (t+1)*PER)
     uint32_t cs = 0;
 #pragma unroll
@@ -298,55 +312,60 @@ __device__ __forceinline__ void sel_resolve(const Dev &d, int prev, uint32_t *h,
     *out_krem = *s_res_krem;
 }
 
-__global__ __launch_bounds__(1024) void k_sel_pass(Dev d, int pass) {
-    __shared__ uint32_t h[SEL_BINS];
-    __shared__ uint32_t s_wave[16];
-    __shared__ u64 s_prefix;
-    __shared__ uint32_t s_krem;
+struct SelShared { uint32_t h[SEL_BINS]; uint32_t wave[RB / 64]; u64 prefix; uint32_t krem; };
+
+template <int BS>
+__device__ __forceinline__ void role_sel_pass(const Dev &d, int pass, int sp, int blk, int nblk, SelShared *sh) {
     const int tid = threadIdx.x;
     u64 prefix;
     uint32_t krem;
-    sel_resolve<1024>(d, pass - 1, h, s_wave, &prefix, &krem, &s_prefix, &s_krem);
-    if (blockIdx.x == 0 && tid == 0) {
-        d.ctr->sel_pass_prefix[pass] = prefix;
-        d.ctr->sel_pass_krem[pass] = krem;
+    sel_resolve<BS>(d, sp, pass - 1, sh->h, sh->wave, &prefix, &krem, &sh->prefix, &sh->krem);
+    if (blk == 0 && tid == 0) {
+        d.ctr->sel_pass_prefix[sp][pass] = prefix;
+        d.ctr->sel_pass_krem[sp][pass] = krem;
     }
     __syncthreads();
     const int shift = sel_shift(pass), bits = sel_bits(pass), nb = 1 << bits;
     const u64 himask = ~0ull << (shift + bits);
-    for (int i = tid; i < nb; i += 1024) h[i] = 0;
+    for (int i = tid; i < nb; i += BS) sh->h[i] = 0;
     __syncthreads();
-    for (int c0 = blockIdx.x * 1024 + (tid & ~63); c0 < d.C; c0 += gridDim.x * 1024) {
+    const u64 *keys = d.key[sp];
+    for (int c0 = blk * BS + (tid & ~63); c0 < d.C; c0 += nblk * BS) {
         const int c = c0 + lane_id();
-        const u64 key = c < d.C ? d.key[c] : 0;
-        hist_add(h, (uint32_t)(key >> shift) & (nb - 1), c < d.C && ((key ^ prefix) & himask) == 0);
+        const u64 key = c < d.C ? keys[c] : 0;
+        hist_add(sh->h, (uint32_t)(key >> shift) & (nb - 1), c < d.C && ((key ^ prefix) & himask) == 0);
     }
     __syncthreads();
-    uint32_t *gh = d.hist + pass * SEL_BINS;
-    for (int i = tid; i < nb; i += 1024)
-        if (h[i]) atomicAdd(&gh[i], h[i]);
+    uint32_t *gh = d.hist + (sp * SEL_MAX_PASSES + pass) * SEL_BINS;
+    for (int i = tid; i < nb; i += BS)
+        if (sh->h[i]) atomicAdd(&gh[i], sh->h[i]);
+}
+
+__global__ __launch_bounds__(RB) void k_sel_pass(Dev d, int pass, int sp) {
+    __shared__ SelShared sh;
+    role_sel_pass<RB>(d, pass, sp, blockIdx.x, gridDim.x, &sh);
 }
 
 // per 256-column block: how many keys are above / equal to the k-th largest
-__global__ __launch_bounds__(256) void k_sp_count(Dev d) {
+__global__ __launch_bounds__(256) void k_sp_count(Dev d, int sp) {
     __shared__ uint32_t s_wave[4];
     __shared__ uint32_t h[SEL_BINS];
     __shared__ u64 s_prefix;
     __shared__ uint32_t s_krem;
     u64 T;
     uint32_t r;
-    sel_resolve<256>(d, d.sel_passes - 1, h, s_wave, &T, &r, &s_prefix, &s_krem);
+    sel_resolve<256>(d, sp, d.sel_passes - 1, h, s_wave, &T, &r, &s_prefix, &s_krem);
     __syncthreads();
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        d.ctr->sel_prefix = T;                  // skipped low digits are zero in every key
-        d.ctr->sel_krem = r;
+        d.ctr->sel_prefix[sp] = T;              // skipped low digits are zero in every key
+        d.ctr->sel_krem[sp] = r;
     }
-    if (d.sel_passes > 1)                       // pass-0 histogram is consumed: clear it for the next step
-        for (int i = blockIdx.x * 256 + threadIdx.x; i < SEL_BINS; i += gridDim.x * 256) d.hist[i] = 0;
+    if (d.sel_passes > 1)                       // pass-0 histogram is consumed: clear it for its next use
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < SEL_BINS; i += gridDim.x * 256) d.hist[sp * SEL_MAX_PASSES * SEL_BINS + i] = 0;
     const int c = blockIdx.x * 256 + threadIdx.x;
     uint32_t v = 0;
     if (c < d.C) {
-        u64 key = d.key[c];
+        u64 key = d.key[sp][c];
         v = (key > T) ? 1u : ((key == T) ? 0x10000u : 0u);
     }
     uint32_t total;
@@ -359,10 +378,10 @@ __global__ __launch_bounds__(256) void k_sp_count(Dev d) {
 // least-used cell (:84-89).  idx = position of column a in the ascending active list.
 struct ColumnWords { uint32_t act, winner, unacc; bool burst; };
 
-__device__ __forceinline__ ColumnWords tm_column_words(const Dev &d, int p, int want_winner, bool col_ok, int a) {
+// pw = prev_state.cell_prediction row of column a (0 when !col_ok)
+__device__ __forceinline__ ColumnWords tm_column_words(const Dev &d, int p, int want_winner, bool col_ok, int a, uint32_t pw) {
     const int lane = lane_id(), half = lane >> 5, j = lane & 31;
     const bool valid = col_ok && j < d.K;
-    const uint32_t pw = col_ok ? d.pred[p ^ 1][a] : 0;       // prev_state.cell_prediction row
     const bool burst = pw == 0;
     const uint32_t act = burst ? cell_mask(d.K) : pw;        // networks.py:115
     const int has_distal = d.ctr->has_distal;
@@ -400,12 +419,14 @@ __device__ __forceinline__ void tm_store_column(const Dev &d, int p, bool col_ok
         d.bursting[idx] = w.burst ? 1 : 0;
         d.colcnt[idx] = (uint32_t)__popc(w.winner) | ((uint32_t)__popc(w.unacc) << 16);
         d.unacc_word[idx] = w.unacc;
+        d.winw_idx[idx] = w.winner;
+        d.actcnt[idx] = (uint8_t)__popc(w.act);
     }
 }
 
-__device__ __forceinline__ void tm_activate_column(const Dev &d, int p, int want_winner, bool col_ok, int a, int idx) {
+__device__ __forceinline__ void tm_activate_column(const Dev &d, int p, int want_winner, bool col_ok, int a, int idx, uint32_t pw) {
     if (d.world == 1) {
-        tm_store_column(d, p, col_ok, a, idx, tm_column_words(d, p, want_winner, col_ok, a));
+        tm_store_column(d, p, col_ok, a, idx, tm_column_words(d, p, want_winner, col_ok, a, pw));
     } else {          // the owner computed the words before the exchange
         ColumnWords w{0, 0, 0, false};
         if (col_ok) {
@@ -439,10 +460,10 @@ __global__ __launch_bounds__(256) void k_shard_pack(Dev d, int p, unsigned char 
     const int i = (blockIdx.x * 256 + threadIdx.x) >> 5;           // local column, one per half-wave
     const bool ok = i < cl;
     const int a = d.c0 + (ok ? i : 0);
-    const ColumnWords w = tm_column_words(d, p, 1, ok, a);
+    const ColumnWords w = tm_column_words(d, p, 1, ok, a, ok ? d.pred[p ^ 1][a] : 0u);
     // bursting bits: one 32-bit word per 32 columns = 16 consecutive waves' halves; use atomics
     if (ok && (lane_id() & 31) == 0) {
-        r_boost[i] = d.boosted[a];
+        r_boost[i] = d.boosted[p][a];
         r_act[i] = w.act;
         r_win[i] = w.winner;
         r_unacc[i] = w.unacc;
@@ -465,17 +486,18 @@ __global__ __launch_bounds__(256) void k_shard_pack_clear(Dev d, unsigned char *
 // histogram of the top key digit (what k_sp_overlap does on an unsharded handle), and the deaths
 // the other ranks reported (only "fewer synapses than the matching threshold" matters here:
 // projections.py:80)
-__global__ __launch_bounds__(1024) void k_shard_unpack(Dev d, const unsigned char *recv, int rank) {
+__global__ __launch_bounds__(1024) void k_shard_unpack(Dev d, const unsigned char *recv, int rank, int sp) {
     __shared__ uint32_t h[SEL_BINS];
     const int gtid = blockIdx.x * blockDim.x + threadIdx.x;
     const int nthreads = gridDim.x * blockDim.x;
     const int cl = d.c1 - d.c0;
     const size_t rb = shard_record_bytes(cl);
-    for (int i = gtid; i < (d.sel_passes - 1) * SEL_BINS; i += nthreads) d.hist[SEL_BINS + i] = 0;
+    uint32_t *ghist = d.hist + sp * SEL_MAX_PASSES * SEL_BINS;
+    for (int i = gtid; i < (d.sel_passes - 1) * SEL_BINS; i += nthreads) ghist[SEL_BINS + i] = 0;
     for (int i = threadIdx.x; i < SEL_BINS; i += 1024) h[i] = 0;
     if (gtid == 0) {
-        d.ctr->sel_pass_prefix[0] = 0;
-        d.ctr->sel_pass_krem[0] = (uint32_t)d.k;
+        d.ctr->sel_pass_prefix[sp][0] = 0;
+        d.ctr->sel_pass_krem[sp][0] = (uint32_t)d.k;
         d.dead_list[0] = 0;                        // reported; start collecting this step's
     }
     __syncthreads();
@@ -488,8 +510,8 @@ __global__ __launch_bounds__(1024) void k_shard_unpack(Dev d, const unsigned cha
             const double bo = ((const double *)rec)[i];
             const uint32_t *r_act = (const uint32_t *)(rec + (size_t)cl * 8);
             key = (u64)__double_as_longlong(bo);
-            d.boosted[c] = bo;
-            d.key[c] = key;
+            d.boosted[sp][c] = bo;
+            d.key[sp][c] = key;
             d.spec_act[c] = r_act[i];
             d.spec_win[c] = r_act[cl + i];
             d.spec_unacc[c] = r_act[2 * cl + i];
@@ -501,7 +523,7 @@ __global__ __launch_bounds__(1024) void k_shard_unpack(Dev d, const unsigned cha
     }
     __syncthreads();
     for (int i = threadIdx.x; i < SEL_BINS; i += 1024)
-        if (h[i]) atomicAdd(&d.hist[i], h[i]);
+        if (h[i]) atomicAdd(&ghist[i], h[i]);
     if (blockIdx.x == 0) {
         for (int r = 0; r < d.world; ++r) {
             if (r == rank) continue;
@@ -533,27 +555,28 @@ __global__ __launch_bounds__(256) void k_sp_emit(Dev d, int p, int want_winner, 
     __shared__ uint32_t h[SEL_BINS];
     __shared__ u64 s_prefix;
     __shared__ uint32_t s_krem;
+    __shared__ uint32_t s_predw[256];
     const int tid = threadIdx.x;
     if (tid == 0) { s_gt = 0; s_eq = 0; s_n = 0; }
+    const int c = blockIdx.x * 256 + tid;
+    // independent of everything below: in flight while the select state is resolved
+    const u64 my_key = c < d.C ? d.key[p][c] : 0;
+    s_predw[tid] = (c < d.C && d.act[0] && d.world == 1) ? d.pred[p ^ 1][c] : 0u;
     u64 T;
     uint32_t r;                                     // how many of the keys == T are selected
     if (fused) {
-        sel_resolve<256>(d, d.sel_passes - 1, h, s_wave, &T, &r, &s_prefix, &s_krem);
+        sel_resolve<256>(d, p, d.sel_passes - 1, h, s_wave, &T, &r, &s_prefix, &s_krem);
         __syncthreads();
-        if (blockIdx.x == 0 && tid == 0) { d.ctr->sel_prefix = T; d.ctr->sel_krem = r; }
-        if (d.sel_passes > 1)                       // pass-0 histogram is consumed: clear it for the next step
-            for (int i = blockIdx.x * 256 + tid; i < SEL_BINS; i += gridDim.x * 256) d.hist[i] = 0;
+        if (blockIdx.x == 0 && tid == 0) { d.ctr->sel_prefix[p] = T; d.ctr->sel_krem[p] = r; }
+        if (d.sel_passes > 1)                       // pass-0 histogram is consumed: clear it for its next use
+            for (int i = blockIdx.x * 256 + tid; i < SEL_BINS; i += gridDim.x * 256) d.hist[p * SEL_MAX_PASSES * SEL_BINS + i] = 0;
     } else {
-        T = d.ctr->sel_prefix;
-        r = d.ctr->sel_krem;
+        T = d.ctr->sel_prefix[p];
+        r = d.ctr->sel_krem[p];
         __syncthreads();
     }
-    const int c = blockIdx.x * 256 + tid;
     uint32_t flag = 0;
-    if (c < d.C) {
-        u64 key = d.key[c];
-        flag = (key > T) ? 1u : ((key == T) ? 0x10000u : 0u);
-    }
+    if (c < d.C) flag = (my_key > T) ? 1u : ((my_key == T) ? 0x10000u : 0u);
     uint32_t total;
     const uint32_t ex = block_excl_scan<256>(flag, s_wave, total);
     uint32_t g = 0, e = 0;
@@ -617,7 +640,8 @@ __global__ __launch_bounds__(256) void k_sp_emit(Dev d, int p, int want_winner, 
     for (int i0 = 0; i0 < n_sel; i0 += 8) {        // 8 half-waves
         const int i = i0 + (tid >> 5);
         const bool ok = i < n_sel;
-        tm_activate_column(d, p, want_winner, ok, ok ? s_col[i] : 0, first_pos + i);
+        const int a = ok ? s_col[i] : 0;
+        tm_activate_column(d, p, want_winner, ok, a, first_pos + i, ok ? s_predw[a - blockIdx.x * 256] : 0u);
     }
 }
 
@@ -662,7 +686,7 @@ __global__ __launch_bounds__(256) void k_tm_activate(Dev d, int p, int n_active,
     const bool ok = idx < n_active;
     const int a = ok ? d.active_cols[idx] : 0;
     if (ok && (threadIdx.x & 31) == 0) atomicOr(&d.colbits[a >> 5], 1u << (a & 31));
-    tm_activate_column(d, p, want_winner, ok, a, idx);
+    tm_activate_column(d, p, want_winner, ok, a, idx, ok ? d.pred[p ^ 1][a] : 0u);
 }
 
 // bind segment `seg` to winner cell `cell` (projections.py:275-281) and queue it for learning at
@@ -732,8 +756,9 @@ __global__ __launch_bounds__(1024) void k_tm_mid(Dev d, int p, int n_active, int
             const int seg = i0 + threadIdx.x;
             bool learn = false, punish = false;
             const uint32_t info = seg < n ? d.seg_info[seg] : 0u;
+            const int cell = seg < n ? d.seg_cell[seg] : 0;         // fetched with the info word, not after it
             if (info & 0x40000000u) {
-                const int cell = d.seg_cell[seg], col = cell >> 5, bit = cell & 31;
+                const int col = cell >> 5, bit = cell & 31;
                 const bool is_winner = (d.win[col] >> bit) & 1u;
                 const bool unpred = !((d.pred[q][col] >> bit) & 1u);                         // :266
                 const bool best = fabsf(d.seg_jit[seg] - __uint_as_float(d.cellmax[cell])) < EPS32;   // :267
@@ -772,12 +797,12 @@ __global__ __launch_bounds__(1024) void k_tm_mid(Dev d, int p, int n_active, int
         const int idx = base + threadIdx.x;
         uint32_t v = 0, ww = 0, uw = 0;
         int a = 0;
-        if (idx < n_active) {
+        if (idx < n_active) {                      // four independent loads, no gather through `a`
             a = d.active_cols[idx];
-            ww = d.win[a];
+            ww = d.winw_idx[idx];
             uw = d.unacc_word[idx];
             v = d.colcnt[idx];
-            n_cells += __popc(d.act[p][a]);
+            n_cells += d.actcnt[idx];
         }
         if (!want_winner) v = 0;
         uint32_t total;
@@ -854,17 +879,20 @@ __global__ __launch_bounds__(1024) void k_tm_mid(Dev d, int p, int n_active, int
 // surviving synapses are re-packed to the front of the row.  Growth: the n_add previous winner
 // cells with the smallest keyed priority that the segment does not have yet.
 template <int EPL>
-__global__ __launch_bounds__(256) void k_tm_learn(Dev d, int p) {
-    __shared__ int s_keep[4][EPL * 64];
-    __shared__ u64 s_cand[4][CAND_CAP];
+struct LearnShared { u64 cand[RB / 64][CAND_CAP]; int keep[RB / 64][EPL * 64]; };
+
+template <int EPL>
+__device__ __forceinline__ void role_learn(const Dev &d, int p, int blk, int nblk, LearnShared<EPL> *sh) {
+    int (*s_keep)[EPL * 64] = sh->keep;
+    u64 (*s_cand)[CAND_CAP] = sh->cand;
     Counters *c = d.ctr;
     {   // forget the previous scan's per-cell maxima (sparse clear; every reader ran in an earlier
         // launch) and reset what the coming scan accumulates
         const int n = c->has_distal ? c->S : 0;
-        for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
+        for (int i = blk * RB + threadIdx.x; i < n; i += nblk * RB)
             if (d.seg_info[i] & 0x40000000u) d.cellmax[d.seg_cell[i]] = 0u;
         const int nb = (c->S + 1023) >> 10;
-        for (int i = blockIdx.x * 256 + threadIdx.x; i < nb; i += gridDim.x * 256) d.recyc_cnt[i] = 0;
+        for (int i = blk * RB + threadIdx.x; i < nb; i += nblk * RB) d.recyc_cnt[i] = 0;
     }
     const int wv = threadIdx.x >> 6, lane = lane_id();
     const int n_work = min(c->n_work, d.work_cap);
@@ -872,7 +900,7 @@ __global__ __launch_bounds__(256) void k_tm_learn(Dev d, int p) {
     const int *winners = d.winners[p ^ 1];
     const int n_w = c->has_winner[p ^ 1] ? c->n_win[p ^ 1] : -1;       // -1: winner_input is None
     const uint32_t base2 = htm_stream_base(d.seed, HTM_STREAM_GROWTH, c->step[p]);
-    for (int item = blockIdx.x * 4 + wv; item < n_work; item += gridDim.x * 4) {
+    for (int item = blk * (RB / 64) + wv; item < n_work; item += nblk * (RB / 64)) {
         const uint32_t w = d.work[item];
         const int seg = (int)(w & 0x7FFFFFFFu), mode = (int)(w >> 31);
         const double dA = mode ? d.pun_act : d.lrn_act, dI = mode ? d.pun_inact : d.lrn_inact;
@@ -976,6 +1004,13 @@ __global__ __launch_bounds__(256) void k_tm_learn(Dev d, int p) {
     }
 }
 
+extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
+
+template <int EPL>
+__global__ __launch_bounds__(RB) void k_tm_learn(Dev d, int p) {
+    role_learn<EPL>(d, p, blockIdx.x, gridDim.x, (LearnShared<EPL> *)dyn_lds);
+}
+
 // PredictiveProjection.process (projections.py:245-255): per segment, potential = active
 // presynaptic cells; matching segments additionally count connected active synapses;
 // per-cell prediction and max jittered potential (:229-239).  8 lanes per segment, 16-byte
@@ -984,22 +1019,32 @@ __global__ __launch_bounds__(256) void k_tm_learn(Dev d, int p) {
 // next step's add_output.  The last duty of a timestep: publish the next step index.
 // use_lds: the bitmap of active columns is staged in LDS and consulted first, so that only the
 // ~2 % of synapses whose presynaptic column is active touch the per-column cell words in L2.
-extern __shared__ __attribute__((aligned(16))) uint32_t s_colbits[];
 // Branch-free: lanes whose column is inactive read act[0] instead (one shared cache line), so all
 // LDS reads and then all global reads of a lane can be in flight together.
-__device__ __forceinline__ uint32_t scan_cell_active(const uint32_t *act, int enc, bool valid, bool use_lds) {
+// use_lds: the bitmap of active columns is consulted in LDS first; only the ~2 % of synapses whose
+// presynaptic column is active then read that column's cell word (lanes of inactive columns read
+// act[0], one shared cache line, so the access stays branch-free).  Measured alternatives: a
+// global gather for every synapse moves 64 B per bit; an LDS-only lookup (bitmap + prefix counts +
+// active words) costs three bank-conflicted LDS reads per synapse and was 1.6x slower.
+struct ScanLds { const uint32_t *colbits; };
+__device__ __forceinline__ uint32_t scan_cell_active(const uint32_t *act, const ScanLds &L, int enc, bool valid, bool use_lds) {
     const int col = enc >> 5;
     uint32_t maybe = valid ? 1u : 0u;
-    if (use_lds) maybe &= (s_colbits[col >> 5] >> (col & 31));
+    if (use_lds) maybe &= (L.colbits[col >> 5] >> (col & 31));
     const uint32_t aw = act[maybe ? col : 0];
     return maybe & (aw >> (enc & 31));
 }
 
-__global__ __launch_bounds__(256) void k_tm_scan(Dev d, int p, int use_lds) {
-    __shared__ int s_recyc;
+// LDS: word 0 = recyclable counter; from word 4: column bitmap [colwords]
+template <int BS>
+__device__ __forceinline__ void role_scan(const Dev &d, int p, int use_lds, int blk, int nblk, uint32_t *lds) {
+    constexpr int SEGS = BS / 4;                   // segments per block iteration: BS/8 lane groups x 2 in flight
+    int &s_recyc = *(int *)lds;
+    uint32_t *s_colbits = lds + 4;
+    const ScanLds L{s_colbits};
     Counters *c = d.ctr;
     const int S = c->S;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (blk == 0 && threadIdx.x == 0) {
         c->step[p ^ 1] = c->step[p] + 1;
         c->has_distal = 1;
         c->n_work_last = c->n_work;
@@ -1011,10 +1056,11 @@ __global__ __launch_bounds__(256) void k_tm_scan(Dev d, int p, int use_lds) {
     // rarely exceed one chunk (growth tops a segment up to 32 active synapses), so a typical row
     // costs exactly 128 bytes of presynaptic ids.
     const int g = threadIdx.x >> 3, l = threadIdx.x & 7;
-    constexpr int U = SCAN_SEGS / 32;              // segments in flight per lane group
+    constexpr int NG = BS / 8;                     // lane groups per block
+    constexpr int U = SEGS / NG;                   // segments in flight per lane group
     bool staged = false;
-    for (int b = blockIdx.x; b * SCAN_SEGS < S; b += gridDim.x) {
-        int seg[U], n[U], pot[U], conn[U], n_true[U];
+    for (int b = blk; b * SEGS < S; b += nblk) {
+        int seg[U], n[U], pot[U], conn[U], n_true[U], cellu[U];
         u64 bits[U];
         int4 ps[U];
         bool mine[U];
@@ -1022,23 +1068,24 @@ __global__ __launch_bounds__(256) void k_tm_scan(Dev d, int p, int use_lds) {
         // masked by the count afterwards): one memory round trip instead of two
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            seg[u] = min(b * SCAN_SEGS + u * 32 + g, S - 1);
+            seg[u] = min(b * SEGS + u * NG + g, S - 1);
             n[u] = d.seg_nsyn[seg[u]];
+            cellu[u] = d.seg_cell[seg[u]];
             mine[u] = true;
-            if (d.world > 1) mine[u] = col_is_local(d, d.seg_cell[seg[u]]);       // rows of other ranks are not here
+            if (d.world > 1) mine[u] = col_is_local(d, cellu[u]);                 // rows of other ranks are not here
             ps[u] = make_int4(0, 0, 0, 0);
             if (mine[u]) ps[u] = *(const int4 *)(d.presyn + (size_t)seg[u] * d.E + l * 4);
         }
         if (!staged) {                               // overlap the bitmap staging with those loads
             if (use_lds)
-                for (int i = threadIdx.x; i < d.colwords; i += 256) s_colbits[i] = d.colbits[i];
+                for (int i = threadIdx.x; i < d.colwords; i += BS) s_colbits[i] = d.colbits[i];
             staged = true;
         }
         if (threadIdx.x == 0) s_recyc = 0;
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const bool ok = b * SCAN_SEGS + u * 32 + g < S;
+            const bool ok = b * SEGS + u * NG + g < S;
             n_true[u] = ok ? n[u] : 0x7FFFFFFF;      // for the recyclable count (all ranks, all segments)
             if (!ok || !mine[u]) n[u] = 0;
             seg[u] = ok ? seg[u] : S;
@@ -1049,7 +1096,7 @@ __global__ __launch_bounds__(256) void k_tm_scan(Dev d, int p, int use_lds) {
             u64 bb = 0;
 #pragma unroll
             for (int qq = 0; qq < 4; ++qq)
-                bb |= (u64)scan_cell_active(act, e[qq], l * 4 + qq < n[u], use_lds) << qq;
+                bb |= (u64)scan_cell_active(act, L, e[qq], l * 4 + qq < n[u], use_lds) << qq;
             bits[u] = bb;
         }
 #pragma unroll
@@ -1061,7 +1108,7 @@ __global__ __launch_bounds__(256) void k_tm_scan(Dev d, int p, int use_lds) {
                     const int e[4] = {pv.x, pv.y, pv.z, pv.w};
 #pragma unroll
                     for (int qq = 0; qq < 4; ++qq)
-                        bits[u] |= (u64)scan_cell_active(act, e[qq], i + qq < n[u], use_lds) << (ch * 4 + qq);
+                        bits[u] |= (u64)scan_cell_active(act, L, e[qq], i + qq < n[u], use_lds) << (ch * 4 + qq);
                 }
             }
             int v = __popcll(bits[u]);
@@ -1094,7 +1141,7 @@ __global__ __launch_bounds__(256) void k_tm_scan(Dev d, int p, int use_lds) {
                 uint32_t info = (uint32_t)pot[u];
                 if (matching) {
                     const bool active = conn[u] >= d.act_thr;                         // :250
-                    const int cell = d.seg_cell[seg[u]];
+                    const int cell = cellu[u];
                     const float jit = htm_jitter((float)pot[u], htm_draw24(base3, (uint32_t)seg[u], 0u));   // :234-235
                     atomicMax(&d.cellmax[cell], __float_as_uint(jit));               // :237
                     if (active) atomicOr(&d.pred[p][cell >> 5], 1u << (cell & 31));   // :251, networks.py:122
@@ -1105,8 +1152,34 @@ __global__ __launch_bounds__(256) void k_tm_scan(Dev d, int p, int use_lds) {
             }
         }
         __syncthreads();
-        if (threadIdx.x == 0 && s_recyc) atomicAdd(&d.recyc_cnt[(b * SCAN_SEGS) >> 10], s_recyc);
+        if (threadIdx.x == 0 && s_recyc) atomicAdd(&d.recyc_cnt[(b * SEGS) >> 10], s_recyc);
     }
+}
+
+__global__ __launch_bounds__(256) void k_tm_scan(Dev d, int p, int use_lds) {
+    role_scan<256>(d, p, use_lds, blockIdx.x, gridDim.x, (uint32_t *)dyn_lds);
+}
+
+// ---- pipelined schedule: two independent roles per launch -----------------------------------
+// Step t's Temporal Memory work (learn, scan) does not depend on step t+1's Spatial Pooler front
+// (overlap + boost, select digits), and vice versa, once step t's SP update and duty cycle are in
+// place.  A forked stream / graph branch costs 17-29 us on this runtime; heterogeneous blocks in one
+// launch cost nothing, so the two chains of dependent memory round trips overlap.
+template <int EPL>
+__global__ __launch_bounds__(RB) void k_learn_overlap(Dev d, int p, int n_learn_blocks, const uint32_t *__restrict__ bank,
+                                                        int n_inputs, int G) {
+    if ((int)blockIdx.x < n_learn_blocks)
+        role_learn<EPL>(d, p, blockIdx.x, n_learn_blocks, (LearnShared<EPL> *)dyn_lds);
+    else
+        role_overlap(d, bank, n_inputs, G, p, p ^ 1, 1, blockIdx.x - n_learn_blocks, gridDim.x - n_learn_blocks, (uint32_t *)dyn_lds);
+}
+
+// 256-thread blocks: the scan is fastest with them; the select role simply loops a little longer
+__global__ __launch_bounds__(256) void k_scan_sel(Dev d, int p, int use_lds, int n_scan_blocks, int pass) {
+    if ((int)blockIdx.x < n_scan_blocks)
+        role_scan<256>(d, p, use_lds, blockIdx.x, n_scan_blocks, (uint32_t *)dyn_lds);
+    else
+        role_sel_pass<256>(d, pass, p ^ 1, blockIdx.x - n_scan_blocks, gridDim.x - n_scan_blocks, (SelShared *)dyn_lds);
 }
 
 // recount recyclable segments after a state import
@@ -1143,6 +1216,9 @@ struct htm_handle {
     std::string err;
     std::vector<void *> allocs;
     int *d_cols_stage;                    // stand-alone TM: active columns
+    bool pf_valid;                        // the SP front of step step_host is already computed ...
+    const uint32_t *pf_bank;              // ... from this bank (pipelined schedule)
+    int pf_n_inputs;
     int rank, world;                      // column sharding
     const uint32_t *shard_bank;           // input of the step between htm_shard_begin and _finish
     int shard_n_inputs;
@@ -1216,52 +1292,119 @@ static int prof_slot(htm_handle *h, const char *name) {
     } while (0)
 #define LAUNCH(h, name, kernel, grid, block, ...) LAUNCH_ON(h, (h)->stream, 0, name, kernel, grid, block, __VA_ARGS__)
 
+static size_t learn_lds(int epl) { return (size_t)(RB / 64) * CAND_CAP * 8 + (size_t)(RB / 64) * epl * 64 * 4; }
+static int learn_epl(const Dev &d) { const int e = d.E / 64; return e <= 1 ? 1 : e == 2 ? 2 : e <= 4 ? 4 : 8; }
+static size_t scan_lds(const Dev &d, int use_lds) { return 16 + (use_lds ? (size_t)d.colwords * 4 : 0); }
+static const int kLearnBlocks = 256;               // x RB/64 waves: one wave per learning / punished segment
+
 static void launch_learn(htm_handle *h, int p) {
     Dev &d = h->d;
-    const int blocks = 512;
-    switch (d.E / 64) {
-        case 1: LAUNCH(h, "tm_learn", k_tm_learn<1>, blocks, 256, d, p); break;
-        case 2: LAUNCH(h, "tm_learn", k_tm_learn<2>, blocks, 256, d, p); break;
-        case 3: case 4: LAUNCH(h, "tm_learn", k_tm_learn<4>, blocks, 256, d, p); break;
-        default: LAUNCH(h, "tm_learn", k_tm_learn<8>, blocks, 256, d, p); break;
+    const int epl = learn_epl(d);
+    const size_t lds = learn_lds(epl);
+    switch (epl) {
+        case 1: LAUNCH_ON(h, h->stream, lds, "tm_learn", k_tm_learn<1>, kLearnBlocks, RB, d, p); break;
+        case 2: LAUNCH_ON(h, h->stream, lds, "tm_learn", k_tm_learn<2>, kLearnBlocks, RB, d, p); break;
+        case 4: LAUNCH_ON(h, h->stream, lds, "tm_learn", k_tm_learn<4>, kLearnBlocks, RB, d, p); break;
+        default: LAUNCH_ON(h, h->stream, lds, "tm_learn", k_tm_learn<8>, kLearnBlocks, RB, d, p); break;
     }
 }
 
-// SpatialPooler.process: overlap + boost (+ select digit 0), select digits 1.., count, emit
-// (+ the TM's per-column activation when the handle has a Temporal Memory)
-static void enqueue_sp(htm_handle *h, const uint32_t *bank, int n_inputs, int learning, int p, int want_winner) {
+// launch 3 of the pipelined schedule: step t's learning beside step t+1's overlap + boost
+static void launch_learn_overlap(htm_handle *h, int p, const uint32_t *bank, int n_inputs) {
     Dev &d = h->d;
-    LAUNCH(h, "sp_overlap", k_sp_overlap, h->sp_blocks, 1024, d, bank, n_inputs, h->G, p);
-    for (int pass = 1; pass < d.sel_passes; ++pass) LAUNCH(h, "sp_select", k_sel_pass, h->sel_blocks, 1024, d, pass);
+    const int epl = learn_epl(d);
+    const size_t lds = std::max(learn_lds(epl), (size_t)SEL_BINS * 4);
+    const int grid = kLearnBlocks + h->sp_blocks;
+    switch (epl) {
+        case 1: LAUNCH_ON(h, h->stream, lds, "tm_learn+sp_overlap", k_learn_overlap<1>, grid, RB, d, p, kLearnBlocks, bank, n_inputs, h->G); break;
+        case 2: LAUNCH_ON(h, h->stream, lds, "tm_learn+sp_overlap", k_learn_overlap<2>, grid, RB, d, p, kLearnBlocks, bank, n_inputs, h->G); break;
+        case 4: LAUNCH_ON(h, h->stream, lds, "tm_learn+sp_overlap", k_learn_overlap<4>, grid, RB, d, p, kLearnBlocks, bank, n_inputs, h->G); break;
+        default: LAUNCH_ON(h, h->stream, lds, "tm_learn+sp_overlap", k_learn_overlap<8>, grid, RB, d, p, kLearnBlocks, bank, n_inputs, h->G); break;
+    }
+}
+
+// Front of SpatialPooler.process for the step with parity sp: overlap + boost (+ select digit 0)
+// and the remaining select digits.  In the pipelined schedule these run one step ahead.
+static void enqueue_sp_front(htm_handle *h, const uint32_t *bank, int n_inputs, int p) {
+    Dev &d = h->d;
+    LAUNCH(h, "sp_overlap", k_sp_overlap, h->sp_blocks, RB, d, bank, n_inputs, h->G, p);
+    for (int pass = 1; pass < d.sel_passes; ++pass) LAUNCH(h, "sp_select", k_sel_pass, h->sel_blocks, RB, d, pass, p);
+}
+
+// Rest of SpatialPooler.process: count + emit (+ the TM's per-column activation when the handle has
+// a Temporal Memory)
+static void enqueue_sp_back(htm_handle *h, const uint32_t *bank, int n_inputs, int learning, int p, int want_winner) {
+    Dev &d = h->d;
     const int fused = h->c256_blocks <= 1024;      // all blocks co-resident: count inside emit
-    if (!fused) LAUNCH(h, "sp_count", k_sp_count, h->c256_blocks, 256, d);
+    if (!fused) LAUNCH(h, "sp_count", k_sp_count, h->c256_blocks, 256, d, p);
     LAUNCH(h, "sp_emit", k_sp_emit, h->c256_blocks, 256, d, p, want_winner, fused);
     // (a forked graph branch for this independent update was measured at +17..29 us per step on
     // this runtime, against 2.3 us for one more kernel in the chain: tools/launch_overhead.hip)
     if (learning && !h->cfg.enable_tm) LAUNCH(h, "sp_learn", k_sp_learn, d.k, 256, d, bank, n_inputs, p);
 }
 
-static void join_sp(htm_handle *, int) {}
-
-// TemporalMemory.process after the per-column activation
+// TemporalMemory.process after the per-column activation.  prefetch: also compute the next step's
+// SP front (input (step + 1) % n_inputs of the same bank) inside the learn and scan launches.
 static void enqueue_tm(htm_handle *h, int n_active, int learning, int want_winner, int p,
-                       const uint32_t *bank, int n_inputs) {
+                       const uint32_t *bank, int n_inputs, bool prefetch) {
     Dev &d = h->d;
     const int n_cls = learning ? 32 : 0;
     const int n_sp_rows = (learning && h->cfg.enable_sp) ? d.k : 0;      // SP permanence update rides along
     LAUNCH(h, "tm_mid", k_tm_mid, 1 + n_cls + n_sp_rows, 1024, d, p, n_active, want_winner, learning, bank, n_inputs,
            n_cls, n_sp_rows);
-    launch_learn(h, p);
-    const int use_lds = (size_t)d.colwords * 4 <= 64 * 1024;
-    LAUNCH_ON(h, h->stream, use_lds ? (size_t)d.colwords * 4 : 0, "tm_scan", k_tm_scan, h->scan_blocks, 256, d, p, use_lds);
+    const int use_lds = scan_lds(d, 1) <= 64 * 1024;
+    if (!prefetch) {
+        launch_learn(h, p);
+        LAUNCH_ON(h, h->stream, scan_lds(d, use_lds), "tm_scan", k_tm_scan, h->scan_blocks, 256, d, p, use_lds);
+        return;
+    }
+    launch_learn_overlap(h, p, bank, n_inputs);
+    if (d.sel_passes > 1) {
+        LAUNCH_ON(h, h->stream, std::max(scan_lds(d, use_lds), sizeof(SelShared)), "tm_scan+sp_select", k_scan_sel,
+                  h->scan_blocks + 64, 256, d, p, use_lds, h->scan_blocks, 1);
+        for (int pass = 2; pass < d.sel_passes; ++pass) LAUNCH(h, "sp_select", k_sel_pass, h->sel_blocks, RB, d, pass, p ^ 1);
+    } else {
+        LAUNCH_ON(h, h->stream, scan_lds(d, use_lds), "tm_scan", k_tm_scan, h->scan_blocks, 256, d, p, use_lds);
+    }
 }
 
-static int enqueue_step(htm_handle *h, const uint32_t *bank, int n_inputs, int learning) {
+// The SP front of the coming step may already have been computed by the previous step's launches.
+static void drop_prefetch(htm_handle *h) {
+    if (!h->pf_valid) return;
+    h->pf_valid = false;
+    // its select digit 0 histogram was accumulated but will not be consumed: clear it
+    const int sp = (int)(h->step_host & 1);
+    hipMemsetAsync(h->d.hist + (size_t)sp * SEL_MAX_PASSES * SEL_BINS, 0, (size_t)SEL_BINS * 4, h->stream);
+}
+
+// make sure the SP front (overlap, boost, select digits) of the coming step exists
+static void ensure_front(htm_handle *h, const uint32_t *bank, int n_inputs) {
+    const bool have = h->pf_valid && h->pf_bank == bank && h->pf_n_inputs == n_inputs;
+    if (!have) {
+        drop_prefetch(h);
+        enqueue_sp_front(h, bank, n_inputs, (int)(h->step_host & 1));
+    }
+    h->pf_valid = false;
+}
+
+// everything after the SP front; with `pipeline` it also computes the next step's front
+static void enqueue_rest(htm_handle *h, const uint32_t *bank, int n_inputs, int learning, bool pipeline) {
     const int p = (int)(h->step_host & 1);
-    enqueue_sp(h, bank, n_inputs, learning, p, 1);
-    enqueue_tm(h, h->d.k, learning, 1, p, bank, n_inputs);
-    join_sp(h, learning);
+    enqueue_sp_back(h, bank, n_inputs, learning, p, 1);
+    enqueue_tm(h, h->d.k, learning, 1, p, bank, n_inputs, pipeline);
+}
+
+static void step_done(htm_handle *h, const uint32_t *bank, int n_inputs, bool pipeline) {
     h->step_host += 1;
+    h->pf_valid = pipeline;
+    h->pf_bank = bank;
+    h->pf_n_inputs = n_inputs;
+}
+
+static int enqueue_step(htm_handle *h, const uint32_t *bank, int n_inputs, int learning, bool pipeline) {
+    ensure_front(h, bank, n_inputs);
+    enqueue_rest(h, bank, n_inputs, learning, pipeline);
+    step_done(h, bank, n_inputs, pipeline);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { h->err = std::string("kernel launch: ") + hipGetErrorString(e); return HTM_ERR_HIP; }
     return 0;
@@ -1325,6 +1468,9 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
     h->prof_last = nullptr;
     h->step_host = 0;
     h->d_cols_stage = nullptr;
+    h->pf_valid = false;
+    h->pf_bank = nullptr;
+    h->pf_n_inputs = 0;
     h->rank = world > 1 ? cfg->shard_rank : 0;
     h->world = world;
     h->shard_bank = nullptr;
@@ -1379,10 +1525,12 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
         rc |= dalloc(h, &d.perm, C * d.Ipad);
         rc |= dalloc(h, &d.mask, C * d.W);
         rc |= dalloc(h, &d.duty, C);
-        rc |= dalloc(h, &d.overlap, C);
-        rc |= dalloc(h, &d.boosted, C);
-        rc |= dalloc(h, &d.key, C);
-        rc |= dalloc(h, &d.hist, (size_t)SEL_MAX_PASSES * SEL_BINS);
+        for (int q = 0; q < 2; ++q) {
+            rc |= dalloc(h, &d.overlap[q], C);
+            rc |= dalloc(h, &d.boosted[q], C);
+            rc |= dalloc(h, &d.key[q], C);
+        }
+        rc |= dalloc(h, &d.hist, (size_t)2 * SEL_MAX_PASSES * SEL_BINS);
         rc |= dalloc(h, &d.sel_blk, (C + 255) / 256);
         rc |= dalloc(h, &d.input_stage, (size_t)d.W);
     }
@@ -1398,6 +1546,8 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
         rc |= dalloc(h, &d.colbits, (size_t)d.colwords);
         rc |= dalloc(h, &d.bursting, k);
         rc |= dalloc(h, &d.colcnt, k);
+        rc |= dalloc(h, &d.winw_idx, k);
+        rc |= dalloc(h, &d.actcnt, k);
         rc |= dalloc(h, &d.unacc_word, k);
         rc |= dalloc(h, &d.unacc_list, k * 32);
         rc |= dalloc(h, &d.seg_cell, S);
@@ -1426,12 +1576,13 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
     while (h->G < d.W4 && h->G < 64) h->G <<= 1;
     // few fat blocks for the kernels that flush a histogram: every block adds into the same few
     // hot bins and same-address global atomics are slow (~88 per us per address)
-    const int rows_per_block = 16 * 4 * (64 / h->G);   // 16 waves x 4 row groups in flight
-    h->sp_blocks = std::max(1, std::min((d.c1 - d.c0 + rows_per_block - 1) / rows_per_block, 128));
-    h->sel_blocks = std::max(1, std::min((d.C + 1023) / 1024, 64));
+    const int rows_per_block = (RB / 64) * 4 * (64 / h->G);   // waves x 4 row groups in flight
+    h->sp_blocks = std::max(1, std::min((d.c1 - d.c0 + rows_per_block - 1) / rows_per_block, 256));
+    h->sel_blocks = std::max(1, std::min((d.C + RB - 1) / RB, 128));
     h->c256_blocks = (d.C + 255) / 256;
     h->s1024_blocks = std::max(1, (d.Scap + 1023) / 1024);
     h->scan_blocks = std::max(1, std::min((d.Scap + SCAN_SEGS - 1) / SCAN_SEGS, 2048));
+    if (const char *e = getenv("BITHTM_SCAN_BLOCKS")) h->scan_blocks = std::max(1, atoi(e));      // tuning knob
     // boosted = float32 factor x integer overlap <= input_dim has at most 24 + bit_length(I)
     // significant bits, so the low 53 - 24 - bit_length(I) bits of every key are zero and the
     // radix passes that would only see them are skipped.
@@ -1470,6 +1621,7 @@ extern "C" int htm_sp_set_permanence(htm_handle *h, const double *rows, int32_t 
     if (row_count == 0) return HTM_OK;
     Dev &d = h->d;
     HIPCHK(h, hipSetDevice(h->device));
+    drop_prefetch(h);
     HIPCHK(h, hipMemcpy2DAsync(d.perm + (size_t)row_begin * d.Ipad, (size_t)d.Ipad * 8, rows, (size_t)d.I * 8,
                                (size_t)d.I * 8, (size_t)row_count, hipMemcpyHostToDevice, h->stream));
     const long long waves = (long long)row_count * (d.Ipad / 64);
@@ -1505,7 +1657,8 @@ extern "C" int htm_step(htm_handle *h, const uint32_t *packed_input, int32_t lea
     HIPCHK(h, hipSetDevice(h->device));
     int rc = stage_input(h, packed_input);
     if (rc) return rc;
-    return enqueue_step(h, h->d.input_stage, 1, learning ? 1 : 0);
+    drop_prefetch(h);                               // the staged input changed: nothing can be reused
+    return enqueue_step(h, h->d.input_stage, 1, learning ? 1 : 0, false);
 }
 
 extern "C" int htm_sp_step(htm_handle *h, const uint32_t *packed_input, int32_t learning) {
@@ -1515,8 +1668,8 @@ extern "C" int htm_sp_step(htm_handle *h, const uint32_t *packed_input, int32_t 
     int rc = stage_input(h, packed_input);
     if (rc) return rc;
     const int p = (int)(h->step_host & 1);
-    enqueue_sp(h, h->d.input_stage, 1, learning ? 1 : 0, p, 0);
-    join_sp(h, learning ? 1 : 0);
+    enqueue_sp_front(h, h->d.input_stage, 1, p);
+    enqueue_sp_back(h, h->d.input_stage, 1, learning ? 1 : 0, p, 0);
     h->step_host += 1;
     return HTM_OK;
 }
@@ -1537,7 +1690,7 @@ extern "C" int htm_tm_step(htm_handle *h, const int32_t *active_column, int32_t 
     const int want = (learning || return_winner_cell) ? 1 : 0;
     LAUNCH(h, "tm_load_active", k_tm_load_active, std::min((d.C + 255) / 256, 1024), 256, d, p, h->d_cols_stage, n);
     LAUNCH(h, "tm_activate", k_tm_activate, std::max(1, (n * 32 + 255) / 256), 256, d, p, n, want);
-    enqueue_tm(h, n, learning ? 1 : 0, want, p, nullptr, 1);
+    enqueue_tm(h, n, learning ? 1 : 0, want, p, nullptr, 1, false);
     h->step_host += 1;
     return HTM_OK;
 }
@@ -1548,33 +1701,33 @@ extern "C" int htm_run(htm_handle *h, const uint32_t *device_inputs, int32_t n_i
     if (h->world > 1) { h->err = "sharded handle: use htm_shard_begin / htm_shard_finish"; return HTM_ERR_STATE; }
     HIPCHK(h, hipSetDevice(h->device));
     learning = learning ? 1 : 0;
-    if (!use_graph || h->profile) {
+    const bool graph = (use_graph & 1) && !h->profile;
+    const bool pipeline = !(use_graph & 2) && !h->profile;     // profiled runs time each role on its own
+    if (!graph) {
         for (int t = 0; t < n_steps; ++t) {
-            int rc = enqueue_step(h, device_inputs, n_inputs, learning);
+            int rc = enqueue_step(h, device_inputs, n_inputs, learning, pipeline);
             if (rc) return rc;
         }
         return HTM_OK;
     }
     for (int t = 0; t < n_steps; ++t) {
         const int p = (int)(h->step_host & 1);
-        auto key = std::make_tuple(p, learning, (const void *)device_inputs, n_inputs);
+        ensure_front(h, device_inputs, n_inputs);          // eager, only when nothing was prefetched
+        auto key = std::make_tuple(p, learning * 2 + (pipeline ? 1 : 0), (const void *)device_inputs, n_inputs);
         auto it = h->graphs.find(key);
         if (it == h->graphs.end()) {
-            hipGraph_t graph;
+            hipGraph_t graph_obj;
             HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-            const long long keep = h->step_host;
-            int rc = enqueue_step(h, device_inputs, n_inputs, learning);
-            h->step_host = keep;
-            hipError_t e = hipStreamEndCapture(h->stream, &graph);
-            if (rc) return rc;
+            enqueue_rest(h, device_inputs, n_inputs, learning, pipeline);
+            hipError_t e = hipStreamEndCapture(h->stream, &graph_obj);
             if (e != hipSuccess) { h->err = std::string("hipStreamEndCapture: ") + hipGetErrorString(e); return HTM_ERR_HIP; }
             hipGraphExec_t exec;
-            HIPCHK(h, hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-            hipGraphDestroy(graph);
+            HIPCHK(h, hipGraphInstantiate(&exec, graph_obj, nullptr, nullptr, 0));
+            hipGraphDestroy(graph_obj);
             it = h->graphs.emplace(key, exec).first;
         }
         HIPCHK(h, hipGraphLaunch(it->second, h->stream));
-        h->step_host += 1;
+        step_done(h, device_inputs, n_inputs, pipeline);
     }
     return HTM_OK;
 }
@@ -1603,7 +1756,7 @@ extern "C" int htm_shard_begin(htm_handle *h, const uint32_t *device_inputs, int
     Dev &d = h->d;
     const int p = (int)(h->step_host & 1);
     const int cl = d.c1 - d.c0;
-    LAUNCH(h, "sp_overlap", k_sp_overlap, h->sp_blocks, 1024, d, h->shard_bank, h->shard_n_inputs, h->G, p);
+    LAUNCH(h, "sp_overlap", k_sp_overlap, h->sp_blocks, RB, d, h->shard_bank, h->shard_n_inputs, h->G, p);
     LAUNCH(h, "shard_pack_clear", k_shard_pack_clear, 1, 256, d, (unsigned char *)send_device);
     LAUNCH(h, "shard_pack", k_shard_pack, (cl * 32 + 255) / 256, 256, d, p, (unsigned char *)send_device);
     h->shard_open = true;
@@ -1618,12 +1771,12 @@ extern "C" int htm_shard_finish(htm_handle *h, const void *recv_device, int32_t 
     Dev &d = h->d;
     const int p = (int)(h->step_host & 1);
     learning = learning ? 1 : 0;
-    LAUNCH(h, "shard_unpack", k_shard_unpack, h->sel_blocks, 1024, d, (const unsigned char *)recv_device, h->rank);
-    for (int pass = 1; pass < d.sel_passes; ++pass) LAUNCH(h, "sp_select", k_sel_pass, h->sel_blocks, 1024, d, pass);
+    LAUNCH(h, "shard_unpack", k_shard_unpack, h->sel_blocks, 1024, d, (const unsigned char *)recv_device, h->rank, p);
+    for (int pass = 1; pass < d.sel_passes; ++pass) LAUNCH(h, "sp_select", k_sel_pass, h->sel_blocks, RB, d, pass, p);
     const int fused = h->c256_blocks <= 1024;
-    if (!fused) LAUNCH(h, "sp_count", k_sp_count, h->c256_blocks, 256, d);
+    if (!fused) LAUNCH(h, "sp_count", k_sp_count, h->c256_blocks, 256, d, p);
     LAUNCH(h, "sp_emit", k_sp_emit, h->c256_blocks, 256, d, p, 1, fused);
-    enqueue_tm(h, d.k, learning, 1, p, h->shard_bank, h->shard_n_inputs);
+    enqueue_tm(h, d.k, learning, 1, p, h->shard_bank, h->shard_n_inputs, false);
     h->step_host += 1;
     h->shard_open = false;
     hipError_t e = hipGetLastError();
@@ -1712,8 +1865,8 @@ extern "C" int64_t htm_read(htm_handle *h, int32_t field, void *dst, int64_t cou
     int64_t n;
     switch (field) {
         case HTM_F_ACTIVE_COLUMN: if ((n = need(true, d.k)) < 0) return n; return copy(d.active_cols, n, 4);
-        case HTM_F_OVERLAPS: if ((n = need(sp, C)) < 0) return n; return copy(d.overlap, n, 4);
-        case HTM_F_BOOSTED: if ((n = need(sp, C)) < 0) return n; return copy(d.boosted, n, 8);
+        case HTM_F_OVERLAPS: if ((n = need(sp, C)) < 0) return n; return copy(d.overlap[q], n, 4);
+        case HTM_F_BOOSTED: if ((n = need(sp, C)) < 0) return n; return copy(d.boosted[q], n, 8);
         case HTM_F_DUTY_CYCLE: if ((n = need(sp, C)) < 0) return n; return copy(d.duty, n, 4);
         case HTM_F_CELL_ACTIVATION: if ((n = need(tm, C)) < 0) return n; return copy(d.act[q], n, 4);
         case HTM_F_CELL_PREDICTION: if ((n = need(tm, C)) < 0) return n; return copy(d.pred[q], n, 4);
@@ -1807,7 +1960,7 @@ extern "C" int htm_write(htm_handle *h, int32_t field, const void *src, int64_t 
         return HTM_ERR_STATE;
     }
     switch (field) {
-        case HTM_F_DUTY_CYCLE: return put(d.duty, src, count, 4, C);
+        case HTM_F_DUTY_CYCLE: drop_prefetch(h); return put(d.duty, src, count, 4, C);
         case HTM_F_CELL_ACTIVATION: return put(d.act[q], src, count, 4, C);
         case HTM_F_CELL_PREDICTION: return put(d.pred[q], src, count, 4, C);
         case HTM_F_SEG_NSYN: return put(d.seg_nsyn, src, count, 4, d.Scap);
@@ -1841,6 +1994,7 @@ extern "C" int htm_write(htm_handle *h, int32_t field, const void *src, int64_t 
 extern "C" int htm_import_begin(htm_handle *h, int64_t step_index) {
     if (!h || step_index < 0) return HTM_ERR_ARGUMENT;
     HIPCHK(h, hipSetDevice(h->device));
+    drop_prefetch(h);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->step_host = step_index;
     return HTM_OK;

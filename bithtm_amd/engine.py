@@ -177,9 +177,10 @@ class Engine:
         self._check(self.lib.htm_bank_upload(self.h, packed.ctypes.data_as(C.c_void_p), n, C.byref(ptr)), "htm_bank_upload")
         return ptr.value
 
-    def run(self, device_bank, n_inputs, n_steps, learning=True, use_graph=True):
+    def run(self, device_bank, n_inputs, n_steps, learning=True, use_graph=True, pipeline=True):
+        flags = (1 if use_graph else 0) | (0 if pipeline else 2)
         self._check(self.lib.htm_run(self.h, C.c_void_p(device_bank), int(n_inputs), int(n_steps), int(bool(learning)),
-                                     int(bool(use_graph))), "htm_run")
+                                     flags), "htm_run")
         self.steps += n_steps
 
     # ---- column-sharded stepping (shard_world > 1): begin -> all-gather by the caller -> finish

@@ -276,7 +276,7 @@ class HierarchicalTemporalMemory:
 
     compute = process
 
-    def run(self, inputs, steps, learning=True, use_graph=True):
+    def run(self, inputs, steps, learning=True, use_graph=True, pipeline=True):
         """`steps` timesteps over the rows of the boolean matrix `inputs`, cycled, with the input
         bank resident in device memory and no per-step host work (the loop of example.py:48-53).
         Returns nothing; read `temporal_memory.last_state` or call process() afterwards."""
@@ -287,7 +287,7 @@ class HierarchicalTemporalMemory:
         bank = getattr(self, "_bank", None)
         if bank is None or bank[0] != key:
             self._bank = bank = (key, eng.upload_bank(inputs))
-        eng.run(bank[1], inputs.shape[0], steps, learning=learning, use_graph=use_graph)
+        eng.run(bank[1], inputs.shape[0], steps, learning=learning, use_graph=use_graph, pipeline=pipeline)
         self.temporal_memory._new_state(None)
         eng.check_capacity()
 

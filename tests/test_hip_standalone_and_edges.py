@@ -144,14 +144,22 @@ def test_batched_run_equals_step_by_step():
     rng = np.random.RandomState(11)
     bank = rng.rand(30, 200) < 0.08
     outs = []
-    for mode in ("graph", "eager", "process"):
+    for mode in ("graph", "eager", "graph-nopipe", "mixed", "process"):
         np.random.seed(12)
         htm = B.HierarchicalTemporalMemory(200, 2048, 16)
         if mode == "process":
             for t in range(95):
                 htm.process(bank[t % 30])
+        elif mode == "mixed":                      # prefetched SP fronts get used, dropped and rebuilt
+            htm.run(bank, 40)
+            for t in range(40, 47):
+                htm.process(bank[t % 30])
+            htm.run(bank, 20, use_graph=False)
+            other = bank.copy()                    # a different bank object with the same content
+            htm.run(other, 8)
+            htm.run(bank, 20, pipeline=False)
         else:
-            htm.run(bank, 95, use_graph=(mode == "graph"))
+            htm.run(bank, 95, use_graph=mode.startswith("graph"), pipeline=(mode != "graph-nopipe"))
         st = htm.engine.read_store()
         outs.append((htm.engine.read_sp_fields()["active_column"], st["seg_cell"], st["seg_nsyn"], st["perm"],
                      htm.temporal_memory.last_state.cell_prediction))
