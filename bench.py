@@ -82,6 +82,22 @@ def kernel_bytes(w, k, store):
     }
 
 
+def recorded_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r01_pmc_summary.json:
+    rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs of this same workload; KB units;
+    FETCH_SIZE doubled as MI355X_MICROARCH.md section HBM prescribes for gfx950).  PMC counters cannot be
+    read from inside this process, so this is a recorded value, not a live one."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+    name = {"tm_scan": "k_tm_scan", "sp_overlap": "k_sp_overlap", "sp_learn": "k_tm_mid"}.get(kernel)
+    try:
+        d = json.load(open(path))
+        f = d["FETCH_SIZE"][name]["mean_last150_KB"]
+        wr = d["WRITE_SIZE"][name]["mean_last150_KB"]
+        return dict(traffic=int((2 * f + wr) * 1024), traffic_source="profiles/r01_pmc_summary.json (recorded PMC pass)")
+    except Exception:
+        return dict(traffic=None)
+
+
 def cpu_baseline(w, htm, noisy, start_step, sample_steps):
     """Time the NumPy oracle on this host from the GPU's learned state (a port of the
     reference's CPU path: dense float64 `>=` + `&` + sum overlap, NumPy segment scan)."""
@@ -148,6 +164,7 @@ def run_single(args):
                     bytes_per_launch=int(kb[dominant]), avg_launch_us=round(avg_us[dominant], 2),
                     whole_step_bytes=int(sum(kb[n] for n in ("sp_overlap", "sp_learn", "tm_scan", "sp_select", "sp_count", "sp_emit"))))
     roofline["whole_step_frac"] = round(roofline["whole_step_bytes"] * steps_per_s / 1e9 / HBM_PEAK_GBS, 4)
+    roofline.update(recorded_traffic(dominant))
 
     cpu = None
     if not args.no_cpu_baseline:

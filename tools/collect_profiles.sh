@@ -10,10 +10,14 @@ cd $GRAFT_REPO_ROOT
 timeout -k 10 400 python bench.py > $OUT/bench.json 2> $OUT/bench.log; echo "bench exit=$?"
 timeout -k 10 300 python tools/pcie_rate.py > $OUT/pcie_rate.txt 2>&1
 timeout -k 10 600 python tools/scan_stress.py --segments 250000 1000000 4000000 --slots 64 > $OUT/scan_stress.jsonl 2> $OUT/scan_stress.log
+timeout -k 10 600 python tools/scan_stress.py --segments 1000000 --slots 128 >> $OUT/scan_stress.jsonl 2>> $OUT/scan_stress.log
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $GRAFT_REPO_ROOT/bench.py --steps 500 --warmup 500 --no-cpu-baseline --no-graph > $OUT/stats.log 2>&1; echo "stats exit=$?"
+# (a) one role per launch: the kernels the roofline line names, standalone
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $GRAFT_REPO_ROOT/bench.py --steps 500 --warmup 500 --no-cpu-baseline --no-graph --no-pipeline > $OUT/stats.log 2>&1; echo "stats exit=$?"
+# (b) the pipelined schedule bench.py times by default (eager instead of hipGraph: rocprofv3 crashes on graph replay here)
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_pipelined -- python3 $GRAFT_REPO_ROOT/bench.py --steps 500 --warmup 500 --no-cpu-baseline --no-graph > $OUT/stats_pipelined.log 2>&1; echo "stats_pipelined exit=$?"
 for ctr in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 300 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $OUT/pmc_$ctr -- python3 $GRAFT_REPO_ROOT/bench.py --steps 200 --warmup 600 --no-cpu-baseline --no-graph > $OUT/pmc_$ctr.log 2>&1; echo "$ctr exit=$?"
+  timeout -k 10 300 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $OUT/pmc_$ctr -- python3 $GRAFT_REPO_ROOT/bench.py --steps 200 --warmup 600 --no-cpu-baseline --no-graph --no-pipeline > $OUT/pmc_$ctr.log 2>&1; echo "$ctr exit=$?"
 done
 # keep the merged-back payload small: drop the per-dispatch traces of the PMC runs after summarising
 python3 - <<'PY'
