@@ -1210,8 +1210,6 @@ struct htm_handle {
     int device;
     hipStream_t stream;
     bool own_stream;
-    hipStream_t side;                     // forked branch: SP permanence update runs beside the TM chain
-    hipEvent_t ev_fork, ev_join;
     long long step_host;
     std::string err;
     std::vector<void *> allocs;
@@ -1423,9 +1421,6 @@ extern "C" void htm_destroy(htm_handle *h) {
         for (auto &pr : v) hipEventDestroy(pr.second);
     for (hipEvent_t e : h->prof_all) hipEventDestroy(e);
     for (void *p : h->allocs) hipFree(p);
-    if (h->side) hipStreamDestroy(h->side);
-    if (h->ev_fork) hipEventDestroy(h->ev_fork);
-    if (h->ev_join) hipEventDestroy(h->ev_join);
     if (h->own_stream) hipStreamDestroy(h->stream);
     delete h;
 }
@@ -1476,8 +1471,6 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
     h->shard_bank = nullptr;
     h->shard_n_inputs = 1;
     h->shard_open = false;
-    h->side = nullptr;
-    h->ev_fork = h->ev_join = nullptr;
     hipError_t e = hipSetDevice(cfg->device);
     if (e != hipSuccess) return fail_create(h, std::string("hipSetDevice: ") + hipGetErrorString(e), HTM_ERR_HIP);
     if (cfg->use_caller_stream) {
@@ -1488,10 +1481,6 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
         if (e != hipSuccess) return fail_create(h, std::string("hipStreamCreate: ") + hipGetErrorString(e), HTM_ERR_HIP);
         h->own_stream = true;
     }
-    if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess)
-        return fail_create(h, "htm_create: cannot create the side stream / events", HTM_ERR_HIP);
     Dev &d = h->d;
     memset(&d, 0, sizeof(d));
     d.I = cfg->enable_sp ? cfg->input_dim : 0;
@@ -1836,6 +1825,7 @@ extern "C" int htm_get_info(htm_handle *h, htm_info *out) {
                  ((c.error & 2) ? " synapse slots (segment_slots)" : "") + ((c.error & 4) ? " work list / growth staging" : "") +
                  ((c.error & 8) ? " dead-segment report (DEAD_CAP)" : "") +
                  ((c.error & 16) ? " (internal) block hand-off timed out in k_sp_emit" : "");
+        return HTM_ERR_CAPACITY;          // *out is filled in all the same
     }
     return HTM_OK;
 }

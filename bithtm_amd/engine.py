@@ -109,8 +109,12 @@ class Engine:
         return rc
 
     def info(self):
+        """htm_info of the last completed step (does not raise on a capacity overflow: see
+        check_capacity)."""
         out = L.HtmInfo()
-        self._check(self.lib.htm_get_info(self.h, C.byref(out)), "htm_get_info")
+        rc = self.lib.htm_get_info(self.h, C.byref(out))
+        if rc != -3:                      # HTM_ERR_CAPACITY still fills `out`
+            self._check(rc, "htm_get_info")
         return out
 
     def check_capacity(self):

@@ -180,7 +180,8 @@ int htm_shard_begin(htm_handle *h, const uint32_t *device_inputs, int32_t n_inpu
 int htm_shard_finish(htm_handle *h, const void *recv_device, int32_t learning);
 
 int htm_sync(htm_handle *h);
-int htm_get_info(htm_handle *h, htm_info *out);      /* synchronises */
+int htm_get_info(htm_handle *h, htm_info *out);      /* synchronises; HTM_ERR_CAPACITY (with *out filled
+                                                         in) once a fixed-capacity pool has overflowed */
 
 /* Lazy read-back of State fields / state export (synchronises); count = number of ELEMENTS
  * the caller's buffer holds; it must be >= the field's current element count. Returns the
