@@ -169,6 +169,17 @@ __device__ __forceinline__ void hist_add(uint32_t *h, uint32_t digit, bool activ
     }
 }
 
+// bits of v moved to the even bit positions of a 64-bit word
+__device__ __forceinline__ u64 spread32(uint32_t v) {
+    u64 x = v;
+    x = (x | (x << 16)) & 0x0000FFFF0000FFFFull;
+    x = (x | (x << 8)) & 0x00FF00FF00FF00FFull;
+    x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0Full;
+    x = (x | (x << 2)) & 0x3333333333333333ull;
+    x = (x | (x << 1)) & 0x5555555555555555ull;
+    return x;
+}
+
 __device__ __forceinline__ uint32_t cell_mask(int K) { return K >= 32 ? 0xFFFFFFFFu : ((1u << K) - 1u); }
 __device__ __forceinline__ uint32_t enc_to_flat(int enc, int K) { return (uint32_t)((enc >> 5) * K + (enc & 31)); }
 
@@ -561,6 +572,8 @@ __global__ __launch_bounds__(256) void k_sp_emit(Dev d, int p, int want_winner, 
     const int c = blockIdx.x * 256 + tid;
     // independent of everything below: in flight while the select state is resolved
     const u64 my_key = c < d.C ? d.key[p][c] : 0;
+    const bool own_col = c < d.C && c >= d.c0 && c < d.c1;
+    const float my_duty = own_col ? d.duty[c] : 0.f;
     s_predw[tid] = (c < d.C && d.act[0] && d.world == 1) ? d.pred[p ^ 1][c] : 0u;
     u64 T;
     uint32_t r;                                     // how many of the keys == T are selected
@@ -617,8 +630,8 @@ __global__ __launch_bounds__(256) void k_sp_emit(Dev d, int p, int want_winner, 
     }
     if (c < d.C) {
         const bool sel = sel_any;
-        if (c >= d.c0 && c < d.c1) {
-            float dc = d.duty[c] * d.mom;
+        if (own_col) {
+            float dc = my_duty * d.mom;
             if (sel) dc = dc + d.dinc;
             d.duty[c] = dc;
         }
@@ -728,22 +741,34 @@ __global__ __launch_bounds__(1024) void k_tm_mid(Dev d, int p, int n_active, int
     Counters *c = d.ctr;
     __shared__ int s_cnt, s_base;
     if ((int)blockIdx.x > n_cls) {
+        // two winner rows per block (512 threads each), two float64 per lane: 16-byte accesses;
+        // a wave covers 128 consecutive elements = four mask words, assembled from the ballots of
+        // its even and odd elements
         const uint32_t *in = bank + (size_t)(c->step[p] % (uint32_t)n_inputs) * d.W;
-        const int row = d.active_cols[blockIdx.x - 1 - n_cls];
+        const int ri = (int)(blockIdx.x - 1 - n_cls) * 2 + (int)(threadIdx.x >> 9);
+        if (ri >= n_sp_rows) return;
+        const int row = d.active_cols[ri];
         if (row < d.c0 || row >= d.c1) return;      // another rank's column
         double *prow = d.perm + (size_t)row * d.Ipad;
         uint32_t *mrow = d.mask + (size_t)row * d.W;
+        const int t = threadIdx.x & 511;
         for (int i0 = 0; i0 < d.Ipad; i0 += 1024) {
-            const int i = i0 + threadIdx.x;
-            bool conn = false;
-            if (i < d.I) {
-                const bool on = (in[i >> 5] >> (i & 31)) & 1u;
-                const double v = prow[i] + (on ? d.sp_don : d.sp_doff);
-                prow[i] = v;
-                conn = v >= d.sp_thr;
+            const int e0 = i0 + 2 * t;               // Ipad is a multiple of 128: e0 + 1 < Ipad whenever e0 < Ipad
+            bool c0 = false, c1 = false;
+            if (e0 < d.Ipad) {
+                double2 v = *(double2 *)(prow + e0);
+                const uint32_t bits = in[e0 >> 5] >> (e0 & 31);
+                if (e0 < d.I) { v.x = v.x + ((bits & 1u) ? d.sp_don : d.sp_doff); c0 = v.x >= d.sp_thr; }
+                if (e0 + 1 < d.I) { v.y = v.y + ((bits & 2u) ? d.sp_don : d.sp_doff); c1 = v.y >= d.sp_thr; }
+                *(double2 *)(prow + e0) = v;
             }
-            const u64 m = __ballot(conn);
-            if (lane_id() == 0 && i < d.Ipad) *(u64 *)&mrow[i >> 5] = m;
+            const u64 b0 = __ballot(c0), b1 = __ballot(c1);
+            const int base = i0 + 2 * (t & ~63);
+            if (lane_id() == 0 && base < d.Ipad) {
+                u64 *mw = (u64 *)&mrow[base >> 5];
+                mw[0] = spread32((uint32_t)b0) | (spread32((uint32_t)b1) << 1);
+                mw[1] = spread32((uint32_t)(b0 >> 32)) | (spread32((uint32_t)(b1 >> 32)) << 1);
+            }
         }
         return;
     }
@@ -1348,7 +1373,7 @@ static void enqueue_tm(htm_handle *h, int n_active, int learning, int want_winne
     Dev &d = h->d;
     const int n_cls = learning ? 32 : 0;
     const int n_sp_rows = (learning && h->cfg.enable_sp) ? d.k : 0;      // SP permanence update rides along
-    LAUNCH(h, "tm_mid", k_tm_mid, 1 + n_cls + n_sp_rows, 1024, d, p, n_active, want_winner, learning, bank, n_inputs,
+    LAUNCH(h, "tm_mid", k_tm_mid, 1 + n_cls + (n_sp_rows + 1) / 2, 1024, d, p, n_active, want_winner, learning, bank, n_inputs,
            n_cls, n_sp_rows);
     const int use_lds = scan_lds(d, 1) <= 64 * 1024;
     if (!prefetch) {
