@@ -121,3 +121,23 @@ def test_full_size_65536x32_state_handoff_and_parity():
     for key in gr.FIELDS:
         u, v = np.asarray(step_outputs(a_sp, a_tm, K)[key]), np.asarray(step_outputs(b_sp, b_tm, K)[key])
         assert u.shape == v.shape and np.array_equal(u, v), f"import round trip: {key}"
+
+
+def test_config1_16384_columns_sp_only():
+    """BASELINE.json configs[1]: 16 384 columns, 2 % input sparsity, SpatialPooler only."""
+    import bithtm_amd as B
+    from oracle import SpatialPoolerOracle
+    I, C = 1024, 16384
+    k = round(C * 0.02)
+    np.random.seed(0)
+    sp = B.SpatialPooler(I, C, k)
+    ora = SpatialPoolerOracle(I, C, k, permanence=sp.proximal_projection.permanence.copy())
+    rng = np.random.RandomState(1)
+    bank = rng.rand(50, I) < 0.02
+    for t in range(150):
+        x = bank[t % 50] ^ (rng.rand(I) < 0.005)
+        got, want = sp.process(x), ora.step(x)
+        assert np.array_equal(got.active_column, want.active_column), t
+        assert np.array_equal(got.overlaps, want.overlaps), t
+        assert np.array_equal(got.boosted_overlaps.view(np.int64), want.boosted_overlaps.view(np.int64)), t
+    assert np.array_equal(sp.proximal_projection.permanence.view(np.int64), ora.permanence.view(np.int64))

@@ -121,3 +121,9 @@ def test_four_shards_stress_parameters_with_recycling():
 
 def test_eight_shards_k16():
     _run(8, I=512, C=4096, K=16, P=50, density=0.04, noise=0.005, steps=200, jump=0.0, seed=9)
+
+
+def test_config3_65536_columns_eight_shards():
+    """BASELINE.json configs[3]: 65 536 columns x 32 cells sharded 8-way (8 192 columns per shard),
+    here with the 8 shards emulated on one GPU; every shard must agree with the unsharded oracle."""
+    _run(8, I=1024, C=65536, K=32, P=12, density=0.02, noise=0.005, steps=60, jump=0.0, seed=0)
