@@ -141,3 +141,18 @@ def test_config1_16384_columns_sp_only():
         assert np.array_equal(got.overlaps, want.overlaps), t
         assert np.array_equal(got.boosted_overlaps.view(np.int64), want.boosted_overlaps.view(np.int64)), t
     assert np.array_equal(sp.proximal_projection.permanence.view(np.int64), ora.permanence.view(np.int64))
+
+
+def test_config4_shape_262144_columns_16_cells():
+    """BASELINE.json configs[4] shape (262 144 columns x 16 cells; learned, not pre-populated): the
+    largest grid of the count-in-emit path (1024 blocks) and a 32 KiB active-column bitmap in LDS."""
+    from hip_impl import lockstep_vs_oracle
+    lockstep_vs_oracle(seed=7, input_dim=1024, column_dim=262144, cell_dim=16, patterns=6, density=0.02,
+                       noise=0.002, steps=26, store_every=25, segment_capacity=1 << 20)
+
+
+def test_more_than_1024_column_blocks_uses_separate_count_kernel():
+    """column_dim > 262 144: the per-block counts come from k_sp_count instead of the in-kernel exchange."""
+    from hip_impl import lockstep_vs_oracle
+    lockstep_vs_oracle(seed=8, input_dim=96, column_dim=327680, cell_dim=4, patterns=5, density=0.1,
+                       noise=0.01, steps=22, store_every=21, segment_capacity=1 << 20)
