@@ -143,7 +143,8 @@ def run_single(args):
     dt = time.perf_counter() - t0
     info = eng.check_capacity()
     steps_per_s = args.steps / dt
-    log(f"[bench] {args.steps} steps in {dt:.3f}s = {steps_per_s:.0f} timesteps/s; S={info.segments}")
+    log(f"[bench] {args.steps} steps in {dt:.3f}s = {steps_per_s:.0f} timesteps/s; S={info.segments}; "
+        f"select fallbacks so far: {info.select_fallbacks} of {info.step_index} steps")
 
     # per-kernel device time (HIP events on the engine's stream), same workload, profiled replay
     prof_steps = min(args.steps, 300)

@@ -54,6 +54,7 @@ struct Counters {
     int32_t n_active_cells;
     int32_t n_work;           // learning / punish work items of this step
     int32_t n_work_last;      // ... of the last completed step (telemetry)
+    int32_t sel_fallbacks;    // steps whose top-k select took the in-kernel fallback (telemetry)
     int32_t n_un;             // winners needing a new segment
     int32_t n_recycled, n_new, S_old;
     int32_t error;            // sticky capacity flags
@@ -66,7 +67,7 @@ struct Counters {
 };
 
 struct Dev {
-    int I, W, W4, Ipad, C, K, k, E, Scap, work_cap, sel_passes, colwords;
+    int I, W, W4, Ipad, C, K, k, E, Scap, work_cap, sel_passes, colwords, low_zero, cand_d;
     int world, c0, c1;        // this rank owns columns [c0, c1) (world == 1: everything)
     double sp_thr, sp_don, sp_doff;
     float coef, mom, dinc;
@@ -83,7 +84,8 @@ struct Dev {
     double *boosted[2];       // [C]
     u64 *key[2];              // [C] bits of boosted (non-negative doubles order like uint64)
     uint32_t *hist;           // [2][SEL_MAX_PASSES][SEL_BINS]
-    uint32_t *sel_blk;        // [ceil(C/1024)] packed (greater, equal) counts
+    uint32_t *sel_blk;        // [ceil(C/256)] packed (greater, equal) counts per 256-column block
+    uint32_t *sel_rec;        // [ceil(C/256)][32] per-block bucket records of k_sp_emit (16 granules)
     int *active_cols;         // [k] ascending
     uint32_t *input_stage;    // [W] host-fed input
     // Temporal Memory
@@ -549,27 +551,82 @@ __global__ __launch_bounds__(1024) void k_shard_unpack(Dev d, const unsigned cha
     }
 }
 
+// ---- finishing the select inside k_sp_emit ---------------------------------------------------
+// Two radix digits (24 key bits) are resolved by launches; after them the threshold bucket holds a
+// handful of distinct keys (or one key many times, when overlaps tie).  Every 256-column block
+// publishes ONE 128-byte record -- how many of its keys lie above the bucket, and its distinct
+// bucket keys with multiplicities -- as self-validating 8-byte granules (write-through stores,
+// L1-bypassing loads: MI355X guide, Guideline 16, form R2).  Every block reads all records, so each one
+// derives the exact k-th key T, the number r of keys equal to T that win, and the winner counts
+// of the blocks before it, without another launch.  A block with more than CAND_D distinct
+// bucket keys (or more than CAND_MAX in total) switches ALL blocks, consistently, to an exact
+// fallback: the remaining digits are resolved block-redundantly from the key array and the
+// per-block counts are exchanged in a second tagged round.
+#define CAND_D 8              // distinct bucket keys one block can publish
+#define CAND_RAW 64           // ... and collect from its waves before merging duplicates
+#define CAND_MAX 1024         // bucket entries a block can merge
+
+// pick the bucket that contains the krem-th largest key of a histogram held in LDS
+// (bins [0, nb)); all BS threads call; returns bucket and the keys above it
+template <int BS>
+__device__ __forceinline__ void sel_pick(const uint32_t *h, int nb, uint32_t krem, uint32_t *s_wave,
+                                         uint32_t *s_out /*[2]*/, uint32_t *bucket, uint32_t *above_out) {
+    const int tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
+    constexpr int PER = SEL_BINS / BS;
+    uint32_t cs = 0;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int b = tid * PER + j;
+        cs += b < nb ? h[b] : 0u;
+    }
+    uint32_t x = cs;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t y = __shfl_down(x, o);
+        if (lane + o < 64) x += y;
+    }
+    if (lane == 0) s_wave[wv] = x;
+    __syncthreads();
+    uint32_t above = x - cs;
+    for (int w = wv + 1; w < BS / 64; ++w) above += s_wave[w];
+    if (above < krem && krem <= above + cs) {
+        for (int b = min((tid + 1) * PER, nb) - 1; b >= tid * PER; --b) {
+            const uint32_t hb = h[b];
+            if (above + hb >= krem) { s_out[0] = (uint32_t)b; s_out[1] = above; break; }
+            above += hb;
+        }
+    }
+    __syncthreads();
+    *bucket = s_out[0];
+    *above_out = s_out[1];
+}
+
 // Emit the winners in ascending column order (ties: lower index first), update the duty cycle
 // (regularizations.py:19-21, float32, two separately rounded operations), clear the dense
 // per-column words of the non-winners, and run the Temporal Memory's per-column activation for
-// the winners of this block.  One block per 256 columns.
-// `fused` (grids of at most 1024 blocks, all co-resident): the per-block counts of k_sp_count are
-// computed here and exchanged through one tagged 32-bit word per block -- a block publishes
-// {epoch, equal, greater} with a write-through store and reads its predecessors' words with
-// L1-bypassing loads until their epoch matches (MI355X guide, Guideline 16, form R2: the data is
-// the flag).  A block's own counts do not depend on other blocks, so there is no serial chain.
+// the winners of this block.  One block per 256 columns.  `fused` (grids of at most 1024 blocks,
+// all co-resident): the select is finished here (above); otherwise T, r and the per-block counts
+// come from k_sel_pass / k_sp_count launches.
 __global__ __launch_bounds__(256) void k_sp_emit(Dev d, int p, int want_winner, int fused) {
     __shared__ uint32_t s_wave[4];
-    __shared__ uint32_t s_gt, s_eq;
+    __shared__ uint32_t s_gt, s_eq, s_out[2], s_flags;
     __shared__ int s_col[256];
-    __shared__ int s_n;
+    __shared__ int s_n, s_nraw, s_ne;
     __shared__ uint32_t h[SEL_BINS];
-    __shared__ u64 s_prefix;
-    __shared__ uint32_t s_krem;
+    __shared__ u64 s_prefix, s_T;
+    __shared__ uint32_t s_krem, s_r;
     __shared__ uint32_t s_predw[256];
-    const int tid = threadIdx.x;
-    if (tid == 0) { s_gt = 0; s_eq = 0; s_n = 0; }
-    const int c = blockIdx.x * 256 + tid;
+    __shared__ u64 s_bk[CAND_RAW];
+    __shared__ uint32_t s_bc[CAND_RAW];
+    // merged bucket entries live in the histogram's LDS once the launched digits are resolved
+    u64 *s_ek = (u64 *)h;                           // [CAND_MAX] keys
+    uint32_t *s_ec = h + 2 * CAND_MAX;              // [CAND_MAX] multiplicities
+    uint16_t *s_eb = (uint16_t *)(h + 3 * CAND_MAX);   // [CAND_MAX] publishing block
+    static_assert(3 * CAND_MAX + CAND_MAX / 2 <= SEL_BINS, "bucket entries must fit the histogram");
+    const int tid = threadIdx.x, lane = lane_id();
+    const int b = blockIdx.x, nblk = gridDim.x;
+    if (tid == 0) { s_gt = 0; s_eq = 0; s_n = 0; s_nraw = 0; s_ne = 0; s_flags = 0; }
+    const int c = b * 256 + tid;
     // independent of everything below: in flight while the select state is resolved
     const u64 my_key = c < d.C ? d.key[p][c] : 0;
     const bool own_col = c < d.C && c >= d.c0 && c < d.c1;
@@ -577,48 +634,195 @@ __global__ __launch_bounds__(256) void k_sp_emit(Dev d, int p, int want_winner, 
     s_predw[tid] = (c < d.C && d.act[0] && d.world == 1) ? d.pred[p ^ 1][c] : 0u;
     u64 T;
     uint32_t r;                                     // how many of the keys == T are selected
+    bool second_round = false;                      // per-block counts still to be exchanged
+    const uint32_t epoch = (d.ctr->step[p] & 0x3FFu) + 1u;              // 1..1024, changes every step
     if (fused) {
-        sel_resolve<256>(d, p, d.sel_passes - 1, h, s_wave, &T, &r, &s_prefix, &s_krem);
+        u64 P;
+        uint32_t krem;
+        sel_resolve<256>(d, p, d.sel_passes - 1, h, s_wave, &P, &krem, &s_prefix, &s_krem);
         __syncthreads();
-        if (blockIdx.x == 0 && tid == 0) { d.ctr->sel_prefix[p] = T; d.ctr->sel_krem[p] = r; }
         if (d.sel_passes > 1)                       // pass-0 histogram is consumed: clear it for its next use
-            for (int i = blockIdx.x * 256 + tid; i < SEL_BINS; i += gridDim.x * 256) d.hist[p * SEL_MAX_PASSES * SEL_BINS + i] = 0;
+            for (int i = b * 256 + tid; i < SEL_BINS; i += nblk * 256) d.hist[p * SEL_MAX_PASSES * SEL_BINS + i] = 0;
+        const int lowbits = sel_shift(d.sel_passes - 1);        // key bits not resolved by launches
+        const u64 hiP = P >> lowbits, hi = my_key >> lowbits;
+        const bool c_gt = c < d.C && hi > hiP, c_cand = c < d.C && hi == hiP;
+        // ---- this block's record
+        {
+            const u64 mg = __ballot(c_gt);
+            if (lane == 0 && mg) atomicAdd(&s_gt, (uint32_t)__popcll(mg));        // s_gt: keys above the bucket, for now
+            u64 todo = __ballot(c_cand);
+            while (todo) {                           // group equal bucket keys inside the wave
+                const int leader = __ffsll((long long)todo) - 1;
+                const u64 kl = ((u64)__shfl((uint32_t)(my_key >> 32), leader) << 32) | __shfl((uint32_t)my_key, leader);
+                const u64 same = __ballot(c_cand && my_key == kl) & todo;
+                if (lane == leader) {
+                    const int slot = atomicAdd(&s_nraw, 1);
+                    if (slot < CAND_RAW) { s_bk[slot] = kl; s_bc[slot] = (uint32_t)__popcll(same); }
+                }
+                todo &= ~same;
+            }
+        }
+        __syncthreads();
+        const int nraw = min(s_nraw, CAND_RAW);
+        const uint32_t my_gt_hi = s_gt;
+        int first = -1;                              // merge duplicates that came from different waves
+        uint32_t my_cnt = 0;
+        if (tid < nraw) {
+            my_cnt = s_bc[tid];
+            for (first = 0; s_bk[first] != s_bk[tid]; ++first) {}
+        }
+        __syncthreads();
+        if (tid < nraw && first != tid) atomicAdd(&s_bc[first], my_cnt);
+        __syncthreads();
+        // record = 16 self-validating 64-bit granules (form R2: every granule carries the epoch, one
+        // aligned 8-byte write-through store each, so no separate tag and no drain):
+        //   [0]      epoch:12 | overflow:1 | pairs:8 | keys above the bucket:16
+        //   [1 + j]  epoch:12 | multiplicity:12 | low 40 key bits   (the high bits are the bucket's)
+        u64 *rec = (u64 *)(d.sel_rec + (size_t)b * 32);
+        const u64 etag = (u64)epoch << 52;
+        const u64 lowmask = (1ull << lowbits) - 1ull;
+        if (tid < 64) {                              // wave 0 compacts the survivors into the record
+            const bool alive = tid < nraw && first == tid;
+            const u64 ma = __ballot(alive);
+            const int n_pairs = __popcll(ma), pos = __popcll(ma & lanemask_lt());
+            const bool overflow = s_nraw > CAND_RAW || n_pairs > d.cand_d;
+            if (alive && pos < CAND_D)
+                __hip_atomic_store(rec + 1 + pos, etag | ((u64)s_bc[tid] << 40) | (s_bk[tid] & lowmask),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0)
+                __hip_atomic_store(rec, etag | (overflow ? (1ull << 24) : 0ull) | ((u64)min(n_pairs, CAND_D) << 16) | my_gt_hi,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (tid == 0) s_gt = 0;
+        // ---- everybody's records: head and all pair granules fetched in one batch per poll
+        uint32_t gthi_before = 0;
+        for (int rb = tid; rb < nblk; rb += 256) {
+            const u64 *rr = (const u64 *)(d.sel_rec + (size_t)rb * 32);
+            u64 g[1 + CAND_D];
+            int np = 0;
+            // poll the head granule alone (one lane-load per spin keeps the polling traffic low), then
+            // fetch the pair granules in one batch; each granule validates itself
+            for (int spins = 0;; ++spins) {
+                g[0] = __hip_atomic_load(rr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((g[0] >> 52) == epoch) break;
+                if (spins >= (1 << 20)) { atomicOr(&d.ctr->error, 16); g[0] = 0; break; }      // a block never arrived
+                __builtin_amdgcn_s_sleep(2);
+            }
+            np = (g[0] >> 52) == epoch ? (int)((g[0] >> 16) & 0xFFu) : 0;
+            for (int spins = 0; np > 0; ++spins) {
+#pragma unroll
+                for (int j = 0; j < CAND_D; ++j) g[1 + j] = __hip_atomic_load(rr + 1 + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                bool ok = true;
+#pragma unroll
+                for (int j = 0; j < CAND_D; ++j) ok = ok && (j >= np || (g[1 + j] >> 52) == epoch);
+                if (ok) break;
+                if (spins >= (1 << 20)) { atomicOr(&d.ctr->error, 16); np = 0; break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            if (rb < b) gthi_before += (uint32_t)(g[0] & 0xFFFFu);
+            if ((g[0] >> 24) & 1ull) atomicOr(&s_flags, 1u);
+#pragma unroll
+            for (int j = 0; j < CAND_D; ++j)
+                if (j < np) {
+                    const int slot = atomicAdd(&s_ne, 1);
+                    if (slot < CAND_MAX) {
+                        s_ek[slot] = (hiP << lowbits) | (g[1 + j] & lowmask);
+                        s_ec[slot] = (uint32_t)((g[1 + j] >> 40) & 0xFFFu);
+                        s_eb[slot] = (uint16_t)rb;
+                    }
+                }
+        }
+        __syncthreads();
+        const int ne = s_ne;
+        if (!(s_flags & 1u) && ne <= CAND_MAX) {
+            for (int e = tid; e < ne; e += 256) {     // the krem-th largest of the merged bucket
+                const u64 ke = s_ek[e];
+                uint32_t ng = 0, nq = 0;
+                for (int f = 0; f < ne; ++f) {
+                    const u64 kf = s_ek[f];
+                    const uint32_t cf = s_ec[f];
+                    ng += kf > ke ? cf : 0u;
+                    nq += kf == ke ? cf : 0u;
+                }
+                if (ng < krem && krem <= ng + nq) { s_T = ke; s_r = krem - ng; }
+            }
+            __syncthreads();
+            T = s_T;
+            r = s_r;
+            uint32_t g = gthi_before, e2 = 0;         // winners of the blocks before this one
+            for (int e = tid; e < ne; e += 256)
+                if (s_eb[e] < b) {
+                    if (s_ek[e] > T) g += s_ec[e];
+                    else if (s_ek[e] == T) e2 += s_ec[e];
+                }
+            for (int o = 32; o > 0; o >>= 1) { g += __shfl_xor(g, o); e2 += __shfl_xor(e2, o); }
+            if (lane == 0) { atomicAdd(&s_gt, g); atomicAdd(&s_eq, e2); }
+        } else {
+            // exact fallback: resolve the remaining digits from the key array, redundantly per block
+            u64 P2 = P;
+            uint32_t k2 = krem;
+            const u64 *keys = d.key[p];
+            for (int top = lowbits; top > d.low_zero;) {
+                const int bits = min(SEL_DIGIT, top), shift = top - bits, nb = 1 << bits;
+                for (int i = tid; i < nb; i += 256) h[i] = 0;
+                __syncthreads();
+                for (int c0 = (tid & ~63); c0 < d.C; c0 += 256) {
+                    const int cc = c0 + lane;
+                    const u64 kk = cc < d.C ? keys[cc] : 0;
+                    hist_add(h, (uint32_t)(kk >> shift) & (nb - 1), cc < d.C && ((kk ^ P2) >> top) == 0);
+                }
+                __syncthreads();
+                uint32_t bucket, above;
+                sel_pick<256>(h, nb, k2, s_wave, s_out, &bucket, &above);
+                P2 |= (u64)bucket << shift;
+                k2 -= above;
+                top = shift;
+                __syncthreads();
+            }
+            T = P2;
+            r = k2;
+            second_round = true;
+            if (b == 0 && tid == 0) d.ctr->sel_fallbacks += 1;
+        }
+        if (b == 0 && tid == 0) { d.ctr->sel_prefix[p] = T; d.ctr->sel_krem[p] = r; }
     } else {
         T = d.ctr->sel_prefix[p];
         r = d.ctr->sel_krem[p];
-        __syncthreads();
     }
+    __syncthreads();
     uint32_t flag = 0;
     if (c < d.C) flag = (my_key > T) ? 1u : ((my_key == T) ? 0x10000u : 0u);
     uint32_t total;
     const uint32_t ex = block_excl_scan<256>(flag, s_wave, total);
-    uint32_t g = 0, e = 0;
-    if (fused) {
-        const uint32_t epoch = (d.ctr->step[p] & 0x7FFu) + 1u;          // 1..2048, changes every step
-        if (tid == 0)
-            __hip_atomic_store(&d.sel_blk[blockIdx.x], (epoch << 20) | ((total >> 16) << 10) | (total & 0xFFFFu),
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        for (int i = tid; i < (int)blockIdx.x; i += 256) {
-            uint32_t v = 0;
-            int spins = 0;
-            do {
-                v = __hip_atomic_load(&d.sel_blk[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((v >> 20) == epoch) break;
-                __builtin_amdgcn_s_sleep(1);
-            } while (++spins < (1 << 22));
-            if ((v >> 20) != epoch) atomicOr(&d.ctr->error, 16);        // a predecessor never arrived
-            g += v & 0x3FFu;
-            e += (v >> 10) & 0x3FFu;
+    if (second_round || !fused) {
+        uint32_t g = 0, e = 0;
+        if (fused) {                                // tagged words, second round of this step
+            const uint32_t tag2 = epoch | 0x800u;
+            if (tid == 0)
+                __hip_atomic_store(&d.sel_blk[b], (tag2 << 20) | ((total >> 16) << 10) | (total & 0xFFFFu),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int i = tid; i < b; i += 256) {
+                uint32_t v = 0;
+                int spins = 0;
+                do {
+                    v = __hip_atomic_load(&d.sel_blk[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((v >> 20) == tag2) break;
+                    __builtin_amdgcn_s_sleep(1);
+                } while (++spins < (1 << 22));
+                if ((v >> 20) != tag2) atomicOr(&d.ctr->error, 16);
+                g += v & 0x3FFu;
+                e += (v >> 10) & 0x3FFu;
+            }
+        } else {
+            for (int i = tid; i < b; i += 256) {
+                const uint32_t v = d.sel_blk[i];
+                g += v & 0xFFFFu;
+                e += v >> 16;
+            }
         }
-    } else {
-        for (int i = tid; i < (int)blockIdx.x; i += 256) {
-            uint32_t v = d.sel_blk[i];
-            g += v & 0xFFFFu;
-            e += v >> 16;
-        }
+        for (int o = 32; o > 0; o >>= 1) { g += __shfl_xor(g, o); e += __shfl_xor(e, o); }
+        if (lane == 0) { atomicAdd(&s_gt, g); atomicAdd(&s_eq, e); }
     }
-    for (int o = 32; o > 0; o >>= 1) { g += __shfl_xor(g, o); e += __shfl_xor(e, o); }
-    if (lane_id() == 0) { atomicAdd(&s_gt, g); atomicAdd(&s_eq, e); }
     __syncthreads();
     const uint32_t gt_before = s_gt, eq_before = s_eq;
     const uint32_t g_run = gt_before + (ex & 0xFFFFu), e_run = eq_before + (ex >> 16);
@@ -1546,6 +1750,7 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
         }
         rc |= dalloc(h, &d.hist, (size_t)2 * SEL_MAX_PASSES * SEL_BINS);
         rc |= dalloc(h, &d.sel_blk, (C + 255) / 256);
+        rc |= dalloc(h, &d.sel_rec, (C + 255) / 256 * 32);
         rc |= dalloc(h, &d.input_stage, (size_t)d.W);
     }
     if (cfg->enable_tm) {
@@ -1605,6 +1810,13 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
         while ((1ll << B) <= (long long)d.I) ++B;
         const int informative = std::min(64, 64 - (29 - B));
         d.sel_passes = std::max(1, std::min(SEL_MAX_PASSES, (informative + SEL_DIGIT - 1) / SEL_DIGIT));
+        d.low_zero = 64 - informative;            // key bits [0, low_zero) are zero in every key
+        // grids of at most 1024 emit blocks finish the select inside k_sp_emit: two digits by launches
+        if ((d.C + 255) / 256 <= 1024) d.sel_passes = std::min(d.sel_passes, 2);
+        // test knobs: more launched digits (smaller buckets); fewer record slots (forces the fallback)
+        if (const char *e = getenv("BITHTM_SEL_LAUNCH_DIGITS")) d.sel_passes = std::max(2, std::min(d.sel_passes, atoi(e)));
+        d.cand_d = CAND_D;
+        if (const char *e = getenv("BITHTM_CAND_D")) d.cand_d = std::max(0, std::min(CAND_D, atoi(e)));
     }
     e = hipStreamSynchronize(h->stream);
     if (e != hipSuccess) return fail_create(h, std::string("hipStreamSynchronize: ") + hipGetErrorString(e), HTM_ERR_HIP);
@@ -1845,6 +2057,7 @@ extern "C" int htm_get_info(htm_handle *h, htm_info *out) {
     out->recycled_segments = c.n_un ? c.n_recycled : 0;
     out->appended_segments = c.n_un ? c.n_new : 0;
     out->work_items = c.n_work_last;
+    out->select_fallbacks = c.sel_fallbacks;
     if (c.error) {
         h->err = std::string("capacity exhausted:") + ((c.error & 1) ? " segment pool (segment_capacity)" : "") +
                  ((c.error & 2) ? " synapse slots (segment_slots)" : "") + ((c.error & 4) ? " work list / growth staging" : "") +

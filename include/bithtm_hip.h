@@ -95,6 +95,8 @@ typedef struct htm_info {
     int32_t recycled_segments;          /* last step: of those, served by recycling (projections.py:80-85) */
     int32_t appended_segments;          /* last step: served by fresh ids (projections.py:90-94) */
     int32_t work_items;                 /* last step: segments that learned or were punished */
+    int32_t select_fallbacks;           /* steps so far whose top-k select overflowed the per-block records
+                                           and took the exact in-kernel fallback (slower, same result) */
 } htm_info;
 
 /* Device arrays readable with htm_read / writable with htm_write. Element type and count

@@ -166,3 +166,26 @@ def test_batched_run_equals_step_by_step():
     for o in outs[1:]:
         for a, b in zip(outs[0], o):
             assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("digits,slots", [("2", "8"), ("3", "8"), ("2", "0"), ("2", "1")])
+def test_select_is_exact_on_the_record_path_and_on_the_fallback(digits, slots, monkeypatch):
+    """k_sp_emit finishes the top-k select from per-block bucket records.  slots=0 makes every block
+    with a bucket key overflow its record, so the exact in-kernel fallback runs every step; slots=1
+    mixes both paths; 3 launched digits is the variant with smaller buckets."""
+    import bithtm_amd as B
+    from oracle import HTMOracle
+    monkeypatch.setenv("BITHTM_SEL_LAUNCH_DIGITS", digits)
+    monkeypatch.setenv("BITHTM_CAND_D", slots)
+    np.random.seed(31)
+    htm = B.HierarchicalTemporalMemory(300, 4096, 8)
+    ora = HTMOracle(300, 4096, 8, seed=0, permanence=htm.spatial_pooler.proximal_projection.permanence.copy())
+    rng = np.random.RandomState(32)
+    bank = rng.rand(40, 300) < 0.05
+    for t in range(130):
+        x = bank[t % 40] ^ (rng.rand(300) < 0.01)
+        s, m = htm.process(x)
+        os_, om = ora.step(x)
+        assert np.array_equal(s.active_column, os_.active_column), (digits, slots, t)
+        assert np.array_equal(m.cell_prediction, om.cell_prediction), (digits, slots, t)
+    htm.engine.check_capacity()
