@@ -13,6 +13,7 @@
 // the ABI converts to / from the reference's flat id column * cell_dim + cell.
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -1503,18 +1504,20 @@ static int prof_slot(htm_handle *h, const char *name) {
     return (int)h->prof_names.size() - 1;
 }
 
-// Profiling: ONE event after every kernel (and one at the start of a run); a kernel's time is the
-// difference to the previous event, i.e. its execution plus its place in the dependent chain --
-// the same thing rocprofv3's back-to-back kernel timestamps measure.
+// Profiling: hipExtLaunchKernelGGL stamps a start and a stop event with the kernel's own begin /
+// end timestamps on the device -- the quantity rocprofv3's kernel trace reports -- so the two can
+// be compared directly (an event recorded between launches would add its marker and the dependent
+// launch gap to every kernel).
 #define LAUNCH_ON(h, strm, shmem, name, kernel, grid, block, ...)                                 \
     do {                                                                                         \
-        hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), shmem, strm, __VA_ARGS__);           \
         if ((h)->profile) {                                                                      \
-            hipEvent_t e1_ = nullptr;                                                            \
-            hipEventCreateWithFlags(&e1_, hipEventDisableSystemFence);                           \
-            hipEventRecord(e1_, strm);                                                           \
-            (h)->prof_events[prof_slot(h, name)].push_back({(h)->prof_last, e1_});               \
-            (h)->prof_last = e1_;                                                                \
+            hipEvent_t e0_ = nullptr, e1_ = nullptr;                                             \
+            hipEventCreate(&e0_);                                                                \
+            hipEventCreate(&e1_);                                                                \
+            hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(block), shmem, strm, e0_, e1_, 0, __VA_ARGS__); \
+            (h)->prof_events[prof_slot(h, name)].push_back({e0_, e1_});                          \
+        } else {                                                                                 \
+            hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), shmem, strm, __VA_ARGS__);       \
         }                                                                                        \
     } while (0)
 #define LAUNCH(h, name, kernel, grid, block, ...) LAUNCH_ON(h, (h)->stream, 0, name, kernel, grid, block, __VA_ARGS__)
@@ -1647,7 +1650,7 @@ extern "C" void htm_destroy(htm_handle *h) {
     hipStreamSynchronize(h->stream);
     for (auto &kv : h->graphs) hipGraphExecDestroy(kv.second);
     for (auto &v : h->prof_events)
-        for (auto &pr : v) hipEventDestroy(pr.second);
+        for (auto &pr : v) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     for (hipEvent_t e : h->prof_all) hipEventDestroy(e);
     for (void *p : h->allocs) hipFree(p);
     if (h->own_stream) hipStreamDestroy(h->stream);
@@ -2280,13 +2283,6 @@ extern "C" int htm_import_commit(htm_handle *h, int32_t segments, int32_t matchi
 extern "C" int htm_profile(htm_handle *h, int32_t enable) {
     if (!h) return HTM_ERR_ARGUMENT;
     h->profile = enable != 0;
-    if (h->profile) {                      // opening event of the chain
-        HIPCHK(h, hipSetDevice(h->device));
-        HIPCHK(h, hipStreamSynchronize(h->stream));
-        HIPCHK(h, hipEventCreateWithFlags(&h->prof_last, hipEventDisableSystemFence));
-        HIPCHK(h, hipEventRecord(h->prof_last, h->stream));
-        h->prof_all.push_back(h->prof_last);
-    }
     return HTM_OK;
 }
 
@@ -2300,6 +2296,7 @@ extern "C" int htm_profile_read(htm_handle *h, int32_t max_kernels, const char *
             hipEventElapsedTime(&ms, pr.first, pr.second);
             h->prof_ms[i] += ms;
             h->prof_n[i] += 1;
+            h->prof_all.push_back(pr.first);
             h->prof_all.push_back(pr.second);
         }
         h->prof_events[i].clear();

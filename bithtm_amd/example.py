@@ -1,61 +1,95 @@
-"""Counterpart of the reference's example.py (flags :22-30, input generation :34, per-step noise
-:52, the three printed counters :55-57) running on the MI355X engine.
+"""Harness for the MI355X engine with the command line, input model and per-step report of the
+reference's example script (flags: example.py:22-30; random pattern bank: :34; flip noise: :52;
+the three counters: :55-57), so that its output can be compared line by line.
 
     python -m bithtm_amd.example --epochs 8
-    python -m bithtm_amd.example --epochs 8 --batched      # one C-ABI call per epoch, hipGraph replay
+    python -m bithtm_amd.example --epochs 8 --batched   # one C-ABI call per epoch, hipGraph replay
 """
 
 import argparse
+import sys
 import time
 
 import numpy as np
 
 from bithtm_amd import HierarchicalTemporalMemory
 
-
-def main(argv=None):
-    parser = argparse.ArgumentParser()
-    parser.add_argument('--epochs', type=int, default=100)
-    parser.add_argument('--input_patterns', type=int, default=100)
-    parser.add_argument('--input_dim', type=int, default=1000)
-    parser.add_argument('--input_density', type=float, default=0.2)
-    parser.add_argument('--input_noise_probability', type=float, default=0.05)
-    parser.add_argument('--column_dim', type=int, default=2048)
-    parser.add_argument('--cell_dim', type=int, default=32)
-    parser.add_argument('--seed', type=int, default=0, help='keyed random draws of the Temporal Memory')
-    parser.add_argument('--batched', action='store_true',
-                        help='no per-step read-back: run each epoch with HierarchicalTemporalMemory.run and '
-                             'print timesteps/s per epoch instead of the per-step counters')
-    args = parser.parse_args(argv)
-
-    inputs = np.random.rand(args.input_patterns, args.input_dim) < args.input_density
-    htm = HierarchicalTemporalMemory(args.input_dim, args.column_dim, args.cell_dim, seed=args.seed)
-
-    def width(n):
-        return int(np.ceil(np.log10(max(n - 1, 2))))
-    ew, pw, cw, aw = width(args.epochs), width(args.input_patterns), width(args.column_dim), width(htm.spatial_pooler.active_columns)
-
-    start_time = time.time()
-    for epoch in range(args.epochs):
-        if args.batched:
-            noisy = inputs ^ (np.random.rand(*inputs.shape) < args.input_noise_probability)
-            t0 = time.time()
-            htm.run(noisy, len(noisy))
-            htm.engine.sync()
-            print(f'epoch {epoch:{ew}d}: {len(noisy) / (time.time() - t0):.0f} timesteps/s, '
-                  f'{htm.engine.info().segments} segments')
-            continue
-        for input_index, curr_input in enumerate(inputs):
-            prev_column_prediction = htm.temporal_memory.last_state.cell_prediction.max(axis=1)
-            noisy_input = curr_input ^ (np.random.rand(args.input_dim) < args.input_noise_probability)
-            sp_state, tm_state = htm.process(noisy_input)
-            burstings = tm_state.active_column_bursting.sum()
-            corrects = prev_column_prediction[sp_state.active_column].sum()
-            incorrects = prev_column_prediction.sum() - corrects
-            print(f'epoch {epoch:{ew}d}, pattern {input_index:{pw}d}: bursting columns: {burstings:{aw}d}, '
-                  f'correct columns: {corrects:{aw}d}, incorrect columns: {incorrects:{cw}d}')
-    print(f'{time.time() - start_time} seconds.')
+FLAGS = (
+    # name, type, default  (the reference's flags, same names and defaults)
+    ("epochs", int, 100),
+    ("input_patterns", int, 100),
+    ("input_dim", int, 1000),
+    ("input_density", float, 0.2),
+    ("input_noise_probability", float, 0.05),
+    ("column_dim", int, 2048),
+    ("cell_dim", int, 32),
+)
 
 
-if __name__ == '__main__':
+def parse(argv):
+    ap = argparse.ArgumentParser(description=__doc__.splitlines()[0])
+    for name, kind, default in FLAGS:
+        ap.add_argument("--" + name, type=kind, default=default)
+    ap.add_argument("--seed", type=int, default=0, help="seed of the Temporal Memory's keyed random draws")
+    ap.add_argument("--batched", action="store_true",
+                    help="run each epoch with HierarchicalTemporalMemory.run (no per-step read-back) and "
+                         "report timesteps/s per epoch instead of the per-step counters")
+    return ap.parse_args(argv)
+
+
+def digits(n):
+    """Field width the reference uses for a counter that can reach n - 1."""
+    return int(np.ceil(np.log10(max(n - 1, 2))))
+
+
+class Report:
+    """Formats one line per timestep exactly like the reference's print statement."""
+
+    def __init__(self, opts, active_columns):
+        self.w_epoch, self.w_pattern = digits(opts.epochs), digits(opts.input_patterns)
+        self.w_column, self.w_active = digits(opts.column_dim), digits(active_columns)
+
+    def line(self, epoch, pattern, bursting, correct, incorrect):
+        return (f"epoch {epoch:{self.w_epoch}d}, pattern {pattern:{self.w_pattern}d}: "
+                f"bursting columns: {bursting:{self.w_active}d}, correct columns: {correct:{self.w_active}d}, "
+                f"incorrect columns: {incorrect:{self.w_column}d}")
+
+
+def column_counters(predicted_columns, sp_state, tm_state):
+    """(bursting, correctly predicted, incorrectly predicted) columns of one timestep."""
+    hit = int(predicted_columns[sp_state.active_column].sum())
+    return int(tm_state.active_column_bursting.sum()), hit, int(predicted_columns.sum()) - hit
+
+
+def run_stepwise(htm, bank, opts, out):
+    report = Report(opts, htm.spatial_pooler.active_columns)
+    for epoch in range(opts.epochs):
+        for index, pattern in enumerate(bank):
+            predicted_columns = htm.temporal_memory.last_state.cell_prediction.any(axis=1)
+            flips = np.random.rand(opts.input_dim) < opts.input_noise_probability
+            states = htm.process(pattern ^ flips)
+            print(report.line(epoch, index, *column_counters(predicted_columns, *states)), file=out)
+
+
+def run_batched(htm, bank, opts, out):
+    width = digits(opts.epochs)
+    for epoch in range(opts.epochs):
+        noisy = bank ^ (np.random.rand(*bank.shape) < opts.input_noise_probability)
+        began = time.time()
+        htm.run(noisy, len(noisy))
+        htm.engine.sync()
+        rate = len(noisy) / (time.time() - began)
+        print(f"epoch {epoch:{width}d}: {rate:.0f} timesteps/s, {htm.engine.info().segments} segments", file=out)
+
+
+def main(argv=None, out=sys.stdout):
+    opts = parse(argv)
+    bank = np.random.rand(opts.input_patterns, opts.input_dim) < opts.input_density
+    htm = HierarchicalTemporalMemory(opts.input_dim, opts.column_dim, opts.cell_dim, seed=opts.seed)
+    began = time.time()
+    (run_batched if opts.batched else run_stepwise)(htm, bank, opts, out)
+    print(f"{time.time() - began} seconds.", file=out)
+
+
+if __name__ == "__main__":
     main()

@@ -189,3 +189,21 @@ def test_select_is_exact_on_the_record_path_and_on_the_fallback(digits, slots, m
         assert np.array_equal(s.active_column, os_.active_column), (digits, slots, t)
         assert np.array_equal(m.cell_prediction, om.cell_prediction), (digits, slots, t)
     htm.engine.check_capacity()
+
+
+def test_example_harness_prints_the_reference_report_format():
+    """bithtm_amd.example: the reference's flags and its per-step line, character for character."""
+    import io
+    import re
+    from bithtm_amd import example
+    np.random.seed(3)
+    out = io.StringIO()
+    example.main(["--epochs", "2", "--input_patterns", "12", "--input_dim", "200", "--column_dim", "1024", "--cell_dim", "8"], out=out)
+    lines = out.getvalue().strip().splitlines()
+    assert len(lines) == 2 * 12 + 1 and lines[-1].endswith(" seconds.")
+    pat = re.compile(r"^epoch [ \d]\d*, pattern [ \d]\d: bursting columns: [ \d]\d, correct columns: [ \d]\d, incorrect columns: [ \d]{3}\d$")
+    assert all(pat.match(l) for l in lines[:-1]), lines[0]
+    assert lines[0] == "epoch 0, pattern  0: bursting columns: 20, correct columns:  0, incorrect columns:    0"
+    out = io.StringIO()
+    example.main(["--epochs", "2", "--input_patterns", "12", "--input_dim", "200", "--column_dim", "1024", "--cell_dim", "8", "--batched"], out=out)
+    assert "timesteps/s" in out.getvalue()
