@@ -197,6 +197,14 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="one role per launch (what the profiled replay always does)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started by hand without the launcher: start one process per GPU as a CHILD (this process has
+        # not touched the GPU) and pass its exit code on
+        import subprocess
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29533"),
+               os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
     if args.gpus > 1 or int(os.environ.get("WORLD_SIZE", "1")) > 1:
         from bench_sharded import run_sharded
         out = run_sharded(args)

@@ -134,7 +134,7 @@ class TemporalMemory:
         def _fetch(self):
             eng = self._engine
             C, K = eng.column_dim, eng.cell_dim
-            info = eng.info()
+            info = eng.check_capacity()          # an overflowed pool must not be read as if nothing happened
             cols = self._active_column
             if cols is None:
                 cols = eng.read(L.F_ACTIVE_COLUMN, np.int32, eng.active_columns).astype(np.int64)
