@@ -276,6 +276,32 @@ class HierarchicalTemporalMemory:
 
     compute = process
 
+    # ---- checkpoint / resume (the reference has none).  The dictionary holds the
+    # reference's own arrays: DenseProjection.permanence, ExponentialBoosting.duty_cycle, and the
+    # SparseProjection / PredictiveProjection store + last State in the layout of oracle export_state.
+    def state_dict(self):
+        eng = self._engine
+        retire_states(eng)
+        out = {"tm_" + k: np.asarray(v) for k, v in eng.export_tm_state().items()}
+        out["sp_permanence"] = eng.get_permanence()
+        out["sp_duty_cycle"] = eng.read_duty_cycle()
+        return out
+
+    def load_state_dict(self, state):
+        eng = self._engine
+        retire_states(eng)
+        eng.set_permanence(np.asarray(state["sp_permanence"], dtype=np.float64))
+        eng.write(L.F_DUTY_CYCLE, np.asarray(state["sp_duty_cycle"], dtype=np.float32), np.float32)
+        eng.import_tm_state({k[3:]: v for k, v in state.items() if k.startswith("tm_")})
+        self.temporal_memory._last_ref = None
+
+    def save(self, path):
+        np.savez_compressed(path, **self.state_dict())
+
+    def load(self, path):
+        with np.load(path) as z:
+            self.load_state_dict({k: z[k] for k in z.files})
+
     def run(self, inputs, steps, learning=True, use_graph=True, pipeline=True):
         """`steps` timesteps over the rows of the boolean matrix `inputs`, cycled, with the input
         bank resident in device memory and no per-step host work (the loop of example.py:48-53).

@@ -207,3 +207,27 @@ def test_example_harness_prints_the_reference_report_format():
     out = io.StringIO()
     example.main(["--epochs", "2", "--input_patterns", "12", "--input_dim", "200", "--column_dim", "1024", "--cell_dim", "8", "--batched"], out=out)
     assert "timesteps/s" in out.getvalue()
+
+
+def test_checkpoint_and_resume(tmp_path):
+    """save() after 90 steps, then a fresh object load()s and continues exactly like the original."""
+    import bithtm_amd as B
+    rng = np.random.RandomState(41)
+    bank = rng.rand(30, 160) < 0.1
+    np.random.seed(42)
+    a = B.HierarchicalTemporalMemory(160, 2048, 8, seed=9)
+    a.run(bank, 90)
+    a.save(tmp_path / "ckpt.npz")
+    np.random.seed(43)                                   # different initial permanences on purpose
+    b = B.HierarchicalTemporalMemory(160, 2048, 8, seed=9)
+    b.load(tmp_path / "ckpt.npz")
+    for t in range(90, 150):
+        sa, ma = a.process(bank[t % 30])
+        sb, mb = b.process(bank[t % 30])
+        assert np.array_equal(sa.active_column, sb.active_column), t
+        assert np.array_equal(ma.cell_prediction, mb.cell_prediction), t
+        assert np.array_equal(ma.winner_cell[0], mb.winner_cell[0]) and np.array_equal(ma.winner_cell[1], mb.winner_cell[1]), t
+    da, db = a.state_dict(), b.state_dict()
+    assert da.keys() == db.keys()
+    for k in da:
+        assert np.array_equal(da[k], db[k]), k
