@@ -1261,13 +1261,14 @@ __device__ __forceinline__ uint32_t scan_cell_active(const uint32_t *act, const 
     const int col = enc >> 5;
     uint32_t maybe = valid ? 1u : 0u;
     if (use_lds) maybe &= (L.colbits[col >> 5] >> (col & 31));
-    const uint32_t aw = act[maybe ? col : 0];
+    uint32_t aw = 0;
+    if (maybe) aw = act[col];          // exec-masked: only lanes of active columns issue a request
     return maybe & (aw >> (enc & 31));
 }
 
 // LDS: word 0 = recyclable counter; from word 4: column bitmap [colwords]
-template <int BS>
-__device__ __forceinline__ void role_scan(const Dev &d, int p, int use_lds, int blk, int nblk, uint32_t *lds) {
+template <int BS, bool use_lds>
+__device__ __forceinline__ void role_scan(const Dev &d, int p, int blk, int nblk, uint32_t *lds) {
     constexpr int SEGS = BS / 4;                   // segments per block iteration: BS/8 lane groups x 2 in flight
     int &s_recyc = *(int *)lds;
     uint32_t *s_colbits = lds + 4;
@@ -1292,21 +1293,18 @@ __device__ __forceinline__ void role_scan(const Dev &d, int p, int use_lds, int 
     for (int b = blk; b * SEGS < S; b += nblk) {
         int seg[U], n[U], pot[U], conn[U], n_true[U], cellu[U];
         u64 bits[U];
-        int4 ps[U];
+        int4 ps[U], ps2[U];
         bool mine[U];
-        // the synapse count and the first chunk of each row are fetched together (the chunk is
-        // masked by the count afterwards): one memory round trip instead of two
+        // round trip 1: synapse count, owner cell and the first chunk of each row, all unconditional
+        // (rows of other ranks' segments exist in the replicated address space; they are masked below)
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             seg[u] = min(b * SEGS + u * NG + g, S - 1);
             n[u] = d.seg_nsyn[seg[u]];
             cellu[u] = d.seg_cell[seg[u]];
-            mine[u] = true;
-            if (d.world > 1) mine[u] = col_is_local(d, cellu[u]);                 // rows of other ranks are not here
-            ps[u] = make_int4(0, 0, 0, 0);
-            if (mine[u]) ps[u] = *(const int4 *)(d.presyn + (size_t)seg[u] * d.E + l * 4);
+            ps[u] = *(const int4 *)(d.presyn + (size_t)seg[u] * d.E + l * 4);
         }
-        if (!staged) {                               // overlap the bitmap staging with those loads
+        if (!staged) {                               // the bitmap staging overlaps with those loads
             if (use_lds)
                 for (int i = threadIdx.x; i < d.colwords; i += BS) s_colbits[i] = d.colbits[i];
             staged = true;
@@ -1316,24 +1314,78 @@ __device__ __forceinline__ void role_scan(const Dev &d, int p, int use_lds, int 
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const bool ok = b * SEGS + u * NG + g < S;
+            mine[u] = d.world == 1 || col_is_local(d, cellu[u]);
             n_true[u] = ok ? n[u] : 0x7FFFFFFF;      // for the recyclable count (all ranks, all segments)
             if (!ok || !mine[u]) n[u] = 0;
             seg[u] = ok ? seg[u] : S;
         }
+        // round trip 2 (only rows longer than one chunk): second chunk, in flight during the lookups of the first
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int e[4] = {ps[u].x, ps[u].y, ps[u].z, ps[u].w};
-            u64 bb = 0;
+            ps2[u] = make_int4(0, 0, 0, 0);
+            if (n[u] > 32) ps2[u] = *(const int4 *)(d.presyn + (size_t)seg[u] * d.E + 32 + l * 4);
+        }
+        // chunk 1: all LDS lookups, then all cell-word reads, each as one batch
+        {
+            int e[U][4];
+            uint32_t on[U][4], aw[U][4];
 #pragma unroll
-            for (int qq = 0; qq < 4; ++qq)
-                bb |= (u64)scan_cell_active(act, L, e[qq], l * 4 + qq < n[u], use_lds) << qq;
-            bits[u] = bb;
+            for (int u = 0; u < U; ++u) { e[u][0] = ps[u].x; e[u][1] = ps[u].y; e[u][2] = ps[u].z; e[u][3] = ps[u].w; }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) {
+                    const int col = e[u][qq] >> 5;
+                    on[u][qq] = use_lds ? (s_colbits[col >> 5] >> (col & 31)) & 1u : 1u;
+                }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) {
+                    if (l * 4 + qq >= n[u]) on[u][qq] = 0;
+                    aw[u][qq] = act[on[u][qq] ? (e[u][qq] >> 5) : 0];     // inactive columns: one shared line
+                }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                u64 bb = 0;
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) bb |= (u64)(on[u][qq] & (aw[u][qq] >> (e[u][qq] & 31))) << qq;
+                bits[u] = bb;
+            }
+        }
+        // chunk 2, same shape (skipped by waves in which no row is that long)
+        bool any_long = false;
+#pragma unroll
+        for (int u = 0; u < U; ++u) any_long |= n[u] > 32;
+        if (__any(any_long)) {
+            int e[U][4];
+            uint32_t on[U][4], aw[U][4];
+#pragma unroll
+            for (int u = 0; u < U; ++u) { e[u][0] = ps2[u].x; e[u][1] = ps2[u].y; e[u][2] = ps2[u].z; e[u][3] = ps2[u].w; }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) {
+                    const int col = e[u][qq] >> 5;
+                    on[u][qq] = use_lds ? (s_colbits[col >> 5] >> (col & 31)) & 1u : 1u;
+                }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) {
+                    if (32 + l * 4 + qq >= n[u]) on[u][qq] = 0;
+                    aw[u][qq] = act[on[u][qq] ? (e[u][qq] >> 5) : 0];
+                }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) bits[u] |= (u64)(on[u][qq] & (aw[u][qq] >> (e[u][qq] & 31))) << (4 + qq);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            if (n[u] > 32) {                         // further chunks of longer rows
+            if (n[u] > 64) {                         // rare: rows longer than two chunks
                 const int *prow = d.presyn + (size_t)seg[u] * d.E;
-                for (int i = 32 + l * 4, ch = 1; i < n[u]; i += 32, ++ch) {
+                for (int i = 64 + l * 4, ch = 2; i < n[u]; i += 32, ++ch) {
                     const int4 pv = *(const int4 *)(prow + i);
                     const int e[4] = {pv.x, pv.y, pv.z, pv.w};
 #pragma unroll
@@ -1386,8 +1438,11 @@ __device__ __forceinline__ void role_scan(const Dev &d, int p, int use_lds, int 
     }
 }
 
-__global__ __launch_bounds__(256) void k_tm_scan(Dev d, int p, int use_lds) {
-    role_scan<256>(d, p, use_lds, blockIdx.x, gridDim.x, (uint32_t *)dyn_lds);
+// use_lds is a compile-time switch: as a run-time flag it put a branch and a wait around every
+// single LDS lookup, which serialised them
+template <bool use_lds>
+__global__ __launch_bounds__(256) void k_tm_scan(Dev d, int p) {
+    role_scan<256, use_lds>(d, p, blockIdx.x, gridDim.x, (uint32_t *)dyn_lds);
 }
 
 // ---- pipelined schedule: two independent roles per launch -----------------------------------
@@ -1405,9 +1460,10 @@ __global__ __launch_bounds__(RB) void k_learn_overlap(Dev d, int p, int n_learn_
 }
 
 // 256-thread blocks: the scan is fastest with them; the select role simply loops a little longer
-__global__ __launch_bounds__(256) void k_scan_sel(Dev d, int p, int use_lds, int n_scan_blocks, int pass) {
+template <bool use_lds>
+__global__ __launch_bounds__(256) void k_scan_sel(Dev d, int p, int n_scan_blocks, int pass) {
     if ((int)blockIdx.x < n_scan_blocks)
-        role_scan<256>(d, p, use_lds, blockIdx.x, n_scan_blocks, (uint32_t *)dyn_lds);
+        role_scan<256, use_lds>(d, p, blockIdx.x, n_scan_blocks, (uint32_t *)dyn_lds);
     else
         role_sel_pass<256>(d, pass, p ^ 1, blockIdx.x - n_scan_blocks, gridDim.x - n_scan_blocks, (SelShared *)dyn_lds);
 }
@@ -1539,6 +1595,12 @@ static void launch_learn(htm_handle *h, int p) {
     }
 }
 
+static void launch_scan(htm_handle *h, int p, int use_lds) {
+    Dev &d = h->d;
+    if (use_lds) LAUNCH_ON(h, h->stream, scan_lds(d, 1), "tm_scan", k_tm_scan<true>, h->scan_blocks, 256, d, p);
+    else LAUNCH_ON(h, h->stream, scan_lds(d, 0), "tm_scan", k_tm_scan<false>, h->scan_blocks, 256, d, p);
+}
+
 // launch 3 of the pipelined schedule: step t's learning beside step t+1's overlap + boost
 static void launch_learn_overlap(htm_handle *h, int p, const uint32_t *bank, int n_inputs) {
     Dev &d = h->d;
@@ -1585,16 +1647,17 @@ static void enqueue_tm(htm_handle *h, int n_active, int learning, int want_winne
     const int use_lds = scan_lds(d, 1) <= 64 * 1024;
     if (!prefetch) {
         launch_learn(h, p);
-        LAUNCH_ON(h, h->stream, scan_lds(d, use_lds), "tm_scan", k_tm_scan, h->scan_blocks, 256, d, p, use_lds);
+        launch_scan(h, p, use_lds);
         return;
     }
     launch_learn_overlap(h, p, bank, n_inputs);
     if (d.sel_passes > 1) {
-        LAUNCH_ON(h, h->stream, std::max(scan_lds(d, use_lds), sizeof(SelShared)), "tm_scan+sp_select", k_scan_sel,
-                  h->scan_blocks + 64, 256, d, p, use_lds, h->scan_blocks, 1);
+        const size_t lds = std::max(scan_lds(d, use_lds), sizeof(SelShared));
+        if (use_lds) LAUNCH_ON(h, h->stream, lds, "tm_scan+sp_select", k_scan_sel<true>, h->scan_blocks + 64, 256, d, p, h->scan_blocks, 1);
+        else LAUNCH_ON(h, h->stream, lds, "tm_scan+sp_select", k_scan_sel<false>, h->scan_blocks + 64, 256, d, p, h->scan_blocks, 1);
         for (int pass = 2; pass < d.sel_passes; ++pass) LAUNCH(h, "sp_select", k_sel_pass, h->sel_blocks, RB, d, pass, p ^ 1);
     } else {
-        LAUNCH_ON(h, h->stream, scan_lds(d, use_lds), "tm_scan", k_tm_scan, h->scan_blocks, 256, d, p, use_lds);
+        launch_scan(h, p, use_lds);
     }
 }
 
