@@ -56,6 +56,7 @@ struct Counters {
     int32_t n_work;           // learning / punish work items of this step
     int32_t n_work_last;      // ... of the last completed step (telemetry)
     int32_t sel_fallbacks;    // steps whose top-k select took the in-kernel fallback (telemetry)
+    uint32_t emit_epoch;      // bumped by every overlap launch: tags the records k_sp_emit's blocks exchange
     int32_t n_un;             // winners needing a new segment
     int32_t n_recycled, n_new, S_old;
     int32_t error;            // sticky capacity flags
@@ -87,13 +88,14 @@ struct Dev {
     uint32_t *hist;           // [2][SEL_MAX_PASSES][SEL_BINS]
     uint32_t *sel_blk;        // [ceil(C/256)] packed (greater, equal) counts per 256-column block
     uint32_t *sel_rec;        // [ceil(C/256)][32] per-block bucket records of k_sp_emit (16 granules)
-    int *active_cols;         // [k] ascending
+    int *active_cols[2];      // [k] ascending; parity double buffer (the pipelined schedule emits step t+1's
+                              // list while step t's scan still reads its own)
     uint32_t *input_stage;    // [W] host-fed input
     // Temporal Memory
     uint32_t *act[2];         // [C] active-cell words, parity double buffer
     uint32_t *pred[2];        // [C] predicted-cell words
-    uint32_t *win;            // [C] winner-cell words of the current step
-    uint32_t *colbits;        // [ceil(C/64)*2] bitmap of this step's active columns
+    uint32_t *win[2];         // [C] winner-cell words
+    uint32_t *colbits[2];     // [ceil(C/64)*2] bitmap of the step's active columns
     int *winners[2];          // [k*32] winner cells (enc), ascending
     uint8_t *bursting;        // [k]
     uint32_t *colcnt;         // [k] popc(winner) | popc(unaccounted) << 16
@@ -211,15 +213,17 @@ __global__ __launch_bounds__(256) void k_sp_build_mask(Dev d, int row_begin, int
 // Roles are written against (blk, nblk) instead of blockIdx / gridDim so that two independent
 // roles can share one launch (pipelined schedule: step t's TM work beside step t+1's SP work).
 // sp = parity buffer of the SP step being computed; step_offset = that step minus the current one.
+template <int BS>
 __device__ __forceinline__ void role_overlap(const Dev &d, const uint32_t *__restrict__ bank, int n_inputs, int G,
                                              int p, int sp, int step_offset, int blk, int nblk, uint32_t *h) {
-    const int gtid = blk * RB + threadIdx.x;
-    const int nthreads = nblk * RB;
+    const int gtid = blk * BS + threadIdx.x;
+    const int nthreads = nblk * BS;
     const bool do_hist = d.world == 1;
     uint32_t *ghist = d.hist + sp * SEL_MAX_PASSES * SEL_BINS;
+    if (gtid == 0) d.ctr->emit_epoch += 1;          // a new generation of k_sp_emit records
     if (do_hist) {
         for (int i = gtid; i < (d.sel_passes - 1) * SEL_BINS; i += nthreads) ghist[SEL_BINS + i] = 0;
-        for (int i = threadIdx.x; i < SEL_BINS; i += RB) h[i] = 0;
+        for (int i = threadIdx.x; i < SEL_BINS; i += BS) h[i] = 0;
         if (gtid == 0) {
             d.ctr->sel_pass_prefix[sp][0] = 0;
             d.ctr->sel_pass_krem[sp][0] = (uint32_t)d.k;
@@ -268,13 +272,13 @@ __device__ __forceinline__ void role_overlap(const Dev &d, const uint32_t *__res
     }
     if (!do_hist) return;
     __syncthreads();
-    for (int i = threadIdx.x; i < SEL_BINS; i += RB)
+    for (int i = threadIdx.x; i < SEL_BINS; i += BS)
         if (h[i]) atomicAdd(&ghist[i], h[i]);
 }
 
 __global__ __launch_bounds__(RB) void k_sp_overlap(Dev d, const uint32_t *__restrict__ bank, int n_inputs, int G, int p) {
     __shared__ uint32_t h[SEL_BINS];               // histogram of the top key digit (select pass 0)
-    role_overlap(d, bank, n_inputs, G, p, p, 0, blockIdx.x, gridDim.x, h);
+    role_overlap<RB>(d, bank, n_inputs, G, p, p, 0, blockIdx.x, gridDim.x, h);
 }
 
 // GlobalInhibition.process (regularizations.py:28-29) as an exact radix select of the k-th
@@ -429,7 +433,7 @@ __device__ __forceinline__ ColumnWords tm_column_words(const Dev &d, int p, int 
 __device__ __forceinline__ void tm_store_column(const Dev &d, int p, bool col_ok, int a, int idx, const ColumnWords &w) {
     if (col_ok && (lane_id() & 31) == 0) {
         d.act[p][a] = w.act;
-        d.win[a] = w.winner;
+        d.win[p][a] = w.winner;
         d.bursting[idx] = w.burst ? 1 : 0;
         d.colcnt[idx] = (uint32_t)__popc(w.winner) | ((uint32_t)__popc(w.unacc) << 16);
         d.unacc_word[idx] = w.unacc;
@@ -602,41 +606,55 @@ __device__ __forceinline__ void sel_pick(const uint32_t *h, int nb, uint32_t kre
     *above_out = s_out[1];
 }
 
-// Emit the winners in ascending column order (ties: lower index first), update the duty cycle
-// (regularizations.py:19-21, float32, two separately rounded operations), clear the dense
-// per-column words of the non-winners, and run the Temporal Memory's per-column activation for
-// the winners of this block.  One block per 256 columns.  `fused` (grids of at most 1024 blocks,
-// all co-resident): the select is finished here (above); otherwise T, r and the per-block counts
-// come from k_sel_pass / k_sp_count launches.
-__global__ __launch_bounds__(256) void k_sp_emit(Dev d, int p, int want_winner, int fused) {
-    __shared__ uint32_t s_wave[4];
-    __shared__ uint32_t s_gt, s_eq, s_out[2], s_flags;
-    __shared__ int s_col[256];
-    __shared__ int s_n, s_nraw, s_ne;
-    __shared__ uint32_t h[SEL_BINS];
-    __shared__ u64 s_prefix, s_T;
-    __shared__ uint32_t s_krem, s_r;
-    __shared__ uint32_t s_predw[256];
-    __shared__ u64 s_bk[CAND_RAW];
-    __shared__ uint32_t s_bc[CAND_RAW];
+// Emit the winners in ascending column order (ties: lower index first), clear the dense per-column
+// words of the non-winners and, as `mode` asks, update the duty cycle (regularizations.py:19-21,
+// float32, two separately rounded operations: EMIT_DUTY) and run the Temporal Memory's per-column
+// activation for the winners of this block (EMIT_ACTIVATE).  One block per 256 columns.  `fused`
+// (grids of at most 1024 blocks, all co-resident): the select is finished here (above); otherwise
+// T, r and the per-block counts come from k_sel_pass / k_sp_count launches.
+// The pipelined schedule runs this role with mode 0 one step ahead, beside the previous step's
+// segment scan: everything it writes is scratch of the coming step (parity buffers), so a prefetch
+// that is dropped leaves no trace; duty cycle and activation follow in k_step_open.
+#define EMIT_DUTY 1
+#define EMIT_ACTIVATE 2
+struct EmitShared {
+    uint32_t h[SEL_BINS];
+    u64 prefix, T;
+    u64 bk[CAND_RAW];
+    uint32_t bc[CAND_RAW];
+    uint32_t predw[256];
+    int col[256];
+    uint32_t wave[4];
+    uint32_t gt, eq, out[2], flags, krem, r;
+    int n, nraw, ne;
+};
+
+__device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, int fused, int mode, int b, int nblk, EmitShared *sh) {
+    uint32_t *h = sh->h;
+    uint32_t *s_wave = sh->wave, *s_out = sh->out, *s_predw = sh->predw, *s_bc = sh->bc;
+    u64 *s_bk = sh->bk;
+    int *s_col = sh->col;
+    uint32_t &s_gt = sh->gt, &s_eq = sh->eq, &s_flags = sh->flags, &s_krem = sh->krem, &s_r = sh->r;
+    u64 &s_prefix = sh->prefix, &s_T = sh->T;
+    int &s_n = sh->n, &s_nraw = sh->nraw, &s_ne = sh->ne;
     // merged bucket entries live in the histogram's LDS once the launched digits are resolved
     u64 *s_ek = (u64 *)h;                           // [CAND_MAX] keys
     uint32_t *s_ec = h + 2 * CAND_MAX;              // [CAND_MAX] multiplicities
     uint16_t *s_eb = (uint16_t *)(h + 3 * CAND_MAX);   // [CAND_MAX] publishing block
     static_assert(3 * CAND_MAX + CAND_MAX / 2 <= SEL_BINS, "bucket entries must fit the histogram");
     const int tid = threadIdx.x, lane = lane_id();
-    const int b = blockIdx.x, nblk = gridDim.x;
     if (tid == 0) { s_gt = 0; s_eq = 0; s_n = 0; s_nraw = 0; s_ne = 0; s_flags = 0; }
     const int c = b * 256 + tid;
     // independent of everything below: in flight while the select state is resolved
     const u64 my_key = c < d.C ? d.key[p][c] : 0;
     const bool own_col = c < d.C && c >= d.c0 && c < d.c1;
-    const float my_duty = own_col ? d.duty[c] : 0.f;
-    s_predw[tid] = (c < d.C && d.act[0] && d.world == 1) ? d.pred[p ^ 1][c] : 0u;
+    const float my_duty = (own_col && (mode & EMIT_DUTY)) ? d.duty[c] : 0.f;
+    const bool tm_here = d.act[0] && (mode & EMIT_ACTIVATE);
+    s_predw[tid] = (c < d.C && tm_here && d.world == 1) ? d.pred[p ^ 1][c] : 0u;
     u64 T;
     uint32_t r;                                     // how many of the keys == T are selected
     bool second_round = false;                      // per-block counts still to be exchanged
-    const uint32_t epoch = (d.ctr->step[p] & 0x3FFu) + 1u;              // 1..1024, changes every step
+    const uint32_t epoch = (d.ctr->emit_epoch & 0x3FFu) + 1u;           // 1..1024, changes with every overlap launch
     if (fused) {
         u64 P;
         uint32_t krem;
@@ -831,43 +849,48 @@ __global__ __launch_bounds__(256) void k_sp_emit(Dev d, int p, int want_winner, 
     const bool sel_any = c < d.C && ((flag & 1u) || ((flag >> 16) && e_run < r));
     if (d.act[0]) {
         const u64 mcol = __ballot(sel_any);
-        if (lane_id() == 0) *(u64 *)&d.colbits[(blockIdx.x * 256 + (tid & ~63)) >> 5] = mcol;
+        if (lane_id() == 0) *(u64 *)&d.colbits[p][(b * 256 + (tid & ~63)) >> 5] = mcol;
     }
     if (c < d.C) {
         const bool sel = sel_any;
-        if (own_col) {
+        if (own_col && (mode & EMIT_DUTY)) {
             float dc = my_duty * d.mom;
             if (sel) dc = dc + d.dinc;
             d.duty[c] = dc;
         }
         if (sel) {
             const int pos = (int)(g_run + min(e_run, r));
-            d.active_cols[pos] = c;
+            d.active_cols[p][pos] = c;
             s_col[pos - first_pos] = c;
             atomicAdd(&s_n, 1);
         }
         if (d.act[0]) {                            // Temporal Memory present
             d.pred[p][c] = 0;
-            if (!sel) { d.act[p][c] = 0; d.win[c] = 0; }
+            if (!sel || !(mode & EMIT_ACTIVATE)) { d.act[p][c] = 0; d.win[p][c] = 0; }
         }
     }
-    if (blockIdx.x == 0 && tid == 0 && !d.act[0]) d.ctr->step[p ^ 1] = d.ctr->step[p] + 1;   // SP-only handle
-    if (!d.act[0]) return;
+    if (b == 0 && tid == 0 && !d.act[0]) d.ctr->step[p ^ 1] = d.ctr->step[p] + 1;   // SP-only handle
+    if (!tm_here) return;
     __syncthreads();
     const int n_sel = s_n;
     for (int i0 = 0; i0 < n_sel; i0 += 8) {        // 8 half-waves
         const int i = i0 + (tid >> 5);
         const bool ok = i < n_sel;
         const int a = ok ? s_col[i] : 0;
-        tm_activate_column(d, p, want_winner, ok, a, first_pos + i, ok ? s_predw[a - blockIdx.x * 256] : 0u);
+        tm_activate_column(d, p, want_winner, ok, a, first_pos + i, ok ? s_predw[a - b * 256] : 0u);
     }
+}
+
+__global__ __launch_bounds__(256) void k_sp_emit(Dev d, int p, int want_winner, int fused, int mode) {
+    __shared__ EmitShared sh;
+    role_emit(d, p, want_winner, fused, mode, blockIdx.x, gridDim.x, &sh);
 }
 
 // DenseProjection.update (projections.py:23-24) on the k winner rows, fused with the rebuild
 // of those rows' connected mask.  One block per winner row.
 __global__ __launch_bounds__(256) void k_sp_learn(Dev d, const uint32_t *__restrict__ bank, int n_inputs, int p) {
     const uint32_t *in = bank + (size_t)(d.ctr->step[p] % (uint32_t)n_inputs) * d.W;
-    const int row = d.active_cols[blockIdx.x];
+    const int row = d.active_cols[p][blockIdx.x];
     double *prow = d.perm + (size_t)row * d.Ipad;
     uint32_t *mrow = d.mask + (size_t)row * d.W;
     for (int i0 = 0; i0 < d.Ipad; i0 += 256) {
@@ -892,9 +915,9 @@ __global__ __launch_bounds__(256) void k_tm_load_active(Dev d, int p, const int 
     for (int c = blockIdx.x * 256 + threadIdx.x; c < d.C; c += gridDim.x * 256) {
         d.act[p][c] = 0;
         d.pred[p][c] = 0;
-        d.win[c] = 0;
-        if (c < n) d.active_cols[c] = cols[c];
-        if (c < d.colwords) d.colbits[c] = 0;
+        d.win[p][c] = 0;
+        if (c < n) d.active_cols[p][c] = cols[c];
+        if (c < d.colwords) d.colbits[p][c] = 0;
     }
 }
 
@@ -902,8 +925,8 @@ __global__ __launch_bounds__(256) void k_tm_load_active(Dev d, int p, const int 
 __global__ __launch_bounds__(256) void k_tm_activate(Dev d, int p, int n_active, int want_winner) {
     const int idx = (blockIdx.x * 256 + threadIdx.x) >> 5;
     const bool ok = idx < n_active;
-    const int a = ok ? d.active_cols[idx] : 0;
-    if (ok && (threadIdx.x & 31) == 0) atomicOr(&d.colbits[a >> 5], 1u << (a & 31));
+    const int a = ok ? d.active_cols[p][idx] : 0;
+    if (ok && (threadIdx.x & 31) == 0) atomicOr(&d.colbits[p][a >> 5], 1u << (a & 31));
     tm_activate_column(d, p, want_winner, ok, a, idx, ok ? d.pred[p ^ 1][a] : 0u);
 }
 
@@ -931,6 +954,37 @@ __device__ __forceinline__ void tm_bind_segment(const Dev &d, int seg, int cell,
     }
 }
 
+// DenseProjection.update (projections.py:23-24) on winner row ri, fused with the rebuild of that
+// row's connected mask, by TPR threads (t = 0..TPR-1): two float64 per lane (16-byte accesses); a
+// wave covers 128 consecutive elements = four mask words, assembled from the ballots of its even
+// and odd elements
+template <int TPR>
+__device__ __forceinline__ void role_sp_row(const Dev &d, int p, const uint32_t *__restrict__ bank, int n_inputs, int ri, int t) {
+    const uint32_t *in = bank + (size_t)(d.ctr->step[p] % (uint32_t)n_inputs) * d.W;
+    const int row = d.active_cols[p][ri];
+    if (row < d.c0 || row >= d.c1) return;          // another rank's column
+    double *prow = d.perm + (size_t)row * d.Ipad;
+    uint32_t *mrow = d.mask + (size_t)row * d.W;
+    for (int i0 = 0; i0 < d.Ipad; i0 += 2 * TPR) {
+        const int e0 = i0 + 2 * t;                   // Ipad is a multiple of 128: e0 + 1 < Ipad whenever e0 < Ipad
+        bool c0 = false, c1 = false;
+        if (e0 < d.Ipad) {
+            double2 v = *(double2 *)(prow + e0);
+            const uint32_t bits = in[e0 >> 5] >> (e0 & 31);
+            if (e0 < d.I) { v.x = v.x + ((bits & 1u) ? d.sp_don : d.sp_doff); c0 = v.x >= d.sp_thr; }
+            if (e0 + 1 < d.I) { v.y = v.y + ((bits & 2u) ? d.sp_don : d.sp_doff); c1 = v.y >= d.sp_thr; }
+            *(double2 *)(prow + e0) = v;
+        }
+        const u64 b0 = __ballot(c0), b1 = __ballot(c1);
+        const int base = i0 + 2 * (t & ~63);
+        if (lane_id() == 0 && base < d.Ipad) {
+            u64 *mw = (u64 *)&mrow[base >> 5];
+            mw[0] = spread32((uint32_t)b0) | (spread32((uint32_t)b1) << 1);
+            mw[1] = spread32((uint32_t)(b0 >> 32)) | (spread32((uint32_t)(b1 >> 32)) << 1);
+        }
+    }
+}
+
 // The middle of TemporalMemory.process / PredictiveProjection.update, one launch:
 //   block 0      ordered lists of winner cells (networks.py:103-104) and of winners that need a new
 //                segment (projections.py:271-273); SparseProjection.add_output (projections.py:79-95):
@@ -941,55 +995,23 @@ __device__ __forceinline__ void tm_bind_segment(const Dev &d, int seg, int cell,
 //   last n_sp_rows blocks   DenseProjection.update (projections.py:23-24) on one winner row each,
 //                fused with the rebuild of that row's connected mask: independent of the TM work and
 //                bandwidth-bound, it rides along with the latency-bound block 0
-__global__ __launch_bounds__(1024) void k_tm_mid(Dev d, int p, int n_active, int want_winner, int learning,
-                                                 const uint32_t *__restrict__ bank, int n_inputs, int n_cls, int n_sp_rows) {
+// block 0 and the classify blocks 1..n_cls of the middle launch (below)
+__device__ __forceinline__ void role_mid(const Dev &d, int p, int n_active, int want_winner, int learning, int blk, int n_cls) {
     Counters *c = d.ctr;
     __shared__ int s_cnt, s_base;
-    if ((int)blockIdx.x > n_cls) {
-        // two winner rows per block (512 threads each), two float64 per lane: 16-byte accesses;
-        // a wave covers 128 consecutive elements = four mask words, assembled from the ballots of
-        // its even and odd elements
-        const uint32_t *in = bank + (size_t)(c->step[p] % (uint32_t)n_inputs) * d.W;
-        const int ri = (int)(blockIdx.x - 1 - n_cls) * 2 + (int)(threadIdx.x >> 9);
-        if (ri >= n_sp_rows) return;
-        const int row = d.active_cols[ri];
-        if (row < d.c0 || row >= d.c1) return;      // another rank's column
-        double *prow = d.perm + (size_t)row * d.Ipad;
-        uint32_t *mrow = d.mask + (size_t)row * d.W;
-        const int t = threadIdx.x & 511;
-        for (int i0 = 0; i0 < d.Ipad; i0 += 1024) {
-            const int e0 = i0 + 2 * t;               // Ipad is a multiple of 128: e0 + 1 < Ipad whenever e0 < Ipad
-            bool c0 = false, c1 = false;
-            if (e0 < d.Ipad) {
-                double2 v = *(double2 *)(prow + e0);
-                const uint32_t bits = in[e0 >> 5] >> (e0 & 31);
-                if (e0 < d.I) { v.x = v.x + ((bits & 1u) ? d.sp_don : d.sp_doff); c0 = v.x >= d.sp_thr; }
-                if (e0 + 1 < d.I) { v.y = v.y + ((bits & 2u) ? d.sp_don : d.sp_doff); c1 = v.y >= d.sp_thr; }
-                *(double2 *)(prow + e0) = v;
-            }
-            const u64 b0 = __ballot(c0), b1 = __ballot(c1);
-            const int base = i0 + 2 * (t & ~63);
-            if (lane_id() == 0 && base < d.Ipad) {
-                u64 *mw = (u64 *)&mrow[base >> 5];
-                mw[0] = spread32((uint32_t)b0) | (spread32((uint32_t)b1) << 1);
-                mw[1] = spread32((uint32_t)(b0 >> 32)) | (spread32((uint32_t)(b1 >> 32)) << 1);
-            }
-        }
-        return;
-    }
-    if (blockIdx.x > 0) {
+    if (blk > 0) {
         if (!learning || !c->has_distal) return;
         const int q = p ^ 1;
         const int n = c->S;          // ids at or above the S of the last scan still hold info == 0
         const int stride = n_cls * 1024;
-        for (int i0 = (blockIdx.x - 1) * 1024; i0 < n; i0 += stride) {
+        for (int i0 = (blk - 1) * 1024; i0 < n; i0 += stride) {
             const int seg = i0 + threadIdx.x;
             bool learn = false, punish = false;
             const uint32_t info = seg < n ? d.seg_info[seg] : 0u;
             const int cell = seg < n ? d.seg_cell[seg] : 0;         // fetched with the info word, not after it
             if (info & 0x40000000u) {
                 const int col = cell >> 5, bit = cell & 31;
-                const bool is_winner = (d.win[col] >> bit) & 1u;
+                const bool is_winner = (d.win[p][col] >> bit) & 1u;
                 const bool unpred = !((d.pred[q][col] >> bit) & 1u);                         // :266
                 const bool best = fabsf(d.seg_jit[seg] - __uint_as_float(d.cellmax[cell])) < EPS32;   // :267
                 learn = is_winner && ((info >> 31) || (unpred && best));                     // :268
@@ -1028,7 +1050,7 @@ __global__ __launch_bounds__(1024) void k_tm_mid(Dev d, int p, int n_active, int
         uint32_t v = 0, ww = 0, uw = 0;
         int a = 0;
         if (idx < n_active) {                      // four independent loads, no gather through `a`
-            a = d.active_cols[idx];
+            a = d.active_cols[p][idx];
             ww = d.winw_idx[idx];
             uw = d.unacc_word[idx];
             v = d.colcnt[idx];
@@ -1102,6 +1124,16 @@ __global__ __launch_bounds__(1024) void k_tm_mid(Dev d, int p, int n_active, int
         c->S_old = S;
         c->S = S + n_new;
     }
+}
+
+__global__ __launch_bounds__(1024) void k_tm_mid(Dev d, int p, int n_active, int want_winner, int learning,
+                                                 const uint32_t *__restrict__ bank, int n_inputs, int n_cls, int n_sp_rows) {
+    if ((int)blockIdx.x > n_cls) {                  // two winner rows per block
+        const int ri = (int)(blockIdx.x - 1 - n_cls) * 2 + (int)(threadIdx.x >> 9);
+        if (ri < n_sp_rows) role_sp_row<512>(d, p, bank, n_inputs, ri, threadIdx.x & 511);
+        return;
+    }
+    role_mid(d, p, n_active, want_winner, learning, blockIdx.x, n_cls);
 }
 
 // SparseProjection.update_permanence (projections.py:97-109) and add_edge (:111-161) for one
@@ -1306,7 +1338,7 @@ __device__ __forceinline__ void role_scan(const Dev &d, int p, int blk, int nblk
         }
         if (!staged) {                               // the bitmap staging overlaps with those loads
             if (use_lds)
-                for (int i = threadIdx.x; i < d.colwords; i += BS) s_colbits[i] = d.colbits[i];
+                for (int i = threadIdx.x; i < d.colwords; i += BS) s_colbits[i] = d.colbits[p][i];
             staged = true;
         }
         if (threadIdx.x == 0) s_recyc = 0;
@@ -1445,27 +1477,69 @@ __global__ __launch_bounds__(256) void k_tm_scan(Dev d, int p) {
     role_scan<256, use_lds>(d, p, blockIdx.x, gridDim.x, (uint32_t *)dyn_lds);
 }
 
-// ---- pipelined schedule: two independent roles per launch -----------------------------------
-// Step t's Temporal Memory work (learn, scan) does not depend on step t+1's Spatial Pooler front
-// (overlap + boost, select digits), and vice versa, once step t's SP update and duty cycle are in
-// place.  A forked stream / graph branch costs 17-29 us on this runtime; heterogeneous blocks in one
-// launch cost nothing, so the two chains of dependent memory round trips overlap.
+// ---- pipelined schedule: independent roles of two consecutive steps share every launch --------
+// A forked stream / graph branch costs 17-29 us on this runtime and every dependent launch about
+// 2.3 us plus its own chain of memory round trips; heterogeneous blocks in one launch cost nothing.
+// So the step is cut where the data dependencies are, and step t+1's Spatial Pooler front -- which
+// needs nothing from step t's Temporal Memory once step t's SP update and duty cycle are in place
+// -- rides along in the same four launches:
+//
+//   k_step_open(t)     activation of step t's winner columns | its SP permanence rows | duty cycle
+//   k_mid_overlap(t)   segment allocation + learn / punish classification | overlap + boost (t+1)
+//   k_learn_sel(t)     synapse learning and growth | select digit 1 (t+1)
+//   k_scan_emit(t)     segment scan | rest of the select and the ordered winner list (t+1)
+//
+// Everything the t+1 roles write is scratch of step t+1 in parity buffers (no duty cycle, no
+// permanence), so a prefetch that turns out unusable (another input follows) is simply dropped.
+__global__ __launch_bounds__(256) void k_step_open(Dev d, int p, int n_active, int want_winner, const uint32_t *__restrict__ bank,
+                                                    int n_inputs, int n_row_blocks, int n_act_blocks) {
+    int b = blockIdx.x;
+    if (b < n_row_blocks) {                        // most bytes: first in the grid
+        role_sp_row<256>(d, p, bank, n_inputs, b, threadIdx.x);
+        return;
+    }
+    b -= n_row_blocks;
+    if (b < n_act_blocks) {                        // one active column per half-wave
+        const int idx = (b * 256 + (int)threadIdx.x) >> 5;
+        const bool ok = idx < n_active;
+        const int a = ok ? d.active_cols[p][idx] : 0;
+        tm_activate_column(d, p, want_winner, ok, a, idx, ok ? d.pred[p ^ 1][a] : 0u);
+        return;
+    }
+    b -= n_act_blocks;
+    const int c = b * 256 + (int)threadIdx.x;      // regularizations.py:19-21, float32, two roundings
+    if (c < d.C) {
+        float dc = d.duty[c] * d.mom;
+        if ((d.colbits[p][c >> 5] >> (c & 31)) & 1u) dc = dc + d.dinc;
+        d.duty[c] = dc;
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_mid_overlap(Dev d, int p, int n_active, int learning, int n_cls,
+                                                      const uint32_t *__restrict__ bank, int n_inputs, int G) {
+    const int n_mid = 1 + n_cls;
+    if ((int)blockIdx.x < n_mid)
+        role_mid(d, p, n_active, 1, learning, blockIdx.x, n_cls);
+    else
+        role_overlap<1024>(d, bank, n_inputs, G, p, p ^ 1, 1, blockIdx.x - n_mid, gridDim.x - n_mid, (uint32_t *)dyn_lds);
+}
+
 template <int EPL>
-__global__ __launch_bounds__(RB) void k_learn_overlap(Dev d, int p, int n_learn_blocks, const uint32_t *__restrict__ bank,
-                                                        int n_inputs, int G) {
+__global__ __launch_bounds__(RB) void k_learn_sel(Dev d, int p, int n_learn_blocks) {
     if ((int)blockIdx.x < n_learn_blocks)
         role_learn<EPL>(d, p, blockIdx.x, n_learn_blocks, (LearnShared<EPL> *)dyn_lds);
     else
-        role_overlap(d, bank, n_inputs, G, p, p ^ 1, 1, blockIdx.x - n_learn_blocks, gridDim.x - n_learn_blocks, (uint32_t *)dyn_lds);
+        role_sel_pass<RB>(d, 1, p ^ 1, blockIdx.x - n_learn_blocks, gridDim.x - n_learn_blocks, (SelShared *)dyn_lds);
 }
 
-// 256-thread blocks: the scan is fastest with them; the select role simply loops a little longer
+// the emit blocks wait for each other's records: they come first in the grid, so that all of them
+// are resident whatever the scan blocks do
 template <bool use_lds>
-__global__ __launch_bounds__(256) void k_scan_sel(Dev d, int p, int n_scan_blocks, int pass) {
-    if ((int)blockIdx.x < n_scan_blocks)
-        role_scan<256, use_lds>(d, p, blockIdx.x, n_scan_blocks, (uint32_t *)dyn_lds);
+__global__ __launch_bounds__(256) void k_scan_emit(Dev d, int p, int n_emit_blocks) {
+    if ((int)blockIdx.x < n_emit_blocks)
+        role_emit(d, p ^ 1, 1, 1, 0, blockIdx.x, n_emit_blocks, (EmitShared *)dyn_lds);
     else
-        role_sel_pass<256>(d, pass, p ^ 1, blockIdx.x - n_scan_blocks, gridDim.x - n_scan_blocks, (SelShared *)dyn_lds);
+        role_scan<256, use_lds>(d, p, blockIdx.x - n_emit_blocks, gridDim.x - n_emit_blocks, (uint32_t *)dyn_lds);
 }
 
 // recount recyclable segments after a state import
@@ -1508,7 +1582,7 @@ struct htm_handle {
     int shard_n_inputs;
     bool shard_open;
     int G;                                // lanes per SP row
-    int sp_blocks, sel_blocks, c256_blocks, s1024_blocks, scan_blocks;
+    int sp_blocks, sp_blocks_1024, sel_blocks, c256_blocks, s1024_blocks, scan_blocks;
     // graphs keyed by (parity, learning, bank, n_inputs)
     std::map<std::tuple<int, int, const void *, int>, hipGraphExec_t> graphs;
     // state import staging (htm_write of the MATCH_* / SEG_POTENTIAL fields, applied at commit)
@@ -1601,17 +1675,16 @@ static void launch_scan(htm_handle *h, int p, int use_lds) {
     else LAUNCH_ON(h, h->stream, scan_lds(d, 0), "tm_scan", k_tm_scan<false>, h->scan_blocks, 256, d, p);
 }
 
-// launch 3 of the pipelined schedule: step t's learning beside step t+1's overlap + boost
-static void launch_learn_overlap(htm_handle *h, int p, const uint32_t *bank, int n_inputs) {
+static void launch_learn_sel(htm_handle *h, int p) {
     Dev &d = h->d;
     const int epl = learn_epl(d);
-    const size_t lds = std::max(learn_lds(epl), (size_t)SEL_BINS * 4);
-    const int grid = kLearnBlocks + h->sp_blocks;
+    const size_t lds = std::max(learn_lds(epl), sizeof(SelShared));
+    const int grid = kLearnBlocks + h->sel_blocks;
     switch (epl) {
-        case 1: LAUNCH_ON(h, h->stream, lds, "tm_learn+sp_overlap", k_learn_overlap<1>, grid, RB, d, p, kLearnBlocks, bank, n_inputs, h->G); break;
-        case 2: LAUNCH_ON(h, h->stream, lds, "tm_learn+sp_overlap", k_learn_overlap<2>, grid, RB, d, p, kLearnBlocks, bank, n_inputs, h->G); break;
-        case 4: LAUNCH_ON(h, h->stream, lds, "tm_learn+sp_overlap", k_learn_overlap<4>, grid, RB, d, p, kLearnBlocks, bank, n_inputs, h->G); break;
-        default: LAUNCH_ON(h, h->stream, lds, "tm_learn+sp_overlap", k_learn_overlap<8>, grid, RB, d, p, kLearnBlocks, bank, n_inputs, h->G); break;
+        case 1: LAUNCH_ON(h, h->stream, lds, "tm_learn+sp_select", k_learn_sel<1>, grid, RB, d, p, kLearnBlocks); break;
+        case 2: LAUNCH_ON(h, h->stream, lds, "tm_learn+sp_select", k_learn_sel<2>, grid, RB, d, p, kLearnBlocks); break;
+        case 4: LAUNCH_ON(h, h->stream, lds, "tm_learn+sp_select", k_learn_sel<4>, grid, RB, d, p, kLearnBlocks); break;
+        default: LAUNCH_ON(h, h->stream, lds, "tm_learn+sp_select", k_learn_sel<8>, grid, RB, d, p, kLearnBlocks); break;
     }
 }
 
@@ -1623,68 +1696,90 @@ static void enqueue_sp_front(htm_handle *h, const uint32_t *bank, int n_inputs, 
     for (int pass = 1; pass < d.sel_passes; ++pass) LAUNCH(h, "sp_select", k_sel_pass, h->sel_blocks, RB, d, pass, p);
 }
 
-// Rest of SpatialPooler.process: count + emit (+ the TM's per-column activation when the handle has
-// a Temporal Memory)
-static void enqueue_sp_back(htm_handle *h, const uint32_t *bank, int n_inputs, int learning, int p, int want_winner) {
+// Rest of SpatialPooler.process: count + emit.  mode = EMIT_DUTY | EMIT_ACTIVATE: all of it, with the
+// TM's per-column activation when the handle has a Temporal Memory; mode = 0: winner list only.
+static void enqueue_sp_back(htm_handle *h, const uint32_t *bank, int n_inputs, int learning, int p, int want_winner, int mode) {
     Dev &d = h->d;
     const int fused = h->c256_blocks <= 1024;      // all blocks co-resident: count inside emit
     if (!fused) LAUNCH(h, "sp_count", k_sp_count, h->c256_blocks, 256, d, p);
-    LAUNCH(h, "sp_emit", k_sp_emit, h->c256_blocks, 256, d, p, want_winner, fused);
+    LAUNCH(h, "sp_emit", k_sp_emit, h->c256_blocks, 256, d, p, want_winner, fused, mode);
     // (a forked graph branch for this independent update was measured at +17..29 us per step on
     // this runtime, against 2.3 us for one more kernel in the chain: tools/launch_overhead.hip)
     if (learning && !h->cfg.enable_tm) LAUNCH(h, "sp_learn", k_sp_learn, d.k, 256, d, bank, n_inputs, p);
 }
 
-// TemporalMemory.process after the per-column activation.  prefetch: also compute the next step's
-// SP front (input (step + 1) % n_inputs of the same bank) inside the learn and scan launches.
+// TemporalMemory.process after the per-column activation, one role per launch.  sp_rows: the SP
+// permanence update of this step rides along in the middle launch.
 static void enqueue_tm(htm_handle *h, int n_active, int learning, int want_winner, int p,
-                       const uint32_t *bank, int n_inputs, bool prefetch) {
+                       const uint32_t *bank, int n_inputs, bool sp_rows) {
     Dev &d = h->d;
     const int n_cls = learning ? 32 : 0;
-    const int n_sp_rows = (learning && h->cfg.enable_sp) ? d.k : 0;      // SP permanence update rides along
+    const int n_sp_rows = (sp_rows && learning && h->cfg.enable_sp) ? d.k : 0;
     LAUNCH(h, "tm_mid", k_tm_mid, 1 + n_cls + (n_sp_rows + 1) / 2, 1024, d, p, n_active, want_winner, learning, bank, n_inputs,
            n_cls, n_sp_rows);
+    launch_learn(h, p);
+    launch_scan(h, p, scan_lds(d, 1) <= 64 * 1024);
+}
+
+// first launch of a step whose winner list already exists (emitted with mode 0)
+static void launch_step_open(htm_handle *h, int p, int learning, const uint32_t *bank, int n_inputs) {
+    Dev &d = h->d;
+    const int n_rows = learning ? d.k : 0, n_act = (d.k * 32 + 255) / 256;
+    LAUNCH(h, "step_open", k_step_open, n_rows + n_act + h->c256_blocks, 256, d, p, d.k, 1, bank, n_inputs, n_rows, n_act);
+}
+
+// the other three launches of the pipelined schedule: step p's TM beside the next step's SP front
+static void enqueue_pipelined(htm_handle *h, int p, int learning, const uint32_t *bank, int n_inputs) {
+    Dev &d = h->d;
+    const int n_cls = learning ? 32 : 0;
+    LAUNCH_ON(h, h->stream, (size_t)SEL_BINS * 4, "tm_mid+sp_overlap", k_mid_overlap, 1 + n_cls + h->sp_blocks_1024, 1024, d, p, d.k,
+              learning, n_cls, bank, n_inputs, h->G);
+    launch_learn_sel(h, p);
     const int use_lds = scan_lds(d, 1) <= 64 * 1024;
-    if (!prefetch) {
-        launch_learn(h, p);
-        launch_scan(h, p, use_lds);
+    const size_t lds = std::max(scan_lds(d, use_lds), sizeof(EmitShared));
+    if (use_lds) LAUNCH_ON(h, h->stream, lds, "tm_scan+sp_emit", k_scan_emit<true>, h->c256_blocks + h->scan_blocks, 256, d, p, h->c256_blocks);
+    else LAUNCH_ON(h, h->stream, lds, "tm_scan+sp_emit", k_scan_emit<false>, h->c256_blocks + h->scan_blocks, 256, d, p, h->c256_blocks);
+}
+
+// the pipelined schedule needs the select finished inside one co-resident emit grid after two
+// launched digits
+static bool can_pipeline(const htm_handle *h) {
+    return h->cfg.enable_sp && h->cfg.enable_tm && h->world == 1 && h->c256_blocks <= 1024 && h->d.sel_passes == 2;
+}
+
+// The coming step's SP front and winner list may already have been computed by the previous step's
+// launches.
+static void drop_prefetch(htm_handle *h) { h->pf_valid = false; }
+
+struct StepPlan { bool have, open; };               // prefetched front usable; step starts with k_step_open
+
+static StepPlan plan_step(htm_handle *h, const uint32_t *bank, int n_inputs, bool pipeline) {
+    const bool have = h->pf_valid && h->pf_bank == bank && h->pf_n_inputs == n_inputs;
+    return StepPlan{have, have || pipeline};
+}
+
+// make sure the SP front of the coming step exists (and, for a step that starts with k_step_open, its
+// winner list)
+static void ensure_front(htm_handle *h, const uint32_t *bank, int n_inputs, StepPlan plan) {
+    const int p = (int)(h->step_host & 1);
+    if (!plan.have) {
+        enqueue_sp_front(h, bank, n_inputs, p);
+        if (plan.open) enqueue_sp_back(h, bank, n_inputs, 0, p, 1, 0);
+    }
+    h->pf_valid = false;
+}
+
+// everything after the front; with `pipeline` it also computes the next step's front
+static void enqueue_rest(htm_handle *h, const uint32_t *bank, int n_inputs, int learning, bool pipeline, StepPlan plan) {
+    const int p = (int)(h->step_host & 1);
+    if (!plan.open) {                               // one role per launch
+        enqueue_sp_back(h, bank, n_inputs, learning, p, 1, EMIT_DUTY | EMIT_ACTIVATE);
+        enqueue_tm(h, h->d.k, learning, 1, p, bank, n_inputs, true);
         return;
     }
-    launch_learn_overlap(h, p, bank, n_inputs);
-    if (d.sel_passes > 1) {
-        const size_t lds = std::max(scan_lds(d, use_lds), sizeof(SelShared));
-        if (use_lds) LAUNCH_ON(h, h->stream, lds, "tm_scan+sp_select", k_scan_sel<true>, h->scan_blocks + 64, 256, d, p, h->scan_blocks, 1);
-        else LAUNCH_ON(h, h->stream, lds, "tm_scan+sp_select", k_scan_sel<false>, h->scan_blocks + 64, 256, d, p, h->scan_blocks, 1);
-        for (int pass = 2; pass < d.sel_passes; ++pass) LAUNCH(h, "sp_select", k_sel_pass, h->sel_blocks, RB, d, pass, p ^ 1);
-    } else {
-        launch_scan(h, p, use_lds);
-    }
-}
-
-// The SP front of the coming step may already have been computed by the previous step's launches.
-static void drop_prefetch(htm_handle *h) {
-    if (!h->pf_valid) return;
-    h->pf_valid = false;
-    // its select digit 0 histogram was accumulated but will not be consumed: clear it
-    const int sp = (int)(h->step_host & 1);
-    hipMemsetAsync(h->d.hist + (size_t)sp * SEL_MAX_PASSES * SEL_BINS, 0, (size_t)SEL_BINS * 4, h->stream);
-}
-
-// make sure the SP front (overlap, boost, select digits) of the coming step exists
-static void ensure_front(htm_handle *h, const uint32_t *bank, int n_inputs) {
-    const bool have = h->pf_valid && h->pf_bank == bank && h->pf_n_inputs == n_inputs;
-    if (!have) {
-        drop_prefetch(h);
-        enqueue_sp_front(h, bank, n_inputs, (int)(h->step_host & 1));
-    }
-    h->pf_valid = false;
-}
-
-// everything after the SP front; with `pipeline` it also computes the next step's front
-static void enqueue_rest(htm_handle *h, const uint32_t *bank, int n_inputs, int learning, bool pipeline) {
-    const int p = (int)(h->step_host & 1);
-    enqueue_sp_back(h, bank, n_inputs, learning, p, 1);
-    enqueue_tm(h, h->d.k, learning, 1, p, bank, n_inputs, pipeline);
+    launch_step_open(h, p, learning, bank, n_inputs);
+    if (pipeline) enqueue_pipelined(h, p, learning, bank, n_inputs);
+    else enqueue_tm(h, h->d.k, learning, 1, p, bank, n_inputs, false);
 }
 
 static void step_done(htm_handle *h, const uint32_t *bank, int n_inputs, bool pipeline) {
@@ -1695,8 +1790,10 @@ static void step_done(htm_handle *h, const uint32_t *bank, int n_inputs, bool pi
 }
 
 static int enqueue_step(htm_handle *h, const uint32_t *bank, int n_inputs, int learning, bool pipeline) {
-    ensure_front(h, bank, n_inputs);
-    enqueue_rest(h, bank, n_inputs, learning, pipeline);
+    pipeline = pipeline && can_pipeline(h);
+    const StepPlan plan = plan_step(h, bank, n_inputs, pipeline);
+    ensure_front(h, bank, n_inputs, plan);
+    enqueue_rest(h, bank, n_inputs, learning, pipeline, plan);
     step_done(h, bank, n_inputs, pipeline);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { h->err = std::string("kernel launch: ") + hipGetErrorString(e); return HTM_ERR_HIP; }
@@ -1804,7 +1901,8 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
     int rc = 0;
     const size_t C = d.C, k = d.k;
     rc |= dalloc(h, &d.ctr, 1);
-    rc |= dalloc(h, &d.active_cols, k);
+    rc |= dalloc(h, &d.active_cols[0], k);
+    rc |= dalloc(h, &d.active_cols[1], k);
     if (cfg->enable_sp) {
         rc |= dalloc(h, &d.perm, C * d.Ipad);
         rc |= dalloc(h, &d.mask, C * d.W);
@@ -1826,9 +1924,11 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
             rc |= dalloc(h, &d.pred[q], C);
             rc |= dalloc(h, &d.winners[q], k * 32);
         }
-        rc |= dalloc(h, &d.win, C);
+        rc |= dalloc(h, &d.win[0], C);
+        rc |= dalloc(h, &d.win[1], C);
         d.colwords = (int)((C + 63) / 64) * 2;
-        rc |= dalloc(h, &d.colbits, (size_t)d.colwords);
+        rc |= dalloc(h, &d.colbits[0], (size_t)d.colwords);
+        rc |= dalloc(h, &d.colbits[1], (size_t)d.colwords);
         rc |= dalloc(h, &d.bursting, k);
         rc |= dalloc(h, &d.colcnt, k);
         rc |= dalloc(h, &d.winw_idx, k);
@@ -1863,6 +1963,7 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
     // hot bins and same-address global atomics are slow (~88 per us per address)
     const int rows_per_block = (RB / 64) * 4 * (64 / h->G);   // waves x 4 row groups in flight
     h->sp_blocks = std::max(1, std::min((d.c1 - d.c0 + rows_per_block - 1) / rows_per_block, 256));
+    h->sp_blocks_1024 = std::max(1, std::min((d.c1 - d.c0 + 2 * rows_per_block - 1) / (2 * rows_per_block), 256));
     h->sel_blocks = std::max(1, std::min((d.C + RB - 1) / RB, 128));
     h->c256_blocks = (d.C + 255) / 256;
     h->s1024_blocks = std::max(1, (d.Scap + 1023) / 1024);
@@ -1961,7 +2062,7 @@ extern "C" int htm_sp_step(htm_handle *h, const uint32_t *packed_input, int32_t 
     if (rc) return rc;
     const int p = (int)(h->step_host & 1);
     enqueue_sp_front(h, h->d.input_stage, 1, p);
-    enqueue_sp_back(h, h->d.input_stage, 1, learning ? 1 : 0, p, 0);
+    enqueue_sp_back(h, h->d.input_stage, 1, learning ? 1 : 0, p, 0, EMIT_DUTY | EMIT_ACTIVATE);
     h->step_host += 1;
     return HTM_OK;
 }
@@ -1994,7 +2095,7 @@ extern "C" int htm_run(htm_handle *h, const uint32_t *device_inputs, int32_t n_i
     HIPCHK(h, hipSetDevice(h->device));
     learning = learning ? 1 : 0;
     const bool graph = (use_graph & 1) && !h->profile;
-    const bool pipeline = !(use_graph & 2) && !h->profile;     // profiled runs time each role on its own
+    const bool pipeline = !(use_graph & 2) && !h->profile && can_pipeline(h);     // profiled runs time each role on its own
     if (!graph) {
         for (int t = 0; t < n_steps; ++t) {
             int rc = enqueue_step(h, device_inputs, n_inputs, learning, pipeline);
@@ -2004,13 +2105,14 @@ extern "C" int htm_run(htm_handle *h, const uint32_t *device_inputs, int32_t n_i
     }
     for (int t = 0; t < n_steps; ++t) {
         const int p = (int)(h->step_host & 1);
-        ensure_front(h, device_inputs, n_inputs);          // eager, only when nothing was prefetched
-        auto key = std::make_tuple(p, learning * 2 + (pipeline ? 1 : 0), (const void *)device_inputs, n_inputs);
+        const StepPlan plan = plan_step(h, device_inputs, n_inputs, pipeline);
+        ensure_front(h, device_inputs, n_inputs, plan);    // eager, only when nothing was prefetched
+        auto key = std::make_tuple(p, learning * 4 + (pipeline ? 2 : 0) + (plan.open ? 1 : 0), (const void *)device_inputs, n_inputs);
         auto it = h->graphs.find(key);
         if (it == h->graphs.end()) {
             hipGraph_t graph_obj;
             HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-            enqueue_rest(h, device_inputs, n_inputs, learning, pipeline);
+            enqueue_rest(h, device_inputs, n_inputs, learning, pipeline, plan);
             hipError_t e = hipStreamEndCapture(h->stream, &graph_obj);
             if (e != hipSuccess) { h->err = std::string("hipStreamEndCapture: ") + hipGetErrorString(e); return HTM_ERR_HIP; }
             hipGraphExec_t exec;
@@ -2067,8 +2169,8 @@ extern "C" int htm_shard_finish(htm_handle *h, const void *recv_device, int32_t 
     for (int pass = 1; pass < d.sel_passes; ++pass) LAUNCH(h, "sp_select", k_sel_pass, h->sel_blocks, RB, d, pass, p);
     const int fused = h->c256_blocks <= 1024;
     if (!fused) LAUNCH(h, "sp_count", k_sp_count, h->c256_blocks, 256, d, p);
-    LAUNCH(h, "sp_emit", k_sp_emit, h->c256_blocks, 256, d, p, 1, fused);
-    enqueue_tm(h, d.k, learning, 1, p, h->shard_bank, h->shard_n_inputs, false);
+    LAUNCH(h, "sp_emit", k_sp_emit, h->c256_blocks, 256, d, p, 1, fused, EMIT_DUTY | EMIT_ACTIVATE);
+    enqueue_tm(h, d.k, learning, 1, p, h->shard_bank, h->shard_n_inputs, true);
     h->step_host += 1;
     h->shard_open = false;
     hipError_t e = hipGetLastError();
@@ -2158,13 +2260,13 @@ extern "C" int64_t htm_read(htm_handle *h, int32_t field, void *dst, int64_t cou
     };
     int64_t n;
     switch (field) {
-        case HTM_F_ACTIVE_COLUMN: if ((n = need(true, d.k)) < 0) return n; return copy(d.active_cols, n, 4);
+        case HTM_F_ACTIVE_COLUMN: if ((n = need(true, d.k)) < 0) return n; return copy(d.active_cols[q], n, 4);
         case HTM_F_OVERLAPS: if ((n = need(sp, C)) < 0) return n; return copy(d.overlap[q], n, 4);
         case HTM_F_BOOSTED: if ((n = need(sp, C)) < 0) return n; return copy(d.boosted[q], n, 8);
         case HTM_F_DUTY_CYCLE: if ((n = need(sp, C)) < 0) return n; return copy(d.duty, n, 4);
         case HTM_F_CELL_ACTIVATION: if ((n = need(tm, C)) < 0) return n; return copy(d.act[q], n, 4);
         case HTM_F_CELL_PREDICTION: if ((n = need(tm, C)) < 0) return n; return copy(d.pred[q], n, 4);
-        case HTM_F_WINNER_WORDS: if ((n = need(tm, C)) < 0) return n; return copy(d.win, n, 4);
+        case HTM_F_WINNER_WORDS: if ((n = need(tm, C)) < 0) return n; return copy(d.win[q], n, 4);
         case HTM_F_BURSTING: if ((n = need(tm, d.k)) < 0) return n; return copy(d.bursting, n, 1);
         case HTM_F_SEG_NSYN: if ((n = need(tm, S)) < 0) return n; return copy(d.seg_nsyn, n, 4);
         case HTM_F_SEG_POTENTIAL:
