@@ -29,6 +29,7 @@ sys.path.insert(0, ROOT)
 
 WORKLOAD = dict(input_dim=1024, column_dim=65536, cell_dim=32, patterns=50, density=0.02, noise=0.005,
                 noisy_copies=20, segment_slots=128)
+PIPELINED_LAUNCHES = ("tm_activate+sp_overlap", "tm_mid+sp_select", "tm_learn+sp_emit", "tm_scan+sp_learn")
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 
 
@@ -149,8 +150,10 @@ def run_single(args):
     # per-kernel device time (HIP events on the engine's stream), same workload, profiled replay
     prof_steps = min(args.steps, 300)
     eng.profile(True)
-    eng.run(bank, n_bank, prof_steps, learning=True, use_graph=False)
+    eng.run(bank, n_bank, prof_steps, learning=True, use_graph=False, pipeline=False)     # one role per launch
     prof = eng.profile_read()
+    eng.run(bank, n_bank, prof_steps, learning=True, use_graph=False, pipeline=True)      # the launches of the timed run
+    prof_pipe = {n: v for n, v in eng.profile_read().items() if n in PIPELINED_LAUNCHES}
     eng.profile(False)
     store = eng.read_store()
     kb = kernel_bytes(w, k, store)
@@ -158,8 +161,12 @@ def run_single(args):
     avg_us = {name: 1e3 * ms / max(n, 1) for name, (ms, n) in prof.items()}
     dominant = max((n for n in per_step_us if n in ("sp_overlap", "sp_learn", "tm_scan")), key=lambda n: per_step_us[n])
     achieved = kb[dominant] / (avg_us[dominant] * 1e-6) / 1e9
-    log("[bench] per-step device time by kernel (us): " +
+    per_step_us = {n: v for n, v in per_step_us.items() if n not in PIPELINED_LAUNCHES}
+    log("[bench] per-step device time by kernel, one role per launch (us): " +
         ", ".join(f"{n}={v:.1f}" for n, v in sorted(per_step_us.items(), key=lambda kv: -kv[1])))
+    pipe_us = {n: 1e3 * ms / max(cnt, 1) for n, (ms, cnt) in prof_pipe.items()}
+    log("[bench] pipelined launches (us): " + ", ".join(f"{n}={pipe_us.get(n, 0):.1f}" for n in PIPELINED_LAUNCHES) +
+        f"; sum {sum(pipe_us.values()):.1f} of {1e6 / steps_per_s:.1f} us per step")
     roofline = dict(bound="hbm", kernel=dominant, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
                     bytes_per_launch=int(kb[dominant]), avg_launch_us=round(avg_us[dominant], 2),
@@ -169,7 +176,7 @@ def run_single(args):
 
     cpu = None
     if not args.no_cpu_baseline:
-        cpu = cpu_baseline(w, htm, noisy, int(info.step_index) + prof_steps, args.cpu_steps)
+        cpu = cpu_baseline(w, htm, noisy, int(eng.info().step_index), args.cpu_steps)
         log(f"[bench] cpu baseline: {cpu['value']:.2f} timesteps/s")
 
     return dict(
@@ -183,7 +190,8 @@ def run_single(args):
                     segments=int(info.segments), segment_slots=w["segment_slots"], hip_graph=use_graph,
                     pipelined=pipeline),
         roofline=roofline, cpu_baseline=cpu,
-        kernel_us_per_step={n: round(v, 2) for n, v in per_step_us.items()})
+        kernel_us_per_step={n: round(v, 2) for n, v in per_step_us.items()},
+        pipelined_launch_us={n: round(v, 2) for n, v in pipe_us.items()})
 
 
 def main():

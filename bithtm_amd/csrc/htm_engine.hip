@@ -32,6 +32,7 @@ typedef unsigned long long u64;
 #define SEL_MAX_PASSES 6
 #define SEL_DIGIT 12
 #define SEL_BINS 4096         // 1 << SEL_DIGIT
+#define HIST_REP 8            // copies of the digit-0 histogram (its few hot bins take one atomic per block)
 #define RB 512                // threads per block of the role kernels (overlap, select, learn, scan)
 #define SCAN_SEGS 64          // segments per 256-thread block iteration of the segment scan
 #define DEAD_CAP 256          // newly dead segment ids one rank can report per exchange
@@ -69,7 +70,7 @@ struct Counters {
 };
 
 struct Dev {
-    int I, W, W4, Ipad, C, K, k, E, Scap, work_cap, sel_passes, colwords, low_zero, cand_d;
+    int I, W, W4, Ipad, C, K, k, E, Scap, work_cap, sel_passes, colwords, low_zero, cand_d, cand_pairwise;
     int world, c0, c1;        // this rank owns columns [c0, c1) (world == 1: everything)
     double sp_thr, sp_don, sp_doff;
     float coef, mom, dinc;
@@ -85,7 +86,8 @@ struct Dev {
     int *overlap[2];          // [C]   parity double buffer, like the select state
     double *boosted[2];       // [C]
     u64 *key[2];              // [C] bits of boosted (non-negative doubles order like uint64)
-    uint32_t *hist;           // [2][SEL_MAX_PASSES][SEL_BINS]
+    uint32_t *hist;           // [2][SEL_MAX_PASSES][SEL_BINS]  (digits 1..)
+    uint32_t *hist0;          // [2][HIST_REP][SEL_BINS]        digit 0: block b adds to copy b % HIST_REP
     uint32_t *sel_blk;        // [ceil(C/256)] packed (greater, equal) counts per 256-column block
     uint32_t *sel_rec;        // [ceil(C/256)][32] per-block bucket records of k_sp_emit (16 granules)
     int *active_cols[2];      // [k] ascending; parity double buffer (the pipelined schedule emits step t+1's
@@ -119,6 +121,7 @@ struct Dev {
     uint32_t *spec_act, *spec_win, *spec_unacc, *spec_burst;      // [C] [C] [C] [ceil(C/32)]
     int *dead_list;           // [1 + DEAD_CAP]: count, ids
     Counters *ctr;
+    unsigned long long *trace;
 };
 
 // ------------------------------------------------------------------------------------------
@@ -238,8 +241,13 @@ __device__ __forceinline__ void role_overlap(const Dev &d, const uint32_t *__res
     constexpr int U = 4;                           // row groups in flight per wave
     for (int row0 = d.c0 + wave * rpw * U; row0 < d.c1; row0 += nwaves * rpw * U) {
         int cnt[U];
+        float dty[U];                              // fetched with the mask rows, not after the reduction
 #pragma unroll
-        for (int u = 0; u < U; ++u) cnt[u] = 0;
+        for (int u = 0; u < U; ++u) {
+            cnt[u] = 0;
+            const int row = row0 + u * rpw + sub;
+            dty[u] = (l == 0 && row < d.c1) ? d.duty[row] : 0.f;
+        }
         for (int j = l; j < d.W4; j += G) {
             const uint4 x = in4[j];
             uint4 m[U];
@@ -261,7 +269,7 @@ __device__ __forceinline__ void role_overlap(const Dev &d, const uint32_t *__res
             u64 key = 0;
             if (owner) {
                 d.overlap[sp][row] = cn;
-                const float f = htm_exp_f32(d.coef * d.duty[row]);     // float32 product, documented exp
+                const float f = htm_exp_f32(d.coef * dty[u]);          // float32 product, documented exp
                 const double bo = (double)f * (double)cn;              // exact (24-bit x <= 16-bit)
                 d.boosted[sp][row] = bo;
                 key = (u64)__double_as_longlong(bo);
@@ -272,8 +280,9 @@ __device__ __forceinline__ void role_overlap(const Dev &d, const uint32_t *__res
     }
     if (!do_hist) return;
     __syncthreads();
+    uint32_t *g0 = d.hist0 + (size_t)(sp * HIST_REP + (blk & (HIST_REP - 1))) * SEL_BINS;
     for (int i = threadIdx.x; i < SEL_BINS; i += BS)
-        if (h[i]) atomicAdd(&ghist[i], h[i]);
+        if (h[i]) atomicAdd(&g0[i], h[i]);
 }
 
 __global__ __launch_bounds__(RB) void k_sp_overlap(Dev d, const uint32_t *__restrict__ bank, int n_inputs, int G, int p) {
@@ -296,13 +305,32 @@ __device__ __forceinline__ void sel_resolve(const Dev &d, int sp, int prev, uint
     const uint32_t krem = d.ctr->sel_pass_krem[sp][prev];
     const uint32_t *gh = d.hist + (sp * SEL_MAX_PASSES + prev) * SEL_BINS;
     constexpr int PER = SEL_BINS / BS;            // bins per thread, thread t owns [t*PER, (t+1)*PER)
+    static_assert(PER % 4 == 0, "16-byte histogram accesses");
+    {   // fetch the histogram with coalesced 16-byte loads, all in flight; regroup through LDS
+        uint4 v[PER / 4];
+#pragma unroll
+        for (int j = 0; j < PER / 4; ++j) {
+            const int b = 4 * (j * BS + tid);
+            v[j] = (prev > 0 && b < nb) ? *(const uint4 *)(gh + b) : make_uint4(0, 0, 0, 0);
+        }
+        if (prev == 0) {                            // digit 0: sum the copies
+            const uint32_t *g0 = d.hist0 + (size_t)sp * HIST_REP * SEL_BINS;
+            for (int r = 0; r < HIST_REP; ++r)
+#pragma unroll
+                for (int j = 0; j < PER / 4; ++j) {
+                    const uint4 a = *(const uint4 *)(g0 + (size_t)r * SEL_BINS + 4 * (j * BS + tid));
+                    v[j].x += a.x; v[j].y += a.y; v[j].z += a.z; v[j].w += a.w;
+                }
+        }
+#pragma unroll
+        for (int j = 0; j < PER / 4; ++j) *(uint4 *)(h + 4 * (j * BS + tid)) = v[j];
+    }
+    __syncthreads();
     uint32_t cs = 0;
 #pragma unroll
-    for (int j = 0; j < PER; ++j) {
-        const int b = tid * PER + j;
-        const uint32_t v = b < nb ? gh[b] : 0u;
-        h[b] = v;
-        cs += v;
+    for (int j = 0; j < PER / 4; ++j) {
+        const uint4 v = *(const uint4 *)(h + tid * PER + 4 * j);
+        cs += v.x + v.y + v.z + v.w;
     }
     uint32_t x = cs;                              // inclusive suffix sum inside the wave
 #pragma unroll
@@ -330,7 +358,7 @@ __device__ __forceinline__ void sel_resolve(const Dev &d, int sp, int prev, uint
     *out_krem = *s_res_krem;
 }
 
-struct SelShared { uint32_t h[SEL_BINS]; uint32_t wave[RB / 64]; u64 prefix; uint32_t krem; };
+struct SelShared { uint32_t h[SEL_BINS]; uint32_t wave[16]; u64 prefix; uint32_t krem; };
 
 template <int BS>
 __device__ __forceinline__ void role_sel_pass(const Dev &d, int pass, int sp, int blk, int nblk, SelShared *sh) {
@@ -379,7 +407,7 @@ __global__ __launch_bounds__(256) void k_sp_count(Dev d, int sp) {
         d.ctr->sel_krem[sp] = r;
     }
     if (d.sel_passes > 1)                       // pass-0 histogram is consumed: clear it for its next use
-        for (int i = blockIdx.x * 256 + threadIdx.x; i < SEL_BINS; i += gridDim.x * 256) d.hist[sp * SEL_MAX_PASSES * SEL_BINS + i] = 0;
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < HIST_REP * SEL_BINS; i += gridDim.x * 256) d.hist0[(size_t)sp * HIST_REP * SEL_BINS + i] = 0;
     const int c = blockIdx.x * 256 + threadIdx.x;
     uint32_t v = 0;
     if (c < d.C) {
@@ -540,8 +568,9 @@ __global__ __launch_bounds__(1024) void k_shard_unpack(Dev d, const unsigned cha
         hist_add(h, (uint32_t)(key >> sel_shift(0)), c < d.C);
     }
     __syncthreads();
+    uint32_t *g0 = d.hist0 + (size_t)(sp * HIST_REP + (blockIdx.x & (HIST_REP - 1))) * SEL_BINS;
     for (int i = threadIdx.x; i < SEL_BINS; i += 1024)
-        if (h[i]) atomicAdd(&ghist[i], h[i]);
+        if (h[i]) atomicAdd(&g0[i], h[i]);
     if (blockIdx.x == 0) {
         for (int r = 0; r < d.world; ++r) {
             if (r == rank) continue;
@@ -569,7 +598,8 @@ __global__ __launch_bounds__(1024) void k_shard_unpack(Dev d, const unsigned cha
 // per-block counts are exchanged in a second tagged round.
 #define CAND_D 8              // distinct bucket keys one block can publish
 #define CAND_RAW 64           // ... and collect from its waves before merging duplicates
-#define CAND_MAX 1024         // bucket entries a block can merge
+#define CAND_MAX 2048         // bucket entries a block can merge
+#define CAND_PAIRWISE 128      // ... by comparing all pairs; above that, by radix refinement in LDS
 
 // pick the bucket that contains the krem-th largest key of a histogram held in LDS
 // (bins [0, nb)); all BS threads call; returns bucket and the keys above it
@@ -612,16 +642,21 @@ __device__ __forceinline__ void sel_pick(const uint32_t *h, int nb, uint32_t kre
 // activation for the winners of this block (EMIT_ACTIVATE).  One block per 256 columns.  `fused`
 // (grids of at most 1024 blocks, all co-resident): the select is finished here (above); otherwise
 // T, r and the per-block counts come from k_sel_pass / k_sp_count launches.
-// The pipelined schedule runs this role with mode 0 one step ahead, beside the previous step's
-// segment scan: everything it writes is scratch of the coming step (parity buffers), so a prefetch
-// that is dropped leaves no trace; duty cycle and activation follow in k_step_open.
+// EMIT_CLEAR: also zero the dense per-column words of the step.  The pipelined schedule runs this
+// role with mode 0 one step ahead, beside the previous step's learning (which still reads the
+// words a clear would zero); duty cycle and clearing follow in k_scan_close, activation in
+// k_open_overlap.
 #define EMIT_DUTY 1
 #define EMIT_ACTIVATE 2
+#define EMIT_CLEAR 4
+#define EMIT_ALL 7
 struct EmitShared {
     uint32_t h[SEL_BINS];
     u64 prefix, T;
     u64 bk[CAND_RAW];
     uint32_t bc[CAND_RAW];
+    uint16_t ec[CAND_MAX], eb[CAND_MAX];
+    uint32_t mh[256];
     uint32_t predw[256];
     int col[256];
     uint32_t wave[4];
@@ -639,10 +674,12 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
     int &s_n = sh->n, &s_nraw = sh->nraw, &s_ne = sh->ne;
     // merged bucket entries live in the histogram's LDS once the launched digits are resolved
     u64 *s_ek = (u64 *)h;                           // [CAND_MAX] keys
-    uint32_t *s_ec = h + 2 * CAND_MAX;              // [CAND_MAX] multiplicities
-    uint16_t *s_eb = (uint16_t *)(h + 3 * CAND_MAX);   // [CAND_MAX] publishing block
-    static_assert(3 * CAND_MAX + CAND_MAX / 2 <= SEL_BINS, "bucket entries must fit the histogram");
+    uint16_t *s_ec = sh->ec, *s_eb = sh->eb;        // [CAND_MAX] multiplicities (12 bits), publishing block
+    uint32_t *s_mh = sh->mh;
+    static_assert(2 * CAND_MAX <= SEL_BINS, "bucket keys must fit the histogram");
     const int tid = threadIdx.x, lane = lane_id();
+#define EMIT_TR(k) do { if (tid == 0 && d.trace && (b & 31) == 0) d.trace[(b >> 5) * 16 + (k)] = wall_clock64(); } while (0)
+    EMIT_TR(0);
     if (tid == 0) { s_gt = 0; s_eq = 0; s_n = 0; s_nraw = 0; s_ne = 0; s_flags = 0; }
     const int c = b * 256 + tid;
     // independent of everything below: in flight while the select state is resolved
@@ -660,8 +697,9 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
         uint32_t krem;
         sel_resolve<256>(d, p, d.sel_passes - 1, h, s_wave, &P, &krem, &s_prefix, &s_krem);
         __syncthreads();
+    EMIT_TR(1);
         if (d.sel_passes > 1)                       // pass-0 histogram is consumed: clear it for its next use
-            for (int i = b * 256 + tid; i < SEL_BINS; i += nblk * 256) d.hist[p * SEL_MAX_PASSES * SEL_BINS + i] = 0;
+            for (int i = b * 256 + tid; i < HIST_REP * SEL_BINS; i += nblk * 256) d.hist0[(size_t)p * HIST_REP * SEL_BINS + i] = 0;
         const int lowbits = sel_shift(d.sel_passes - 1);        // key bits not resolved by launches
         const u64 hiP = P >> lowbits, hi = my_key >> lowbits;
         const bool c_gt = c < d.C && hi > hiP, c_cand = c < d.C && hi == hiP;
@@ -693,6 +731,7 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
         __syncthreads();
         if (tid < nraw && first != tid) atomicAdd(&s_bc[first], my_cnt);
         __syncthreads();
+    EMIT_TR(2);
         // record = 16 self-validating 64-bit granules (form R2: every granule carries the epoch, one
         // aligned 8-byte write-through store each, so no separate tag and no drain):
         //   [0]      epoch:12 | overflow:1 | pairs:8 | keys above the bucket:16
@@ -713,6 +752,7 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (tid == 0) s_gt = 0;
+    EMIT_TR(3);
         // ---- everybody's records: head and all pair granules fetched in one batch per poll
         uint32_t gthi_before = 0;
         for (int rb = tid; rb < nblk; rb += 256) {
@@ -746,28 +786,54 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
                     const int slot = atomicAdd(&s_ne, 1);
                     if (slot < CAND_MAX) {
                         s_ek[slot] = (hiP << lowbits) | (g[1 + j] & lowmask);
-                        s_ec[slot] = (uint32_t)((g[1 + j] >> 40) & 0xFFFu);
+                        s_ec[slot] = (uint16_t)((g[1 + j] >> 40) & 0xFFFu);
                         s_eb[slot] = (uint16_t)rb;
                     }
                 }
         }
         __syncthreads();
+    EMIT_TR(4);
         const int ne = s_ne;
         if (!(s_flags & 1u) && ne <= CAND_MAX) {
-            for (int e = tid; e < ne; e += 256) {     // the krem-th largest of the merged bucket
-                const u64 ke = s_ek[e];
-                uint32_t ng = 0, nq = 0;
-                for (int f = 0; f < ne; ++f) {
-                    const u64 kf = s_ek[f];
-                    const uint32_t cf = s_ec[f];
-                    ng += kf > ke ? cf : 0u;
-                    nq += kf == ke ? cf : 0u;
+            if (ne <= d.cand_pairwise) {                // the krem-th largest of the merged bucket: all pairs
+                for (int e = tid; e < ne; e += 256) {
+                    const u64 ke = s_ek[e];
+                    uint32_t ng = 0, nq = 0;
+                    for (int f = 0; f < ne; ++f) {
+                        const u64 kf = s_ek[f];
+                        const uint32_t cf = s_ec[f];
+                        ng += kf > ke ? cf : 0u;
+                        nq += kf == ke ? cf : 0u;
+                    }
+                    if (ng < krem && krem <= ng + nq) { s_T = ke; s_r = krem - ng; }
                 }
-                if (ng < krem && krem <= ng + nq) { s_T = ke; s_r = krem - ng; }
+                __syncthreads();
+                T = s_T;
+                r = s_r;
+            } else {                                  // many entries (overlaps tie in most blocks): 8-bit radix
+                u64 pref = 0;                         // refinement over the entries, one bin per thread
+                uint32_t rem = krem;
+                for (int top = lowbits; top > d.low_zero;) {
+                    const int bits = min(8, top), shift = top - bits, nb = 1 << bits;
+                    s_mh[tid] = 0;
+                    __syncthreads();
+                    for (int e = tid; e < ne; e += 256) {
+                        const u64 kl = s_ek[e] & lowmask;
+                        if (((kl ^ pref) >> top) == 0) atomicAdd(&s_mh[(uint32_t)(kl >> shift) & (nb - 1)], (uint32_t)s_ec[e]);
+                    }
+                    __syncthreads();
+                    const uint32_t rv = s_mh[255 - tid];      // bins from the top; bins >= nb are empty
+                    uint32_t total;
+                    const uint32_t above = block_excl_scan<256>(rv, s_wave, total);
+                    if (rv && above < rem && rem <= above + rv) { s_out[0] = 255u - (uint32_t)tid; s_out[1] = above; }
+                    __syncthreads();
+                    pref |= (u64)s_out[0] << shift;
+                    rem -= s_out[1];
+                    top = shift;
+                }
+                T = (hiP << lowbits) | pref;
+                r = rem;
             }
-            __syncthreads();
-            T = s_T;
-            r = s_r;
             uint32_t g = gthi_before, e2 = 0;         // winners of the blocks before this one
             for (int e = tid; e < ne; e += 256)
                 if (s_eb[e] < b) {
@@ -809,6 +875,7 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
         r = d.ctr->sel_krem[p];
     }
     __syncthreads();
+    EMIT_TR(5);
     uint32_t flag = 0;
     if (c < d.C) flag = (my_key > T) ? 1u : ((my_key == T) ? 0x10000u : 0u);
     uint32_t total;
@@ -843,6 +910,7 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
         if (lane == 0) { atomicAdd(&s_gt, g); atomicAdd(&s_eq, e); }
     }
     __syncthreads();
+    EMIT_TR(6);
     const uint32_t gt_before = s_gt, eq_before = s_eq;
     const uint32_t g_run = gt_before + (ex & 0xFFFFu), e_run = eq_before + (ex >> 16);
     const int first_pos = (int)(gt_before + min(eq_before, r));
@@ -864,12 +932,13 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
             s_col[pos - first_pos] = c;
             atomicAdd(&s_n, 1);
         }
-        if (d.act[0]) {                            // Temporal Memory present
+        if (d.act[0] && (mode & EMIT_CLEAR)) {     // Temporal Memory present
             d.pred[p][c] = 0;
             if (!sel || !(mode & EMIT_ACTIVATE)) { d.act[p][c] = 0; d.win[p][c] = 0; }
         }
     }
     if (b == 0 && tid == 0 && !d.act[0]) d.ctr->step[p ^ 1] = d.ctr->step[p] + 1;   // SP-only handle
+    EMIT_TR(7);
     if (!tm_here) return;
     __syncthreads();
     const int n_sel = s_n;
@@ -959,8 +1028,11 @@ __device__ __forceinline__ void tm_bind_segment(const Dev &d, int seg, int cell,
 // wave covers 128 consecutive elements = four mask words, assembled from the ballots of its even
 // and odd elements
 template <int TPR>
-__device__ __forceinline__ void role_sp_row(const Dev &d, int p, const uint32_t *__restrict__ bank, int n_inputs, int ri, int t) {
-    const uint32_t *in = bank + (size_t)(d.ctr->step[p] % (uint32_t)n_inputs) * d.W;
+// p: parity of the step the rows belong to; ahead = 1 when that step's index is not published yet
+// (the row update runs beside the previous step's scan): it is step[p ^ 1] + 1 then
+__device__ __forceinline__ void role_sp_row(const Dev &d, int p, const uint32_t *__restrict__ bank, int n_inputs, int ahead, int ri, int t) {
+    const uint32_t step = ahead ? d.ctr->step[p ^ 1] + 1u : d.ctr->step[p];
+    const uint32_t *in = bank + (size_t)(step % (uint32_t)n_inputs) * d.W;
     const int row = d.active_cols[p][ri];
     if (row < d.c0 || row >= d.c1) return;          // another rank's column
     double *prow = d.perm + (size_t)row * d.Ipad;
@@ -981,6 +1053,46 @@ __device__ __forceinline__ void role_sp_row(const Dev &d, int p, const uint32_t 
             u64 *mw = (u64 *)&mrow[base >> 5];
             mw[0] = spread32((uint32_t)b0) | (spread32((uint32_t)b1) << 1);
             mw[1] = spread32((uint32_t)(b0 >> 32)) | (spread32((uint32_t)(b1 >> 32)) << 1);
+        }
+    }
+}
+
+// the same for R winner rows at once (row[q] < 0: absent), two chunks of each in flight: every
+// load of a round is issued before the first is consumed; all TPR threads of the block call
+template <int TPR, int R>
+__device__ __forceinline__ void role_sp_rows(const Dev &d, const uint32_t *__restrict__ in, const int (&row)[R], int t) {
+    for (int i0 = 0; i0 < d.Ipad; i0 += 4 * TPR) {
+        double2 v[R][2];
+        uint32_t bits[2];
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch) {
+            const int e0 = i0 + ch * 2 * TPR + 2 * t;
+            const bool in_row = e0 < d.Ipad;
+            bits[ch] = in_row ? in[e0 >> 5] >> (e0 & 31) : 0u;
+#pragma unroll
+            for (int q = 0; q < R; ++q)
+                v[q][ch] = (in_row && row[q] >= 0) ? *(const double2 *)(d.perm + (size_t)row[q] * d.Ipad + e0) : make_double2(0.0, 0.0);
+        }
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch) {
+            const int e0 = i0 + ch * 2 * TPR + 2 * t;
+            const int base = i0 + ch * 2 * TPR + 2 * (t & ~63);
+#pragma unroll
+            for (int q = 0; q < R; ++q) {
+                bool c0 = false, c1 = false;
+                if (e0 < d.Ipad && row[q] >= 0) {
+                    double2 w = v[q][ch];
+                    if (e0 < d.I) { w.x = w.x + ((bits[ch] & 1u) ? d.sp_don : d.sp_doff); c0 = w.x >= d.sp_thr; }
+                    if (e0 + 1 < d.I) { w.y = w.y + ((bits[ch] & 2u) ? d.sp_don : d.sp_doff); c1 = w.y >= d.sp_thr; }
+                    *(double2 *)(d.perm + (size_t)row[q] * d.Ipad + e0) = w;
+                }
+                const u64 b0 = __ballot(c0), b1 = __ballot(c1);
+                if (lane_id() == 0 && base < d.Ipad && row[q] >= 0) {
+                    u64 *mw = (u64 *)&d.mask[(size_t)row[q] * d.W + (base >> 5)];
+                    mw[0] = spread32((uint32_t)b0) | (spread32((uint32_t)b1) << 1);
+                    mw[1] = spread32((uint32_t)(b0 >> 32)) | (spread32((uint32_t)(b1 >> 32)) << 1);
+                }
+            }
         }
     }
 }
@@ -1130,7 +1242,7 @@ __global__ __launch_bounds__(1024) void k_tm_mid(Dev d, int p, int n_active, int
                                                  const uint32_t *__restrict__ bank, int n_inputs, int n_cls, int n_sp_rows) {
     if ((int)blockIdx.x > n_cls) {                  // two winner rows per block
         const int ri = (int)(blockIdx.x - 1 - n_cls) * 2 + (int)(threadIdx.x >> 9);
-        if (ri < n_sp_rows) role_sp_row<512>(d, p, bank, n_inputs, ri, threadIdx.x & 511);
+        if (ri < n_sp_rows) role_sp_row<512>(d, p, bank, n_inputs, 0, ri, threadIdx.x & 511);
         return;
     }
     role_mid(d, p, n_active, want_winner, learning, blockIdx.x, n_cls);
@@ -1140,21 +1252,21 @@ __global__ __launch_bounds__(1024) void k_tm_mid(Dev d, int p, int n_active, int
 // work item per wave.  Permanences: float64 sum, float32 store, prune on the float64 value; the
 // surviving synapses are re-packed to the front of the row.  Growth: the n_add previous winner
 // cells with the smallest keyed priority that the segment does not have yet.
-template <int EPL>
-struct LearnShared { u64 cand[RB / 64][CAND_CAP]; int keep[RB / 64][EPL * 64]; };
+template <int EPL, int BS>
+struct LearnShared { u64 cand[BS / 64][CAND_CAP]; int keep[BS / 64][EPL * 64]; };
 
-template <int EPL>
-__device__ __forceinline__ void role_learn(const Dev &d, int p, int blk, int nblk, LearnShared<EPL> *sh) {
+template <int EPL, int BS>
+__device__ __forceinline__ void role_learn(const Dev &d, int p, int blk, int nblk, LearnShared<EPL, BS> *sh) {
     int (*s_keep)[EPL * 64] = sh->keep;
     u64 (*s_cand)[CAND_CAP] = sh->cand;
     Counters *c = d.ctr;
     {   // forget the previous scan's per-cell maxima (sparse clear; every reader ran in an earlier
         // launch) and reset what the coming scan accumulates
         const int n = c->has_distal ? c->S : 0;
-        for (int i = blk * RB + threadIdx.x; i < n; i += nblk * RB)
+        for (int i = blk * BS + threadIdx.x; i < n; i += nblk * BS)
             if (d.seg_info[i] & 0x40000000u) d.cellmax[d.seg_cell[i]] = 0u;
         const int nb = (c->S + 1023) >> 10;
-        for (int i = blk * RB + threadIdx.x; i < nb; i += nblk * RB) d.recyc_cnt[i] = 0;
+        for (int i = blk * BS + threadIdx.x; i < nb; i += nblk * BS) d.recyc_cnt[i] = 0;
     }
     const int wv = threadIdx.x >> 6, lane = lane_id();
     const int n_work = min(c->n_work, d.work_cap);
@@ -1162,7 +1274,7 @@ __device__ __forceinline__ void role_learn(const Dev &d, int p, int blk, int nbl
     const int *winners = d.winners[p ^ 1];
     const int n_w = c->has_winner[p ^ 1] ? c->n_win[p ^ 1] : -1;       // -1: winner_input is None
     const uint32_t base2 = htm_stream_base(d.seed, HTM_STREAM_GROWTH, c->step[p]);
-    for (int item = blk * (RB / 64) + wv; item < n_work; item += nblk * (RB / 64)) {
+    for (int item = blk * (BS / 64) + wv; item < n_work; item += nblk * (BS / 64)) {
         const uint32_t w = d.work[item];
         const int seg = (int)(w & 0x7FFFFFFFu), mode = (int)(w >> 31);
         const double dA = mode ? d.pun_act : d.lrn_act, dI = mode ? d.pun_inact : d.lrn_inact;
@@ -1270,7 +1382,7 @@ extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
 
 template <int EPL>
 __global__ __launch_bounds__(RB) void k_tm_learn(Dev d, int p) {
-    role_learn<EPL>(d, p, blockIdx.x, gridDim.x, (LearnShared<EPL> *)dyn_lds);
+    role_learn<EPL, RB>(d, p, blockIdx.x, gridDim.x, (LearnShared<EPL, RB> *)dyn_lds);
 }
 
 // PredictiveProjection.process (projections.py:245-255): per segment, potential = active
@@ -1301,6 +1413,7 @@ __device__ __forceinline__ uint32_t scan_cell_active(const uint32_t *act, const 
 // LDS: word 0 = recyclable counter; from word 4: column bitmap [colwords]
 template <int BS, bool use_lds>
 __device__ __forceinline__ void role_scan(const Dev &d, int p, int blk, int nblk, uint32_t *lds) {
+    if (threadIdx.x == 0 && d.trace && (blk & 255) == 0) d.trace[256 + (blk >> 8) * 2] = wall_clock64();
     constexpr int SEGS = BS / 4;                   // segments per block iteration: BS/8 lane groups x 2 in flight
     int &s_recyc = *(int *)lds;
     uint32_t *s_colbits = lds + 4;
@@ -1473,73 +1586,105 @@ __device__ __forceinline__ void role_scan(const Dev &d, int p, int blk, int nblk
 // use_lds is a compile-time switch: as a run-time flag it put a branch and a wait around every
 // single LDS lookup, which serialised them
 template <bool use_lds>
-__global__ __launch_bounds__(256) void k_tm_scan(Dev d, int p) {
+__global__ __launch_bounds__(256, 6) void k_tm_scan(Dev d, int p) {
     role_scan<256, use_lds>(d, p, blockIdx.x, gridDim.x, (uint32_t *)dyn_lds);
+    if (threadIdx.x == 0 && d.trace && (blockIdx.x & 255) == 0) d.trace[256 + (blockIdx.x >> 8) * 2 + 1] = wall_clock64();
 }
 
 // ---- pipelined schedule: independent roles of two consecutive steps share every launch --------
 // A forked stream / graph branch costs 17-29 us on this runtime and every dependent launch about
 // 2.3 us plus its own chain of memory round trips; heterogeneous blocks in one launch cost nothing.
-// So the step is cut where the data dependencies are, and step t+1's Spatial Pooler front -- which
-// needs nothing from step t's Temporal Memory once step t's SP update and duty cycle are in place
-// -- rides along in the same four launches:
+// The Spatial Pooler never reads Temporal Memory state, so inside a batched run its step t+1 runs
+// beside the Temporal Memory's step t, role by role, in the same four launches:
 //
-//   k_step_open(t)     activation of step t's winner columns | its SP permanence rows | duty cycle
-//   k_mid_overlap(t)   segment allocation + learn / punish classification | overlap + boost (t+1)
-//   k_learn_sel(t)     synapse learning and growth | select digit 1 (t+1)
-//   k_scan_emit(t)     segment scan | rest of the select and the ordered winner list (t+1)
+//   k_open_overlap(t)   activation of step t's winner columns        | overlap + boost + digit 0 (t+1)
+//   k_mid_sel(t)        segment allocation, learn/punish work list   | select digit 1 (t+1)
+//   k_learn_emit(t)     synapse learning and growth                  | rest of the select, winner list (t+1)
+//   k_scan_close(t)     segment scan                                 | SP permanence rows, duty cycle (t+1)
 //
-// Everything the t+1 roles write is scratch of step t+1 in parity buffers (no duty cycle, no
-// permanence), so a prefetch that turns out unusable (another input follows) is simply dropped.
-__global__ __launch_bounds__(256) void k_step_open(Dev d, int p, int n_active, int want_winner, const uint32_t *__restrict__ bank,
-                                                    int n_inputs, int n_row_blocks, int n_act_blocks) {
-    int b = blockIdx.x;
-    if (b < n_row_blocks) {                        // most bytes: first in the grid
-        role_sp_row<256>(d, p, bank, n_inputs, b, threadIdx.x);
-        return;
+// The latency-bound select finish is paired with the learning (coalesced rows), not with the scan,
+// whose gathers fill the memory pipeline and stretch every dependent access of a co-resident
+// wave; the scan shares its launch with the streaming row update instead.  The t+1 roles include
+// the SP's persistent updates, so the last step of a run does not look ahead (htm_run knows it).
+struct TraceScope {
+    unsigned long long *t;
+    __device__ TraceScope(const Dev &d, int slot) {
+        t = (d.trace && blockIdx.x < 4096) ? d.trace + 1024 + ((size_t)slot * 4096 + blockIdx.x) * 2 : nullptr;
+        if (t && threadIdx.x == 0) t[0] = wall_clock64();
     }
-    b -= n_row_blocks;
-    if (b < n_act_blocks) {                        // one active column per half-wave
-        const int idx = (b * 256 + (int)threadIdx.x) >> 5;
+    __device__ ~TraceScope() { if (t && threadIdx.x == 0) t[1] = wall_clock64(); }
+};
+
+__global__ __launch_bounds__(RB) void k_open_overlap(Dev d, int p, int n_active, int n_act_blocks, const uint32_t *__restrict__ bank,
+                                                      int n_inputs, int G) {
+    TraceScope ts(d, 0 + 4 * p);
+    if ((int)blockIdx.x < n_act_blocks) {          // one active column per half-wave
+        const int idx = ((int)blockIdx.x * RB + (int)threadIdx.x) >> 5;
         const bool ok = idx < n_active;
         const int a = ok ? d.active_cols[p][idx] : 0;
-        tm_activate_column(d, p, want_winner, ok, a, idx, ok ? d.pred[p ^ 1][a] : 0u);
-        return;
-    }
-    b -= n_act_blocks;
-    const int c = b * 256 + (int)threadIdx.x;      // regularizations.py:19-21, float32, two roundings
-    if (c < d.C) {
-        float dc = d.duty[c] * d.mom;
-        if ((d.colbits[p][c >> 5] >> (c & 31)) & 1u) dc = dc + d.dinc;
-        d.duty[c] = dc;
+        tm_activate_column(d, p, 1, ok, a, idx, ok ? d.pred[p ^ 1][a] : 0u);
+    } else {
+        role_overlap<RB>(d, bank, n_inputs, G, p, p ^ 1, 1, blockIdx.x - n_act_blocks, gridDim.x - n_act_blocks, (uint32_t *)dyn_lds);
     }
 }
 
-__global__ __launch_bounds__(1024) void k_mid_overlap(Dev d, int p, int n_active, int learning, int n_cls,
-                                                      const uint32_t *__restrict__ bank, int n_inputs, int G) {
+__global__ __launch_bounds__(1024) void k_mid_sel(Dev d, int p, int n_active, int learning, int n_cls) {
+    TraceScope ts(d, 1 + 4 * p);
     const int n_mid = 1 + n_cls;
     if ((int)blockIdx.x < n_mid)
         role_mid(d, p, n_active, 1, learning, blockIdx.x, n_cls);
     else
-        role_overlap<1024>(d, bank, n_inputs, G, p, p ^ 1, 1, blockIdx.x - n_mid, gridDim.x - n_mid, (uint32_t *)dyn_lds);
-}
-
-template <int EPL>
-__global__ __launch_bounds__(RB) void k_learn_sel(Dev d, int p, int n_learn_blocks) {
-    if ((int)blockIdx.x < n_learn_blocks)
-        role_learn<EPL>(d, p, blockIdx.x, n_learn_blocks, (LearnShared<EPL> *)dyn_lds);
-    else
-        role_sel_pass<RB>(d, 1, p ^ 1, blockIdx.x - n_learn_blocks, gridDim.x - n_learn_blocks, (SelShared *)dyn_lds);
+        role_sel_pass<1024>(d, 1, p ^ 1, blockIdx.x - n_mid, gridDim.x - n_mid, (SelShared *)dyn_lds);
 }
 
 // the emit blocks wait for each other's records: they come first in the grid, so that all of them
-// are resident whatever the scan blocks do
-template <bool use_lds>
-__global__ __launch_bounds__(256) void k_scan_emit(Dev d, int p, int n_emit_blocks) {
+// are resident whatever the learning blocks do
+template <int EPL>
+__global__ __launch_bounds__(256) void k_learn_emit(Dev d, int p, int n_emit_blocks) {
+    TraceScope ts(d, 2 + 4 * p);
     if ((int)blockIdx.x < n_emit_blocks)
         role_emit(d, p ^ 1, 1, 1, 0, blockIdx.x, n_emit_blocks, (EmitShared *)dyn_lds);
     else
-        role_scan<256, use_lds>(d, p, blockIdx.x - n_emit_blocks, gridDim.x - n_emit_blocks, (uint32_t *)dyn_lds);
+        role_learn<EPL, 256>(d, p, blockIdx.x - n_emit_blocks, gridDim.x - n_emit_blocks, (LearnShared<EPL, 256> *)dyn_lds);
+}
+
+// The SP's closing work for the coming step comes first in the grid, in few blocks that start at
+// once (n_close = one per 256 columns): the duty cycle and per-column clears of their columns, then
+// winner rows j, j + n_close, ... two at a time.  Behind scan blocks they would only start when the
+// first scan blocks retire (every CU slot is taken) and lengthen the launch by their own duration.
+template <bool use_lds>
+__global__ __launch_bounds__(256, 6) void k_scan_close(Dev d, int p, int n_close, int n_rows, const uint32_t *__restrict__ bank,
+                                                        int n_inputs) {
+    TraceScope ts(d, 3 + 4 * p);
+    const int b = blockIdx.x;
+    if (b >= n_close) {
+        role_scan<256, use_lds>(d, p, b - n_close, gridDim.x - n_close, (uint32_t *)dyn_lds);
+        return;
+    }
+    const int q = p ^ 1;                           // the coming step; its input is bank row (step[p] + 1) % n_inputs
+    const int c = b * 256 + (int)threadIdx.x;
+    if (c < d.C) {
+        float dc = d.duty[c] * d.mom;              // regularizations.py:19-21, float32, two roundings
+        if ((d.colbits[q][c >> 5] >> (c & 31)) & 1u) dc = dc + d.dinc;
+        d.duty[c] = dc;
+        d.act[q][c] = 0;                           // what EMIT_CLEAR would have zeroed
+        d.win[q][c] = 0;
+        d.pred[q][c] = 0;
+    }
+    constexpr int R = 3;                           // winner rows in flight per block
+    const uint32_t *in = bank + (size_t)((d.ctr->step[p] + 1u) % (uint32_t)n_inputs) * d.W;
+    const int *cols = d.active_cols[q];
+    int cur[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) cur[j] = b + j * n_close < n_rows ? cols[b + j * n_close] : -1;
+    for (int ri = b; ri < n_rows; ri += R * n_close) {
+        int nxt[R];                                // the next round's rows are fetched beside this round's
+#pragma unroll
+        for (int j = 0; j < R; ++j) nxt[j] = ri + (R + j) * n_close < n_rows ? cols[ri + (R + j) * n_close] : -1;
+        role_sp_rows<256, R>(d, in, cur, threadIdx.x);
+#pragma unroll
+        for (int j = 0; j < R; ++j) cur[j] = nxt[j];
+    }
 }
 
 // recount recyclable segments after a state import
@@ -1574,15 +1719,12 @@ struct htm_handle {
     std::string err;
     std::vector<void *> allocs;
     int *d_cols_stage;                    // stand-alone TM: active columns
-    bool pf_valid;                        // the SP front of step step_host is already computed ...
-    const uint32_t *pf_bank;              // ... from this bank (pipelined schedule)
-    int pf_n_inputs;
     int rank, world;                      // column sharding
     const uint32_t *shard_bank;           // input of the step between htm_shard_begin and _finish
     int shard_n_inputs;
     bool shard_open;
     int G;                                // lanes per SP row
-    int sp_blocks, sp_blocks_1024, sel_blocks, c256_blocks, s1024_blocks, scan_blocks;
+    int sp_blocks, sel_blocks, c256_blocks, s1024_blocks, scan_blocks;
     // graphs keyed by (parity, learning, bank, n_inputs)
     std::map<std::tuple<int, int, const void *, int>, hipGraphExec_t> graphs;
     // state import staging (htm_write of the MATCH_* / SEG_POTENTIAL fields, applied at commit)
@@ -1652,9 +1794,10 @@ static int prof_slot(htm_handle *h, const char *name) {
     } while (0)
 #define LAUNCH(h, name, kernel, grid, block, ...) LAUNCH_ON(h, (h)->stream, 0, name, kernel, grid, block, __VA_ARGS__)
 
-static size_t learn_lds(int epl) { return (size_t)(RB / 64) * CAND_CAP * 8 + (size_t)(RB / 64) * epl * 64 * 4; }
+static size_t learn_lds(int epl, int bs = RB) { return (size_t)(bs / 64) * CAND_CAP * 8 + (size_t)(bs / 64) * epl * 64 * 4; }
 static int learn_epl(const Dev &d) { const int e = d.E / 64; return e <= 1 ? 1 : e == 2 ? 2 : e <= 4 ? 4 : 8; }
 static size_t scan_lds(const Dev &d, int use_lds) { return 16 + (use_lds ? (size_t)d.colwords * 4 : 0); }
+static const int kClassifyBlocks = 96;            // x 1024 segments per pass of the learn / punish classification
 static const int kLearnBlocks = 256;               // x RB/64 waves: one wave per learning / punished segment
 
 static void launch_learn(htm_handle *h, int p) {
@@ -1675,37 +1818,25 @@ static void launch_scan(htm_handle *h, int p, int use_lds) {
     else LAUNCH_ON(h, h->stream, scan_lds(d, 0), "tm_scan", k_tm_scan<false>, h->scan_blocks, 256, d, p);
 }
 
-static void launch_learn_sel(htm_handle *h, int p) {
-    Dev &d = h->d;
-    const int epl = learn_epl(d);
-    const size_t lds = std::max(learn_lds(epl), sizeof(SelShared));
-    const int grid = kLearnBlocks + h->sel_blocks;
-    switch (epl) {
-        case 1: LAUNCH_ON(h, h->stream, lds, "tm_learn+sp_select", k_learn_sel<1>, grid, RB, d, p, kLearnBlocks); break;
-        case 2: LAUNCH_ON(h, h->stream, lds, "tm_learn+sp_select", k_learn_sel<2>, grid, RB, d, p, kLearnBlocks); break;
-        case 4: LAUNCH_ON(h, h->stream, lds, "tm_learn+sp_select", k_learn_sel<4>, grid, RB, d, p, kLearnBlocks); break;
-        default: LAUNCH_ON(h, h->stream, lds, "tm_learn+sp_select", k_learn_sel<8>, grid, RB, d, p, kLearnBlocks); break;
-    }
-}
-
 // Front of SpatialPooler.process for the step with parity sp: overlap + boost (+ select digit 0)
-// and the remaining select digits.  In the pipelined schedule these run one step ahead.
+// and the remaining select digits.
 static void enqueue_sp_front(htm_handle *h, const uint32_t *bank, int n_inputs, int p) {
     Dev &d = h->d;
     LAUNCH(h, "sp_overlap", k_sp_overlap, h->sp_blocks, RB, d, bank, n_inputs, h->G, p);
     for (int pass = 1; pass < d.sel_passes; ++pass) LAUNCH(h, "sp_select", k_sel_pass, h->sel_blocks, RB, d, pass, p);
 }
 
-// Rest of SpatialPooler.process: count + emit.  mode = EMIT_DUTY | EMIT_ACTIVATE: all of it, with the
-// TM's per-column activation when the handle has a Temporal Memory; mode = 0: winner list only.
-static void enqueue_sp_back(htm_handle *h, const uint32_t *bank, int n_inputs, int learning, int p, int want_winner, int mode) {
+// Rest of SpatialPooler.process: count + emit.  mode = EMIT_ALL: all of it, with the TM's per-column
+// activation when the handle has a Temporal Memory.  sp_learn: the permanence update as a launch of
+// its own (handles without a Temporal Memory, and the first step of a pipelined run).
+static void enqueue_sp_back(htm_handle *h, const uint32_t *bank, int n_inputs, int p, int want_winner, int mode, bool sp_learn) {
     Dev &d = h->d;
     const int fused = h->c256_blocks <= 1024;      // all blocks co-resident: count inside emit
     if (!fused) LAUNCH(h, "sp_count", k_sp_count, h->c256_blocks, 256, d, p);
     LAUNCH(h, "sp_emit", k_sp_emit, h->c256_blocks, 256, d, p, want_winner, fused, mode);
     // (a forked graph branch for this independent update was measured at +17..29 us per step on
     // this runtime, against 2.3 us for one more kernel in the chain: tools/launch_overhead.hip)
-    if (learning && !h->cfg.enable_tm) LAUNCH(h, "sp_learn", k_sp_learn, d.k, 256, d, bank, n_inputs, p);
+    if (sp_learn) LAUNCH(h, "sp_learn", k_sp_learn, d.k, 256, d, bank, n_inputs, p);
 }
 
 // TemporalMemory.process after the per-column activation, one role per launch.  sp_rows: the SP
@@ -1713,7 +1844,7 @@ static void enqueue_sp_back(htm_handle *h, const uint32_t *bank, int n_inputs, i
 static void enqueue_tm(htm_handle *h, int n_active, int learning, int want_winner, int p,
                        const uint32_t *bank, int n_inputs, bool sp_rows) {
     Dev &d = h->d;
-    const int n_cls = learning ? 32 : 0;
+    const int n_cls = learning ? kClassifyBlocks : 0;
     const int n_sp_rows = (sp_rows && learning && h->cfg.enable_sp) ? d.k : 0;
     LAUNCH(h, "tm_mid", k_tm_mid, 1 + n_cls + (n_sp_rows + 1) / 2, 1024, d, p, n_active, want_winner, learning, bank, n_inputs,
            n_cls, n_sp_rows);
@@ -1721,24 +1852,30 @@ static void enqueue_tm(htm_handle *h, int n_active, int learning, int want_winne
     launch_scan(h, p, scan_lds(d, 1) <= 64 * 1024);
 }
 
-// first launch of a step whose winner list already exists (emitted with mode 0)
-static void launch_step_open(htm_handle *h, int p, int learning, const uint32_t *bank, int n_inputs) {
-    Dev &d = h->d;
-    const int n_rows = learning ? d.k : 0, n_act = (d.k * 32 + 255) / 256;
-    LAUNCH(h, "step_open", k_step_open, n_rows + n_act + h->c256_blocks, 256, d, p, d.k, 1, bank, n_inputs, n_rows, n_act);
-}
-
-// the other three launches of the pipelined schedule: step p's TM beside the next step's SP front
+// the four launches of a pipelined step: step p's Temporal Memory beside the next step's Spatial Pooler
 static void enqueue_pipelined(htm_handle *h, int p, int learning, const uint32_t *bank, int n_inputs) {
     Dev &d = h->d;
-    const int n_cls = learning ? 32 : 0;
-    LAUNCH_ON(h, h->stream, (size_t)SEL_BINS * 4, "tm_mid+sp_overlap", k_mid_overlap, 1 + n_cls + h->sp_blocks_1024, 1024, d, p, d.k,
-              learning, n_cls, bank, n_inputs, h->G);
-    launch_learn_sel(h, p);
+    const int n_cls = learning ? kClassifyBlocks : 0;
+    const int n_act = (d.k * 32 + RB - 1) / RB;
+    LAUNCH_ON(h, h->stream, (size_t)SEL_BINS * 4, "tm_activate+sp_overlap", k_open_overlap, n_act + h->sp_blocks, RB, d, p, d.k, n_act,
+              bank, n_inputs, h->G);
+    LAUNCH_ON(h, h->stream, sizeof(SelShared), "tm_mid+sp_select", k_mid_sel, 1 + n_cls + 64, 1024, d, p, d.k, learning, n_cls);
+    {
+        const int epl = learn_epl(d);
+        const size_t lds = std::max(learn_lds(epl, 256), sizeof(EmitShared));
+        const int grid = h->c256_blocks + 2 * kLearnBlocks;
+        switch (epl) {
+            case 1: LAUNCH_ON(h, h->stream, lds, "tm_learn+sp_emit", k_learn_emit<1>, grid, 256, d, p, h->c256_blocks); break;
+            case 2: LAUNCH_ON(h, h->stream, lds, "tm_learn+sp_emit", k_learn_emit<2>, grid, 256, d, p, h->c256_blocks); break;
+            case 4: LAUNCH_ON(h, h->stream, lds, "tm_learn+sp_emit", k_learn_emit<4>, grid, 256, d, p, h->c256_blocks); break;
+            default: LAUNCH_ON(h, h->stream, lds, "tm_learn+sp_emit", k_learn_emit<8>, grid, 256, d, p, h->c256_blocks); break;
+        }
+    }
     const int use_lds = scan_lds(d, 1) <= 64 * 1024;
-    const size_t lds = std::max(scan_lds(d, use_lds), sizeof(EmitShared));
-    if (use_lds) LAUNCH_ON(h, h->stream, lds, "tm_scan+sp_emit", k_scan_emit<true>, h->c256_blocks + h->scan_blocks, 256, d, p, h->c256_blocks);
-    else LAUNCH_ON(h, h->stream, lds, "tm_scan+sp_emit", k_scan_emit<false>, h->c256_blocks + h->scan_blocks, 256, d, p, h->c256_blocks);
+    const int n_rows = learning ? d.k : 0;
+    const int grid = h->c256_blocks + h->scan_blocks;
+    if (use_lds) LAUNCH_ON(h, h->stream, scan_lds(d, 1), "tm_scan+sp_learn", k_scan_close<true>, grid, 256, d, p, h->c256_blocks, n_rows, bank, n_inputs);
+    else LAUNCH_ON(h, h->stream, scan_lds(d, 0), "tm_scan+sp_learn", k_scan_close<false>, grid, 256, d, p, h->c256_blocks, n_rows, bank, n_inputs);
 }
 
 // the pipelined schedule needs the select finished inside one co-resident emit grid after two
@@ -1747,58 +1884,44 @@ static bool can_pipeline(const htm_handle *h) {
     return h->cfg.enable_sp && h->cfg.enable_tm && h->world == 1 && h->c256_blocks <= 1024 && h->d.sel_passes == 2;
 }
 
-// The coming step's SP front and winner list may already have been computed by the previous step's
-// launches.
-static void drop_prefetch(htm_handle *h) { h->pf_valid = false; }
+// How a step is launched.  `ahead_in`: the Spatial Pooler has already done this step (winner list,
+// permanence and duty cycle updates) during the previous one; `ahead_out`: do the same for the next.
+// The SP's look-ahead includes its persistent updates, so it only ever happens between two steps of
+// one htm_run call (same bank, same learning flag); no call returns with a look-ahead outstanding.
+struct StepPlan { bool ahead_in, ahead_out; };
 
-struct StepPlan { bool have, open; };               // prefetched front usable; step starts with k_step_open
-
-static StepPlan plan_step(htm_handle *h, const uint32_t *bank, int n_inputs, bool pipeline) {
-    const bool have = h->pf_valid && h->pf_bank == bank && h->pf_n_inputs == n_inputs;
-    return StepPlan{have, have || pipeline};
-}
-
-// make sure the SP front of the coming step exists (and, for a step that starts with k_step_open, its
-// winner list)
-static void ensure_front(htm_handle *h, const uint32_t *bank, int n_inputs, StepPlan plan) {
+// work of a step that is not captured in its graph: a pipelined step without look-ahead from the
+// previous one first runs the Spatial Pooler on its own
+static void enqueue_cold_front(htm_handle *h, const uint32_t *bank, int n_inputs, int learning, StepPlan plan) {
     const int p = (int)(h->step_host & 1);
-    if (!plan.have) {
-        enqueue_sp_front(h, bank, n_inputs, p);
-        if (plan.open) enqueue_sp_back(h, bank, n_inputs, 0, p, 1, 0);
-    }
-    h->pf_valid = false;
+    if (plan.ahead_in) return;
+    enqueue_sp_front(h, bank, n_inputs, p);
+    if (plan.ahead_out) enqueue_sp_back(h, bank, n_inputs, p, 1, EMIT_DUTY | EMIT_CLEAR, learning != 0);
 }
 
-// everything after the front; with `pipeline` it also computes the next step's front
-static void enqueue_rest(htm_handle *h, const uint32_t *bank, int n_inputs, int learning, bool pipeline, StepPlan plan) {
-    const int p = (int)(h->step_host & 1);
-    if (!plan.open) {                               // one role per launch
-        enqueue_sp_back(h, bank, n_inputs, learning, p, 1, EMIT_DUTY | EMIT_ACTIVATE);
-        enqueue_tm(h, h->d.k, learning, 1, p, bank, n_inputs, true);
-        return;
+static void enqueue_rest(htm_handle *h, int p, const uint32_t *bank, int n_inputs, int learning, StepPlan plan) {
+    Dev &d = h->d;
+    if (plan.ahead_out) {
+        enqueue_pipelined(h, p, learning, bank, n_inputs);
+    } else if (plan.ahead_in) {                     // last step of a pipelined run: the TM alone, one role per launch
+        LAUNCH(h, "tm_activate", k_tm_activate, (d.k * 32 + 255) / 256, 256, d, p, d.k, 1);
+        enqueue_tm(h, d.k, learning, 1, p, bank, n_inputs, false);
+    } else {                                        // one role per launch
+        enqueue_sp_back(h, bank, n_inputs, p, 1, EMIT_ALL, false);
+        enqueue_tm(h, d.k, learning, 1, p, bank, n_inputs, true);
     }
-    launch_step_open(h, p, learning, bank, n_inputs);
-    if (pipeline) enqueue_pipelined(h, p, learning, bank, n_inputs);
-    else enqueue_tm(h, h->d.k, learning, 1, p, bank, n_inputs, false);
 }
 
-static void step_done(htm_handle *h, const uint32_t *bank, int n_inputs, bool pipeline) {
+static int enqueue_step(htm_handle *h, const uint32_t *bank, int n_inputs, int learning, StepPlan plan) {
+    enqueue_cold_front(h, bank, n_inputs, learning, plan);
+    enqueue_rest(h, (int)(h->step_host & 1), bank, n_inputs, learning, plan);
     h->step_host += 1;
-    h->pf_valid = pipeline;
-    h->pf_bank = bank;
-    h->pf_n_inputs = n_inputs;
-}
-
-static int enqueue_step(htm_handle *h, const uint32_t *bank, int n_inputs, int learning, bool pipeline) {
-    pipeline = pipeline && can_pipeline(h);
-    const StepPlan plan = plan_step(h, bank, n_inputs, pipeline);
-    ensure_front(h, bank, n_inputs, plan);
-    enqueue_rest(h, bank, n_inputs, learning, pipeline, plan);
-    step_done(h, bank, n_inputs, pipeline);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { h->err = std::string("kernel launch: ") + hipGetErrorString(e); return HTM_ERR_HIP; }
     return 0;
 }
+
+extern "C" int htm_debug_trace(htm_handle *h, unsigned long long *dst) { hipStreamSynchronize(h->stream); return h->d.trace ? (int)hipMemcpy(dst, h->d.trace, 8 * (1024 + 8 * 4096 * 2), hipMemcpyDeviceToHost) : -1; }
 
 extern "C" int htm_abi_version(void) { return BITHTM_ABI_VERSION; }
 
@@ -1855,9 +1978,6 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
     h->prof_last = nullptr;
     h->step_host = 0;
     h->d_cols_stage = nullptr;
-    h->pf_valid = false;
-    h->pf_bank = nullptr;
-    h->pf_n_inputs = 0;
     h->rank = world > 1 ? cfg->shard_rank : 0;
     h->world = world;
     h->shard_bank = nullptr;
@@ -1913,6 +2033,7 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
             rc |= dalloc(h, &d.key[q], C);
         }
         rc |= dalloc(h, &d.hist, (size_t)2 * SEL_MAX_PASSES * SEL_BINS);
+        rc |= dalloc(h, &d.hist0, (size_t)2 * HIST_REP * SEL_BINS);
         rc |= dalloc(h, &d.sel_blk, (C + 255) / 256);
         rc |= dalloc(h, &d.sel_rec, (C + 255) / 256 * 32);
         rc |= dalloc(h, &d.input_stage, (size_t)d.W);
@@ -1963,7 +2084,8 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
     // hot bins and same-address global atomics are slow (~88 per us per address)
     const int rows_per_block = (RB / 64) * 4 * (64 / h->G);   // waves x 4 row groups in flight
     h->sp_blocks = std::max(1, std::min((d.c1 - d.c0 + rows_per_block - 1) / rows_per_block, 256));
-    h->sp_blocks_1024 = std::max(1, std::min((d.c1 - d.c0 + 2 * rows_per_block - 1) / (2 * rows_per_block), 256));
+    d.trace = nullptr;
+    if (getenv("BITHTM_TRACE")) rc |= dalloc(h, &d.trace, 1024 + 8 * 4096 * 2);
     h->sel_blocks = std::max(1, std::min((d.C + RB - 1) / RB, 128));
     h->c256_blocks = (d.C + 255) / 256;
     h->s1024_blocks = std::max(1, (d.Scap + 1023) / 1024);
@@ -1984,6 +2106,8 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
         if (const char *e = getenv("BITHTM_SEL_LAUNCH_DIGITS")) d.sel_passes = std::max(2, std::min(d.sel_passes, atoi(e)));
         d.cand_d = CAND_D;
         if (const char *e = getenv("BITHTM_CAND_D")) d.cand_d = std::max(0, std::min(CAND_D, atoi(e)));
+        d.cand_pairwise = CAND_PAIRWISE;
+        if (const char *e = getenv("BITHTM_CAND_PAIRWISE")) d.cand_pairwise = std::max(0, atoi(e));     // test knob
     }
     e = hipStreamSynchronize(h->stream);
     if (e != hipSuccess) return fail_create(h, std::string("hipStreamSynchronize: ") + hipGetErrorString(e), HTM_ERR_HIP);
@@ -2014,7 +2138,6 @@ extern "C" int htm_sp_set_permanence(htm_handle *h, const double *rows, int32_t 
     if (row_count == 0) return HTM_OK;
     Dev &d = h->d;
     HIPCHK(h, hipSetDevice(h->device));
-    drop_prefetch(h);
     HIPCHK(h, hipMemcpy2DAsync(d.perm + (size_t)row_begin * d.Ipad, (size_t)d.Ipad * 8, rows, (size_t)d.I * 8,
                                (size_t)d.I * 8, (size_t)row_count, hipMemcpyHostToDevice, h->stream));
     const long long waves = (long long)row_count * (d.Ipad / 64);
@@ -2050,8 +2173,7 @@ extern "C" int htm_step(htm_handle *h, const uint32_t *packed_input, int32_t lea
     HIPCHK(h, hipSetDevice(h->device));
     int rc = stage_input(h, packed_input);
     if (rc) return rc;
-    drop_prefetch(h);                               // the staged input changed: nothing can be reused
-    return enqueue_step(h, h->d.input_stage, 1, learning ? 1 : 0, false);
+    return enqueue_step(h, h->d.input_stage, 1, learning ? 1 : 0, StepPlan{false, false});
 }
 
 extern "C" int htm_sp_step(htm_handle *h, const uint32_t *packed_input, int32_t learning) {
@@ -2062,7 +2184,7 @@ extern "C" int htm_sp_step(htm_handle *h, const uint32_t *packed_input, int32_t 
     if (rc) return rc;
     const int p = (int)(h->step_host & 1);
     enqueue_sp_front(h, h->d.input_stage, 1, p);
-    enqueue_sp_back(h, h->d.input_stage, 1, learning ? 1 : 0, p, 0, EMIT_DUTY | EMIT_ACTIVATE);
+    enqueue_sp_back(h, h->d.input_stage, 1, p, 0, EMIT_ALL, learning && !h->cfg.enable_tm);
     h->step_host += 1;
     return HTM_OK;
 }
@@ -2095,24 +2217,33 @@ extern "C" int htm_run(htm_handle *h, const uint32_t *device_inputs, int32_t n_i
     HIPCHK(h, hipSetDevice(h->device));
     learning = learning ? 1 : 0;
     const bool graph = (use_graph & 1) && !h->profile;
-    const bool pipeline = !(use_graph & 2) && !h->profile && can_pipeline(h);     // profiled runs time each role on its own
-    if (!graph) {
-        for (int t = 0; t < n_steps; ++t) {
-            int rc = enqueue_step(h, device_inputs, n_inputs, learning, pipeline);
+    const bool pipeline = !(use_graph & 2) && can_pipeline(h);
+    // Graphs hold the launches of one step, or of kGraphSteps consecutive steady-state steps (a graph
+    // launch boundary costs about 5 us more than a kernel boundary inside a graph: tools/launch_anatomy.hip
+    // and the device-clock trace in DESIGN.md).  Nothing in a graph depends on the step index: kernels
+    // read it, and with it the bank row, from the device counter.
+    const int kGraphSteps = 16;
+    bool ahead = false;                             // the SP has already done the coming step
+    for (int t = 0; t < n_steps;) {
+        const StepPlan plan{ahead, pipeline && t + 1 < n_steps};
+        ahead = plan.ahead_out;
+        if (!graph) {
+            int rc = enqueue_step(h, device_inputs, n_inputs, learning, plan);
             if (rc) return rc;
+            t += 1;
+            continue;
         }
-        return HTM_OK;
-    }
-    for (int t = 0; t < n_steps; ++t) {
         const int p = (int)(h->step_host & 1);
-        const StepPlan plan = plan_step(h, device_inputs, n_inputs, pipeline);
-        ensure_front(h, device_inputs, n_inputs, plan);    // eager, only when nothing was prefetched
-        auto key = std::make_tuple(p, learning * 4 + (pipeline ? 2 : 0) + (plan.open ? 1 : 0), (const void *)device_inputs, n_inputs);
+        // steady state: this and the next kGraphSteps - 1 steps all have a look-ahead in and out
+        const int span = (plan.ahead_in && plan.ahead_out && t + kGraphSteps < n_steps) ? kGraphSteps : 1;
+        enqueue_cold_front(h, device_inputs, n_inputs, learning, plan);      // eager: first step of a pipelined run only
+        auto key = std::make_tuple(p, learning * 8 + (span > 1 ? 4 : 0) + (plan.ahead_in ? 2 : 0) + (plan.ahead_out ? 1 : 0),
+                                   (const void *)device_inputs, n_inputs);
         auto it = h->graphs.find(key);
         if (it == h->graphs.end()) {
             hipGraph_t graph_obj;
             HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-            enqueue_rest(h, device_inputs, n_inputs, learning, pipeline, plan);
+            for (int i = 0; i < span; ++i) enqueue_rest(h, (p + i) & 1, device_inputs, n_inputs, learning, plan);
             hipError_t e = hipStreamEndCapture(h->stream, &graph_obj);
             if (e != hipSuccess) { h->err = std::string("hipStreamEndCapture: ") + hipGetErrorString(e); return HTM_ERR_HIP; }
             hipGraphExec_t exec;
@@ -2121,7 +2252,8 @@ extern "C" int htm_run(htm_handle *h, const uint32_t *device_inputs, int32_t n_i
             it = h->graphs.emplace(key, exec).first;
         }
         HIPCHK(h, hipGraphLaunch(it->second, h->stream));
-        step_done(h, device_inputs, n_inputs, pipeline);
+        h->step_host += span;
+        t += span;
     }
     return HTM_OK;
 }
@@ -2169,7 +2301,7 @@ extern "C" int htm_shard_finish(htm_handle *h, const void *recv_device, int32_t 
     for (int pass = 1; pass < d.sel_passes; ++pass) LAUNCH(h, "sp_select", k_sel_pass, h->sel_blocks, RB, d, pass, p);
     const int fused = h->c256_blocks <= 1024;
     if (!fused) LAUNCH(h, "sp_count", k_sp_count, h->c256_blocks, 256, d, p);
-    LAUNCH(h, "sp_emit", k_sp_emit, h->c256_blocks, 256, d, p, 1, fused, EMIT_DUTY | EMIT_ACTIVATE);
+    LAUNCH(h, "sp_emit", k_sp_emit, h->c256_blocks, 256, d, p, 1, fused, EMIT_ALL);
     enqueue_tm(h, d.k, learning, 1, p, h->shard_bank, h->shard_n_inputs, true);
     h->step_host += 1;
     h->shard_open = false;
@@ -2356,7 +2488,7 @@ extern "C" int htm_write(htm_handle *h, int32_t field, const void *src, int64_t 
         return HTM_ERR_STATE;
     }
     switch (field) {
-        case HTM_F_DUTY_CYCLE: drop_prefetch(h); return put(d.duty, src, count, 4, C);
+        case HTM_F_DUTY_CYCLE: return put(d.duty, src, count, 4, C);
         case HTM_F_CELL_ACTIVATION: return put(d.act[q], src, count, 4, C);
         case HTM_F_CELL_PREDICTION: return put(d.pred[q], src, count, 4, C);
         case HTM_F_SEG_NSYN: return put(d.seg_nsyn, src, count, 4, d.Scap);
@@ -2390,7 +2522,6 @@ extern "C" int htm_write(htm_handle *h, int32_t field, const void *src, int64_t 
 extern "C" int htm_import_begin(htm_handle *h, int64_t step_index) {
     if (!h || step_index < 0) return HTM_ERR_ARGUMENT;
     HIPCHK(h, hipSetDevice(h->device));
-    drop_prefetch(h);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->step_host = step_index;
     return HTM_OK;
