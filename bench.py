@@ -29,7 +29,7 @@ sys.path.insert(0, ROOT)
 
 WORKLOAD = dict(input_dim=1024, column_dim=65536, cell_dim=32, patterns=50, density=0.02, noise=0.005,
                 noisy_copies=20, segment_slots=128)
-PIPELINED_LAUNCHES = ("tm_activate+sp_overlap", "tm_mid+sp_select", "tm_learn+sp_emit", "tm_scan+sp_learn")
+PIPELINED_LAUNCHES = ("tm_activate+sp_emit", "tm_mid+sp_learn", "tm_learn+sp_overlap", "tm_scan+sp_select")
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 
 

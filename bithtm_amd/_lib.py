@@ -67,6 +67,7 @@ EXPORTS = {
     "htm_profile": (C.c_int, [C.c_void_p, C.c_int32]),
     "htm_profile_read": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_double),
                                    C.POINTER(C.c_int64)]),
+    "htm_trace_read": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_int64]),
 }
 
 _lib = None

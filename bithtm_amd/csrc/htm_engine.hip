@@ -121,7 +121,8 @@ struct Dev {
     uint32_t *spec_act, *spec_win, *spec_unacc, *spec_burst;      // [C] [C] [C] [ceil(C/32)]
     int *dead_list;           // [1 + DEAD_CAP]: count, ids
     Counters *ctr;
-    unsigned long long *trace;
+    unsigned long long *trace;    // [8][4096][2] BITHTM_TRACE=1: device clock at the start / end of every block of the
+                                  // pipelined launches (slot = launch + 4 * step parity), else null
 };
 
 // ------------------------------------------------------------------------------------------
@@ -285,9 +286,9 @@ __device__ __forceinline__ void role_overlap(const Dev &d, const uint32_t *__res
         if (h[i]) atomicAdd(&g0[i], h[i]);
 }
 
-__global__ __launch_bounds__(RB) void k_sp_overlap(Dev d, const uint32_t *__restrict__ bank, int n_inputs, int G, int p) {
+__global__ __launch_bounds__(RB) void k_sp_overlap(Dev d, const uint32_t *__restrict__ bank, int n_inputs, int G, int p, int sp, int step_offset) {
     __shared__ uint32_t h[SEL_BINS];               // histogram of the top key digit (select pass 0)
-    role_overlap<RB>(d, bank, n_inputs, G, p, p, 0, blockIdx.x, gridDim.x, h);
+    role_overlap<RB>(d, bank, n_inputs, G, p, sp, step_offset, blockIdx.x, gridDim.x, h);
 }
 
 // GlobalInhibition.process (regularizations.py:28-29) as an exact radix select of the k-th
@@ -644,8 +645,7 @@ __device__ __forceinline__ void sel_pick(const uint32_t *h, int nb, uint32_t kre
 // T, r and the per-block counts come from k_sel_pass / k_sp_count launches.
 // EMIT_CLEAR: also zero the dense per-column words of the step.  The pipelined schedule runs this
 // role with mode 0 one step ahead, beside the previous step's learning (which still reads the
-// words a clear would zero); duty cycle and clearing follow in k_scan_close, activation in
-// k_open_overlap.
+// words a clear would zero); see the pipelined schedule below.
 #define EMIT_DUTY 1
 #define EMIT_ACTIVATE 2
 #define EMIT_CLEAR 4
@@ -678,8 +678,6 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
     uint32_t *s_mh = sh->mh;
     static_assert(2 * CAND_MAX <= SEL_BINS, "bucket keys must fit the histogram");
     const int tid = threadIdx.x, lane = lane_id();
-#define EMIT_TR(k) do { if (tid == 0 && d.trace && (b & 31) == 0) d.trace[(b >> 5) * 16 + (k)] = wall_clock64(); } while (0)
-    EMIT_TR(0);
     if (tid == 0) { s_gt = 0; s_eq = 0; s_n = 0; s_nraw = 0; s_ne = 0; s_flags = 0; }
     const int c = b * 256 + tid;
     // independent of everything below: in flight while the select state is resolved
@@ -697,7 +695,6 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
         uint32_t krem;
         sel_resolve<256>(d, p, d.sel_passes - 1, h, s_wave, &P, &krem, &s_prefix, &s_krem);
         __syncthreads();
-    EMIT_TR(1);
         if (d.sel_passes > 1)                       // pass-0 histogram is consumed: clear it for its next use
             for (int i = b * 256 + tid; i < HIST_REP * SEL_BINS; i += nblk * 256) d.hist0[(size_t)p * HIST_REP * SEL_BINS + i] = 0;
         const int lowbits = sel_shift(d.sel_passes - 1);        // key bits not resolved by launches
@@ -731,7 +728,6 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
         __syncthreads();
         if (tid < nraw && first != tid) atomicAdd(&s_bc[first], my_cnt);
         __syncthreads();
-    EMIT_TR(2);
         // record = 16 self-validating 64-bit granules (form R2: every granule carries the epoch, one
         // aligned 8-byte write-through store each, so no separate tag and no drain):
         //   [0]      epoch:12 | overflow:1 | pairs:8 | keys above the bucket:16
@@ -752,7 +748,6 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (tid == 0) s_gt = 0;
-    EMIT_TR(3);
         // ---- everybody's records: head and all pair granules fetched in one batch per poll
         uint32_t gthi_before = 0;
         for (int rb = tid; rb < nblk; rb += 256) {
@@ -792,7 +787,6 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
                 }
         }
         __syncthreads();
-    EMIT_TR(4);
         const int ne = s_ne;
         if (!(s_flags & 1u) && ne <= CAND_MAX) {
             if (ne <= d.cand_pairwise) {                // the krem-th largest of the merged bucket: all pairs
@@ -875,7 +869,6 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
         r = d.ctr->sel_krem[p];
     }
     __syncthreads();
-    EMIT_TR(5);
     uint32_t flag = 0;
     if (c < d.C) flag = (my_key > T) ? 1u : ((my_key == T) ? 0x10000u : 0u);
     uint32_t total;
@@ -910,7 +903,6 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
         if (lane == 0) { atomicAdd(&s_gt, g); atomicAdd(&s_eq, e); }
     }
     __syncthreads();
-    EMIT_TR(6);
     const uint32_t gt_before = s_gt, eq_before = s_eq;
     const uint32_t g_run = gt_before + (ex & 0xFFFFu), e_run = eq_before + (ex >> 16);
     const int first_pos = (int)(gt_before + min(eq_before, r));
@@ -938,7 +930,6 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
         }
     }
     if (b == 0 && tid == 0 && !d.act[0]) d.ctr->step[p ^ 1] = d.ctr->step[p] + 1;   // SP-only handle
-    EMIT_TR(7);
     if (!tm_here) return;
     __syncthreads();
     const int n_sel = s_n;
@@ -1053,46 +1044,6 @@ __device__ __forceinline__ void role_sp_row(const Dev &d, int p, const uint32_t 
             u64 *mw = (u64 *)&mrow[base >> 5];
             mw[0] = spread32((uint32_t)b0) | (spread32((uint32_t)b1) << 1);
             mw[1] = spread32((uint32_t)(b0 >> 32)) | (spread32((uint32_t)(b1 >> 32)) << 1);
-        }
-    }
-}
-
-// the same for R winner rows at once (row[q] < 0: absent), two chunks of each in flight: every
-// load of a round is issued before the first is consumed; all TPR threads of the block call
-template <int TPR, int R>
-__device__ __forceinline__ void role_sp_rows(const Dev &d, const uint32_t *__restrict__ in, const int (&row)[R], int t) {
-    for (int i0 = 0; i0 < d.Ipad; i0 += 4 * TPR) {
-        double2 v[R][2];
-        uint32_t bits[2];
-#pragma unroll
-        for (int ch = 0; ch < 2; ++ch) {
-            const int e0 = i0 + ch * 2 * TPR + 2 * t;
-            const bool in_row = e0 < d.Ipad;
-            bits[ch] = in_row ? in[e0 >> 5] >> (e0 & 31) : 0u;
-#pragma unroll
-            for (int q = 0; q < R; ++q)
-                v[q][ch] = (in_row && row[q] >= 0) ? *(const double2 *)(d.perm + (size_t)row[q] * d.Ipad + e0) : make_double2(0.0, 0.0);
-        }
-#pragma unroll
-        for (int ch = 0; ch < 2; ++ch) {
-            const int e0 = i0 + ch * 2 * TPR + 2 * t;
-            const int base = i0 + ch * 2 * TPR + 2 * (t & ~63);
-#pragma unroll
-            for (int q = 0; q < R; ++q) {
-                bool c0 = false, c1 = false;
-                if (e0 < d.Ipad && row[q] >= 0) {
-                    double2 w = v[q][ch];
-                    if (e0 < d.I) { w.x = w.x + ((bits[ch] & 1u) ? d.sp_don : d.sp_doff); c0 = w.x >= d.sp_thr; }
-                    if (e0 + 1 < d.I) { w.y = w.y + ((bits[ch] & 2u) ? d.sp_don : d.sp_doff); c1 = w.y >= d.sp_thr; }
-                    *(double2 *)(d.perm + (size_t)row[q] * d.Ipad + e0) = w;
-                }
-                const u64 b0 = __ballot(c0), b1 = __ballot(c1);
-                if (lane_id() == 0 && base < d.Ipad && row[q] >= 0) {
-                    u64 *mw = (u64 *)&d.mask[(size_t)row[q] * d.W + (base >> 5)];
-                    mw[0] = spread32((uint32_t)b0) | (spread32((uint32_t)b1) << 1);
-                    mw[1] = spread32((uint32_t)(b0 >> 32)) | (spread32((uint32_t)(b1 >> 32)) << 1);
-                }
-            }
         }
     }
 }
@@ -1413,7 +1364,6 @@ __device__ __forceinline__ uint32_t scan_cell_active(const uint32_t *act, const 
 // LDS: word 0 = recyclable counter; from word 4: column bitmap [colwords]
 template <int BS, bool use_lds>
 __device__ __forceinline__ void role_scan(const Dev &d, int p, int blk, int nblk, uint32_t *lds) {
-    if (threadIdx.x == 0 && d.trace && (blk & 255) == 0) d.trace[256 + (blk >> 8) * 2] = wall_clock64();
     constexpr int SEGS = BS / 4;                   // segments per block iteration: BS/8 lane groups x 2 in flight
     int &s_recyc = *(int *)lds;
     uint32_t *s_colbits = lds + 4;
@@ -1588,102 +1538,108 @@ __device__ __forceinline__ void role_scan(const Dev &d, int p, int blk, int nblk
 template <bool use_lds>
 __global__ __launch_bounds__(256, 6) void k_tm_scan(Dev d, int p) {
     role_scan<256, use_lds>(d, p, blockIdx.x, gridDim.x, (uint32_t *)dyn_lds);
-    if (threadIdx.x == 0 && d.trace && (blockIdx.x & 255) == 0) d.trace[256 + (blockIdx.x >> 8) * 2 + 1] = wall_clock64();
 }
 
-// ---- pipelined schedule: independent roles of two consecutive steps share every launch --------
-// A forked stream / graph branch costs 17-29 us on this runtime and every dependent launch about
-// 2.3 us plus its own chain of memory round trips; heterogeneous blocks in one launch cost nothing.
-// The Spatial Pooler never reads Temporal Memory state, so inside a batched run its step t+1 runs
-// beside the Temporal Memory's step t, role by role, in the same four launches:
+// ---- pipelined schedule: roles of different steps share every launch ---------------------------
+// A forked stream / graph branch costs 17-29 us on this runtime and every dependent launch 1.2-3 us
+// plus its own chain of memory round trips; heterogeneous blocks in one launch cost nothing.  The
+// Spatial Pooler never reads Temporal Memory state, so inside a batched run it works ahead of the
+// Temporal Memory, role by role, in the same four launches (t = the TM's step):
 //
-//   k_open_overlap(t)   activation of step t's winner columns        | overlap + boost + digit 0 (t+1)
-//   k_mid_sel(t)        segment allocation, learn/punish work list   | select digit 1 (t+1)
-//   k_learn_emit(t)     synapse learning and growth                  | rest of the select, winner list (t+1)
-//   k_scan_close(t)     segment scan                                 | SP permanence rows, duty cycle (t+1)
+//   k_open_emit(t)      activation of step t's winner columns     | rest of the select + winner list (t+1)
+//   k_mid_rows(t)       segment allocation, learn/punish list     | SP permanence rows + duty cycle (t+1)
+//   k_learn_overlap(t)  synapse learning and growth               | overlap + boost + select digit 0 (t+2)
+//   k_scan_sel(t)       segment scan                              | select digit 1 (t+2), clears for t+1
 //
-// The latency-bound select finish is paired with the learning (coalesced rows), not with the scan,
-// whose gathers fill the memory pipeline and stretch every dependent access of a co-resident
-// wave; the scan shares its launch with the streaming row update instead.  The t+1 roles include
-// the SP's persistent updates, so the last step of a run does not look ahead (htm_run knows it).
-struct TraceScope {
+// The pairing follows what was measured with the device clock (tools/step_timeline.py): the scan's
+// gathers fill the memory pipeline and stretch every dependent access of a co-resident wave, and its
+// blocks take every CU slot, so it shares its launch only with the lightest SP role; the
+// latency-bound select finish runs beside the cheap activation; the two streaming roles (rows,
+// overlap) sit beside the latency-bound mid and learn roles.  The look-ahead includes the SP's
+// persistent updates (rows, duty cycle), so it only happens between two steps of one htm_run
+// call: the last two steps of a run look ahead less (StepPlan) and no call returns with SP work
+// outstanding.
+struct TraceScope {                                 // BITHTM_TRACE=1: first / last device clock of every block
     unsigned long long *t;
     __device__ TraceScope(const Dev &d, int slot) {
-        t = (d.trace && blockIdx.x < 4096) ? d.trace + 1024 + ((size_t)slot * 4096 + blockIdx.x) * 2 : nullptr;
+        t = (d.trace && blockIdx.x < 4096) ? d.trace + ((size_t)slot * 4096 + blockIdx.x) * 2 : nullptr;
         if (t && threadIdx.x == 0) t[0] = wall_clock64();
     }
     __device__ ~TraceScope() { if (t && threadIdx.x == 0) t[1] = wall_clock64(); }
 };
 
-__global__ __launch_bounds__(RB) void k_open_overlap(Dev d, int p, int n_active, int n_act_blocks, const uint32_t *__restrict__ bank,
-                                                      int n_inputs, int G) {
+// the emit blocks wait for each other's records: they come first in the grid, so that all of them
+// are resident whatever the other blocks do
+__global__ __launch_bounds__(256) void k_open_emit(Dev d, int p, int n_emit_blocks, int n_active) {
     TraceScope ts(d, 0 + 4 * p);
-    if ((int)blockIdx.x < n_act_blocks) {          // one active column per half-wave
-        const int idx = ((int)blockIdx.x * RB + (int)threadIdx.x) >> 5;
+    if ((int)blockIdx.x < n_emit_blocks) {
+        role_emit(d, p ^ 1, 1, 1, 0, blockIdx.x, n_emit_blocks, (EmitShared *)dyn_lds);
+    } else {                                       // one active column per half-wave
+        const int idx = (((int)blockIdx.x - n_emit_blocks) * 256 + (int)threadIdx.x) >> 5;
         const bool ok = idx < n_active;
         const int a = ok ? d.active_cols[p][idx] : 0;
         tm_activate_column(d, p, 1, ok, a, idx, ok ? d.pred[p ^ 1][a] : 0u);
-    } else {
-        role_overlap<RB>(d, bank, n_inputs, G, p, p ^ 1, 1, blockIdx.x - n_act_blocks, gridDim.x - n_act_blocks, (uint32_t *)dyn_lds);
     }
 }
 
-__global__ __launch_bounds__(1024) void k_mid_sel(Dev d, int p, int n_active, int learning, int n_cls) {
+// blocks [0, 1 + n_cls): the middle of the TM step; then two winner rows of the coming step per block;
+// then its duty cycle (regularizations.py:19-21, float32, two roundings), 1024 columns per block
+__global__ __launch_bounds__(1024) void k_mid_rows(Dev d, int p, int n_active, int learning, int n_cls,
+                                                   const uint32_t *__restrict__ bank, int n_inputs, int n_rows, int n_duty_blocks) {
     TraceScope ts(d, 1 + 4 * p);
-    const int n_mid = 1 + n_cls;
-    if ((int)blockIdx.x < n_mid)
-        role_mid(d, p, n_active, 1, learning, blockIdx.x, n_cls);
-    else
-        role_sel_pass<1024>(d, 1, p ^ 1, blockIdx.x - n_mid, gridDim.x - n_mid, (SelShared *)dyn_lds);
-}
-
-// the emit blocks wait for each other's records: they come first in the grid, so that all of them
-// are resident whatever the learning blocks do
-template <int EPL>
-__global__ __launch_bounds__(256) void k_learn_emit(Dev d, int p, int n_emit_blocks) {
-    TraceScope ts(d, 2 + 4 * p);
-    if ((int)blockIdx.x < n_emit_blocks)
-        role_emit(d, p ^ 1, 1, 1, 0, blockIdx.x, n_emit_blocks, (EmitShared *)dyn_lds);
-    else
-        role_learn<EPL, 256>(d, p, blockIdx.x - n_emit_blocks, gridDim.x - n_emit_blocks, (LearnShared<EPL, 256> *)dyn_lds);
-}
-
-// The SP's closing work for the coming step comes first in the grid, in few blocks that start at
-// once (n_close = one per 256 columns): the duty cycle and per-column clears of their columns, then
-// winner rows j, j + n_close, ... two at a time.  Behind scan blocks they would only start when the
-// first scan blocks retire (every CU slot is taken) and lengthen the launch by their own duration.
-template <bool use_lds>
-__global__ __launch_bounds__(256, 6) void k_scan_close(Dev d, int p, int n_close, int n_rows, const uint32_t *__restrict__ bank,
-                                                        int n_inputs) {
-    TraceScope ts(d, 3 + 4 * p);
-    const int b = blockIdx.x;
-    if (b >= n_close) {
-        role_scan<256, use_lds>(d, p, b - n_close, gridDim.x - n_close, (uint32_t *)dyn_lds);
+    int b = blockIdx.x;
+    if (b <= n_cls) {
+        role_mid(d, p, n_active, 1, learning, b, n_cls);
         return;
     }
-    const int q = p ^ 1;                           // the coming step; its input is bank row (step[p] + 1) % n_inputs
-    const int c = b * 256 + (int)threadIdx.x;
-    if (c < d.C) {
-        float dc = d.duty[c] * d.mom;              // regularizations.py:19-21, float32, two roundings
+    b -= 1 + n_cls;
+    const int q = p ^ 1, n_row_blocks = (n_rows + 1) / 2;
+    if (b < n_row_blocks) {
+        const int ri = b * 2 + (int)(threadIdx.x >> 9);
+        if (ri < n_rows) role_sp_row<512>(d, q, bank, n_inputs, 1, ri, threadIdx.x & 511);
+        return;
+    }
+    b -= n_row_blocks;
+    const int c = b * 1024 + (int)threadIdx.x;
+    if (b < n_duty_blocks && c < d.C) {
+        float dc = d.duty[c] * d.mom;
         if ((d.colbits[q][c >> 5] >> (c & 31)) & 1u) dc = dc + d.dinc;
         d.duty[c] = dc;
-        d.act[q][c] = 0;                           // what EMIT_CLEAR would have zeroed
+    }
+}
+
+template <int EPL>
+__global__ __launch_bounds__(RB) void k_learn_overlap(Dev d, int p, int n_learn_blocks, const uint32_t *__restrict__ bank,
+                                                        int n_inputs, int G, int sp, int step_offset) {
+    TraceScope ts(d, 2 + 4 * p);
+    if ((int)blockIdx.x < n_learn_blocks)
+        role_learn<EPL, RB>(d, p, blockIdx.x, n_learn_blocks, (LearnShared<EPL, RB> *)dyn_lds);
+    else
+        role_overlap<RB>(d, bank, n_inputs, G, p, sp, step_offset, blockIdx.x - n_learn_blocks, gridDim.x - n_learn_blocks, (uint32_t *)dyn_lds);
+}
+
+// blocks [0, n_scan): the scan; then n_sel blocks of select digit 1 for the SP step with parity sp;
+// the rest zero the dense per-column words of the coming step (what EMIT_CLEAR does when the winner
+// list is emitted in a launch of its own: here the learning role still needed them after the emit)
+template <bool use_lds>
+__global__ __launch_bounds__(256, 6) void k_scan_sel(Dev d, int p, int n_scan_blocks, int n_sel_blocks, int sp) {
+    TraceScope ts(d, 3 + 4 * p);
+    int b = blockIdx.x;
+    if (b < n_scan_blocks) {
+        role_scan<256, use_lds>(d, p, b, n_scan_blocks, (uint32_t *)dyn_lds);
+        return;
+    }
+    b -= n_scan_blocks;
+    if (b < n_sel_blocks) {
+        role_sel_pass<256>(d, 1, sp, b, n_sel_blocks, (SelShared *)dyn_lds);
+        return;
+    }
+    b -= n_sel_blocks;
+    const int c = b * 256 + (int)threadIdx.x, q = p ^ 1;
+    if (c < d.C) {
+        d.act[q][c] = 0;
         d.win[q][c] = 0;
         d.pred[q][c] = 0;
-    }
-    constexpr int R = 3;                           // winner rows in flight per block
-    const uint32_t *in = bank + (size_t)((d.ctr->step[p] + 1u) % (uint32_t)n_inputs) * d.W;
-    const int *cols = d.active_cols[q];
-    int cur[R];
-#pragma unroll
-    for (int j = 0; j < R; ++j) cur[j] = b + j * n_close < n_rows ? cols[b + j * n_close] : -1;
-    for (int ri = b; ri < n_rows; ri += R * n_close) {
-        int nxt[R];                                // the next round's rows are fetched beside this round's
-#pragma unroll
-        for (int j = 0; j < R; ++j) nxt[j] = ri + (R + j) * n_close < n_rows ? cols[ri + (R + j) * n_close] : -1;
-        role_sp_rows<256, R>(d, in, cur, threadIdx.x);
-#pragma unroll
-        for (int j = 0; j < R; ++j) cur[j] = nxt[j];
     }
 }
 
@@ -1822,7 +1778,7 @@ static void launch_scan(htm_handle *h, int p, int use_lds) {
 // and the remaining select digits.
 static void enqueue_sp_front(htm_handle *h, const uint32_t *bank, int n_inputs, int p) {
     Dev &d = h->d;
-    LAUNCH(h, "sp_overlap", k_sp_overlap, h->sp_blocks, RB, d, bank, n_inputs, h->G, p);
+    LAUNCH(h, "sp_overlap", k_sp_overlap, h->sp_blocks, RB, d, bank, n_inputs, h->G, p, p, 0);
     for (int pass = 1; pass < d.sel_passes; ++pass) LAUNCH(h, "sp_select", k_sel_pass, h->sel_blocks, RB, d, pass, p);
 }
 
@@ -1852,31 +1808,15 @@ static void enqueue_tm(htm_handle *h, int n_active, int learning, int want_winne
     launch_scan(h, p, scan_lds(d, 1) <= 64 * 1024);
 }
 
-// the four launches of a pipelined step: step p's Temporal Memory beside the next step's Spatial Pooler
-static void enqueue_pipelined(htm_handle *h, int p, int learning, const uint32_t *bank, int n_inputs) {
-    Dev &d = h->d;
-    const int n_cls = learning ? kClassifyBlocks : 0;
-    const int n_act = (d.k * 32 + RB - 1) / RB;
-    LAUNCH_ON(h, h->stream, (size_t)SEL_BINS * 4, "tm_activate+sp_overlap", k_open_overlap, n_act + h->sp_blocks, RB, d, p, d.k, n_act,
-              bank, n_inputs, h->G);
-    LAUNCH_ON(h, h->stream, sizeof(SelShared), "tm_mid+sp_select", k_mid_sel, 1 + n_cls + 64, 1024, d, p, d.k, learning, n_cls);
-    {
-        const int epl = learn_epl(d);
-        const size_t lds = std::max(learn_lds(epl, 256), sizeof(EmitShared));
-        const int grid = h->c256_blocks + 2 * kLearnBlocks;
-        switch (epl) {
-            case 1: LAUNCH_ON(h, h->stream, lds, "tm_learn+sp_emit", k_learn_emit<1>, grid, 256, d, p, h->c256_blocks); break;
-            case 2: LAUNCH_ON(h, h->stream, lds, "tm_learn+sp_emit", k_learn_emit<2>, grid, 256, d, p, h->c256_blocks); break;
-            case 4: LAUNCH_ON(h, h->stream, lds, "tm_learn+sp_emit", k_learn_emit<4>, grid, 256, d, p, h->c256_blocks); break;
-            default: LAUNCH_ON(h, h->stream, lds, "tm_learn+sp_emit", k_learn_emit<8>, grid, 256, d, p, h->c256_blocks); break;
-        }
-    }
-    const int use_lds = scan_lds(d, 1) <= 64 * 1024;
-    const int n_rows = learning ? d.k : 0;
-    const int grid = h->c256_blocks + h->scan_blocks;
-    if (use_lds) LAUNCH_ON(h, h->stream, scan_lds(d, 1), "tm_scan+sp_learn", k_scan_close<true>, grid, 256, d, p, h->c256_blocks, n_rows, bank, n_inputs);
-    else LAUNCH_ON(h, h->stream, scan_lds(d, 0), "tm_scan+sp_learn", k_scan_close<false>, grid, 256, d, p, h->c256_blocks, n_rows, bank, n_inputs);
-}
+// How a step is launched inside htm_run.
+//   sp_done   the Spatial Pooler has already done this step (winner list, permanence rows, duty cycle)
+//   next_sp   finish the SP's next step beside this step's TM (winner list, rows, duty cycle; its
+//             overlap and select digits were computed one step earlier, or by the cold start)
+//   next_front  compute overlap + select digits of the step after the next
+// The look-ahead includes the SP's persistent updates, so it only ever happens between steps of one
+// htm_run call (same bank, same learning flag): the last step of a run has neither, the one before it
+// no next_front, and no call returns with SP work outstanding.
+struct StepPlan { bool sp_done, next_sp, next_front; };
 
 // the pipelined schedule needs the select finished inside one co-resident emit grid after two
 // launched digits
@@ -1884,44 +1824,65 @@ static bool can_pipeline(const htm_handle *h) {
     return h->cfg.enable_sp && h->cfg.enable_tm && h->world == 1 && h->c256_blocks <= 1024 && h->d.sel_passes == 2;
 }
 
-// How a step is launched.  `ahead_in`: the Spatial Pooler has already done this step (winner list,
-// permanence and duty cycle updates) during the previous one; `ahead_out`: do the same for the next.
-// The SP's look-ahead includes its persistent updates, so it only ever happens between two steps of
-// one htm_run call (same bank, same learning flag); no call returns with a look-ahead outstanding.
-struct StepPlan { bool ahead_in, ahead_out; };
+// the four launches of a pipelined step (see the kernels): step p's Temporal Memory beside SP work of
+// the following steps
+static void enqueue_pipelined(htm_handle *h, int p, int learning, const uint32_t *bank, int n_inputs, StepPlan plan) {
+    Dev &d = h->d;
+    const int n_cls = learning ? kClassifyBlocks : 0;
+    const int n_emit = plan.next_sp ? h->c256_blocks : 0;
+    LAUNCH_ON(h, h->stream, sizeof(EmitShared), "tm_activate+sp_emit", k_open_emit, n_emit + (d.k * 32 + 255) / 256, 256, d, p, n_emit, d.k);
+    const int n_rows = (plan.next_sp && learning) ? d.k : 0, n_duty = plan.next_sp ? (d.C + 1023) / 1024 : 0;
+    LAUNCH(h, "tm_mid+sp_learn", k_mid_rows, 1 + n_cls + (n_rows + 1) / 2 + n_duty, 1024, d, p, d.k, learning, n_cls, bank, n_inputs, n_rows,
+           n_duty);
+    {
+        const int epl = learn_epl(d);
+        const size_t lds = std::max(learn_lds(epl), (size_t)SEL_BINS * 4);
+        const int grid = kLearnBlocks + (plan.next_front ? h->sp_blocks : 0);
+        switch (epl) {       // the front is that of step + 2: same parity as this step
+            case 1: LAUNCH_ON(h, h->stream, lds, "tm_learn+sp_overlap", k_learn_overlap<1>, grid, RB, d, p, kLearnBlocks, bank, n_inputs, h->G, p, 2); break;
+            case 2: LAUNCH_ON(h, h->stream, lds, "tm_learn+sp_overlap", k_learn_overlap<2>, grid, RB, d, p, kLearnBlocks, bank, n_inputs, h->G, p, 2); break;
+            case 4: LAUNCH_ON(h, h->stream, lds, "tm_learn+sp_overlap", k_learn_overlap<4>, grid, RB, d, p, kLearnBlocks, bank, n_inputs, h->G, p, 2); break;
+            default: LAUNCH_ON(h, h->stream, lds, "tm_learn+sp_overlap", k_learn_overlap<8>, grid, RB, d, p, kLearnBlocks, bank, n_inputs, h->G, p, 2); break;
+        }
+    }
+    const int use_lds = scan_lds(d, 1) <= 64 * 1024;
+    const int n_sel = plan.next_front ? 64 : 0, n_clear = plan.next_sp ? h->c256_blocks : 0;
+    const size_t lds = std::max(scan_lds(d, use_lds), sizeof(SelShared));
+    const int grid = h->scan_blocks + n_sel + n_clear;
+    if (use_lds) LAUNCH_ON(h, h->stream, lds, "tm_scan+sp_select", k_scan_sel<true>, grid, 256, d, p, h->scan_blocks, n_sel, p);
+    else LAUNCH_ON(h, h->stream, lds, "tm_scan+sp_select", k_scan_sel<false>, grid, 256, d, p, h->scan_blocks, n_sel, p);
+}
 
-// work of a step that is not captured in its graph: a pipelined step without look-ahead from the
-// previous one first runs the Spatial Pooler on its own
-static void enqueue_cold_front(htm_handle *h, const uint32_t *bank, int n_inputs, int learning, StepPlan plan) {
+// work of a step that is not captured in its graph: the first step of a pipelined run has no SP work
+// done for it; run the SP's step on its own, and the front of the next one
+static void enqueue_cold_start(htm_handle *h, const uint32_t *bank, int n_inputs, int learning, StepPlan plan) {
+    Dev &d = h->d;
     const int p = (int)(h->step_host & 1);
-    if (plan.ahead_in) return;
+    if (plan.sp_done || !plan.next_sp) return;
     enqueue_sp_front(h, bank, n_inputs, p);
-    if (plan.ahead_out) enqueue_sp_back(h, bank, n_inputs, p, 1, EMIT_DUTY | EMIT_CLEAR, learning != 0);
+    enqueue_sp_back(h, bank, n_inputs, p, 1, EMIT_DUTY | EMIT_CLEAR, learning != 0);
+    LAUNCH(h, "sp_overlap", k_sp_overlap, h->sp_blocks, RB, d, bank, n_inputs, h->G, p, p ^ 1, 1);
+    LAUNCH(h, "sp_select", k_sel_pass, h->sel_blocks, RB, d, 1, p ^ 1);
 }
 
 static void enqueue_rest(htm_handle *h, int p, const uint32_t *bank, int n_inputs, int learning, StepPlan plan) {
-    Dev &d = h->d;
-    if (plan.ahead_out) {
-        enqueue_pipelined(h, p, learning, bank, n_inputs);
-    } else if (plan.ahead_in) {                     // last step of a pipelined run: the TM alone, one role per launch
-        LAUNCH(h, "tm_activate", k_tm_activate, (d.k * 32 + 255) / 256, 256, d, p, d.k, 1);
-        enqueue_tm(h, d.k, learning, 1, p, bank, n_inputs, false);
+    if (plan.sp_done || plan.next_sp) {
+        enqueue_pipelined(h, p, learning, bank, n_inputs, plan);
     } else {                                        // one role per launch
         enqueue_sp_back(h, bank, n_inputs, p, 1, EMIT_ALL, false);
-        enqueue_tm(h, d.k, learning, 1, p, bank, n_inputs, true);
+        enqueue_tm(h, h->d.k, learning, 1, p, bank, n_inputs, true);
     }
 }
 
 static int enqueue_step(htm_handle *h, const uint32_t *bank, int n_inputs, int learning, StepPlan plan) {
-    enqueue_cold_front(h, bank, n_inputs, learning, plan);
+    if (!plan.sp_done && !plan.next_sp) enqueue_sp_front(h, bank, n_inputs, (int)(h->step_host & 1));
+    enqueue_cold_start(h, bank, n_inputs, learning, plan);
     enqueue_rest(h, (int)(h->step_host & 1), bank, n_inputs, learning, plan);
     h->step_host += 1;
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { h->err = std::string("kernel launch: ") + hipGetErrorString(e); return HTM_ERR_HIP; }
     return 0;
 }
-
-extern "C" int htm_debug_trace(htm_handle *h, unsigned long long *dst) { hipStreamSynchronize(h->stream); return h->d.trace ? (int)hipMemcpy(dst, h->d.trace, 8 * (1024 + 8 * 4096 * 2), hipMemcpyDeviceToHost) : -1; }
 
 extern "C" int htm_abi_version(void) { return BITHTM_ABI_VERSION; }
 
@@ -2085,7 +2046,7 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
     const int rows_per_block = (RB / 64) * 4 * (64 / h->G);   // waves x 4 row groups in flight
     h->sp_blocks = std::max(1, std::min((d.c1 - d.c0 + rows_per_block - 1) / rows_per_block, 256));
     d.trace = nullptr;
-    if (getenv("BITHTM_TRACE")) rc |= dalloc(h, &d.trace, 1024 + 8 * 4096 * 2);
+    if (getenv("BITHTM_TRACE")) rc |= dalloc(h, &d.trace, (size_t)8 * 4096 * 2);
     h->sel_blocks = std::max(1, std::min((d.C + RB - 1) / RB, 128));
     h->c256_blocks = (d.C + 255) / 256;
     h->s1024_blocks = std::max(1, (d.Scap + 1023) / 1024);
@@ -2173,7 +2134,7 @@ extern "C" int htm_step(htm_handle *h, const uint32_t *packed_input, int32_t lea
     HIPCHK(h, hipSetDevice(h->device));
     int rc = stage_input(h, packed_input);
     if (rc) return rc;
-    return enqueue_step(h, h->d.input_stage, 1, learning ? 1 : 0, StepPlan{false, false});
+    return enqueue_step(h, h->d.input_stage, 1, learning ? 1 : 0, StepPlan{false, false, false});
 }
 
 extern "C" int htm_sp_step(htm_handle *h, const uint32_t *packed_input, int32_t learning) {
@@ -2219,14 +2180,14 @@ extern "C" int htm_run(htm_handle *h, const uint32_t *device_inputs, int32_t n_i
     const bool graph = (use_graph & 1) && !h->profile;
     const bool pipeline = !(use_graph & 2) && can_pipeline(h);
     // Graphs hold the launches of one step, or of kGraphSteps consecutive steady-state steps (a graph
-    // launch boundary costs about 5 us more than a kernel boundary inside a graph: tools/launch_anatomy.hip
-    // and the device-clock trace in DESIGN.md).  Nothing in a graph depends on the step index: kernels
-    // read it, and with it the bank row, from the device counter.
+    // launch boundary costs about 5 us more than a kernel boundary inside a graph: tools/step_timeline.py).
+    // Nothing in a graph depends on the step index: kernels read it, and with it the bank row, from
+    // the device counter.
     const int kGraphSteps = 16;
-    bool ahead = false;                             // the SP has already done the coming step
+    bool sp_done = false;                           // the SP has already done the coming step
     for (int t = 0; t < n_steps;) {
-        const StepPlan plan{ahead, pipeline && t + 1 < n_steps};
-        ahead = plan.ahead_out;
+        const StepPlan plan{sp_done, pipeline && t + 1 < n_steps, pipeline && t + 2 < n_steps};
+        sp_done = plan.next_sp;
         if (!graph) {
             int rc = enqueue_step(h, device_inputs, n_inputs, learning, plan);
             if (rc) return rc;
@@ -2234,10 +2195,11 @@ extern "C" int htm_run(htm_handle *h, const uint32_t *device_inputs, int32_t n_i
             continue;
         }
         const int p = (int)(h->step_host & 1);
-        // steady state: this and the next kGraphSteps - 1 steps all have a look-ahead in and out
-        const int span = (plan.ahead_in && plan.ahead_out && t + kGraphSteps < n_steps) ? kGraphSteps : 1;
-        enqueue_cold_front(h, device_inputs, n_inputs, learning, plan);      // eager: first step of a pipelined run only
-        auto key = std::make_tuple(p, learning * 8 + (span > 1 ? 4 : 0) + (plan.ahead_in ? 2 : 0) + (plan.ahead_out ? 1 : 0),
+        // steady state: this and the next kGraphSteps - 1 steps all look ahead fully
+        const int span = (plan.sp_done && plan.next_front && t + kGraphSteps + 1 < n_steps) ? kGraphSteps : 1;
+        if (!plan.sp_done && !plan.next_sp) enqueue_sp_front(h, device_inputs, n_inputs, p);    // eager
+        enqueue_cold_start(h, device_inputs, n_inputs, learning, plan);                         // eager: first step of a pipelined run
+        auto key = std::make_tuple(p, learning * 16 + (span > 1 ? 8 : 0) + (plan.sp_done ? 4 : 0) + (plan.next_sp ? 2 : 0) + (plan.next_front ? 1 : 0),
                                    (const void *)device_inputs, n_inputs);
         auto it = h->graphs.find(key);
         if (it == h->graphs.end()) {
@@ -2282,7 +2244,7 @@ extern "C" int htm_shard_begin(htm_handle *h, const uint32_t *device_inputs, int
     Dev &d = h->d;
     const int p = (int)(h->step_host & 1);
     const int cl = d.c1 - d.c0;
-    LAUNCH(h, "sp_overlap", k_sp_overlap, h->sp_blocks, RB, d, h->shard_bank, h->shard_n_inputs, h->G, p);
+    LAUNCH(h, "sp_overlap", k_sp_overlap, h->sp_blocks, RB, d, h->shard_bank, h->shard_n_inputs, h->G, p, p, 0);
     LAUNCH(h, "shard_pack_clear", k_shard_pack_clear, 1, 256, d, (unsigned char *)send_device);
     LAUNCH(h, "shard_pack", k_shard_pack, (cl * 32 + 255) / 256, 256, d, p, (unsigned char *)send_device);
     h->shard_open = true;
@@ -2580,6 +2542,17 @@ extern "C" int htm_profile(htm_handle *h, int32_t enable) {
     if (!h) return HTM_ERR_ARGUMENT;
     h->profile = enable != 0;
     return HTM_OK;
+}
+
+extern "C" int64_t htm_trace_read(htm_handle *h, uint64_t *dst, int64_t count) {
+    if (!h || !dst) return HTM_ERR_ARGUMENT;
+    if (!h->d.trace) { h->err = "htm_trace_read: handle was not created with BITHTM_TRACE=1"; return HTM_ERR_STATE; }
+    const int64_t n = (int64_t)8 * 4096 * 2;
+    if (count < n) { h->err = "htm_trace_read: buffer too small"; return HTM_ERR_ARGUMENT; }
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(dst, h->d.trace, (size_t)n * 8, hipMemcpyDeviceToHost));
+    return n;
 }
 
 extern "C" int htm_profile_read(htm_handle *h, int32_t max_kernels, const char **names, double *total_ms, int64_t *launches) {

@@ -213,6 +213,13 @@ class Engine:
         n = self._check(self.lib.htm_profile_read(self.h, max_kernels, names, ms, cnt), "htm_profile_read")
         return {names[i].decode(): (ms[i], cnt[i]) for i in range(n)}
 
+    def trace_read(self):
+        """Device-clock timeline of the pipelined launches (handle created under BITHTM_TRACE=1):
+        int64 array [slot = launch + 4 * step parity][block][start, end], 100 MHz ticks, 0 = not run."""
+        buf = np.zeros(8 * 4096 * 2, np.uint64)
+        self._check(self.lib.htm_trace_read(self.h, buf.ctypes.data_as(C.c_void_p), buf.size), "htm_trace_read")
+        return buf.astype(np.int64).reshape(8, 4096, 2)
+
     # ---- State fields (host views of the last completed step)
     def read_sp_fields(self):
         return dict(

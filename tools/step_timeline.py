@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""Device-clock timeline of the pipelined schedule at the bench workload (configs[2]).
+
+Every block of the four pipelined launches stamps the 100 MHz device wall clock when it starts and
+when it ends (BITHTM_TRACE=1, include/bithtm_hip.h htm_trace_read).  This prints, for the last two
+look-ahead steps of a graph-replayed run, each launch's span, the gap to the previous launch and
+the time range of every role inside it -- the numbers DESIGN.md's schedule discussion quotes.
+
+    python tools/step_timeline.py [--steps 35]
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+os.environ["BITHTM_TRACE"] = "1"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+
+LAUNCHES = ("tm_activate+sp_emit", "tm_mid+sp_learn", "tm_learn+sp_overlap", "tm_scan+sp_select")
+
+
+def roles(launch, k, C):
+    """(first block, last block + 1, name) of the roles of each launch, as bench's handle lays them out."""
+    c256, cls = (C + 255) // 256, 96
+    if launch == 0:
+        return ((0, c256, "sp_emit"), (c256, 4096, "tm_activate"))
+    if launch == 1:
+        rows = (k + 1) // 2
+        return ((0, 1, "tm_mid block 0"), (1, 1 + cls, "tm_mid classify"), (1 + cls, 1 + cls + rows, "sp rows"), (1 + cls + rows, 4096, "sp duty"))
+    if launch == 2:
+        return ((0, 256, "tm_learn"), (256, 4096, "sp_overlap"))
+    return ((0, 2048, "tm_scan"), (2048, 2048 + 64, "sp_select"), (2048 + 64, 4096, "clear"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=35, help="length of the traced run (17 more than a multiple of 16 keeps the traced steps inside a 16-step graph)")
+    ap.add_argument("--warmup", type=int, default=1500)
+    args = ap.parse_args()
+    w = dict(bench.WORKLOAD)
+    noisy, perm = bench.make_inputs(w)
+    htm = bench.build_htm(w, perm, 0)
+    eng = htm.engine
+    bank = eng.upload_bank(noisy)
+    eng.run(bank, noisy.shape[0], args.warmup, learning=True)
+    eng.run(bank, noisy.shape[0], args.steps, learning=True, use_graph=True, pipeline=True)
+    eng.sync()
+    t = eng.trace_read()
+    k, C = htm.active_columns, w["column_dim"]
+    # A launch only overwrites the stamps of the blocks it runs, and the last two steps of a run leave
+    # the look-ahead roles out: per slot keep the most recent launch in which every role ran.
+    events = []
+    for slot in range(8):
+        ran = np.nonzero(t[slot][:, 0] > 0)[0]
+        if not len(ran):
+            continue
+        order = ran[np.argsort(t[slot][ran, 0])]
+        starts = t[slot][order, 0]
+        cuts = np.nonzero(np.diff(starts) > 2000)[0] + 1           # 20 us without a block start: another step
+        groups = np.split(order, cuts)
+        full = max(len(g) for g in groups)
+        blocks = [g for g in groups if len(g) == full][-1]
+        events.append((t[slot][blocks, 0].min(), t[slot][blocks, 1].max(), slot, np.sort(blocks)))
+    events.sort(key=lambda e: e[0])
+    t0, prev = events[0][0], None
+    for first, last, slot, blocks in events:
+        gap = "" if prev is None or first - prev > 3000 else f"  gap {(first - prev) / 100:5.2f}"
+        print(f"parity {slot // 4} {LAUNCHES[slot % 4]:20s} {(first - t0) / 100:7.2f} .. {(last - t0) / 100:7.2f} us  span {(last - first) / 100:6.2f}{gap}")
+        prev = last
+        for lo, hi, name in roles(slot % 4, k, C):
+            sel = blocks[(blocks >= lo) & (blocks < hi)]
+            if len(sel):
+                st, en = t[slot][sel, 0] - first, t[slot][sel, 1] - first
+                dur = (en - st) / 100
+                slow = sel[np.argsort(dur)[-3:]] - lo
+                print(f"      {name:16s} {len(sel):5d} blocks  start {st.min() / 100:5.2f}..{st.max() / 100:5.2f}  end {en.min() / 100:5.2f}..{en.max() / 100:5.2f}"
+                      f"  block time median {np.median(dur):5.2f} max {dur.max():5.2f} (slowest: {slow.tolist()})")
+                if name == "tm_scan":
+                    q = [np.median(dur[i::8]) for i in range(0)]
+                    dec = [float(np.max(dur[i * len(sel) // 8:(i + 1) * len(sel) // 8])) for i in range(8)]
+                    print("        max block time by eighth of the grid: " + " ".join(f"{x:5.2f}" for x in dec))
+
+
+if __name__ == "__main__":
+    main()
