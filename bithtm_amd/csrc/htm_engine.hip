@@ -600,7 +600,7 @@ __global__ __launch_bounds__(1024) void k_shard_unpack(Dev d, const unsigned cha
 #define CAND_D 8              // distinct bucket keys one block can publish
 #define CAND_RAW 64           // ... and collect from its waves before merging duplicates
 #define CAND_MAX 2048         // bucket entries a block can merge
-#define CAND_PAIRWISE 128      // ... by comparing all pairs; above that, by radix refinement in LDS
+#define CAND_PAIRWISE 160      // ... by comparing all pairs; above that, by radix refinement in LDS
 
 // pick the bucket that contains the krem-th largest key of a histogram held in LDS
 // (bins [0, nb)); all BS threads call; returns bucket and the keys above it
@@ -728,60 +728,69 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
         __syncthreads();
         if (tid < nraw && first != tid) atomicAdd(&s_bc[first], my_cnt);
         __syncthreads();
-        // record = 16 self-validating 64-bit granules (form R2: every granule carries the epoch, one
+        // record = up to 8 self-validating 64-bit granules (form R2: every granule carries the epoch, one
         // aligned 8-byte write-through store each, so no separate tag and no drain):
-        //   [0]      epoch:12 | overflow:1 | pairs:8 | keys above the bucket:16
-        //   [1 + j]  epoch:12 | multiplicity:12 | low 40 key bits   (the high bits are the bucket's)
+        //   [0]      epoch:12 | overflow:1 | pairs:4 | keys above the bucket:9 | multiplicity:9 | key bits:29
+        //   [j >= 1] epoch:12 | multiplicity:12 | low 40 key bits   (the high bits are the bucket's)
+        // The first pair rides in the head granule -- the low_zero bottom bits of every key are zero, so
+        // 29 bits hold the rest for input_dim up to 2^17 -- and a block with at most one bucket key, the
+        // usual case and the one of a many-way tie, is read with a single load.
         u64 *rec = (u64 *)(d.sel_rec + (size_t)b * 32);
         const u64 etag = (u64)epoch << 52;
         const u64 lowmask = (1ull << lowbits) - 1ull;
+        const bool inline_ok = lowbits - d.low_zero <= 29;
         if (tid < 64) {                              // wave 0 compacts the survivors into the record
             const bool alive = tid < nraw && first == tid;
             const u64 ma = __ballot(alive);
             const int n_pairs = __popcll(ma), pos = __popcll(ma & lanemask_lt());
-            const bool overflow = s_nraw > CAND_RAW || n_pairs > d.cand_d;
-            if (alive && pos < CAND_D)
-                __hip_atomic_store(rec + 1 + pos, etag | ((u64)s_bc[tid] << 40) | (s_bk[tid] & lowmask),
+            const bool overflow = s_nraw > CAND_RAW || n_pairs > d.cand_d || (n_pairs > 0 && !inline_ok);
+            const u64 mine = alive ? (s_bk[tid] & lowmask) : 0ull;
+            const uint32_t cnt = alive ? s_bc[tid] : 0u;
+            if (alive && pos >= 1 && pos < CAND_D)
+                __hip_atomic_store(rec + pos, etag | ((u64)cnt << 40) | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int l0 = ma ? __ffsll((long long)ma) - 1 : 0;      // the lane of pair 0
+            const u64 k0 = ((u64)__shfl((uint32_t)(mine >> 32), l0) << 32) | __shfl((uint32_t)mine, l0);
+            const uint32_t c0 = __shfl(cnt, l0);
+            if (tid == 0) {
+                const u64 pair0 = (ma && inline_ok) ? (((u64)(c0 & 0x1FFu) << 29) | (k0 >> d.low_zero)) : 0ull;
+                __hip_atomic_store(rec, etag | (overflow ? (1ull << 51) : 0ull) | ((u64)min(n_pairs, CAND_D) << 47) | ((u64)my_gt_hi << 38) | pair0,
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (tid == 0)
-                __hip_atomic_store(rec, etag | (overflow ? (1ull << 24) : 0ull) | ((u64)min(n_pairs, CAND_D) << 16) | my_gt_hi,
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
         if (tid == 0) s_gt = 0;
-        // ---- everybody's records: head and all pair granules fetched in one batch per poll
+        // ---- everybody's records: the head granule is polled alone (one lane-load per spin keeps the
+        // polling traffic low); further pairs, if any, are fetched in one batch; each granule validates itself
         uint32_t gthi_before = 0;
         for (int rb = tid; rb < nblk; rb += 256) {
             const u64 *rr = (const u64 *)(d.sel_rec + (size_t)rb * 32);
-            u64 g[1 + CAND_D];
-            int np = 0;
-            // poll the head granule alone (one lane-load per spin keeps the polling traffic low), then
-            // fetch the pair granules in one batch; each granule validates itself
+            u64 g[CAND_D];
             for (int spins = 0;; ++spins) {
                 g[0] = __hip_atomic_load(rr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if ((g[0] >> 52) == epoch) break;
                 if (spins >= (1 << 20)) { atomicOr(&d.ctr->error, 16); g[0] = 0; break; }      // a block never arrived
                 __builtin_amdgcn_s_sleep(2);
             }
-            np = (g[0] >> 52) == epoch ? (int)((g[0] >> 16) & 0xFFu) : 0;
-            for (int spins = 0; np > 0; ++spins) {
+            int np = (g[0] >> 52) == epoch ? (int)((g[0] >> 47) & 0xFu) : 0;
+            for (int spins = 0; np > 1; ++spins) {
 #pragma unroll
-                for (int j = 0; j < CAND_D; ++j) g[1 + j] = __hip_atomic_load(rr + 1 + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int j = 1; j < CAND_D; ++j) g[j] = __hip_atomic_load(rr + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 bool ok = true;
 #pragma unroll
-                for (int j = 0; j < CAND_D; ++j) ok = ok && (j >= np || (g[1 + j] >> 52) == epoch);
+                for (int j = 1; j < CAND_D; ++j) ok = ok && (j >= np || (g[j] >> 52) == epoch);
                 if (ok) break;
                 if (spins >= (1 << 20)) { atomicOr(&d.ctr->error, 16); np = 0; break; }
                 __builtin_amdgcn_s_sleep(2);
             }
-            if (rb < b) gthi_before += (uint32_t)(g[0] & 0xFFFFu);
-            if ((g[0] >> 24) & 1ull) atomicOr(&s_flags, 1u);
+            if (rb < b) gthi_before += (uint32_t)((g[0] >> 38) & 0x1FFu);
+            if ((g[0] >> 51) & 1ull) atomicOr(&s_flags, 1u);
 #pragma unroll
             for (int j = 0; j < CAND_D; ++j)
                 if (j < np) {
                     const int slot = atomicAdd(&s_ne, 1);
                     if (slot < CAND_MAX) {
-                        s_ek[slot] = (hiP << lowbits) | (g[1 + j] & lowmask);
-                        s_ec[slot] = (uint16_t)((g[1 + j] >> 40) & 0xFFFu);
+                        const u64 low = j == 0 ? (g[0] & 0x1FFFFFFFull) << d.low_zero : g[j] & lowmask;
+                        s_ek[slot] = (hiP << lowbits) | low;
+                        s_ec[slot] = (uint16_t)(j == 0 ? (g[0] >> 29) & 0x1FFu : (g[j] >> 40) & 0xFFFu);
                         s_eb[slot] = (uint16_t)rb;
                     }
                 }
@@ -1594,7 +1603,7 @@ __global__ __launch_bounds__(1024) void k_mid_rows(Dev d, int p, int n_active, i
     }
     b -= 1 + n_cls;
     const int q = p ^ 1, n_row_blocks = (n_rows + 1) / 2;
-    if (b < n_row_blocks) {
+    if (b < n_row_blocks) {                        // (four rows per block were measured slower)
         const int ri = b * 2 + (int)(threadIdx.x >> 9);
         if (ri < n_rows) role_sp_row<512>(d, q, bank, n_inputs, 1, ri, threadIdx.x & 511);
         return;
