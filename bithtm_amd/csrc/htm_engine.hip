@@ -1627,29 +1627,30 @@ __global__ __launch_bounds__(RB) void k_learn_overlap(Dev d, int p, int n_learn_
         role_overlap<RB>(d, bank, n_inputs, G, p, sp, step_offset, blockIdx.x - n_learn_blocks, gridDim.x - n_learn_blocks, (uint32_t *)dyn_lds);
 }
 
-// blocks [0, n_scan): the scan; then n_sel blocks of select digit 1 for the SP step with parity sp;
-// the rest zero the dense per-column words of the coming step (what EMIT_CLEAR does when the winner
-// list is emitted in a launch of its own: here the learning role still needed them after the emit)
+// blocks [0, n_sel): select digit 1 for the SP step with parity sp; then n_clear blocks that zero the
+// dense per-column words of the coming step (what EMIT_CLEAR does when the winner list is emitted in a
+// launch of its own: here the learning role still needed them after the emit); the rest: the scan.
+// The few short SP blocks come first: behind the scan blocks they would wait for a free CU slot.
 template <bool use_lds>
-__global__ __launch_bounds__(256, 6) void k_scan_sel(Dev d, int p, int n_scan_blocks, int n_sel_blocks, int sp) {
+__global__ __launch_bounds__(256, 6) void k_scan_sel(Dev d, int p, int n_sel_blocks, int n_clear_blocks, int sp) {
     TraceScope ts(d, 3 + 4 * p);
     int b = blockIdx.x;
-    if (b < n_scan_blocks) {
-        role_scan<256, use_lds>(d, p, b, n_scan_blocks, (uint32_t *)dyn_lds);
-        return;
-    }
-    b -= n_scan_blocks;
     if (b < n_sel_blocks) {
         role_sel_pass<256>(d, 1, sp, b, n_sel_blocks, (SelShared *)dyn_lds);
         return;
     }
     b -= n_sel_blocks;
-    const int c = b * 256 + (int)threadIdx.x, q = p ^ 1;
-    if (c < d.C) {
-        d.act[q][c] = 0;
-        d.win[q][c] = 0;
-        d.pred[q][c] = 0;
+    if (b < n_clear_blocks) {
+        const int c = b * 256 + (int)threadIdx.x, q = p ^ 1;
+        if (c < d.C) {
+            d.act[q][c] = 0;
+            d.win[q][c] = 0;
+            d.pred[q][c] = 0;
+        }
+        return;
     }
+    b -= n_clear_blocks;
+    role_scan<256, use_lds>(d, p, b, gridDim.x - n_sel_blocks - n_clear_blocks, (uint32_t *)dyn_lds);
 }
 
 // recount recyclable segments after a state import
@@ -1858,8 +1859,8 @@ static void enqueue_pipelined(htm_handle *h, int p, int learning, const uint32_t
     const int n_sel = plan.next_front ? 64 : 0, n_clear = plan.next_sp ? h->c256_blocks : 0;
     const size_t lds = std::max(scan_lds(d, use_lds), sizeof(SelShared));
     const int grid = h->scan_blocks + n_sel + n_clear;
-    if (use_lds) LAUNCH_ON(h, h->stream, lds, "tm_scan+sp_select", k_scan_sel<true>, grid, 256, d, p, h->scan_blocks, n_sel, p);
-    else LAUNCH_ON(h, h->stream, lds, "tm_scan+sp_select", k_scan_sel<false>, grid, 256, d, p, h->scan_blocks, n_sel, p);
+    if (use_lds) LAUNCH_ON(h, h->stream, lds, "tm_scan+sp_select", k_scan_sel<true>, grid, 256, d, p, n_sel, n_clear, p);
+    else LAUNCH_ON(h, h->stream, lds, "tm_scan+sp_select", k_scan_sel<false>, grid, 256, d, p, n_sel, n_clear, p);
 }
 
 // work of a step that is not captured in its graph: the first step of a pipelined run has no SP work

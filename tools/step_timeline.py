@@ -31,7 +31,7 @@ def roles(launch, k, C):
         return ((0, 1, "tm_mid block 0"), (1, 1 + cls, "tm_mid classify"), (1 + cls, 1 + cls + rows, "sp rows"), (1 + cls + rows, 4096, "sp duty"))
     if launch == 2:
         return ((0, 256, "tm_learn"), (256, 4096, "sp_overlap"))
-    return ((0, 2048, "tm_scan"), (2048, 2048 + 64, "sp_select"), (2048 + 64, 4096, "clear"))
+    return ((0, 64, "sp_select"), (64, 64 + c256, "clear"), (64 + c256, 4096, "tm_scan"))
 
 
 def main():
