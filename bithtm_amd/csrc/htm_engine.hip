@@ -123,6 +123,7 @@ struct Dev {
     Counters *ctr;
     unsigned long long *trace;    // [8][4096][2] BITHTM_TRACE=1: device clock at the start / end of every block of the
                                   // pipelined launches (slot = launch + 4 * step parity), else null
+    uint32_t trace_until;         // ... of steps with an index below this (BITHTM_TRACE_UNTIL; default: all)
 };
 
 // ------------------------------------------------------------------------------------------
@@ -1274,39 +1275,55 @@ __device__ __forceinline__ void role_learn(const Dev &d, int p, int blk, int nbl
                     u64 est = ((u64)(2 * n_add + 16) << 24) / (u64)max(n_w - n_active, 1);
                     T = (uint32_t)min(est, (u64)(1u << 24));
                 }
+                // Each try stages every winner with priority < T, then drops the ones the segment already
+                // has: one lane per staged winner walks the kept synapses once.  (Testing membership
+                // inside the scan of the winner list made the whole wave walk them in every 64-winner
+                // chunk with a hit: 30 us for a full row.)
                 int found = 0;
                 for (int iter = 0; iter < 64; ++iter) {
-                    found = 0;
+                    int staged = 0;
                     for (int b0 = 0; b0 < n_w; b0 += 64) {
                         const int i = b0 + lane;
-                        bool take = false;
                         uint32_t pr = 0;
+                        bool take = false;
                         if (i < n_w) {
-                            const int cell = winners[i];
-                            pr = htm_draw24(base2, (uint32_t)seg, enc_to_flat(cell, d.K));     // :120
-                            if (pr < T) {
-                                take = true;                                                   // :121-123
-                                for (int qq = 0; qq < n_keep; ++qq)
-                                    if (s_keep[wv][qq] == cell) { take = false; break; }
-                            }
+                            pr = htm_draw24(base2, (uint32_t)seg, enc_to_flat(winners[i], d.K));     // :120
+                            take = pr < T;
                         }
                         const u64 mt = __ballot(take);
                         if (take) {
-                            const int pos = found + __popcll(mt & lanemask_lt());
+                            const int pos = staged + __popcll(mt & lanemask_lt());
                             if (pos < CAND_CAP) s_cand[wv][pos] = ((u64)pr << 32) | (uint32_t)i;
                         }
-                        found += __popcll(mt);
+                        staged += __popcll(mt);
                     }
-                    if (found >= n_add && found <= CAND_CAP) break;
-                    if (found < n_add) {
-                        if (T == (1u << 24)) break;               // fewer absent winners than n_add: take all
-                        lo = T;
-                        T = (hi == (1u << 24)) ? (uint32_t)min((u64)T * 4u + 16u, (u64)hi) : (lo + hi + 1) / 2;
-                    } else {
+                    if (staged > CAND_CAP) {                      // too many for the staging area: lower T
                         hi = T;
-                        if (hi - lo <= 1) { atomicOr(&c->error, 4); break; }
+                        if (hi - lo <= 1) { atomicOr(&c->error, 4); found = 0; break; }
                         T = (lo + hi) / 2;
+                        continue;
                     }
+                    __builtin_amdgcn_wave_barrier();
+                    found = 0;
+                    for (int e0 = 0; e0 < staged; e0 += 64) {     // :121-123, compacting in place (pos <= e)
+                        const int e = e0 + lane;
+                        u64 key = 0;
+                        bool absent = false;
+                        if (e < staged) {
+                            key = s_cand[wv][e];
+                            const int cell = winners[(uint32_t)key];
+                            absent = true;
+                            for (int qq = 0; qq < n_keep; ++qq)
+                                if (s_keep[wv][qq] == cell) { absent = false; break; }
+                        }
+                        const u64 ma = __ballot(absent);
+                        __builtin_amdgcn_wave_barrier();
+                        if (absent) s_cand[wv][found + __popcll(ma & lanemask_lt())] = key;
+                        found += __popcll(ma);
+                    }
+                    if (found >= n_add || T == (1u << 24)) break; // enough, or fewer absent winners than n_add: take all
+                    lo = T;
+                    T = (hi == (1u << 24)) ? (uint32_t)min((u64)T * 4u + 16u, (u64)hi) : (lo + hi + 1) / 2;
                 }
                 __builtin_amdgcn_wave_barrier();
                 const int n_c = min(found, CAND_CAP), take_n = min(n_add, n_c);        // :125-127
@@ -1571,7 +1588,7 @@ __global__ __launch_bounds__(256, 6) void k_tm_scan(Dev d, int p) {
 struct TraceScope {                                 // BITHTM_TRACE=1: first / last device clock of every block
     unsigned long long *t;
     __device__ TraceScope(const Dev &d, int slot) {
-        t = (d.trace && blockIdx.x < 4096) ? d.trace + ((size_t)slot * 4096 + blockIdx.x) * 2 : nullptr;
+        t = (d.trace && blockIdx.x < 4096 && d.ctr->step[slot >> 2] < d.trace_until) ? d.trace + ((size_t)slot * 4096 + blockIdx.x) * 2 : nullptr;
         if (t && threadIdx.x == 0) t[0] = wall_clock64();
     }
     __device__ ~TraceScope() { if (t && threadIdx.x == 0) t[1] = wall_clock64(); }
@@ -2057,6 +2074,7 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
     h->sp_blocks = std::max(1, std::min((d.c1 - d.c0 + rows_per_block - 1) / rows_per_block, 256));
     d.trace = nullptr;
     if (getenv("BITHTM_TRACE")) rc |= dalloc(h, &d.trace, (size_t)8 * 4096 * 2);
+    d.trace_until = getenv("BITHTM_TRACE_UNTIL") ? (uint32_t)strtoul(getenv("BITHTM_TRACE_UNTIL"), nullptr, 10) : 0xFFFFFFFFu;
     h->sel_blocks = std::max(1, std::min((d.C + RB - 1) / RB, 128));
     h->c256_blocks = (d.C + 255) / 256;
     h->s1024_blocks = std::max(1, (d.Scap + 1023) / 1024);

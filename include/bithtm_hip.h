@@ -211,7 +211,9 @@ int htm_profile_read(htm_handle *h, int32_t max_kernels, const char **names, dou
  * variable BITHTM_TRACE=1, otherwise HTM_ERR_STATE).  dst receives 8 x 4096 x 2 values: for slot =
  * launch (0..3) + 4 * step parity and block b, the 100 MHz device wall clock when the block
  * started and when it ended, 0 where that block did not run.  Each launch overwrites its slot,
- * so after a run the buffer holds the last two steps.  Returns the number of values. */
+ * so after a run the buffer holds the last two steps -- of those with an index below BITHTM_TRACE_UNTIL,
+ * if that is set (the last two steps of a run look ahead less than the steady state).  Returns the
+ * number of values. */
 #define HTM_TRACE_VALUES (8 * 4096 * 2)
 int64_t htm_trace_read(htm_handle *h, uint64_t *dst, int64_t count);
 

@@ -6,7 +6,7 @@ when it ends (BITHTM_TRACE=1, include/bithtm_hip.h htm_trace_read).  This prints
 look-ahead steps of a graph-replayed run, each launch's span, the gap to the previous launch and
 the time range of every role inside it -- the numbers DESIGN.md's schedule discussion quotes.
 
-    python tools/step_timeline.py [--steps 35]
+    python tools/step_timeline.py
 """
 import argparse
 import os
@@ -15,6 +15,8 @@ import sys
 import numpy as np
 
 os.environ["BITHTM_TRACE"] = "1"
+WARMUP, STEPS = 1500, 35
+os.environ["BITHTM_TRACE_UNTIL"] = str(WARMUP + STEPS - 2)      # the last two steps look ahead less: keep the steady state
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 
@@ -35,10 +37,7 @@ def roles(launch, k, C):
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--steps", type=int, default=35, help="length of the traced run (17 more than a multiple of 16 keeps the traced steps inside a 16-step graph)")
-    ap.add_argument("--warmup", type=int, default=1500)
-    args = ap.parse_args()
+    args = argparse.Namespace(steps=STEPS, warmup=WARMUP)
     w = dict(bench.WORKLOAD)
     noisy, perm = bench.make_inputs(w)
     htm = bench.build_htm(w, perm, 0)
@@ -49,20 +48,11 @@ def main():
     eng.sync()
     t = eng.trace_read()
     k, C = htm.active_columns, w["column_dim"]
-    # A launch only overwrites the stamps of the blocks it runs, and the last two steps of a run leave
-    # the look-ahead roles out: per slot keep the most recent launch in which every role ran.
     events = []
     for slot in range(8):
-        ran = np.nonzero(t[slot][:, 0] > 0)[0]
-        if not len(ran):
-            continue
-        order = ran[np.argsort(t[slot][ran, 0])]
-        starts = t[slot][order, 0]
-        cuts = np.nonzero(np.diff(starts) > 2000)[0] + 1           # 20 us without a block start: another step
-        groups = np.split(order, cuts)
-        full = max(len(g) for g in groups)
-        blocks = [g for g in groups if len(g) == full][-1]
-        events.append((t[slot][blocks, 0].min(), t[slot][blocks, 1].max(), slot, np.sort(blocks)))
+        blocks = np.nonzero(t[slot][:, 0] > 0)[0]
+        if len(blocks):
+            events.append((t[slot][blocks, 0].min(), t[slot][blocks, 1].max(), slot, blocks))
     events.sort(key=lambda e: e[0])
     t0, prev = events[0][0], None
     for first, last, slot, blocks in events:
