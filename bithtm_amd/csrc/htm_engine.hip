@@ -1389,7 +1389,7 @@ __device__ __forceinline__ uint32_t scan_cell_active(const uint32_t *act, const 
 
 // LDS: word 0 = recyclable counter; from word 4: column bitmap [colwords]
 template <int BS, bool use_lds>
-__device__ __forceinline__ void role_scan(const Dev &d, int p, int blk, int nblk, uint32_t *lds) {
+__device__ __forceinline__ void role_scan(const Dev &d, int p, int blk, int nblk, int n_spec, uint32_t *lds) {
     constexpr int SEGS = BS / 4;                   // segments per block iteration: BS/8 lane groups x 2 in flight
     int &s_recyc = *(int *)lds;
     uint32_t *s_colbits = lds + 4;
@@ -1411,7 +1411,12 @@ __device__ __forceinline__ void role_scan(const Dev &d, int p, int blk, int nblk
     constexpr int NG = BS / 8;                     // lane groups per block
     constexpr int U = SEGS / NG;                   // segments in flight per lane group
     bool staged = false;
-    for (int b = blk; b * SEGS < S; b += nblk) {
+    // In the first n_spec blocks (the ones that had segments when the host last saw the segment count)
+    // the loads of the first batch do not wait for the count: rows up to the pool's capacity exist, so they
+    // are fetched for ids clamped to it and masked once S has arrived: one dependent round trip less.
+    for (int b = blk;; b += nblk) {
+        const bool speculative = b == blk && blk < n_spec;
+        if (!speculative && b * SEGS >= S) break;
         int seg[U], n[U], pot[U], conn[U], n_true[U], cellu[U];
         u64 bits[U];
         int4 ps[U], ps2[U];
@@ -1420,7 +1425,7 @@ __device__ __forceinline__ void role_scan(const Dev &d, int p, int blk, int nblk
         // (rows of other ranks' segments exist in the replicated address space; they are masked below)
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            seg[u] = min(b * SEGS + u * NG + g, S - 1);
+            seg[u] = min(b * SEGS + u * NG + g, d.Scap - 1);
             n[u] = d.seg_nsyn[seg[u]];
             cellu[u] = d.seg_cell[seg[u]];
             ps[u] = *(const int4 *)(d.presyn + (size_t)seg[u] * d.E + l * 4);
@@ -1432,6 +1437,7 @@ __device__ __forceinline__ void role_scan(const Dev &d, int p, int blk, int nblk
         }
         if (threadIdx.x == 0) s_recyc = 0;
         __syncthreads();
+        if (speculative && b * SEGS >= S) break;     // (uniform in the block)
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const bool ok = b * SEGS + u * NG + g < S;
@@ -1562,8 +1568,8 @@ __device__ __forceinline__ void role_scan(const Dev &d, int p, int blk, int nblk
 // use_lds is a compile-time switch: as a run-time flag it put a branch and a wait around every
 // single LDS lookup, which serialised them
 template <bool use_lds>
-__global__ __launch_bounds__(256, 6) void k_tm_scan(Dev d, int p) {
-    role_scan<256, use_lds>(d, p, blockIdx.x, gridDim.x, (uint32_t *)dyn_lds);
+__global__ __launch_bounds__(256, 6) void k_tm_scan(Dev d, int p, int n_spec) {
+    role_scan<256, use_lds>(d, p, blockIdx.x, gridDim.x, n_spec, (uint32_t *)dyn_lds);
 }
 
 // ---- pipelined schedule: roles of different steps share every launch ---------------------------
@@ -1649,7 +1655,7 @@ __global__ __launch_bounds__(RB) void k_learn_overlap(Dev d, int p, int n_learn_
 // launch of its own: here the learning role still needed them after the emit); the rest: the scan.
 // The few short SP blocks come first: behind the scan blocks they would wait for a free CU slot.
 template <bool use_lds>
-__global__ __launch_bounds__(256, 6) void k_scan_sel(Dev d, int p, int n_sel_blocks, int n_clear_blocks, int sp) {
+__global__ __launch_bounds__(256, 6) void k_scan_sel(Dev d, int p, int n_sel_blocks, int n_clear_blocks, int sp, int n_spec) {
     TraceScope ts(d, 3 + 4 * p);
     int b = blockIdx.x;
     if (b < n_sel_blocks) {
@@ -1667,7 +1673,7 @@ __global__ __launch_bounds__(256, 6) void k_scan_sel(Dev d, int p, int n_sel_blo
         return;
     }
     b -= n_clear_blocks;
-    role_scan<256, use_lds>(d, p, b, gridDim.x - n_sel_blocks - n_clear_blocks, (uint32_t *)dyn_lds);
+    role_scan<256, use_lds>(d, p, b, gridDim.x - n_sel_blocks - n_clear_blocks, n_spec, (uint32_t *)dyn_lds);
 }
 
 // recount recyclable segments after a state import
@@ -1707,6 +1713,8 @@ struct htm_handle {
     int shard_n_inputs;
     bool shard_open;
     int G;                                // lanes per SP row
+    int seg_hint;                         // a lower bound of the segment count (see scan_spec_blocks)
+    int *seg_pinned;                      // pinned word the end of each htm_run copies the count into
     int sp_blocks, sel_blocks, c256_blocks, s1024_blocks, scan_blocks;
     // graphs keyed by (parity, learning, bank, n_inputs)
     std::map<std::tuple<int, int, const void *, int>, hipGraphExec_t> graphs;
@@ -1795,10 +1803,15 @@ static void launch_learn(htm_handle *h, int p) {
     }
 }
 
+// scan blocks that certainly have segments: the count only grows, and the host sees it now and then
+// (htm_get_info, state import, and a copy queued at the end of every htm_run)
+// (rounded down to a multiple of 64 blocks: the value is baked into captured graphs)
+static int scan_spec_blocks(const htm_handle *h) { return std::min(h->seg_hint / SCAN_SEGS, h->scan_blocks) & ~63; }
+
 static void launch_scan(htm_handle *h, int p, int use_lds) {
     Dev &d = h->d;
-    if (use_lds) LAUNCH_ON(h, h->stream, scan_lds(d, 1), "tm_scan", k_tm_scan<true>, h->scan_blocks, 256, d, p);
-    else LAUNCH_ON(h, h->stream, scan_lds(d, 0), "tm_scan", k_tm_scan<false>, h->scan_blocks, 256, d, p);
+    if (use_lds) LAUNCH_ON(h, h->stream, scan_lds(d, 1), "tm_scan", k_tm_scan<true>, h->scan_blocks, 256, d, p, scan_spec_blocks(h));
+    else LAUNCH_ON(h, h->stream, scan_lds(d, 0), "tm_scan", k_tm_scan<false>, h->scan_blocks, 256, d, p, scan_spec_blocks(h));
 }
 
 // Front of SpatialPooler.process for the step with parity sp: overlap + boost (+ select digit 0)
@@ -1876,8 +1889,8 @@ static void enqueue_pipelined(htm_handle *h, int p, int learning, const uint32_t
     const int n_sel = plan.next_front ? 64 : 0, n_clear = plan.next_sp ? h->c256_blocks : 0;
     const size_t lds = std::max(scan_lds(d, use_lds), sizeof(SelShared));
     const int grid = h->scan_blocks + n_sel + n_clear;
-    if (use_lds) LAUNCH_ON(h, h->stream, lds, "tm_scan+sp_select", k_scan_sel<true>, grid, 256, d, p, n_sel, n_clear, p);
-    else LAUNCH_ON(h, h->stream, lds, "tm_scan+sp_select", k_scan_sel<false>, grid, 256, d, p, n_sel, n_clear, p);
+    if (use_lds) LAUNCH_ON(h, h->stream, lds, "tm_scan+sp_select", k_scan_sel<true>, grid, 256, d, p, n_sel, n_clear, p, scan_spec_blocks(h));
+    else LAUNCH_ON(h, h->stream, lds, "tm_scan+sp_select", k_scan_sel<false>, grid, 256, d, p, n_sel, n_clear, p, scan_spec_blocks(h));
 }
 
 // work of a step that is not captured in its graph: the first step of a pipelined run has no SP work
@@ -1924,6 +1937,7 @@ extern "C" void htm_destroy(htm_handle *h) {
         for (auto &pr : v) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     for (hipEvent_t e : h->prof_all) hipEventDestroy(e);
     for (void *p : h->allocs) hipFree(p);
+    if (h->seg_pinned) hipHostFree(h->seg_pinned);
     if (h->own_stream) hipStreamDestroy(h->stream);
     delete h;
 }
@@ -2067,6 +2081,9 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
     if (rc) return fail_create(h, h->err, HTM_ERR_HIP);
     // lanes per SP row: the smallest power of two >= W4, at most 64
     h->G = 1;
+    h->seg_hint = 0;
+    h->seg_pinned = nullptr;
+    if (hipHostMalloc((void **)&h->seg_pinned, sizeof(int), hipHostMallocDefault) == hipSuccess) *h->seg_pinned = 0; else h->seg_pinned = nullptr;
     while (h->G < d.W4 && h->G < 64) h->G <<= 1;
     // few fat blocks for the kernels that flush a histogram: every block adds into the same few
     // hot bins and same-address global atomics are slow (~88 per us per address)
@@ -2212,6 +2229,7 @@ extern "C" int htm_run(htm_handle *h, const uint32_t *device_inputs, int32_t n_i
     // Nothing in a graph depends on the step index: kernels read it, and with it the bank row, from
     // the device counter.
     const int kGraphSteps = 16;
+    if (h->seg_pinned) { const int seen = *(volatile int *)h->seg_pinned; h->seg_hint = std::max(h->seg_hint, seen); }      // what the last run left
     bool sp_done = false;                           // the SP has already done the coming step
     for (int t = 0; t < n_steps;) {
         const StepPlan plan{sp_done, pipeline && t + 1 < n_steps, pipeline && t + 2 < n_steps};
@@ -2227,7 +2245,7 @@ extern "C" int htm_run(htm_handle *h, const uint32_t *device_inputs, int32_t n_i
         const int span = (plan.sp_done && plan.next_front && t + kGraphSteps + 1 < n_steps) ? kGraphSteps : 1;
         if (!plan.sp_done && !plan.next_sp) enqueue_sp_front(h, device_inputs, n_inputs, p);    // eager
         enqueue_cold_start(h, device_inputs, n_inputs, learning, plan);                         // eager: first step of a pipelined run
-        auto key = std::make_tuple(p, learning * 16 + (span > 1 ? 8 : 0) + (plan.sp_done ? 4 : 0) + (plan.next_sp ? 2 : 0) + (plan.next_front ? 1 : 0),
+        auto key = std::make_tuple(p, learning * 16 + (span > 1 ? 8 : 0) + (plan.sp_done ? 4 : 0) + (plan.next_sp ? 2 : 0) + (plan.next_front ? 1 : 0) + 32 * scan_spec_blocks(h),
                                    (const void *)device_inputs, n_inputs);
         auto it = h->graphs.find(key);
         if (it == h->graphs.end()) {
@@ -2245,6 +2263,8 @@ extern "C" int htm_run(htm_handle *h, const uint32_t *device_inputs, int32_t n_i
         h->step_host += span;
         t += span;
     }
+    // leave the segment count where the next call finds it (no wait: it may see the one before)
+    if (h->seg_pinned && n_steps > 0) HIPCHK(h, hipMemcpyAsync(h->seg_pinned, &h->d.ctr->S, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     return HTM_OK;
 }
 
@@ -2320,6 +2340,8 @@ static int read_counters(htm_handle *h, Counters *out) {
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipMemcpy(out, h->d.ctr, sizeof(Counters), hipMemcpyDeviceToHost));
+    h->seg_hint = out->S;                           // exact: the stream is idle
+    if (h->seg_pinned) *h->seg_pinned = out->S;
     return 0;
 }
 
@@ -2530,6 +2552,8 @@ extern "C" int htm_import_commit(htm_handle *h, int32_t segments, int32_t matchi
     c.step[h->step_host & 1] = (uint32_t)h->step_host;
     c.n_work = 0;
     c.S = segments;
+    h->seg_hint = segments;                         // (the one place where the count can go down)
+    if (h->seg_pinned) *h->seg_pinned = segments;
     {   // dense per-segment info from the staged PredictiveProjection.State lists
         const size_t M = (size_t)matching_segments;
         if (has_distal_state && (h->imp_pot.size() != (size_t)segments || h->imp_match_seg.size() != M ||
