@@ -1069,6 +1069,7 @@ __device__ __forceinline__ void role_sp_row(const Dev &d, int p, const uint32_t 
 //                fused with the rebuild of that row's connected mask: independent of the TM work and
 //                bandwidth-bound, it rides along with the latency-bound block 0
 // block 0 and the classify blocks 1..n_cls of the middle launch (below)
+template <int BS>
 __device__ __forceinline__ void role_mid(const Dev &d, int p, int n_active, int want_winner, int learning, int blk, int n_cls) {
     Counters *c = d.ctr;
     __shared__ int s_cnt, s_base;
@@ -1076,8 +1077,8 @@ __device__ __forceinline__ void role_mid(const Dev &d, int p, int n_active, int 
         if (!learning || !c->has_distal) return;
         const int q = p ^ 1;
         const int n = c->S;          // ids at or above the S of the last scan still hold info == 0
-        const int stride = n_cls * 1024;
-        for (int i0 = (blk - 1) * 1024; i0 < n; i0 += stride) {
+        const int stride = n_cls * BS;
+        for (int i0 = (blk - 1) * BS; i0 < n; i0 += stride) {
             const int seg = i0 + threadIdx.x;
             bool learn = false, punish = false;
             const uint32_t info = seg < n ? d.seg_info[seg] : 0u;
@@ -1118,24 +1119,31 @@ __device__ __forceinline__ void role_mid(const Dev &d, int p, int n_active, int 
     __shared__ int s_nneed;
     if (threadIdx.x == 0) { s_cells = 0; s_nneed = 0; }
     uint32_t carry_w = 0, carry_u = 0, n_cells = 0;
-    for (int base = 0; base < n_active; base += 1024) {
-        const int idx = base + threadIdx.x;
-        uint32_t v = 0, ww = 0, uw = 0;
-        int a = 0;
-        if (idx < n_active) {                      // four independent loads, no gather through `a`
-            a = d.active_cols[p][idx];
-            ww = d.winw_idx[idx];
-            uw = d.unacc_word[idx];
-            v = d.colcnt[idx];
-            n_cells += d.actcnt[idx];
+    for (int base = 0; base < n_active; base += 4 * BS) {      // four consecutive columns per thread, one scan
+        const int i0 = base + 4 * (int)threadIdx.x;
+        uint32_t v[4], ww[4], uw[4];
+        int a[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {              // independent loads, no gather through `a`
+            const int idx = i0 + j;
+            const bool ok = idx < n_active;
+            a[j] = ok ? d.active_cols[p][idx] : 0;
+            ww[j] = ok ? d.winw_idx[idx] : 0u;
+            uw[j] = ok ? d.unacc_word[idx] : 0u;
+            v[j] = (ok && want_winner) ? d.colcnt[idx] : 0u;
+            n_cells += ok ? d.actcnt[idx] : 0;
         }
-        if (!want_winner) v = 0;
         uint32_t total;
-        uint32_t ex = block_excl_scan<1024>(v, s_wave, total);
-        if (idx < n_active && want_winner) {
-            int pw = carry_w + (ex & 0xFFFFu), pu = carry_u + (ex >> 16);
-            while (ww) { int b = __ffs(ww) - 1; ww &= ww - 1; d.winners[p][pw++] = a * 32 + b; }
-            while (uw) { int b = __ffs(uw) - 1; uw &= uw - 1; d.unacc_list[pu++] = a * 32 + b; }
+        uint32_t run = block_excl_scan<BS>(v[0] + v[1] + v[2] + v[3], s_wave, total);
+        if (want_winner) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int pw = carry_w + (run & 0xFFFFu), pu = carry_u + (run >> 16);
+                uint32_t w1 = ww[j], u1 = uw[j];
+                while (w1) { int b = __ffs(w1) - 1; w1 &= w1 - 1; d.winners[p][pw++] = a[j] * 32 + b; }
+                while (u1) { int b = __ffs(u1) - 1; u1 &= u1 - 1; d.unacc_list[pu++] = a[j] * 32 + b; }
+                run += v[j];
+            }
         }
         carry_w += total & 0xFFFFu;
         carry_u += total >> 16;
@@ -1153,11 +1161,11 @@ __device__ __forceinline__ void role_mid(const Dev &d, int p, int n_active, int 
     if (n_un == 0) return;
     const int S = c->S, nb = (S + 1023) >> 10;
     uint32_t carry = 0;                       // recyclable segments seen so far
-    for (int base = 0; base < nb; base += 1024) {
+    for (int base = 0; base < nb; base += BS) {
         const int b = base + threadIdx.x;
         const uint32_t v = b < nb ? (uint32_t)d.recyc_cnt[b] : 0u;
         uint32_t total;
-        const uint32_t ex = block_excl_scan<1024>(v, s_wave, total);
+        const uint32_t ex = block_excl_scan<BS>(v, s_wave, total);
         if (v > 0 && carry + ex < (uint32_t)n_un) {
             const int slot = atomicAdd(&s_nneed, 1);
             d.recyc_need[2 * slot] = b;
@@ -1182,14 +1190,24 @@ __device__ __forceinline__ void role_mid(const Dev &d, int p, int n_active, int 
     const int n_need = s_nneed;
     for (int i = 0; i < n_need; ++i) {          // each needed 1024-block: rank its recyclable segments
         const int b = d.recyc_need[2 * i], off = d.recyc_need[2 * i + 1];
-        const int seg = b * 1024 + threadIdx.x;
-        const uint32_t fl = (seg < S && d.seg_nsyn[seg] < d.match_thr) ? 1u : 0u;
+        constexpr int IPT = 1024 / BS;             // consecutive segments per thread
+        uint32_t fl[IPT], cnt = 0;
+#pragma unroll
+        for (int j = 0; j < IPT; ++j) {
+            const int seg = b * 1024 + (int)threadIdx.x * IPT + j;
+            fl[j] = (seg < S && d.seg_nsyn[seg] < d.match_thr) ? 1u : 0u;
+            cnt += fl[j];
+        }
         uint32_t total;
-        const uint32_t ex = block_excl_scan<1024>(fl, s_wave, total);
-        const int rank = off + (int)ex;
-        if (fl && rank < n_r) tm_bind_segment(d, seg, d.unacc_list[rank], true, whole ? wbase + rank : -1, grown);
+        int rank = off + (int)block_excl_scan<BS>(cnt, s_wave, total);
+#pragma unroll
+        for (int j = 0; j < IPT; ++j) {
+            const int seg = b * 1024 + (int)threadIdx.x * IPT + j;
+            if (fl[j] && rank < n_r) tm_bind_segment(d, seg, d.unacc_list[rank], true, whole ? wbase + rank : -1, grown);
+            rank += (int)fl[j];
+        }
     }
-    for (int i = threadIdx.x; i < n_new; i += 1024)
+    for (int i = threadIdx.x; i < n_new; i += BS)
         tm_bind_segment(d, S + i, d.unacc_list[n_r + i], false, whole ? wbase + n_r + i : -1, grown);
     if (threadIdx.x == 0) {
         c->n_recycled = n_r;
@@ -1206,7 +1224,7 @@ __global__ __launch_bounds__(1024) void k_tm_mid(Dev d, int p, int n_active, int
         if (ri < n_sp_rows) role_sp_row<512>(d, p, bank, n_inputs, 0, ri, threadIdx.x & 511);
         return;
     }
-    role_mid(d, p, n_active, want_winner, learning, blockIdx.x, n_cls);
+    role_mid<1024>(d, p, n_active, want_winner, learning, blockIdx.x, n_cls);
 }
 
 // SparseProjection.update_permanence (projections.py:97-109) and add_edge (:111-161) for one
@@ -1614,25 +1632,26 @@ __global__ __launch_bounds__(256) void k_open_emit(Dev d, int p, int n_emit_bloc
     }
 }
 
-// blocks [0, 1 + n_cls): the middle of the TM step; then two winner rows of the coming step per block;
-// then its duty cycle (regularizations.py:19-21, float32, two roundings), 1024 columns per block
-__global__ __launch_bounds__(1024) void k_mid_rows(Dev d, int p, int n_active, int learning, int n_cls,
-                                                   const uint32_t *__restrict__ bank, int n_inputs, int n_rows, int n_duty_blocks) {
+// blocks [0, 1 + n_cls): the middle of the TM step; then one winner row of the coming step per block;
+// then its duty cycle (regularizations.py:19-21, float32, two roundings).  256-thread blocks: the
+// dispatcher places them about five times faster, wave for wave, than 1024-thread ones (measured:
+// 2000 small blocks start within 1 us, 800 large ones take 7), and all of them are resident at once.
+__global__ __launch_bounds__(256) void k_mid_rows(Dev d, int p, int n_active, int learning, int n_cls,
+                                                  const uint32_t *__restrict__ bank, int n_inputs, int n_rows, int n_duty_blocks) {
     TraceScope ts(d, 1 + 4 * p);
     int b = blockIdx.x;
     if (b <= n_cls) {
-        role_mid(d, p, n_active, 1, learning, b, n_cls);
+        role_mid<256>(d, p, n_active, 1, learning, b, n_cls);
         return;
     }
     b -= 1 + n_cls;
-    const int q = p ^ 1, n_row_blocks = (n_rows + 1) / 2;
-    if (b < n_row_blocks) {                        // (four rows per block were measured slower)
-        const int ri = b * 2 + (int)(threadIdx.x >> 9);
-        if (ri < n_rows) role_sp_row<512>(d, q, bank, n_inputs, 1, ri, threadIdx.x & 511);
+    const int q = p ^ 1;
+    if (b < n_rows) {
+        role_sp_row<256>(d, q, bank, n_inputs, 1, b, threadIdx.x);
         return;
     }
-    b -= n_row_blocks;
-    const int c = b * 1024 + (int)threadIdx.x;
+    b -= n_rows;
+    const int c = b * 256 + (int)threadIdx.x;
     if (b < n_duty_blocks && c < d.C) {
         float dc = d.duty[c] * d.mom;
         if ((d.colbits[q][c >> 5] >> (c & 31)) & 1u) dc = dc + d.dinc;
@@ -1871,8 +1890,8 @@ static void enqueue_pipelined(htm_handle *h, int p, int learning, const uint32_t
     const int n_cls = learning ? kClassifyBlocks : 0;
     const int n_emit = plan.next_sp ? h->c256_blocks : 0;
     LAUNCH_ON(h, h->stream, sizeof(EmitShared), "tm_activate+sp_emit", k_open_emit, n_emit + (d.k * 32 + 255) / 256, 256, d, p, n_emit, d.k);
-    const int n_rows = (plan.next_sp && learning) ? d.k : 0, n_duty = plan.next_sp ? (d.C + 1023) / 1024 : 0;
-    LAUNCH(h, "tm_mid+sp_learn", k_mid_rows, 1 + n_cls + (n_rows + 1) / 2 + n_duty, 1024, d, p, d.k, learning, n_cls, bank, n_inputs, n_rows,
+    const int n_rows = (plan.next_sp && learning) ? d.k : 0, n_duty = plan.next_sp ? h->c256_blocks : 0;
+    LAUNCH(h, "tm_mid+sp_learn", k_mid_rows, 1 + 4 * n_cls + n_rows + n_duty, 256, d, p, d.k, learning, 4 * n_cls, bank, n_inputs, n_rows,
            n_duty);
     {
         const int epl = learn_epl(d);

@@ -29,8 +29,8 @@ def roles(launch, k, C):
     if launch == 0:
         return ((0, c256, "sp_emit"), (c256, 4096, "tm_activate"))
     if launch == 1:
-        rows = (k + 1) // 2
-        return ((0, 1, "tm_mid block 0"), (1, 1 + cls, "tm_mid classify"), (1 + cls, 1 + cls + rows, "sp rows"), (1 + cls + rows, 4096, "sp duty"))
+        cls4 = 4 * cls
+        return ((0, 1, "tm_mid block 0"), (1, 1 + cls4, "tm_mid classify"), (1 + cls4, 1 + cls4 + k, "sp rows"), (1 + cls4 + k, 4096, "sp duty"))
     if launch == 2:
         return ((0, 256, "tm_learn"), (256, 4096, "sp_overlap"))
     return ((0, 64, "sp_select"), (64, 64 + c256, "clear"), (64 + c256, 4096, "tm_scan"))
