@@ -1542,22 +1542,40 @@ __device__ __forceinline__ void role_scan(const Dev &d, int p, int blk, int nblk
             for (int o = 4; o > 0; o >>= 1) v += __shfl_xor(v, o);
             pot[u] = v;
         }
+        {   // connected active synapses of the matching segments (:171-172): the permanences of the first two
+            // chunks of every matching row are fetched in one batch (one round trip, not one per chunk and row)
+            float4 pm[U][2];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const bool matching = pot[u] >= d.match_thr;                             // :247
-            int cn = 0;
-            if (matching) {
+            for (int u = 0; u < U; ++u) {
+                const bool matching = pot[u] >= d.match_thr;                         // :247
                 const float *mrow = d.sperm + (size_t)seg[u] * d.E;
-                for (int i = l * 4, ch = 0; i < n[u]; i += 32, ++ch) {
-                    const float4 pm = *(const float4 *)(mrow + i);
-                    const float e[4] = {pm.x, pm.y, pm.z, pm.w};
+#pragma unroll
+                for (int ch = 0; ch < 2; ++ch)
+                    pm[u][ch] = (matching && ch * 32 + l * 4 < n[u]) ? *(const float4 *)(mrow + ch * 32 + l * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                int cn = 0;
+#pragma unroll
+                for (int ch = 0; ch < 2; ++ch) {
+                    const float e[4] = {pm[u][ch].x, pm[u][ch].y, pm[u][ch].z, pm[u][ch].w};
 #pragma unroll
                     for (int qq = 0; qq < 4; ++qq)
-                        cn += ((bits[u] >> (ch * 4 + qq)) & 1ull) && (e[qq] >= d.perm_thr);   // :171-172
+                        cn += ((bits[u] >> (ch * 4 + qq)) & 1ull) && (e[qq] >= d.perm_thr);
                 }
+                if (pot[u] >= d.match_thr && n[u] > 64) {                            // rare: longer rows
+                    const float *mrow = d.sperm + (size_t)seg[u] * d.E;
+                    for (int i = 64 + l * 4, ch = 2; i < n[u]; i += 32, ++ch) {
+                        const float4 pv = *(const float4 *)(mrow + i);
+                        const float e[4] = {pv.x, pv.y, pv.z, pv.w};
+#pragma unroll
+                        for (int qq = 0; qq < 4; ++qq)
+                            cn += ((bits[u] >> (ch * 4 + qq)) & 1ull) && (e[qq] >= d.perm_thr);
+                    }
+                }
+                for (int o = 4; o > 0; o >>= 1) cn += __shfl_xor(cn, o);
+                conn[u] = cn;
             }
-            for (int o = 4; o > 0; o >>= 1) cn += __shfl_xor(cn, o);
-            conn[u] = cn;
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -1732,6 +1750,7 @@ struct htm_handle {
     int shard_n_inputs;
     bool shard_open;
     int G;                                // lanes per SP row
+    int graph_steps;                      // steady-state steps per captured graph (BITHTM_GRAPH_STEPS)
     int seg_hint;                         // a lower bound of the segment count (see scan_spec_blocks)
     int *seg_pinned;                      // pinned word the end of each htm_run copies the count into
     int sp_blocks, sel_blocks, c256_blocks, s1024_blocks, scan_blocks;
@@ -2101,6 +2120,8 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
     // lanes per SP row: the smallest power of two >= W4, at most 64
     h->G = 1;
     h->seg_hint = 0;
+    h->graph_steps = 16;
+    if (const char *e = getenv("BITHTM_GRAPH_STEPS")) h->graph_steps = std::max(1, std::min(256, atoi(e)));
     h->seg_pinned = nullptr;
     if (hipHostMalloc((void **)&h->seg_pinned, sizeof(int), hipHostMallocDefault) == hipSuccess) *h->seg_pinned = 0; else h->seg_pinned = nullptr;
     while (h->G < d.W4 && h->G < 64) h->G <<= 1;
@@ -2247,7 +2268,7 @@ extern "C" int htm_run(htm_handle *h, const uint32_t *device_inputs, int32_t n_i
     // launch boundary costs about 5 us more than a kernel boundary inside a graph: tools/step_timeline.py).
     // Nothing in a graph depends on the step index: kernels read it, and with it the bank row, from
     // the device counter.
-    const int kGraphSteps = 16;
+    const int kGraphSteps = h->graph_steps;
     if (h->seg_pinned) { const int seen = *(volatile int *)h->seg_pinned; h->seg_hint = std::max(h->seg_hint, seen); }      // what the last run left
     bool sp_done = false;                           // the SP has already done the coming step
     for (int t = 0; t < n_steps;) {
