@@ -1603,8 +1603,11 @@ __device__ __forceinline__ void role_scan(const Dev &d, int p, int blk, int nblk
 
 // use_lds is a compile-time switch: as a run-time flag it put a branch and a wait around every
 // single LDS lookup, which serialised them
-template <bool use_lds>
-__global__ __launch_bounds__(256, 6) void k_tm_scan(Dev d, int p, int n_spec) {
+// MINW = 6 caps the kernel at 80 registers so that 6 blocks fit a CU and a pool of up to ~98 k
+// segments is scanned by blocks that are all resident at once (the latency-bound regime of the bench
+// workload); large pools are bandwidth-bound and run faster without the cap (MINW = 1).
+template <bool use_lds, int MINW>
+__global__ __launch_bounds__(256, MINW) void k_tm_scan(Dev d, int p, int n_spec) {
     role_scan<256, use_lds>(d, p, blockIdx.x, gridDim.x, n_spec, (uint32_t *)dyn_lds);
 }
 
@@ -1691,8 +1694,8 @@ __global__ __launch_bounds__(RB) void k_learn_overlap(Dev d, int p, int n_learn_
 // dense per-column words of the coming step (what EMIT_CLEAR does when the winner list is emitted in a
 // launch of its own: here the learning role still needed them after the emit); the rest: the scan.
 // The few short SP blocks come first: behind the scan blocks they would wait for a free CU slot.
-template <bool use_lds>
-__global__ __launch_bounds__(256, 6) void k_scan_sel(Dev d, int p, int n_sel_blocks, int n_clear_blocks, int sp, int n_spec) {
+template <bool use_lds, int MINW>
+__global__ __launch_bounds__(256, MINW) void k_scan_sel(Dev d, int p, int n_sel_blocks, int n_clear_blocks, int sp, int n_spec) {
     TraceScope ts(d, 3 + 4 * p);
     int b = blockIdx.x;
     if (b < n_sel_blocks) {
@@ -1846,10 +1849,19 @@ static void launch_learn(htm_handle *h, int p) {
 // (rounded down to a multiple of 64 blocks: the value is baked into captured graphs)
 static int scan_spec_blocks(const htm_handle *h) { return std::min(h->seg_hint / SCAN_SEGS, h->scan_blocks) & ~63; }
 
+// more segments than three rounds of resident blocks: the scan is bandwidth-bound (see k_tm_scan)
+static bool scan_pool_is_large(const htm_handle *h) { return h->seg_hint > 3 * 1536 * SCAN_SEGS; }
+
 static void launch_scan(htm_handle *h, int p, int use_lds) {
     Dev &d = h->d;
-    if (use_lds) LAUNCH_ON(h, h->stream, scan_lds(d, 1), "tm_scan", k_tm_scan<true>, h->scan_blocks, 256, d, p, scan_spec_blocks(h));
-    else LAUNCH_ON(h, h->stream, scan_lds(d, 0), "tm_scan", k_tm_scan<false>, h->scan_blocks, 256, d, p, scan_spec_blocks(h));
+    const int spec = scan_spec_blocks(h);
+    if (scan_pool_is_large(h)) {
+        if (use_lds) LAUNCH_ON(h, h->stream, scan_lds(d, 1), "tm_scan", (k_tm_scan<true, 1>), h->scan_blocks, 256, d, p, spec);
+        else LAUNCH_ON(h, h->stream, scan_lds(d, 0), "tm_scan", (k_tm_scan<false, 1>), h->scan_blocks, 256, d, p, spec);
+    } else {
+        if (use_lds) LAUNCH_ON(h, h->stream, scan_lds(d, 1), "tm_scan", (k_tm_scan<true, 6>), h->scan_blocks, 256, d, p, spec);
+        else LAUNCH_ON(h, h->stream, scan_lds(d, 0), "tm_scan", (k_tm_scan<false, 6>), h->scan_blocks, 256, d, p, spec);
+    }
 }
 
 // Front of SpatialPooler.process for the step with parity sp: overlap + boost (+ select digit 0)
@@ -1927,8 +1939,14 @@ static void enqueue_pipelined(htm_handle *h, int p, int learning, const uint32_t
     const int n_sel = plan.next_front ? 64 : 0, n_clear = plan.next_sp ? h->c256_blocks : 0;
     const size_t lds = std::max(scan_lds(d, use_lds), sizeof(SelShared));
     const int grid = h->scan_blocks + n_sel + n_clear;
-    if (use_lds) LAUNCH_ON(h, h->stream, lds, "tm_scan+sp_select", k_scan_sel<true>, grid, 256, d, p, n_sel, n_clear, p, scan_spec_blocks(h));
-    else LAUNCH_ON(h, h->stream, lds, "tm_scan+sp_select", k_scan_sel<false>, grid, 256, d, p, n_sel, n_clear, p, scan_spec_blocks(h));
+    const int spec = scan_spec_blocks(h);
+    if (scan_pool_is_large(h)) {
+        if (use_lds) LAUNCH_ON(h, h->stream, lds, "tm_scan+sp_select", (k_scan_sel<true, 1>), grid, 256, d, p, n_sel, n_clear, p, spec);
+        else LAUNCH_ON(h, h->stream, lds, "tm_scan+sp_select", (k_scan_sel<false, 1>), grid, 256, d, p, n_sel, n_clear, p, spec);
+    } else {
+        if (use_lds) LAUNCH_ON(h, h->stream, lds, "tm_scan+sp_select", (k_scan_sel<true, 6>), grid, 256, d, p, n_sel, n_clear, p, spec);
+        else LAUNCH_ON(h, h->stream, lds, "tm_scan+sp_select", (k_scan_sel<false, 6>), grid, 256, d, p, n_sel, n_clear, p, spec);
+    }
 }
 
 // work of a step that is not captured in its graph: the first step of a pipelined run has no SP work
@@ -2285,7 +2303,7 @@ extern "C" int htm_run(htm_handle *h, const uint32_t *device_inputs, int32_t n_i
         const int span = (plan.sp_done && plan.next_front && t + kGraphSteps + 1 < n_steps) ? kGraphSteps : 1;
         if (!plan.sp_done && !plan.next_sp) enqueue_sp_front(h, device_inputs, n_inputs, p);    // eager
         enqueue_cold_start(h, device_inputs, n_inputs, learning, plan);                         // eager: first step of a pipelined run
-        auto key = std::make_tuple(p, learning * 16 + (span > 1 ? 8 : 0) + (plan.sp_done ? 4 : 0) + (plan.next_sp ? 2 : 0) + (plan.next_front ? 1 : 0) + 32 * scan_spec_blocks(h),
+        auto key = std::make_tuple(p, learning * 16 + (span > 1 ? 8 : 0) + (plan.sp_done ? 4 : 0) + (plan.next_sp ? 2 : 0) + (plan.next_front ? 1 : 0) + 32 * scan_spec_blocks(h) + (scan_pool_is_large(h) ? (1 << 20) : 0),
                                    (const void *)device_inputs, n_inputs);
         auto it = h->graphs.find(key);
         if (it == h->graphs.end()) {
