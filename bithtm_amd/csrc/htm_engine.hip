@@ -54,7 +54,8 @@ struct Counters {
     int32_t has_winner[2];    // winner list of parity p is valid (winner_cell is not None)
     int32_t has_distal;       // a scan has run (distal_state is not None)
     int32_t n_active_cells;
-    int32_t n_work;           // learning / punish work items of this step
+    int32_t n_work;           // learning / punish work items of this step (front of the work array)
+    int32_t n_bind;           // newly bound segments of this step (back of the work array, growing down)
     int32_t n_work_last;      // ... of the last completed step (telemetry)
     int32_t sel_fallbacks;    // steps whose top-k select took the in-kernel fallback (telemetry)
     uint32_t emit_epoch;      // bumped by every overlap launch: tags the records k_sp_emit's blocks exchange
@@ -100,7 +101,6 @@ struct Dev {
     uint32_t *colbits[2];     // [ceil(C/64)*2] bitmap of the step's active columns
     int *winners[2];          // [k*32] winner cells (enc), ascending
     uint8_t *bursting;        // [k]
-    uint32_t *colcnt;         // [k] popc(winner) | popc(unaccounted) << 16
     uint32_t *winw_idx;       // [k] winner word of the idx-th active column (same as win[active_cols[idx]])
     uint8_t *actcnt;          // [k] popc(active word) of the idx-th active column
     uint32_t *unacc_word;     // [k]
@@ -465,7 +465,6 @@ __device__ __forceinline__ void tm_store_column(const Dev &d, int p, bool col_ok
         d.act[p][a] = w.act;
         d.win[p][a] = w.winner;
         d.bursting[idx] = w.burst ? 1 : 0;
-        d.colcnt[idx] = (uint32_t)__popc(w.winner) | ((uint32_t)__popc(w.unacc) << 16);
         d.unacc_word[idx] = w.unacc;
         d.winw_idx[idx] = w.winner;
         d.actcnt[idx] = (uint8_t)__popc(w.act);
@@ -1118,26 +1117,48 @@ __device__ __forceinline__ void role_mid(const Dev &d, int p, int n_active, int 
     __shared__ uint32_t s_cells;
     __shared__ int s_nneed;
     if (threadIdx.x == 0) { s_cells = 0; s_nneed = 0; }
+    const int S = c->S, nb = (S + 1023) >> 10;
+    // first batch of the per-1024-segment recyclable counts: fetched with the column lists, not after them
+    const uint32_t recyc_first = (int)threadIdx.x < nb ? (uint32_t)d.recyc_cnt[threadIdx.x] : 0u;
     uint32_t carry_w = 0, carry_u = 0, n_cells = 0;
-    for (int base = 0; base < n_active; base += 4 * BS) {      // four consecutive columns per thread, one scan
-        const int i0 = base + 4 * (int)threadIdx.x;
-        uint32_t v[4], ww[4], uw[4];
-        int a[4];
+    // LPT consecutive columns per thread, one scan per pass: with 256 threads one pass covers 2048 winner
+    // columns, so every load of the lists is in flight at once (under the load of the row updates that
+    // share this launch a dependent round trip costs about 3 us)
+    constexpr int LPT = 8;
+    static_assert(LPT == 8, "the list pass loads 8 entries per thread");
+    for (int base = 0; base < n_active; base += LPT * BS) {
+        const int i0 = base + LPT * (int)threadIdx.x;
+        uint32_t v[LPT], ww[LPT], uw[LPT];
+        int a[LPT];
+        uint32_t vsum = 0;
+        if (i0 < n_active) {                       // 16-byte loads (the arrays are padded by 8 entries), masked below
+            const int4 a0 = *(const int4 *)(d.active_cols[p] + i0), a1 = *(const int4 *)(d.active_cols[p] + i0 + 4);
+            const uint4 w0 = *(const uint4 *)(d.winw_idx + i0), w1 = *(const uint4 *)(d.winw_idx + i0 + 4);
+            const uint4 u0 = *(const uint4 *)(d.unacc_word + i0), u1 = *(const uint4 *)(d.unacc_word + i0 + 4);
+            const u64 ac = *(const u64 *)(d.actcnt + i0);
+            a[0] = a0.x; a[1] = a0.y; a[2] = a0.z; a[3] = a0.w; a[4] = a1.x; a[5] = a1.y; a[6] = a1.z; a[7] = a1.w;
+            ww[0] = w0.x; ww[1] = w0.y; ww[2] = w0.z; ww[3] = w0.w; ww[4] = w1.x; ww[5] = w1.y; ww[6] = w1.z; ww[7] = w1.w;
+            uw[0] = u0.x; uw[1] = u0.y; uw[2] = u0.z; uw[3] = u0.w; uw[4] = u1.x; uw[5] = u1.y; uw[6] = u1.z; uw[7] = u1.w;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {              // independent loads, no gather through `a`
-            const int idx = i0 + j;
-            const bool ok = idx < n_active;
-            a[j] = ok ? d.active_cols[p][idx] : 0;
-            ww[j] = ok ? d.winw_idx[idx] : 0u;
-            uw[j] = ok ? d.unacc_word[idx] : 0u;
-            v[j] = (ok && want_winner) ? d.colcnt[idx] : 0u;
-            n_cells += ok ? d.actcnt[idx] : 0;
+            for (int j = 0; j < LPT; ++j) {
+                const bool ok = i0 + j < n_active;
+                if (!ok) { ww[j] = 0; uw[j] = 0; }
+                n_cells += ok ? (uint32_t)((ac >> (8 * j)) & 0xFFu) : 0u;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < LPT; ++j) { a[j] = 0; ww[j] = 0; uw[j] = 0; }
+        }
+#pragma unroll
+        for (int j = 0; j < LPT; ++j) {
+            v[j] = want_winner ? (uint32_t)__popc(ww[j]) | ((uint32_t)__popc(uw[j]) << 16) : 0u;      // winners | needing a segment
+            vsum += v[j];
         }
         uint32_t total;
-        uint32_t run = block_excl_scan<BS>(v[0] + v[1] + v[2] + v[3], s_wave, total);
+        uint32_t run = block_excl_scan<BS>(vsum, s_wave, total);
         if (want_winner) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < LPT; ++j) {
                 int pw = carry_w + (run & 0xFFFFu), pu = carry_u + (run >> 16);
                 uint32_t w1 = ww[j], u1 = uw[j];
                 while (w1) { int b = __ffs(w1) - 1; w1 &= w1 - 1; d.winners[p][pw++] = a[j] * 32 + b; }
@@ -1157,13 +1178,13 @@ __device__ __forceinline__ void role_mid(const Dev &d, int p, int n_active, int 
         c->has_winner[p] = want_winner;
         c->n_un = n_un;
         c->n_active_cells = (int)s_cells;
+        if (n_un == 0) c->n_bind = 0;
     }
     if (n_un == 0) return;
-    const int S = c->S, nb = (S + 1023) >> 10;
     uint32_t carry = 0;                       // recyclable segments seen so far
     for (int base = 0; base < nb; base += BS) {
         const int b = base + threadIdx.x;
-        const uint32_t v = b < nb ? (uint32_t)d.recyc_cnt[b] : 0u;
+        const uint32_t v = base == 0 ? recyc_first : (b < nb ? (uint32_t)d.recyc_cnt[b] : 0u);
         uint32_t total;
         const uint32_t ex = block_excl_scan<BS>(v, s_wave, total);
         if (v > 0 && carry + ex < (uint32_t)n_un) {
@@ -1181,10 +1202,11 @@ __device__ __forceinline__ void role_mid(const Dev &d, int p, int n_active, int 
         if (threadIdx.x == 0) atomicOr(&c->error, 1);
         n_new = max(d.Scap - S, 0);
     }
-    const bool whole = d.world == 1;            // sharded: only the binds to own cells are queued
-    if (threadIdx.x == 0 && whole) s_base = atomicAdd(&c->n_work, n_r + n_new);      // one reservation for all binds
+    // the bound segments are queued from the back of the work array (no reservation to wait for);
+    // sharded: only the binds to own cells are queued, each with its own reservation at the front
+    const bool whole = d.world == 1;
     __syncthreads();
-    const int wbase = s_base;
+    const int wbase = d.work_cap - (n_r + n_new);
     const int n_w = c->has_winner[p ^ 1] ? c->n_win[p ^ 1] : -1;
     const int grown = n_w > 0 ? min(d.sample, n_w) : 0;
     const int n_need = s_nneed;
@@ -1212,6 +1234,7 @@ __device__ __forceinline__ void role_mid(const Dev &d, int p, int n_active, int 
     if (threadIdx.x == 0) {
         c->n_recycled = n_r;
         c->n_new = n_new;
+        c->n_bind = whole ? n_r + n_new : 0;
         c->S_old = S;
         c->S = S + n_new;
     }
@@ -1248,13 +1271,15 @@ __device__ __forceinline__ void role_learn(const Dev &d, int p, int blk, int nbl
         for (int i = blk * BS + threadIdx.x; i < nb; i += nblk * BS) d.recyc_cnt[i] = 0;
     }
     const int wv = threadIdx.x >> 6, lane = lane_id();
-    const int n_work = min(c->n_work, d.work_cap);
+    const int n_front = min(c->n_work, d.work_cap), n_back = c->n_bind;
+    if (n_front + n_back > d.work_cap && blk == 0 && threadIdx.x == 0) atomicOr(&c->error, 4);
+    const int n_work = min(n_front + n_back, d.work_cap);
     const uint32_t *act_prev = d.act[p ^ 1];
     const int *winners = d.winners[p ^ 1];
     const int n_w = c->has_winner[p ^ 1] ? c->n_win[p ^ 1] : -1;       // -1: winner_input is None
     const uint32_t base2 = htm_stream_base(d.seed, HTM_STREAM_GROWTH, c->step[p]);
     for (int item = blk * (BS / 64) + wv; item < n_work; item += nblk * (BS / 64)) {
-        const uint32_t w = d.work[item];
+        const uint32_t w = d.work[item < n_front ? item : d.work_cap - n_back + (item - n_front)];
         const int seg = (int)(w & 0x7FFFFFFFu), mode = (int)(w >> 31);
         const double dA = mode ? d.pun_act : d.lrn_act, dI = mode ? d.pun_inact : d.lrn_inact;
         const bool prune = mode ? d.pun_prune : d.lrn_prune;
@@ -1417,8 +1442,9 @@ __device__ __forceinline__ void role_scan(const Dev &d, int p, int blk, int nblk
     if (blk == 0 && threadIdx.x == 0) {
         c->step[p ^ 1] = c->step[p] + 1;
         c->has_distal = 1;
-        c->n_work_last = c->n_work;
+        c->n_work_last = c->n_work + c->n_bind;
         c->n_work = 0;
+        c->n_bind = 0;
     }
     const uint32_t *act = d.act[p];
     const uint32_t base3 = htm_stream_base(d.seed, HTM_STREAM_SEGMENT_JITTER, c->step[p]);
@@ -2079,8 +2105,8 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
     int rc = 0;
     const size_t C = d.C, k = d.k;
     rc |= dalloc(h, &d.ctr, 1);
-    rc |= dalloc(h, &d.active_cols[0], k);
-    rc |= dalloc(h, &d.active_cols[1], k);
+    rc |= dalloc(h, &d.active_cols[0], k + 8);     // (+8: the TM's list pass reads 8 entries per thread)
+    rc |= dalloc(h, &d.active_cols[1], k + 8);
     if (cfg->enable_sp) {
         rc |= dalloc(h, &d.perm, C * d.Ipad);
         rc |= dalloc(h, &d.mask, C * d.W);
@@ -2109,10 +2135,9 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
         rc |= dalloc(h, &d.colbits[0], (size_t)d.colwords);
         rc |= dalloc(h, &d.colbits[1], (size_t)d.colwords);
         rc |= dalloc(h, &d.bursting, k);
-        rc |= dalloc(h, &d.colcnt, k);
-        rc |= dalloc(h, &d.winw_idx, k);
-        rc |= dalloc(h, &d.actcnt, k);
-        rc |= dalloc(h, &d.unacc_word, k);
+        rc |= dalloc(h, &d.winw_idx, k + 8);
+        rc |= dalloc(h, &d.actcnt, k + 8);
+        rc |= dalloc(h, &d.unacc_word, k + 8);
         rc |= dalloc(h, &d.unacc_list, k * 32);
         rc |= dalloc(h, &d.seg_cell, S);
         rc |= dalloc(h, &d.seg_nsyn, S);
@@ -2609,6 +2634,7 @@ extern "C" int htm_import_commit(htm_handle *h, int32_t segments, int32_t matchi
     const int q = (int)((h->step_host + 1) & 1);
     c.step[h->step_host & 1] = (uint32_t)h->step_host;
     c.n_work = 0;
+    c.n_bind = 0;
     c.S = segments;
     h->seg_hint = segments;                         // (the one place where the count can go down)
     if (h->seg_pinned) *h->seg_pinned = segments;
