@@ -139,18 +139,21 @@ def test_bad_arguments_fail_loudly():
 
 
 def test_batched_run_equals_step_by_step():
-    """htm.run (device-resident bank, hipGraph replay) == the same inputs through process()."""
+    """htm.run (device-resident bank, hipGraph replay, the Spatial Pooler working ahead of the Temporal
+    Memory) == the same inputs through process().  The run lengths exercise every launch plan: single
+    steps, the two shortened steps at the end of a run, the eager cold start, single-step graphs and
+    the 16-step steady-state graph with its remainders."""
     import bithtm_amd as B
     rng = np.random.RandomState(11)
     bank = rng.rand(30, 200) < 0.08
     outs = []
-    for mode in ("graph", "eager", "graph-nopipe", "mixed", "process"):
+    for mode in ("graph", "eager", "graph-nopipe", "mixed", "chunks", "chunks-eager", "process"):
         np.random.seed(12)
         htm = B.HierarchicalTemporalMemory(200, 2048, 16)
         if mode == "process":
             for t in range(95):
                 htm.process(bank[t % 30])
-        elif mode == "mixed":                      # prefetched SP fronts get used, dropped and rebuilt
+        elif mode == "mixed":                      # batched runs, host-fed steps and another bank object in turn
             htm.run(bank, 40)
             for t in range(40, 47):
                 htm.process(bank[t % 30])
@@ -158,11 +161,15 @@ def test_batched_run_equals_step_by_step():
             other = bank.copy()                    # a different bank object with the same content
             htm.run(other, 8)
             htm.run(bank, 20, pipeline=False)
+        elif mode.startswith("chunks"):
+            for n in (1, 2, 3, 1, 17, 18, 19, 34):
+                htm.run(bank, n, use_graph=(mode == "chunks"))
         else:
             htm.run(bank, 95, use_graph=mode.startswith("graph"), pipeline=(mode != "graph-nopipe"))
         st = htm.engine.read_store()
         outs.append((htm.engine.read_sp_fields()["active_column"], st["seg_cell"], st["seg_nsyn"], st["perm"],
-                     htm.temporal_memory.last_state.cell_prediction))
+                     htm.temporal_memory.last_state.cell_prediction, htm.engine.read_duty_cycle(),
+                     htm.engine.read_sp_fields()["boosted_overlaps"]))
     for o in outs[1:]:
         for a, b in zip(outs[0], o):
             assert np.array_equal(a, b)
