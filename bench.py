@@ -92,8 +92,9 @@ def recorded_traffic(kernel):
     name = {"tm_scan": "k_tm_scan", "sp_overlap": "k_sp_overlap", "sp_learn": "k_tm_mid"}.get(kernel)
     try:
         d = json.load(open(path))
-        f = d["FETCH_SIZE"][name]["mean_last150_KB"]
-        wr = d["WRITE_SIZE"][name]["mean_last150_KB"]
+        key = next(k for k in d["FETCH_SIZE"] if name in k)          # template kernels: "void k_tm_scan<true, 6>"
+        f = d["FETCH_SIZE"][key]["mean_last150_KB"]
+        wr = d["WRITE_SIZE"][key]["mean_last150_KB"]
         return dict(traffic=int((2 * f + wr) * 1024), traffic_source="profiles/r01_pmc_summary.json (recorded PMC pass)")
     except Exception:
         return dict(traffic=None)
