@@ -71,7 +71,7 @@ struct Counters {
 };
 
 struct Dev {
-    int I, W, W4, Ipad, C, K, k, E, Scap, work_cap, sel_passes, colwords, low_zero, cand_d, cand_pairwise;
+    int I, W, W4, Ipad, C, K, k, E, Scap, work_cap, sel_passes, colwords, low_zero, cand_d, cand_pairwise, cand_others;
     int world, c0, c1;        // this rank owns columns [c0, c1) (world == 1: everything)
     double sp_thr, sp_don, sp_doff;
     float coef, mom, dinc;
@@ -600,6 +600,7 @@ __global__ __launch_bounds__(1024) void k_shard_unpack(Dev d, const unsigned cha
 #define CAND_D 8              // distinct bucket keys one block can publish
 #define CAND_RAW 64           // ... and collect from its waves before merging duplicates
 #define CAND_MAX 2048         // bucket entries a block can merge
+#define CAND_OTHERS 160         // ... after folding the copies of one key, if at most this many others remain
 #define CAND_PAIRWISE 160      // ... by comparing all pairs; above that, by radix refinement in LDS
 
 // pick the bucket that contains the krem-th largest key of a histogram held in LDS
@@ -657,6 +658,9 @@ struct EmitShared {
     uint32_t bc[CAND_RAW];
     uint16_t ec[CAND_MAX], eb[CAND_MAX];
     uint32_t mh[256];
+    u64 ok[CAND_OTHERS + 1];
+    uint32_t oc[CAND_OTHERS + 1], c0;
+    int n_others;
     uint32_t predw[256];
     int col[256];
     uint32_t wave[4];
@@ -695,8 +699,6 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
         uint32_t krem;
         sel_resolve<256>(d, p, d.sel_passes - 1, h, s_wave, &P, &krem, &s_prefix, &s_krem);
         __syncthreads();
-        if (d.sel_passes > 1)                       // pass-0 histogram is consumed: clear it for its next use
-            for (int i = b * 256 + tid; i < HIST_REP * SEL_BINS; i += nblk * 256) d.hist0[(size_t)p * HIST_REP * SEL_BINS + i] = 0;
         const int lowbits = sel_shift(d.sel_passes - 1);        // key bits not resolved by launches
         const u64 hiP = P >> lowbits, hi = my_key >> lowbits;
         const bool c_gt = c < d.C && hi > hiP, c_cand = c < d.C && hi == hiP;
@@ -798,6 +800,7 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
         __syncthreads();
         const int ne = s_ne;
         if (!(s_flags & 1u) && ne <= CAND_MAX) {
+            bool folded = false;
             if (ne <= d.cand_pairwise) {                // the krem-th largest of the merged bucket: all pairs
                 for (int e = tid; e < ne; e += 256) {
                     const u64 ke = s_ek[e];
@@ -813,8 +816,48 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
                 __syncthreads();
                 T = s_T;
                 r = s_r;
-            } else {                                  // many entries (overlaps tie in most blocks): 8-bit radix
-                u64 pref = 0;                         // refinement over the entries, one bin per thread
+            } else {
+                // many entries: overlaps tie and most blocks report the same key.  Fold the copies of the
+                // first entry's key into one entry; if few others remain, all pairs again
+                const u64 K0 = s_ek[0];
+                if (tid == 0) { sh->n_others = 0; sh->c0 = 0; }
+                __syncthreads();
+                uint32_t c0 = 0;
+                for (int e = tid; e < ne; e += 256) {
+                    const u64 ke = s_ek[e];
+                    if (ke == K0) {
+                        c0 += s_ec[e];
+                    } else {
+                        const int pos = atomicAdd(&sh->n_others, 1);
+                        if (pos < CAND_OTHERS) { sh->ok[pos] = ke; sh->oc[pos] = s_ec[e]; }
+                    }
+                }
+                for (int o = 32; o > 0; o >>= 1) c0 += __shfl_xor(c0, o);
+                if (lane == 0 && c0) atomicAdd(&sh->c0, c0);
+                __syncthreads();
+                const int no = sh->n_others;
+                folded = no < d.cand_others;
+                if (folded) {
+                    if (tid == 0) { sh->ok[no] = K0; sh->oc[no] = sh->c0; }
+                    __syncthreads();
+                    for (int e = tid; e <= no; e += 256) {
+                        const u64 ke = sh->ok[e];
+                        uint32_t ng = 0, nq = 0;
+                        for (int f = 0; f <= no; ++f) {
+                            const u64 kf = sh->ok[f];
+                            const uint32_t cf = sh->oc[f];
+                            ng += kf > ke ? cf : 0u;
+                            nq += kf == ke ? cf : 0u;
+                        }
+                        if (ng < krem && krem <= ng + nq) { s_T = ke; s_r = krem - ng; }
+                    }
+                    __syncthreads();
+                    T = s_T;
+                    r = s_r;
+                }
+            }
+            if (ne > d.cand_pairwise && !folded) {    // still many distinct keys: 8-bit radix refinement
+                u64 pref = 0;                         // over the entries, one bin per thread
                 uint32_t rem = krem;
                 for (int top = lowbits; top > d.low_zero;) {
                     const int bits = min(8, top), shift = top - bits, nb = 1 << bits;
@@ -873,6 +916,10 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
             if (b == 0 && tid == 0) d.ctr->sel_fallbacks += 1;
         }
         if (b == 0 && tid == 0) { d.ctr->sel_prefix[p] = T; d.ctr->sel_krem[p] = r; }
+        // the pass-0 histogram is consumed: clear it for its next use (here, not earlier: a barrier
+        // waits for outstanding stores, and the record exchange above is the critical chain)
+        if (d.sel_passes > 1)
+            for (int i = b * 256 + tid; i < HIST_REP * SEL_BINS; i += nblk * 256) d.hist0[(size_t)p * HIST_REP * SEL_BINS + i] = 0;
     } else {
         T = d.ctr->sel_prefix[p];
         r = d.ctr->sel_krem[p];
@@ -2196,7 +2243,9 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
         d.cand_d = CAND_D;
         if (const char *e = getenv("BITHTM_CAND_D")) d.cand_d = std::max(0, std::min(CAND_D, atoi(e)));
         d.cand_pairwise = CAND_PAIRWISE;
-        if (const char *e = getenv("BITHTM_CAND_PAIRWISE")) d.cand_pairwise = std::max(0, atoi(e));     // test knob
+        if (const char *e = getenv("BITHTM_CAND_PAIRWISE")) d.cand_pairwise = std::max(0, atoi(e));     // test knobs
+        d.cand_others = CAND_OTHERS;
+        if (const char *e = getenv("BITHTM_CAND_OTHERS")) d.cand_others = std::max(0, std::min(CAND_OTHERS, atoi(e)));
     }
     e = hipStreamSynchronize(h->stream);
     if (e != hipSuccess) return fail_create(h, std::string("hipStreamSynchronize: ") + hipGetErrorString(e), HTM_ERR_HIP);

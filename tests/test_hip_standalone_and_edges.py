@@ -175,18 +175,20 @@ def test_batched_run_equals_step_by_step():
             assert np.array_equal(a, b)
 
 
-@pytest.mark.parametrize("digits,slots,pairwise", [("2", "8", "128"), ("3", "8", "128"), ("2", "0", "128"), ("2", "1", "128"),
-                                                   ("2", "8", "0")])
-def test_select_is_exact_on_the_record_path_and_on_the_fallback(digits, slots, pairwise, monkeypatch):
+@pytest.mark.parametrize("digits,slots,pairwise,others", [("2", "8", "160", "160"), ("3", "8", "160", "160"), ("2", "0", "160", "160"),
+                                                          ("2", "1", "160", "160"), ("2", "8", "0", "160"), ("2", "8", "0", "0")])
+def test_select_is_exact_on_the_record_path_and_on_the_fallback(digits, slots, pairwise, others, monkeypatch):
     """k_sp_emit finishes the top-k select from per-block bucket records.  slots=0 makes every block
     with a bucket key overflow its record, so the exact in-kernel fallback runs every step; slots=1
     mixes both paths; 3 launched digits is the variant with smaller buckets; pairwise=0 merges the
-    records by radix refinement on every step instead of only when many blocks report ties."""
+    records on every step the way a many-way tie is merged (copies of one key folded, then all
+    pairs), and with others=0 by radix refinement."""
     import bithtm_amd as B
     from oracle import HTMOracle
     monkeypatch.setenv("BITHTM_SEL_LAUNCH_DIGITS", digits)
     monkeypatch.setenv("BITHTM_CAND_D", slots)
     monkeypatch.setenv("BITHTM_CAND_PAIRWISE", pairwise)
+    monkeypatch.setenv("BITHTM_CAND_OTHERS", others)
     np.random.seed(31)
     htm = B.HierarchicalTemporalMemory(300, 4096, 8)
     ora = HTMOracle(300, 4096, 8, seed=0, permanence=htm.spatial_pooler.proximal_projection.permanence.copy())
@@ -196,8 +198,8 @@ def test_select_is_exact_on_the_record_path_and_on_the_fallback(digits, slots, p
         x = bank[t % 40] ^ (rng.rand(300) < 0.01)
         s, m = htm.process(x)
         os_, om = ora.step(x)
-        assert np.array_equal(s.active_column, os_.active_column), (digits, slots, t)
-        assert np.array_equal(m.cell_prediction, om.cell_prediction), (digits, slots, t)
+        assert np.array_equal(s.active_column, os_.active_column), (digits, slots, pairwise, others, t)
+        assert np.array_equal(m.cell_prediction, om.cell_prediction), (digits, slots, pairwise, others, t)
     htm.engine.check_capacity()
 
 
