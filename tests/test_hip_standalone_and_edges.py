@@ -175,14 +175,15 @@ def test_batched_run_equals_step_by_step():
             assert np.array_equal(a, b)
 
 
-@pytest.mark.parametrize("digits,slots,pairwise,others", [("2", "8", "160", "160"), ("3", "8", "160", "160"), ("2", "0", "160", "160"),
-                                                          ("2", "1", "160", "160"), ("2", "8", "0", "160"), ("2", "8", "0", "0")])
+@pytest.mark.parametrize("digits,slots,pairwise,others", [("2", "8", "160", "128"), ("3", "8", "160", "128"), ("2", "0", "160", "128"),
+                                                          ("2", "1", "160", "128"), ("2", "8", "0", "128"), ("2", "8", "0", "4"), ("2", "8", "0", "0")])
 def test_select_is_exact_on_the_record_path_and_on_the_fallback(digits, slots, pairwise, others, monkeypatch):
     """k_sp_emit finishes the top-k select from per-block bucket records.  slots=0 makes every block
     with a bucket key overflow its record, so the exact in-kernel fallback runs every step; slots=1
     mixes both paths; 3 launched digits is the variant with smaller buckets; pairwise=0 merges the
-    records on every step the way a many-way tie is merged (copies of one key folded, then all
-    pairs), and with others=0 by radix refinement."""
+    records on every step the way a many-way tie is merged (the copies of one key folded into one
+    entry, then all pairs if fewer than `others` other entries remain, else radix refinement:
+    others=4 mixes both, others=0 is radix only)."""
     import bithtm_amd as B
     from oracle import HTMOracle
     monkeypatch.setenv("BITHTM_SEL_LAUNCH_DIGITS", digits)
