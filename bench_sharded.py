@@ -77,6 +77,28 @@ def run_sharded(args):
     dist.all_reduce(lo, op=dist.ReduceOp.MIN)
     dist.all_reduce(hi, op=dist.ReduceOp.MAX)
     consistent = bool((lo == hi).all().item())
+    # per-kernel device time on this rank (HIP events on the engine's stream) over a short profiled replay;
+    # every rank takes part, the exchange is collective
+    roofline = None
+    try:
+        prof_steps = min(args.steps, 100)
+        eng.profile(True)
+        htm.run(bank, n_bank, prof_steps)
+        prof = eng.profile_read()
+        eng.profile(False)
+        if rank == 0 and "tm_scan" in prof:
+            store = eng.read_store()
+            c0, c1 = htm.column_range
+            own = (store["seg_cell"] // K >= c0) & (store["seg_cell"] // K < c1)
+            nbytes = 4 * int(store["seg_nsyn"][own].sum()) + 8 * len(store["seg_nsyn"])
+            ms, n = prof["tm_scan"]
+            us = 1e3 * ms / max(n, 1)
+            roofline = dict(bound="hbm", kernel="tm_scan (rank 0's own segments)", achieved=round(nbytes / us / 1e3, 1), peak=bench.HBM_PEAK_GBS,
+                            unit="GB/s", frac=round(nbytes / us / 1e3 / bench.HBM_PEAK_GBS, 4), traffic=None, bytes_per_launch=nbytes,
+                            avg_launch_us=round(us, 2),
+                            kernel_us_per_step={k: round(1e3 * v[0] / prof_steps, 2) for k, v in prof.items()})
+    except Exception as e:                           # the roofline object is a report, never a reason to lose the line
+        bench.log(f"[bench_sharded] roofline pass skipped: {e}")
     out = None
     if rank == 0:
         steps_per_s = args.steps / dt
@@ -90,7 +112,7 @@ def run_sharded(args):
                         patterns=w["patterns"], input_density=w["density"], flip_noise=w["noise"],
                         segments=int(info.segments), segment_slots=w["segment_slots"], backend=backend,
                         exchange_bytes_per_rank=int(eng.shard_record_bytes()), ranks_consistent=consistent),
-            roofline=None, cpu_baseline=None)
+            roofline=roofline, cpu_baseline=None)
     dist.barrier()
     dist.destroy_process_group()
     return out

@@ -1287,16 +1287,6 @@ __device__ __forceinline__ void role_mid(const Dev &d, int p, int n_active, int 
     }
 }
 
-__global__ __launch_bounds__(1024) void k_tm_mid(Dev d, int p, int n_active, int want_winner, int learning,
-                                                 const uint32_t *__restrict__ bank, int n_inputs, int n_cls, int n_sp_rows) {
-    if ((int)blockIdx.x > n_cls) {                  // two winner rows per block
-        const int ri = (int)(blockIdx.x - 1 - n_cls) * 2 + (int)(threadIdx.x >> 9);
-        if (ri < n_sp_rows) role_sp_row<512>(d, p, bank, n_inputs, 0, ri, threadIdx.x & 511);
-        return;
-    }
-    role_mid<1024>(d, p, n_active, want_winner, learning, blockIdx.x, n_cls);
-}
-
 // SparseProjection.update_permanence (projections.py:97-109) and add_edge (:111-161) for one
 // work item per wave.  Permanences: float64 sum, float32 store, prune on the float64 value; the
 // surviving synapses are re-packed to the front of the row.  Growth: the n_add previous winner
@@ -1726,22 +1716,23 @@ __global__ __launch_bounds__(256) void k_open_emit(Dev d, int p, int n_emit_bloc
     }
 }
 
-// blocks [0, 1 + n_cls): the middle of the TM step; then one winner row of the coming step per block;
-// then its duty cycle (regularizations.py:19-21, float32, two roundings).  256-thread blocks: the
+// blocks [0, 1 + n_cls): the middle of the TM step; then one SP winner row per block -- of this step
+// (rows_ahead = 0: one role per launch) or of the coming one (pipelined schedule) --; then the coming
+// step's duty cycle (regularizations.py:19-21, float32, two roundings).  256-thread blocks: the
 // dispatcher places them about five times faster, wave for wave, than 1024-thread ones (measured:
 // 2000 small blocks start within 1 us, 800 large ones take 7), and all of them are resident at once.
-__global__ __launch_bounds__(256) void k_mid_rows(Dev d, int p, int n_active, int learning, int n_cls,
-                                                  const uint32_t *__restrict__ bank, int n_inputs, int n_rows, int n_duty_blocks) {
+__global__ __launch_bounds__(256) void k_mid_rows(Dev d, int p, int n_active, int want_winner, int learning, int n_cls,
+                                                  const uint32_t *__restrict__ bank, int n_inputs, int n_rows, int rows_ahead, int n_duty_blocks) {
     TraceScope ts(d, 1 + 4 * p);
     int b = blockIdx.x;
     if (b <= n_cls) {
-        role_mid<256>(d, p, n_active, 1, learning, b, n_cls);
+        role_mid<256>(d, p, n_active, want_winner, learning, b, n_cls);
         return;
     }
     b -= 1 + n_cls;
     const int q = p ^ 1;
     if (b < n_rows) {
-        role_sp_row<256>(d, q, bank, n_inputs, 1, b, threadIdx.x);
+        role_sp_row<256>(d, rows_ahead ? q : p, bank, n_inputs, rows_ahead, b, threadIdx.x);
         return;
     }
     b -= n_rows;
@@ -1902,7 +1893,7 @@ static int prof_slot(htm_handle *h, const char *name) {
 static size_t learn_lds(int epl, int bs = RB) { return (size_t)(bs / 64) * CAND_CAP * 8 + (size_t)(bs / 64) * epl * 64 * 4; }
 static int learn_epl(const Dev &d) { const int e = d.E / 64; return e <= 1 ? 1 : e == 2 ? 2 : e <= 4 ? 4 : 8; }
 static size_t scan_lds(const Dev &d, int use_lds) { return 16 + (use_lds ? (size_t)d.colwords * 4 : 0); }
-static const int kClassifyBlocks = 96;            // x 1024 segments per pass of the learn / punish classification
+static const int kClassifyBlocks = 384;           // x 256 segments per pass of the learn / punish classification
 static const int kLearnBlocks = 256;               // x RB/64 waves: one wave per learning / punished segment
 
 static void launch_learn(htm_handle *h, int p) {
@@ -1965,8 +1956,7 @@ static void enqueue_tm(htm_handle *h, int n_active, int learning, int want_winne
     Dev &d = h->d;
     const int n_cls = learning ? kClassifyBlocks : 0;
     const int n_sp_rows = (sp_rows && learning && h->cfg.enable_sp) ? d.k : 0;
-    LAUNCH(h, "tm_mid", k_tm_mid, 1 + n_cls + (n_sp_rows + 1) / 2, 1024, d, p, n_active, want_winner, learning, bank, n_inputs,
-           n_cls, n_sp_rows);
+    LAUNCH(h, "tm_mid", k_mid_rows, 1 + n_cls + n_sp_rows, 256, d, p, n_active, want_winner, learning, n_cls, bank, n_inputs, n_sp_rows, 0, 0);
     launch_learn(h, p);
     launch_scan(h, p, scan_lds(d, 1) <= 64 * 1024);
 }
@@ -1995,8 +1985,7 @@ static void enqueue_pipelined(htm_handle *h, int p, int learning, const uint32_t
     const int n_emit = plan.next_sp ? h->c256_blocks : 0;
     LAUNCH_ON(h, h->stream, sizeof(EmitShared), "tm_activate+sp_emit", k_open_emit, n_emit + (d.k * 32 + 255) / 256, 256, d, p, n_emit, d.k);
     const int n_rows = (plan.next_sp && learning) ? d.k : 0, n_duty = plan.next_sp ? h->c256_blocks : 0;
-    LAUNCH(h, "tm_mid+sp_learn", k_mid_rows, 1 + 4 * n_cls + n_rows + n_duty, 256, d, p, d.k, learning, 4 * n_cls, bank, n_inputs, n_rows,
-           n_duty);
+    LAUNCH(h, "tm_mid+sp_learn", k_mid_rows, 1 + n_cls + n_rows + n_duty, 256, d, p, d.k, 1, learning, n_cls, bank, n_inputs, n_rows, 1, n_duty);
     {
         const int epl = learn_epl(d);
         const size_t lds = std::max(learn_lds(epl), (size_t)SEL_BINS * 4);
