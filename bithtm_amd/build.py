@@ -8,7 +8,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libbithtm_hip.so")
 SOURCES = ["htm_engine.hip"]
-HEADERS = ["htm_rng.h", "htm_fexp.h", os.path.join("..", "..", "include", "bithtm_hip.h")]
+HEADERS = ["htm_dev.h", "htm_sp_kernels.h", "htm_tm_kernels.h", "htm_pipeline.h", "htm_rng.h", "htm_fexp.h",
+           os.path.join("..", "..", "include", "bithtm_hip.h")]
 # -ffp-contract=off: several kernels must round exactly like the NumPy expressions they replace
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
          "-fno-fast-math", "-Wall", "-Wno-unused-result", "-Wno-unused-value"]

@@ -1,0 +1,173 @@
+// Constants, the device counter block, the kernel argument struct and small device helpers.
+// Part of the single translation unit htm_engine.hip (included there, in this order:
+// htm_dev.h, htm_sp_kernels.h, htm_tm_kernels.h, htm_pipeline.h).
+#ifndef BITHTM_HTM_DEV_H
+#define BITHTM_HTM_DEV_H
+
+typedef unsigned long long u64;
+
+#define SEL_MAX_PASSES 6
+#define SEL_DIGIT 12
+#define SEL_BINS 4096         // 1 << SEL_DIGIT
+#define HIST_REP 8            // copies of the digit-0 histogram (its few hot bins take one atomic per block)
+#define RB 512                // threads per block of the role kernels (overlap, select, learn, scan)
+#define SCAN_SEGS 64          // segments per 256-thread block iteration of the segment scan
+#define DEAD_CAP 256          // newly dead segment ids one rank can report per exchange
+#define CAND_CAP 256          // growth candidates staged per wave
+#define MAX_SLOTS 512
+#define EPS32 1e-8f           // `epsilon=1e-8` against float32 arrays (weak Python scalar)
+
+// radix-select digit p covers key bits [shift, shift + bits): 12 bits from the top, the last one 4
+__host__ __device__ __forceinline__ int sel_shift(int pass) { return pass < 5 ? 52 - SEL_DIGIT * pass : 0; }
+__host__ __device__ __forceinline__ int sel_bits(int pass) { return pass < 5 ? SEL_DIGIT : 4; }
+
+// ------------------------------------------------------------------------------------------
+// device-resident scalars
+struct Counters {
+    uint32_t step[2];         // timestep index (key of the random draws); step t reads step[t & 1]
+                              // and its last kernel writes step[(t + 1) & 1] = t + 1
+    int32_t S;                // allocated segment ids
+    int32_t n_win[2];         // winner cells of step parity p
+    int32_t has_winner[2];    // winner list of parity p is valid (winner_cell is not None)
+    int32_t has_distal;       // a scan has run (distal_state is not None)
+    int32_t n_active_cells;
+    int32_t n_work;           // learning / punish work items of this step (front of the work array)
+    int32_t n_bind;           // newly bound segments of this step (back of the work array, growing down)
+    int32_t n_work_last;      // ... of the last completed step (telemetry)
+    int32_t sel_fallbacks;    // steps whose top-k select took the in-kernel fallback (telemetry)
+    uint32_t emit_epoch;      // bumped by every overlap launch: tags the records k_sp_emit's blocks exchange
+    int32_t n_un;             // winners needing a new segment
+    int32_t n_recycled, n_new, S_old;
+    int32_t error;            // sticky capacity flags
+    // Spatial Pooler select state, double-buffered by the parity of the step it belongs to (the
+    // pipelined schedule computes step t+1's overlap / select digits while step t's TM runs)
+    u64 sel_prefix[2];        // k-th largest key and how many of the keys equal to it are winners
+    uint32_t sel_krem[2];
+    u64 sel_pass_prefix[2][SEL_MAX_PASSES + 1];    // radix-select state entering pass p
+    uint32_t sel_pass_krem[2][SEL_MAX_PASSES + 1];
+};
+
+struct Dev {
+    int I, W, W4, Ipad, C, K, k, E, Scap, work_cap, sel_passes, colwords, low_zero, cand_d, cand_pairwise, cand_others;
+    int world, c0, c1;        // this rank owns columns [c0, c1) (world == 1: everything)
+    double sp_thr, sp_don, sp_doff;
+    float coef, mom, dinc;
+    double lrn_act, lrn_inact, pun_act, pun_inact;
+    int lrn_prune, pun_prune;
+    float perm_init, perm_thr;
+    int act_thr, match_thr, sample;
+    uint32_t seed;
+    // Spatial Pooler
+    double *perm;             // [C][Ipad] float64 permanences (projections.py:16)
+    uint32_t *mask;           // [C][W]    bit-packed `permanence >= threshold` (projections.py:19)
+    float *duty;              // [C]
+    int *overlap[2];          // [C]   parity double buffer, like the select state
+    double *boosted[2];       // [C]
+    u64 *key[2];              // [C] bits of boosted (non-negative doubles order like uint64)
+    uint32_t *hist;           // [2][SEL_MAX_PASSES][SEL_BINS]  (digits 1..)
+    uint32_t *hist0;          // [2][HIST_REP][SEL_BINS]        digit 0: block b adds to copy b % HIST_REP
+    uint32_t *sel_blk;        // [ceil(C/256)] packed (greater, equal) counts per 256-column block
+    uint32_t *sel_rec;        // [ceil(C/256)][32] per-block bucket records of k_sp_emit (16 granules)
+    int *active_cols[2];      // [k] ascending; parity double buffer (the pipelined schedule emits step t+1's
+                              // list while step t's scan still reads its own)
+    uint32_t *input_stage;    // [W] host-fed input
+    // Temporal Memory
+    uint32_t *act[2];         // [C] active-cell words, parity double buffer
+    uint32_t *pred[2];        // [C] predicted-cell words
+    uint32_t *win[2];         // [C] winner-cell words
+    uint32_t *colbits[2];     // [ceil(C/64)*2] bitmap of the step's active columns
+    int *winners[2];          // [k*32] winner cells (enc), ascending
+    uint8_t *bursting;        // [k]
+    uint32_t *winw_idx;       // [k] winner word of the idx-th active column (same as win[active_cols[idx]])
+    uint8_t *actcnt;          // [k] popc(active word) of the idx-th active column
+    uint32_t *unacc_word;     // [k]
+    int *unacc_list;          // [k*32] winners without a matching segment, ascending
+    int *seg_cell;            // [Scap] owning cell (enc)
+    int *seg_nsyn;            // [Scap] valid synapses; rows are packed: slots [0, nsyn) are valid
+    int *presyn;              // [Scap][E] presynaptic cell (enc)
+    float *sperm;             // [Scap][E] float32 permanence
+    int *segcount;            // [C*32] segments per cell
+    uint32_t *cellmax;        // [C*32] float bits of max jittered potential per cell (0 = none)
+    uint32_t *seg_info;       // [Scap] last scan: potential | activation << 12 | matching << 30 | active << 31
+    float *seg_jit;           // [Scap] jittered potential of the matching segments
+    uint32_t *work;           // [work_cap] segment | mode << 31 (0 = learn + grow, 1 = punish)
+    int *recyc_cnt;           // [ceil(Scap/1024)] recyclable segments per 1024-segment block
+    int *recyc_need;          // [2*k*32] (block, first rank) pairs of the blocks add_output draws from
+    // column sharding (world > 1): speculative per-column words of ALL columns after the exchange,
+    // and the ids of owned segments that fell below the matching threshold while learning
+    uint32_t *spec_act, *spec_win, *spec_unacc, *spec_burst;      // [C] [C] [C] [ceil(C/32)]
+    int *dead_list;           // [1 + DEAD_CAP]: count, ids
+    Counters *ctr;
+    unsigned long long *trace;    // [8][4096][2] BITHTM_TRACE=1: device clock at the start / end of every block of the
+                                  // pipelined launches (slot = launch + 4 * step parity), else null
+    uint32_t trace_until;         // ... of steps with an index below this (BITHTM_TRACE_UNTIL; default: all)
+};
+
+// ------------------------------------------------------------------------------------------
+// small device helpers
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ u64 lanemask_lt() { return (1ull << lane_id()) - 1ull; }
+
+template <int BS>
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *s_wave, uint32_t &total) {
+    const int lane = lane_id(), wv = threadIdx.x >> 6;
+    uint32_t x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t y = __shfl_up(x, o);
+        if (lane >= o) x += y;
+    }
+    if (lane == 63) s_wave[wv] = x;
+    __syncthreads();
+    uint32_t woff = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < BS / 64; ++i) {
+        uint32_t t = s_wave[i];
+        if (i < wv) woff += t;
+        tot += t;
+    }
+    __syncthreads();
+    total = tot;
+    return woff + x - v;
+}
+
+// all lanes of the wave must call; returns the slot for lanes with pred, -1 otherwise
+__device__ __forceinline__ int wave_append(int *counter, bool pred) {
+    u64 m = __ballot(pred);
+    if (m == 0) return -1;
+    int leader = __ffsll((long long)m) - 1;
+    int base = 0;
+    if (lane_id() == leader) base = atomicAdd(counter, __popcll(m));
+    base = __shfl(base, leader);
+    return pred ? base + __popcll(m & lanemask_lt()) : -1;
+}
+
+// h[digit] += 1 for every lane with `active`, one LDS atomic per distinct digit in the wave (keys
+// of neighbouring columns mostly share their leading digits: per-lane atomics would serialise).
+// All lanes of the wave must call.
+__device__ __forceinline__ void hist_add(uint32_t *h, uint32_t digit, bool active) {
+    u64 todo = __ballot(active);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const uint32_t dl = __shfl(digit, leader);
+        const u64 same = __ballot(active && digit == dl) & todo;
+        if (lane_id() == leader) atomicAdd(&h[dl], (uint32_t)__popcll(same));
+        todo &= ~same;
+    }
+}
+
+// bits of v moved to the even bit positions of a 64-bit word
+__device__ __forceinline__ u64 spread32(uint32_t v) {
+    u64 x = v;
+    x = (x | (x << 16)) & 0x0000FFFF0000FFFFull;
+    x = (x | (x << 8)) & 0x00FF00FF00FF00FFull;
+    x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0Full;
+    x = (x | (x << 2)) & 0x3333333333333333ull;
+    x = (x | (x << 1)) & 0x5555555555555555ull;
+    return x;
+}
+
+__device__ __forceinline__ uint32_t cell_mask(int K) { return K >= 32 ? 0xFFFFFFFFu : ((1u << K) - 1u); }
+__device__ __forceinline__ uint32_t enc_to_flat(int enc, int K) { return (uint32_t)((enc >> 5) * K + (enc & 31)); }
+
+#endif

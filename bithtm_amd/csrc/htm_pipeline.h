@@ -1,0 +1,113 @@
+// The four fused launches of the pipelined schedule and the device-clock trace.
+// Part of the single translation unit htm_engine.hip (included there, in this order:
+// htm_dev.h, htm_sp_kernels.h, htm_tm_kernels.h, htm_pipeline.h).
+#ifndef BITHTM_HTM_PIPELINE_H
+#define BITHTM_HTM_PIPELINE_H
+
+// ---- pipelined schedule: roles of different steps share every launch ---------------------------
+// A forked stream / graph branch costs 17-29 us on this runtime and every dependent launch 1.2-3 us
+// plus its own chain of memory round trips; heterogeneous blocks in one launch cost nothing.  The
+// Spatial Pooler never reads Temporal Memory state, so inside a batched run it works ahead of the
+// Temporal Memory, role by role, in the same four launches (t = the TM's step):
+//
+//   k_open_emit(t)      activation of step t's winner columns     | rest of the select + winner list (t+1)
+//   k_mid_rows(t)       segment allocation, learn/punish list     | SP permanence rows + duty cycle (t+1)
+//   k_learn_overlap(t)  synapse learning and growth               | overlap + boost + select digit 0 (t+2)
+//   k_scan_sel(t)       segment scan                              | select digit 1 (t+2), clears for t+1
+//
+// The pairing follows what was measured with the device clock (tools/step_timeline.py): the scan's
+// gathers fill the memory pipeline and stretch every dependent access of a co-resident wave, and its
+// blocks take every CU slot, so it shares its launch only with the lightest SP role; the
+// latency-bound select finish runs beside the cheap activation; the two streaming roles (rows,
+// overlap) sit beside the latency-bound mid and learn roles.  The look-ahead includes the SP's
+// persistent updates (rows, duty cycle), so it only happens between two steps of one htm_run
+// call: the last two steps of a run look ahead less (StepPlan) and no call returns with SP work
+// outstanding.
+struct TraceScope {                                 // BITHTM_TRACE=1: first / last device clock of every block
+    unsigned long long *t;
+    __device__ TraceScope(const Dev &d, int slot) {
+        t = (d.trace && blockIdx.x < 4096 && d.ctr->step[slot >> 2] < d.trace_until) ? d.trace + ((size_t)slot * 4096 + blockIdx.x) * 2 : nullptr;
+        if (t && threadIdx.x == 0) t[0] = wall_clock64();
+    }
+    __device__ ~TraceScope() { if (t && threadIdx.x == 0) t[1] = wall_clock64(); }
+};
+
+// the emit blocks wait for each other's records: they come first in the grid, so that all of them
+// are resident whatever the other blocks do
+__global__ __launch_bounds__(256) void k_open_emit(Dev d, int p, int n_emit_blocks, int n_active) {
+    TraceScope ts(d, 0 + 4 * p);
+    if ((int)blockIdx.x < n_emit_blocks) {
+        role_emit(d, p ^ 1, 1, 1, 0, blockIdx.x, n_emit_blocks, (EmitShared *)dyn_lds);
+    } else {                                       // one active column per half-wave
+        const int idx = (((int)blockIdx.x - n_emit_blocks) * 256 + (int)threadIdx.x) >> 5;
+        const bool ok = idx < n_active;
+        const int a = ok ? d.active_cols[p][idx] : 0;
+        tm_activate_column(d, p, 1, ok, a, idx, ok ? d.pred[p ^ 1][a] : 0u);
+    }
+}
+
+// blocks [0, 1 + n_cls): the middle of the TM step; then one SP winner row per block -- of this step
+// (rows_ahead = 0: one role per launch) or of the coming one (pipelined schedule) --; then the coming
+// step's duty cycle (regularizations.py:19-21, float32, two roundings).  256-thread blocks: the
+// dispatcher places them about five times faster, wave for wave, than 1024-thread ones (measured:
+// 2000 small blocks start within 1 us, 800 large ones take 7), and all of them are resident at once.
+__global__ __launch_bounds__(256) void k_mid_rows(Dev d, int p, int n_active, int want_winner, int learning, int n_cls,
+                                                  const uint32_t *__restrict__ bank, int n_inputs, int n_rows, int rows_ahead, int n_duty_blocks) {
+    TraceScope ts(d, 1 + 4 * p);
+    int b = blockIdx.x;
+    if (b <= n_cls) {
+        role_mid<256>(d, p, n_active, want_winner, learning, b, n_cls);
+        return;
+    }
+    b -= 1 + n_cls;
+    const int q = p ^ 1;
+    if (b < n_rows) {
+        role_sp_row<256>(d, rows_ahead ? q : p, bank, n_inputs, rows_ahead, b, threadIdx.x);
+        return;
+    }
+    b -= n_rows;
+    const int c = b * 256 + (int)threadIdx.x;
+    if (b < n_duty_blocks && c < d.C) {
+        float dc = d.duty[c] * d.mom;
+        if ((d.colbits[q][c >> 5] >> (c & 31)) & 1u) dc = dc + d.dinc;
+        d.duty[c] = dc;
+    }
+}
+
+template <int EPL>
+__global__ __launch_bounds__(RB) void k_learn_overlap(Dev d, int p, int n_learn_blocks, const uint32_t *__restrict__ bank,
+                                                        int n_inputs, int G, int sp, int step_offset) {
+    TraceScope ts(d, 2 + 4 * p);
+    if ((int)blockIdx.x < n_learn_blocks)
+        role_learn<EPL, RB>(d, p, blockIdx.x, n_learn_blocks, (LearnShared<EPL, RB> *)dyn_lds);
+    else
+        role_overlap<RB>(d, bank, n_inputs, G, p, sp, step_offset, blockIdx.x - n_learn_blocks, gridDim.x - n_learn_blocks, (uint32_t *)dyn_lds);
+}
+
+// blocks [0, n_sel): select digit 1 for the SP step with parity sp; then n_clear blocks that zero the
+// dense per-column words of the coming step (what EMIT_CLEAR does when the winner list is emitted in a
+// launch of its own: here the learning role still needed them after the emit); the rest: the scan.
+// The few short SP blocks come first: behind the scan blocks they would wait for a free CU slot.
+template <bool use_lds, int MINW>
+__global__ __launch_bounds__(256, MINW) void k_scan_sel(Dev d, int p, int n_sel_blocks, int n_clear_blocks, int sp, int n_spec) {
+    TraceScope ts(d, 3 + 4 * p);
+    int b = blockIdx.x;
+    if (b < n_sel_blocks) {
+        role_sel_pass<256>(d, 1, sp, b, n_sel_blocks, (SelShared *)dyn_lds);
+        return;
+    }
+    b -= n_sel_blocks;
+    if (b < n_clear_blocks) {
+        const int c = b * 256 + (int)threadIdx.x, q = p ^ 1;
+        if (c < d.C) {
+            d.act[q][c] = 0;
+            d.win[q][c] = 0;
+            d.pred[q][c] = 0;
+        }
+        return;
+    }
+    b -= n_clear_blocks;
+    role_scan<256, use_lds>(d, p, b, gridDim.x - n_sel_blocks - n_clear_blocks, n_spec, (uint32_t *)dyn_lds);
+}
+
+#endif

@@ -1,0 +1,838 @@
+// Spatial Pooler roles and kernels: mask build, overlap + boost, radix select, select finish + emit (with the
+// Temporal Memory per-column activation it ends in), permanence rows; the two kernels around the sharded exchange.
+// Part of the single translation unit htm_engine.hip (included there, in this order:
+// htm_dev.h, htm_sp_kernels.h, htm_tm_kernels.h, htm_pipeline.h).
+#ifndef BITHTM_HTM_SP_KERNELS_H
+#define BITHTM_HTM_SP_KERNELS_H
+
+// ------------------------------------------------------------------------------------------
+// Spatial Pooler
+
+// projections.py:19 for whole rows (after htm_sp_set_permanence)
+__global__ __launch_bounds__(256) void k_sp_build_mask(Dev d, int row_begin, int row_count) {
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    const int lane = lane_id();
+    const int chunks = d.Ipad >> 6;                       // 64 elements per ballot
+    for (long long t = wave; t < (long long)row_count * chunks; t += nwaves) {
+        int row = row_begin + (int)(t / chunks), ch = (int)(t % chunks);
+        int i = ch * 64 + lane;
+        bool conn = (i < d.I) && (d.perm[(size_t)row * d.Ipad + i] >= d.sp_thr);
+        u64 m = __ballot(conn);
+        if (lane == 0) *(u64 *)&d.mask[(size_t)row * d.W + ch * 2] = m;
+    }
+}
+
+// DenseProjection.process (projections.py:18-21) + ExponentialBoosting.process
+// (regularizations.py:15-17).  G lanes share one row (G = power of two, W4 16-byte chunks per row).
+// Sharded handles run it on their own rows only and leave the histogram to k_shard_unpack, which
+// sees the keys of all columns.
+// Roles are written against (blk, nblk) instead of blockIdx / gridDim so that two independent
+// roles can share one launch (pipelined schedule: step t's TM work beside step t+1's SP work).
+// sp = parity buffer of the SP step being computed; step_offset = that step minus the current one.
+template <int BS>
+__device__ __forceinline__ void role_overlap(const Dev &d, const uint32_t *__restrict__ bank, int n_inputs, int G,
+                                             int p, int sp, int step_offset, int blk, int nblk, uint32_t *h) {
+    const int gtid = blk * BS + threadIdx.x;
+    const int nthreads = nblk * BS;
+    const bool do_hist = d.world == 1;
+    uint32_t *ghist = d.hist + sp * SEL_MAX_PASSES * SEL_BINS;
+    if (gtid == 0) d.ctr->emit_epoch += 1;          // a new generation of k_sp_emit records
+    if (do_hist) {
+        for (int i = gtid; i < (d.sel_passes - 1) * SEL_BINS; i += nthreads) ghist[SEL_BINS + i] = 0;
+        for (int i = threadIdx.x; i < SEL_BINS; i += BS) h[i] = 0;
+        if (gtid == 0) {
+            d.ctr->sel_pass_prefix[sp][0] = 0;
+            d.ctr->sel_pass_krem[sp][0] = (uint32_t)d.k;
+        }
+        __syncthreads();
+    }
+    const uint4 *in4 = (const uint4 *)(bank + (size_t)((d.ctr->step[p] + (uint32_t)step_offset) % (uint32_t)n_inputs) * d.W);
+    const uint4 *mask4 = (const uint4 *)d.mask;
+    const int lane = lane_id();
+    const int rpw = 64 / G, sub = lane / G, l = lane % G;
+    const int wave = gtid >> 6, nwaves = nthreads >> 6;
+    constexpr int U = 4;                           // row groups in flight per wave
+    for (int row0 = d.c0 + wave * rpw * U; row0 < d.c1; row0 += nwaves * rpw * U) {
+        int cnt[U];
+        float dty[U];                              // fetched with the mask rows, not after the reduction
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            cnt[u] = 0;
+            const int row = row0 + u * rpw + sub;
+            dty[u] = (l == 0 && row < d.c1) ? d.duty[row] : 0.f;
+        }
+        for (int j = l; j < d.W4; j += G) {
+            const uint4 x = in4[j];
+            uint4 m[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int row = row0 + u * rpw + sub;
+                m[u] = row < d.c1 ? mask4[(size_t)row * d.W4 + j] : make_uint4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                cnt[u] += __popc(m[u].x & x.x) + __popc(m[u].y & x.y) + __popc(m[u].z & x.z) + __popc(m[u].w & x.w);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            int cn = cnt[u];
+            for (int o = G >> 1; o > 0; o >>= 1) cn += __shfl_xor(cn, o);
+            const int row = row0 + u * rpw + sub;
+            const bool owner = l == 0 && row < d.c1;
+            u64 key = 0;
+            if (owner) {
+                d.overlap[sp][row] = cn;
+                const float f = htm_exp_f32(d.coef * dty[u]);          // float32 product, documented exp
+                const double bo = (double)f * (double)cn;              // exact (24-bit x <= 16-bit)
+                d.boosted[sp][row] = bo;
+                key = (u64)__double_as_longlong(bo);
+                d.key[sp][row] = key;
+            }
+            if (do_hist) hist_add(h, (uint32_t)(key >> sel_shift(0)), owner);
+        }
+    }
+    if (!do_hist) return;
+    __syncthreads();
+    uint32_t *g0 = d.hist0 + (size_t)(sp * HIST_REP + (blk & (HIST_REP - 1))) * SEL_BINS;
+    for (int i = threadIdx.x; i < SEL_BINS; i += BS)
+        if (h[i]) atomicAdd(&g0[i], h[i]);
+}
+
+__global__ __launch_bounds__(RB) void k_sp_overlap(Dev d, const uint32_t *__restrict__ bank, int n_inputs, int G, int p, int sp, int step_offset) {
+    __shared__ uint32_t h[SEL_BINS];               // histogram of the top key digit (select pass 0)
+    role_overlap<RB>(d, bank, n_inputs, G, p, sp, step_offset, blockIdx.x, gridDim.x, h);
+}
+
+// GlobalInhibition.process (regularizations.py:28-29) as an exact radix select of the k-th
+// largest key, one 12-bit digit per launch.  There is no intra-kernel hand-off: every block of
+// pass p re-derives the bucket chosen by pass p-1 from that pass's (complete) histogram.
+//
+// sel_resolve: given the state entering pass `prev` and its histogram, the state entering
+// pass prev+1.  Called by all BS threads of the block; h is SEL_BINS words of LDS scratch.
+template <int BS>
+__device__ __forceinline__ void sel_resolve(const Dev &d, int sp, int prev, uint32_t *h, uint32_t *s_wave,
+                                            u64 *out_prefix, uint32_t *out_krem, u64 *s_res_prefix, uint32_t *s_res_krem) {
+    const int tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
+    const int shift = sel_shift(prev), nb = 1 << sel_bits(prev);
+    const u64 prefix = d.ctr->sel_pass_prefix[sp][prev];
+    const uint32_t krem = d.ctr->sel_pass_krem[sp][prev];
+    const uint32_t *gh = d.hist + (sp * SEL_MAX_PASSES + prev) * SEL_BINS;
+    constexpr int PER = SEL_BINS / BS;            // bins per thread, thread t owns [t*PER, (t+1)*PER)
+    static_assert(PER % 4 == 0, "16-byte histogram accesses");
+    {   // fetch the histogram with coalesced 16-byte loads, all in flight; regroup through LDS
+        uint4 v[PER / 4];
+#pragma unroll
+        for (int j = 0; j < PER / 4; ++j) {
+            const int b = 4 * (j * BS + tid);
+            v[j] = (prev > 0 && b < nb) ? *(const uint4 *)(gh + b) : make_uint4(0, 0, 0, 0);
+        }
+        if (prev == 0) {                            // digit 0: sum the copies
+            const uint32_t *g0 = d.hist0 + (size_t)sp * HIST_REP * SEL_BINS;
+            for (int r = 0; r < HIST_REP; ++r)
+#pragma unroll
+                for (int j = 0; j < PER / 4; ++j) {
+                    const uint4 a = *(const uint4 *)(g0 + (size_t)r * SEL_BINS + 4 * (j * BS + tid));
+                    v[j].x += a.x; v[j].y += a.y; v[j].z += a.z; v[j].w += a.w;
+                }
+        }
+#pragma unroll
+        for (int j = 0; j < PER / 4; ++j) *(uint4 *)(h + 4 * (j * BS + tid)) = v[j];
+    }
+    __syncthreads();
+    uint32_t cs = 0;
+#pragma unroll
+    for (int j = 0; j < PER / 4; ++j) {
+        const uint4 v = *(const uint4 *)(h + tid * PER + 4 * j);
+        cs += v.x + v.y + v.z + v.w;
+    }
+    uint32_t x = cs;                              // inclusive suffix sum inside the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t y = __shfl_down(x, o);
+        if (lane + o < 64) x += y;
+    }
+    if (lane == 0) s_wave[wv] = x;                // wave total
+    __syncthreads();
+    uint32_t above = x - cs;                      // keys in bins above my chunk, inside my wave ...
+    for (int w = wv + 1; w < BS / 64; ++w) above += s_wave[w];      // ... plus the higher waves
+    if (above < krem && krem <= above + cs) {     // exactly one thread
+        for (int b = min((tid + 1) * PER, nb) - 1; b >= tid * PER; --b) {
+            const uint32_t hb = h[b];
+            if (above + hb >= krem) {
+                *s_res_prefix = prefix | ((u64)b << shift);
+                *s_res_krem = krem - above;
+                break;
+            }
+            above += hb;
+        }
+    }
+    __syncthreads();
+    *out_prefix = *s_res_prefix;
+    *out_krem = *s_res_krem;
+}
+
+struct SelShared { uint32_t h[SEL_BINS]; uint32_t wave[16]; u64 prefix; uint32_t krem; };
+
+template <int BS>
+__device__ __forceinline__ void role_sel_pass(const Dev &d, int pass, int sp, int blk, int nblk, SelShared *sh) {
+    const int tid = threadIdx.x;
+    u64 prefix;
+    uint32_t krem;
+    sel_resolve<BS>(d, sp, pass - 1, sh->h, sh->wave, &prefix, &krem, &sh->prefix, &sh->krem);
+    if (blk == 0 && tid == 0) {
+        d.ctr->sel_pass_prefix[sp][pass] = prefix;
+        d.ctr->sel_pass_krem[sp][pass] = krem;
+    }
+    __syncthreads();
+    const int shift = sel_shift(pass), bits = sel_bits(pass), nb = 1 << bits;
+    const u64 himask = ~0ull << (shift + bits);
+    for (int i = tid; i < nb; i += BS) sh->h[i] = 0;
+    __syncthreads();
+    const u64 *keys = d.key[sp];
+    for (int c0 = blk * BS + (tid & ~63); c0 < d.C; c0 += nblk * BS) {
+        const int c = c0 + lane_id();
+        const u64 key = c < d.C ? keys[c] : 0;
+        hist_add(sh->h, (uint32_t)(key >> shift) & (nb - 1), c < d.C && ((key ^ prefix) & himask) == 0);
+    }
+    __syncthreads();
+    uint32_t *gh = d.hist + (sp * SEL_MAX_PASSES + pass) * SEL_BINS;
+    for (int i = tid; i < nb; i += BS)
+        if (sh->h[i]) atomicAdd(&gh[i], sh->h[i]);
+}
+
+__global__ __launch_bounds__(RB) void k_sel_pass(Dev d, int pass, int sp) {
+    __shared__ SelShared sh;
+    role_sel_pass<RB>(d, pass, sp, blockIdx.x, gridDim.x, &sh);
+}
+
+// per 256-column block: how many keys are above / equal to the k-th largest
+__global__ __launch_bounds__(256) void k_sp_count(Dev d, int sp) {
+    __shared__ uint32_t s_wave[4];
+    __shared__ uint32_t h[SEL_BINS];
+    __shared__ u64 s_prefix;
+    __shared__ uint32_t s_krem;
+    u64 T;
+    uint32_t r;
+    sel_resolve<256>(d, sp, d.sel_passes - 1, h, s_wave, &T, &r, &s_prefix, &s_krem);
+    __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        d.ctr->sel_prefix[sp] = T;              // skipped low digits are zero in every key
+        d.ctr->sel_krem[sp] = r;
+    }
+    if (d.sel_passes > 1)                       // pass-0 histogram is consumed: clear it for its next use
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < HIST_REP * SEL_BINS; i += gridDim.x * 256) d.hist0[(size_t)sp * HIST_REP * SEL_BINS + i] = 0;
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    uint32_t v = 0;
+    if (c < d.C) {
+        u64 key = d.key[sp][c];
+        v = (key > T) ? 1u : ((key == T) ? 0x10000u : 0u);
+    }
+    uint32_t total;
+    block_excl_scan<256>(v, s_wave, total);
+    if (threadIdx.x == 0) d.sel_blk[blockIdx.x] = total;
+}
+
+// TemporalMemory.process up to the winner cells (networks.py:95-104) for ONE active column,
+// executed by a half-wave (lane j = cell j): bursting, best-matching cell (networks.py:73-82),
+// least-used cell (:84-89).  idx = position of column a in the ascending active list.
+struct ColumnWords { uint32_t act, winner, unacc; bool burst; };
+
+// pw = prev_state.cell_prediction row of column a (0 when !col_ok)
+__device__ __forceinline__ ColumnWords tm_column_words(const Dev &d, int p, int want_winner, bool col_ok, int a, uint32_t pw) {
+    const int lane = lane_id(), half = lane >> 5, j = lane & 31;
+    const bool valid = col_ok && j < d.K;
+    const bool burst = pw == 0;
+    const uint32_t act = burst ? cell_mask(d.K) : pw;        // networks.py:115
+    const int has_distal = d.ctr->has_distal;
+    float cm = -1.0f;
+    if (valid && has_distal) cm = __uint_as_float(d.cellmax[a * 32 + j]);
+    uint32_t winner = pw, unacc = 0;
+    if (want_winner) {
+        float colmax = cm;
+        for (int o = 16; o > 0; o >>= 1) colmax = fmaxf(colmax, __shfl_xor(colmax, o));
+        const bool col_matching = has_distal && colmax >= (float)d.match_thr;      // networks.py:80
+        const bool best = valid && has_distal && fabsf(cm - colmax) < EPS32;       // :81
+        float jit = 3.0e38f;
+        if (valid) {
+            uint32_t base = htm_stream_base(d.seed, HTM_STREAM_LEAST_USED, d.ctr->step[p]);
+            jit = htm_jitter((float)d.segcount[a * 32 + j], htm_draw24(base, (uint32_t)(a * d.K + j), 0u));   // :86-87
+        }
+        float mn = jit;
+        for (int o = 16; o > 0; o >>= 1) mn = fminf(mn, __shfl_xor(mn, o));
+        const bool least = valid && fabsf(jit - mn) < EPS32;                       // :88
+        const bool wbit = col_matching ? best : least;
+        const u64 bw = __ballot(wbit);
+        const uint32_t pick = (uint32_t)(bw >> (half * 32));
+        if (burst) winner = pick;                                                  // :102
+        const u64 bm = __ballot(valid && has_distal && !(cm < EPS32));             // cell has a matching segment
+        unacc = has_distal ? (winner & ~(uint32_t)(bm >> (half * 32))) : 0u;       // projections.py:271
+    }
+    return ColumnWords{act, want_winner ? winner : 0u, unacc, burst};
+}
+
+// store the words of active column a, the idx-th of the ascending active list
+__device__ __forceinline__ void tm_store_column(const Dev &d, int p, bool col_ok, int a, int idx, const ColumnWords &w) {
+    if (col_ok && (lane_id() & 31) == 0) {
+        d.act[p][a] = w.act;
+        d.win[p][a] = w.winner;
+        d.bursting[idx] = w.burst ? 1 : 0;
+        d.unacc_word[idx] = w.unacc;
+        d.winw_idx[idx] = w.winner;
+        d.actcnt[idx] = (uint8_t)__popc(w.act);
+    }
+}
+
+__device__ __forceinline__ void tm_activate_column(const Dev &d, int p, int want_winner, bool col_ok, int a, int idx, uint32_t pw) {
+    if (d.world == 1) {
+        tm_store_column(d, p, col_ok, a, idx, tm_column_words(d, p, want_winner, col_ok, a, pw));
+    } else {          // the owner computed the words before the exchange
+        ColumnWords w{0, 0, 0, false};
+        if (col_ok) {
+            w.act = d.spec_act[a];
+            w.winner = want_winner ? d.spec_win[a] : 0u;
+            w.unacc = want_winner ? d.spec_unacc[a] : 0u;
+            w.burst = (d.spec_burst[a >> 5] >> (a & 31)) & 1u;
+        }
+        tm_store_column(d, p, col_ok, a, idx, w);
+    }
+}
+
+// ---- column sharding: the two kernels around the exchange ---------------------------------
+// wire format of one rank's record (oracle/sharded.py record_nbytes):
+//   [boosted f64 x Cl][act u32 x Cl][win u32 x Cl][unacc u32 x Cl][bursting bits u32 x ceil(Cl/32)]
+//   [n_dead u32][dead ids u32 x DEAD_CAP], padded to 16 bytes
+__host__ __device__ __forceinline__ size_t shard_record_bytes(int cl) {
+    size_t n = (size_t)cl * 20 + 4 * (size_t)((cl + 31) / 32) + 4 + 4 * DEAD_CAP;
+    return (n + 15) / 16 * 16;
+}
+
+// before the exchange: what each OWN column would look like if it became active (this only
+// needs the rank's own previous predictions, segment maxima and segment counts), its boosted
+// overlap, and the segments that died during the previous step's learning
+__global__ __launch_bounds__(256) void k_shard_pack(Dev d, int p, unsigned char *send) {
+    const int cl = d.c1 - d.c0;
+    double *r_boost = (double *)send;
+    uint32_t *r_act = (uint32_t *)(send + (size_t)cl * 8);
+    uint32_t *r_win = r_act + cl, *r_unacc = r_win + cl, *r_burst = r_unacc + cl;
+    uint32_t *r_dead = r_burst + (cl + 31) / 32;
+    const int i = (blockIdx.x * 256 + threadIdx.x) >> 5;           // local column, one per half-wave
+    const bool ok = i < cl;
+    const int a = d.c0 + (ok ? i : 0);
+    const ColumnWords w = tm_column_words(d, p, 1, ok, a, ok ? d.pred[p ^ 1][a] : 0u);
+    // bursting bits: one 32-bit word per 32 columns = 16 consecutive waves' halves; use atomics
+    if (ok && (lane_id() & 31) == 0) {
+        r_boost[i] = d.boosted[p][a];
+        r_act[i] = w.act;
+        r_win[i] = w.winner;
+        r_unacc[i] = w.unacc;
+        if (w.burst) atomicOr(&r_burst[i >> 5], 1u << (i & 31));
+    }
+    if (blockIdx.x == 0) {
+        const int n = min(d.dead_list[0], DEAD_CAP);
+        if (threadIdx.x == 0) r_dead[0] = (uint32_t)n;
+        for (int j = threadIdx.x; j < n; j += 256) r_dead[1 + j] = (uint32_t)d.dead_list[1 + j];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_shard_pack_clear(Dev d, unsigned char *send) {
+    const int cl = d.c1 - d.c0;
+    uint32_t *r_burst = (uint32_t *)(send + (size_t)cl * 20);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < (cl + 31) / 32; i += gridDim.x * 256) r_burst[i] = 0;
+}
+
+// after the exchange: the keys and speculative words of ALL columns in global column order, the
+// histogram of the top key digit (what k_sp_overlap does on an unsharded handle), and the deaths
+// the other ranks reported (only "fewer synapses than the matching threshold" matters here:
+// projections.py:80)
+__global__ __launch_bounds__(1024) void k_shard_unpack(Dev d, const unsigned char *recv, int rank, int sp) {
+    __shared__ uint32_t h[SEL_BINS];
+    const int gtid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nthreads = gridDim.x * blockDim.x;
+    const int cl = d.c1 - d.c0;
+    const size_t rb = shard_record_bytes(cl);
+    uint32_t *ghist = d.hist + sp * SEL_MAX_PASSES * SEL_BINS;
+    for (int i = gtid; i < (d.sel_passes - 1) * SEL_BINS; i += nthreads) ghist[SEL_BINS + i] = 0;
+    for (int i = threadIdx.x; i < SEL_BINS; i += 1024) h[i] = 0;
+    if (gtid == 0) {
+        d.ctr->sel_pass_prefix[sp][0] = 0;
+        d.ctr->sel_pass_krem[sp][0] = (uint32_t)d.k;
+        d.dead_list[0] = 0;                        // reported; start collecting this step's
+    }
+    __syncthreads();
+    for (int c0 = blockIdx.x * 1024 + (threadIdx.x & ~63); c0 < d.C; c0 += gridDim.x * 1024) {
+        const int c = c0 + lane_id();
+        u64 key = 0;
+        if (c < d.C) {
+            const int r = c / cl, i = c - r * cl;
+            const unsigned char *rec = recv + (size_t)r * rb;
+            const double bo = ((const double *)rec)[i];
+            const uint32_t *r_act = (const uint32_t *)(rec + (size_t)cl * 8);
+            key = (u64)__double_as_longlong(bo);
+            d.boosted[sp][c] = bo;
+            d.key[sp][c] = key;
+            d.spec_act[c] = r_act[i];
+            d.spec_win[c] = r_act[cl + i];
+            d.spec_unacc[c] = r_act[2 * cl + i];
+            if ((c & 31) == 0) {                   // cl is a multiple of 32: words do not straddle ranks
+                d.spec_burst[c >> 5] = r_act[3 * cl + (i >> 5)];
+            }
+        }
+        hist_add(h, (uint32_t)(key >> sel_shift(0)), c < d.C);
+    }
+    __syncthreads();
+    uint32_t *g0 = d.hist0 + (size_t)(sp * HIST_REP + (blockIdx.x & (HIST_REP - 1))) * SEL_BINS;
+    for (int i = threadIdx.x; i < SEL_BINS; i += 1024)
+        if (h[i]) atomicAdd(&g0[i], h[i]);
+    if (blockIdx.x == 0) {
+        for (int r = 0; r < d.world; ++r) {
+            if (r == rank) continue;
+            const uint32_t *r_dead = (const uint32_t *)(recv + (size_t)r * rb + (size_t)cl * 20) + (cl + 31) / 32;
+            const int n = min((int)r_dead[0], DEAD_CAP);
+            for (int j = threadIdx.x; j < n; j += 1024) {
+                const int seg = (int)r_dead[1 + j];
+                d.seg_nsyn[seg] = 0;
+                atomicAdd(&d.recyc_cnt[seg >> 10], 1);
+            }
+        }
+    }
+}
+
+// ---- finishing the select inside k_sp_emit ---------------------------------------------------
+// Two radix digits (24 key bits) are resolved by launches; after them the threshold bucket holds a
+// handful of distinct keys (or one key many times, when overlaps tie).  Every 256-column block
+// publishes ONE 128-byte record -- how many of its keys lie above the bucket, and its distinct
+// bucket keys with multiplicities -- as self-validating 8-byte granules (write-through stores,
+// L1-bypassing loads: MI355X guide, Guideline 16, form R2).  Every block reads all records, so each one
+// derives the exact k-th key T, the number r of keys equal to T that win, and the winner counts
+// of the blocks before it, without another launch.  A block with more than CAND_D distinct
+// bucket keys (or more than CAND_MAX in total) switches ALL blocks, consistently, to an exact
+// fallback: the remaining digits are resolved block-redundantly from the key array and the
+// per-block counts are exchanged in a second tagged round.
+#define CAND_D 8              // distinct bucket keys one block can publish
+#define CAND_RAW 64           // ... and collect from its waves before merging duplicates
+#define CAND_MAX 2048         // bucket entries a block can merge
+#define CAND_OTHERS 160         // ... after folding the copies of one key, if at most this many others remain
+#define CAND_PAIRWISE 160      // ... by comparing all pairs; above that, by radix refinement in LDS
+
+// pick the bucket that contains the krem-th largest key of a histogram held in LDS
+// (bins [0, nb)); all BS threads call; returns bucket and the keys above it
+template <int BS>
+__device__ __forceinline__ void sel_pick(const uint32_t *h, int nb, uint32_t krem, uint32_t *s_wave,
+                                         uint32_t *s_out /*[2]*/, uint32_t *bucket, uint32_t *above_out) {
+    const int tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
+    constexpr int PER = SEL_BINS / BS;
+    uint32_t cs = 0;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int b = tid * PER + j;
+        cs += b < nb ? h[b] : 0u;
+    }
+    uint32_t x = cs;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t y = __shfl_down(x, o);
+        if (lane + o < 64) x += y;
+    }
+    if (lane == 0) s_wave[wv] = x;
+    __syncthreads();
+    uint32_t above = x - cs;
+    for (int w = wv + 1; w < BS / 64; ++w) above += s_wave[w];
+    if (above < krem && krem <= above + cs) {
+        for (int b = min((tid + 1) * PER, nb) - 1; b >= tid * PER; --b) {
+            const uint32_t hb = h[b];
+            if (above + hb >= krem) { s_out[0] = (uint32_t)b; s_out[1] = above; break; }
+            above += hb;
+        }
+    }
+    __syncthreads();
+    *bucket = s_out[0];
+    *above_out = s_out[1];
+}
+
+// Emit the winners in ascending column order (ties: lower index first), clear the dense per-column
+// words of the non-winners and, as `mode` asks, update the duty cycle (regularizations.py:19-21,
+// float32, two separately rounded operations: EMIT_DUTY) and run the Temporal Memory's per-column
+// activation for the winners of this block (EMIT_ACTIVATE).  One block per 256 columns.  `fused`
+// (grids of at most 1024 blocks, all co-resident): the select is finished here (above); otherwise
+// T, r and the per-block counts come from k_sel_pass / k_sp_count launches.
+// EMIT_CLEAR: also zero the dense per-column words of the step.  The pipelined schedule runs this
+// role with mode 0 one step ahead, beside the previous step's learning (which still reads the
+// words a clear would zero); see the pipelined schedule below.
+#define EMIT_DUTY 1
+#define EMIT_ACTIVATE 2
+#define EMIT_CLEAR 4
+#define EMIT_ALL 7
+struct EmitShared {
+    uint32_t h[SEL_BINS];
+    u64 prefix, T;
+    u64 bk[CAND_RAW];
+    uint32_t bc[CAND_RAW];
+    uint16_t ec[CAND_MAX], eb[CAND_MAX];
+    uint32_t mh[256];
+    u64 ok[CAND_OTHERS + 1];
+    uint32_t oc[CAND_OTHERS + 1], c0;
+    int n_others;
+    uint32_t predw[256];
+    int col[256];
+    uint32_t wave[4];
+    uint32_t gt, eq, out[2], flags, krem, r;
+    int n, nraw, ne;
+};
+
+__device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, int fused, int mode, int b, int nblk, EmitShared *sh) {
+    uint32_t *h = sh->h;
+    uint32_t *s_wave = sh->wave, *s_out = sh->out, *s_predw = sh->predw, *s_bc = sh->bc;
+    u64 *s_bk = sh->bk;
+    int *s_col = sh->col;
+    uint32_t &s_gt = sh->gt, &s_eq = sh->eq, &s_flags = sh->flags, &s_krem = sh->krem, &s_r = sh->r;
+    u64 &s_prefix = sh->prefix, &s_T = sh->T;
+    int &s_n = sh->n, &s_nraw = sh->nraw, &s_ne = sh->ne;
+    // merged bucket entries live in the histogram's LDS once the launched digits are resolved
+    u64 *s_ek = (u64 *)h;                           // [CAND_MAX] keys
+    uint16_t *s_ec = sh->ec, *s_eb = sh->eb;        // [CAND_MAX] multiplicities (12 bits), publishing block
+    uint32_t *s_mh = sh->mh;
+    static_assert(2 * CAND_MAX <= SEL_BINS, "bucket keys must fit the histogram");
+    const int tid = threadIdx.x, lane = lane_id();
+    if (tid == 0) { s_gt = 0; s_eq = 0; s_n = 0; s_nraw = 0; s_ne = 0; s_flags = 0; }
+    const int c = b * 256 + tid;
+    // independent of everything below: in flight while the select state is resolved
+    const u64 my_key = c < d.C ? d.key[p][c] : 0;
+    const bool own_col = c < d.C && c >= d.c0 && c < d.c1;
+    const float my_duty = (own_col && (mode & EMIT_DUTY)) ? d.duty[c] : 0.f;
+    const bool tm_here = d.act[0] && (mode & EMIT_ACTIVATE);
+    s_predw[tid] = (c < d.C && tm_here && d.world == 1) ? d.pred[p ^ 1][c] : 0u;
+    u64 T;
+    uint32_t r;                                     // how many of the keys == T are selected
+    bool second_round = false;                      // per-block counts still to be exchanged
+    const uint32_t epoch = (d.ctr->emit_epoch & 0x3FFu) + 1u;           // 1..1024, changes with every overlap launch
+    if (fused) {
+        u64 P;
+        uint32_t krem;
+        sel_resolve<256>(d, p, d.sel_passes - 1, h, s_wave, &P, &krem, &s_prefix, &s_krem);
+        __syncthreads();
+        const int lowbits = sel_shift(d.sel_passes - 1);        // key bits not resolved by launches
+        const u64 hiP = P >> lowbits, hi = my_key >> lowbits;
+        const bool c_gt = c < d.C && hi > hiP, c_cand = c < d.C && hi == hiP;
+        // ---- this block's record
+        {
+            const u64 mg = __ballot(c_gt);
+            if (lane == 0 && mg) atomicAdd(&s_gt, (uint32_t)__popcll(mg));        // s_gt: keys above the bucket, for now
+            u64 todo = __ballot(c_cand);
+            while (todo) {                           // group equal bucket keys inside the wave
+                const int leader = __ffsll((long long)todo) - 1;
+                const u64 kl = ((u64)__shfl((uint32_t)(my_key >> 32), leader) << 32) | __shfl((uint32_t)my_key, leader);
+                const u64 same = __ballot(c_cand && my_key == kl) & todo;
+                if (lane == leader) {
+                    const int slot = atomicAdd(&s_nraw, 1);
+                    if (slot < CAND_RAW) { s_bk[slot] = kl; s_bc[slot] = (uint32_t)__popcll(same); }
+                }
+                todo &= ~same;
+            }
+        }
+        __syncthreads();
+        const int nraw = min(s_nraw, CAND_RAW);
+        const uint32_t my_gt_hi = s_gt;
+        int first = -1;                              // merge duplicates that came from different waves
+        uint32_t my_cnt = 0;
+        if (tid < nraw) {
+            my_cnt = s_bc[tid];
+            for (first = 0; s_bk[first] != s_bk[tid]; ++first) {}
+        }
+        __syncthreads();
+        if (tid < nraw && first != tid) atomicAdd(&s_bc[first], my_cnt);
+        __syncthreads();
+        // record = up to 8 self-validating 64-bit granules (form R2: every granule carries the epoch, one
+        // aligned 8-byte write-through store each, so no separate tag and no drain):
+        //   [0]      epoch:12 | overflow:1 | pairs:4 | keys above the bucket:9 | multiplicity:9 | key bits:29
+        //   [j >= 1] epoch:12 | multiplicity:12 | low 40 key bits   (the high bits are the bucket's)
+        // The first pair rides in the head granule -- the low_zero bottom bits of every key are zero, so
+        // 29 bits hold the rest for input_dim up to 2^17 -- and a block with at most one bucket key, the
+        // usual case and the one of a many-way tie, is read with a single load.
+        u64 *rec = (u64 *)(d.sel_rec + (size_t)b * 32);
+        const u64 etag = (u64)epoch << 52;
+        const u64 lowmask = (1ull << lowbits) - 1ull;
+        const bool inline_ok = lowbits - d.low_zero <= 29;
+        if (tid < 64) {                              // wave 0 compacts the survivors into the record
+            const bool alive = tid < nraw && first == tid;
+            const u64 ma = __ballot(alive);
+            const int n_pairs = __popcll(ma), pos = __popcll(ma & lanemask_lt());
+            const bool overflow = s_nraw > CAND_RAW || n_pairs > d.cand_d || (n_pairs > 0 && !inline_ok);
+            const u64 mine = alive ? (s_bk[tid] & lowmask) : 0ull;
+            const uint32_t cnt = alive ? s_bc[tid] : 0u;
+            if (alive && pos >= 1 && pos < CAND_D)
+                __hip_atomic_store(rec + pos, etag | ((u64)cnt << 40) | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int l0 = ma ? __ffsll((long long)ma) - 1 : 0;      // the lane of pair 0
+            const u64 k0 = ((u64)__shfl((uint32_t)(mine >> 32), l0) << 32) | __shfl((uint32_t)mine, l0);
+            const uint32_t c0 = __shfl(cnt, l0);
+            if (tid == 0) {
+                const u64 pair0 = (ma && inline_ok) ? (((u64)(c0 & 0x1FFu) << 29) | (k0 >> d.low_zero)) : 0ull;
+                __hip_atomic_store(rec, etag | (overflow ? (1ull << 51) : 0ull) | ((u64)min(n_pairs, CAND_D) << 47) | ((u64)my_gt_hi << 38) | pair0,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        if (tid == 0) s_gt = 0;
+        // ---- everybody's records: the head granule is polled alone (one lane-load per spin keeps the
+        // polling traffic low); further pairs, if any, are fetched in one batch; each granule validates itself
+        uint32_t gthi_before = 0;
+        for (int rb = tid; rb < nblk; rb += 256) {
+            const u64 *rr = (const u64 *)(d.sel_rec + (size_t)rb * 32);
+            u64 g[CAND_D];
+            for (int spins = 0;; ++spins) {
+                g[0] = __hip_atomic_load(rr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((g[0] >> 52) == epoch) break;
+                if (spins >= (1 << 20)) { atomicOr(&d.ctr->error, 16); g[0] = 0; break; }      // a block never arrived
+                __builtin_amdgcn_s_sleep(2);
+            }
+            int np = (g[0] >> 52) == epoch ? (int)((g[0] >> 47) & 0xFu) : 0;
+            for (int spins = 0; np > 1; ++spins) {
+#pragma unroll
+                for (int j = 1; j < CAND_D; ++j) g[j] = __hip_atomic_load(rr + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                bool ok = true;
+#pragma unroll
+                for (int j = 1; j < CAND_D; ++j) ok = ok && (j >= np || (g[j] >> 52) == epoch);
+                if (ok) break;
+                if (spins >= (1 << 20)) { atomicOr(&d.ctr->error, 16); np = 0; break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            if (rb < b) gthi_before += (uint32_t)((g[0] >> 38) & 0x1FFu);
+            if ((g[0] >> 51) & 1ull) atomicOr(&s_flags, 1u);
+#pragma unroll
+            for (int j = 0; j < CAND_D; ++j)
+                if (j < np) {
+                    const int slot = atomicAdd(&s_ne, 1);
+                    if (slot < CAND_MAX) {
+                        const u64 low = j == 0 ? (g[0] & 0x1FFFFFFFull) << d.low_zero : g[j] & lowmask;
+                        s_ek[slot] = (hiP << lowbits) | low;
+                        s_ec[slot] = (uint16_t)(j == 0 ? (g[0] >> 29) & 0x1FFu : (g[j] >> 40) & 0xFFFu);
+                        s_eb[slot] = (uint16_t)rb;
+                    }
+                }
+        }
+        __syncthreads();
+        const int ne = s_ne;
+        if (!(s_flags & 1u) && ne <= CAND_MAX) {
+            bool folded = false;
+            if (ne <= d.cand_pairwise) {                // the krem-th largest of the merged bucket: all pairs
+                for (int e = tid; e < ne; e += 256) {
+                    const u64 ke = s_ek[e];
+                    uint32_t ng = 0, nq = 0;
+                    for (int f = 0; f < ne; ++f) {
+                        const u64 kf = s_ek[f];
+                        const uint32_t cf = s_ec[f];
+                        ng += kf > ke ? cf : 0u;
+                        nq += kf == ke ? cf : 0u;
+                    }
+                    if (ng < krem && krem <= ng + nq) { s_T = ke; s_r = krem - ng; }
+                }
+                __syncthreads();
+                T = s_T;
+                r = s_r;
+            } else {
+                // many entries: overlaps tie and most blocks report the same key.  Fold the copies of the
+                // first entry's key into one entry; if few others remain, all pairs again
+                const u64 K0 = s_ek[0];
+                if (tid == 0) { sh->n_others = 0; sh->c0 = 0; }
+                __syncthreads();
+                uint32_t c0 = 0;
+                for (int e = tid; e < ne; e += 256) {
+                    const u64 ke = s_ek[e];
+                    if (ke == K0) {
+                        c0 += s_ec[e];
+                    } else {
+                        const int pos = atomicAdd(&sh->n_others, 1);
+                        if (pos < CAND_OTHERS) { sh->ok[pos] = ke; sh->oc[pos] = s_ec[e]; }
+                    }
+                }
+                for (int o = 32; o > 0; o >>= 1) c0 += __shfl_xor(c0, o);
+                if (lane == 0 && c0) atomicAdd(&sh->c0, c0);
+                __syncthreads();
+                const int no = sh->n_others;
+                folded = no < d.cand_others;
+                if (folded) {
+                    if (tid == 0) { sh->ok[no] = K0; sh->oc[no] = sh->c0; }
+                    __syncthreads();
+                    for (int e = tid; e <= no; e += 256) {
+                        const u64 ke = sh->ok[e];
+                        uint32_t ng = 0, nq = 0;
+                        for (int f = 0; f <= no; ++f) {
+                            const u64 kf = sh->ok[f];
+                            const uint32_t cf = sh->oc[f];
+                            ng += kf > ke ? cf : 0u;
+                            nq += kf == ke ? cf : 0u;
+                        }
+                        if (ng < krem && krem <= ng + nq) { s_T = ke; s_r = krem - ng; }
+                    }
+                    __syncthreads();
+                    T = s_T;
+                    r = s_r;
+                }
+            }
+            if (ne > d.cand_pairwise && !folded) {    // still many distinct keys: 8-bit radix refinement
+                u64 pref = 0;                         // over the entries, one bin per thread
+                uint32_t rem = krem;
+                for (int top = lowbits; top > d.low_zero;) {
+                    const int bits = min(8, top), shift = top - bits, nb = 1 << bits;
+                    s_mh[tid] = 0;
+                    __syncthreads();
+                    for (int e = tid; e < ne; e += 256) {
+                        const u64 kl = s_ek[e] & lowmask;
+                        if (((kl ^ pref) >> top) == 0) atomicAdd(&s_mh[(uint32_t)(kl >> shift) & (nb - 1)], (uint32_t)s_ec[e]);
+                    }
+                    __syncthreads();
+                    const uint32_t rv = s_mh[255 - tid];      // bins from the top; bins >= nb are empty
+                    uint32_t total;
+                    const uint32_t above = block_excl_scan<256>(rv, s_wave, total);
+                    if (rv && above < rem && rem <= above + rv) { s_out[0] = 255u - (uint32_t)tid; s_out[1] = above; }
+                    __syncthreads();
+                    pref |= (u64)s_out[0] << shift;
+                    rem -= s_out[1];
+                    top = shift;
+                }
+                T = (hiP << lowbits) | pref;
+                r = rem;
+            }
+            uint32_t g = gthi_before, e2 = 0;         // winners of the blocks before this one
+            for (int e = tid; e < ne; e += 256)
+                if (s_eb[e] < b) {
+                    if (s_ek[e] > T) g += s_ec[e];
+                    else if (s_ek[e] == T) e2 += s_ec[e];
+                }
+            for (int o = 32; o > 0; o >>= 1) { g += __shfl_xor(g, o); e2 += __shfl_xor(e2, o); }
+            if (lane == 0) { atomicAdd(&s_gt, g); atomicAdd(&s_eq, e2); }
+        } else {
+            // exact fallback: resolve the remaining digits from the key array, redundantly per block
+            u64 P2 = P;
+            uint32_t k2 = krem;
+            const u64 *keys = d.key[p];
+            for (int top = lowbits; top > d.low_zero;) {
+                const int bits = min(SEL_DIGIT, top), shift = top - bits, nb = 1 << bits;
+                for (int i = tid; i < nb; i += 256) h[i] = 0;
+                __syncthreads();
+                for (int c0 = (tid & ~63); c0 < d.C; c0 += 256) {
+                    const int cc = c0 + lane;
+                    const u64 kk = cc < d.C ? keys[cc] : 0;
+                    hist_add(h, (uint32_t)(kk >> shift) & (nb - 1), cc < d.C && ((kk ^ P2) >> top) == 0);
+                }
+                __syncthreads();
+                uint32_t bucket, above;
+                sel_pick<256>(h, nb, k2, s_wave, s_out, &bucket, &above);
+                P2 |= (u64)bucket << shift;
+                k2 -= above;
+                top = shift;
+                __syncthreads();
+            }
+            T = P2;
+            r = k2;
+            second_round = true;
+            if (b == 0 && tid == 0) d.ctr->sel_fallbacks += 1;
+        }
+        if (b == 0 && tid == 0) { d.ctr->sel_prefix[p] = T; d.ctr->sel_krem[p] = r; }
+        // the pass-0 histogram is consumed: clear it for its next use (here, not earlier: a barrier
+        // waits for outstanding stores, and the record exchange above is the critical chain)
+        if (d.sel_passes > 1)
+            for (int i = b * 256 + tid; i < HIST_REP * SEL_BINS; i += nblk * 256) d.hist0[(size_t)p * HIST_REP * SEL_BINS + i] = 0;
+    } else {
+        T = d.ctr->sel_prefix[p];
+        r = d.ctr->sel_krem[p];
+    }
+    __syncthreads();
+    uint32_t flag = 0;
+    if (c < d.C) flag = (my_key > T) ? 1u : ((my_key == T) ? 0x10000u : 0u);
+    uint32_t total;
+    const uint32_t ex = block_excl_scan<256>(flag, s_wave, total);
+    if (second_round || !fused) {
+        uint32_t g = 0, e = 0;
+        if (fused) {                                // tagged words, second round of this step
+            const uint32_t tag2 = epoch | 0x800u;
+            if (tid == 0)
+                __hip_atomic_store(&d.sel_blk[b], (tag2 << 20) | ((total >> 16) << 10) | (total & 0xFFFFu),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int i = tid; i < b; i += 256) {
+                uint32_t v = 0;
+                int spins = 0;
+                do {
+                    v = __hip_atomic_load(&d.sel_blk[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((v >> 20) == tag2) break;
+                    __builtin_amdgcn_s_sleep(1);
+                } while (++spins < (1 << 22));
+                if ((v >> 20) != tag2) atomicOr(&d.ctr->error, 16);
+                g += v & 0x3FFu;
+                e += (v >> 10) & 0x3FFu;
+            }
+        } else {
+            for (int i = tid; i < b; i += 256) {
+                const uint32_t v = d.sel_blk[i];
+                g += v & 0xFFFFu;
+                e += v >> 16;
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) { g += __shfl_xor(g, o); e += __shfl_xor(e, o); }
+        if (lane == 0) { atomicAdd(&s_gt, g); atomicAdd(&s_eq, e); }
+    }
+    __syncthreads();
+    const uint32_t gt_before = s_gt, eq_before = s_eq;
+    const uint32_t g_run = gt_before + (ex & 0xFFFFu), e_run = eq_before + (ex >> 16);
+    const int first_pos = (int)(gt_before + min(eq_before, r));
+    const bool sel_any = c < d.C && ((flag & 1u) || ((flag >> 16) && e_run < r));
+    if (d.act[0]) {
+        const u64 mcol = __ballot(sel_any);
+        if (lane_id() == 0) *(u64 *)&d.colbits[p][(b * 256 + (tid & ~63)) >> 5] = mcol;
+    }
+    if (c < d.C) {
+        const bool sel = sel_any;
+        if (own_col && (mode & EMIT_DUTY)) {
+            float dc = my_duty * d.mom;
+            if (sel) dc = dc + d.dinc;
+            d.duty[c] = dc;
+        }
+        if (sel) {
+            const int pos = (int)(g_run + min(e_run, r));
+            d.active_cols[p][pos] = c;
+            s_col[pos - first_pos] = c;
+            atomicAdd(&s_n, 1);
+        }
+        if (d.act[0] && (mode & EMIT_CLEAR)) {     // Temporal Memory present
+            d.pred[p][c] = 0;
+            if (!sel || !(mode & EMIT_ACTIVATE)) { d.act[p][c] = 0; d.win[p][c] = 0; }
+        }
+    }
+    if (b == 0 && tid == 0 && !d.act[0]) d.ctr->step[p ^ 1] = d.ctr->step[p] + 1;   // SP-only handle
+    if (!tm_here) return;
+    __syncthreads();
+    const int n_sel = s_n;
+    for (int i0 = 0; i0 < n_sel; i0 += 8) {        // 8 half-waves
+        const int i = i0 + (tid >> 5);
+        const bool ok = i < n_sel;
+        const int a = ok ? s_col[i] : 0;
+        tm_activate_column(d, p, want_winner, ok, a, first_pos + i, ok ? s_predw[a - b * 256] : 0u);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_sp_emit(Dev d, int p, int want_winner, int fused, int mode) {
+    __shared__ EmitShared sh;
+    role_emit(d, p, want_winner, fused, mode, blockIdx.x, gridDim.x, &sh);
+}
+
+// DenseProjection.update (projections.py:23-24) on the k winner rows, fused with the rebuild
+// of those rows' connected mask.  One block per winner row.
+__global__ __launch_bounds__(256) void k_sp_learn(Dev d, const uint32_t *__restrict__ bank, int n_inputs, int p) {
+    const uint32_t *in = bank + (size_t)(d.ctr->step[p] % (uint32_t)n_inputs) * d.W;
+    const int row = d.active_cols[p][blockIdx.x];
+    double *prow = d.perm + (size_t)row * d.Ipad;
+    uint32_t *mrow = d.mask + (size_t)row * d.W;
+    for (int i0 = 0; i0 < d.Ipad; i0 += 256) {
+        int i = i0 + threadIdx.x;
+        bool conn = false;
+        if (i < d.I) {
+            bool on = (in[i >> 5] >> (i & 31)) & 1u;
+            double v = prow[i] + (on ? d.sp_don : d.sp_doff);
+            prow[i] = v;
+            conn = v >= d.sp_thr;
+        }
+        u64 m = __ballot(conn);
+        if (lane_id() == 0 && i < d.Ipad) *(u64 *)&mrow[i >> 5] = m;
+    }
+}
+
+#endif

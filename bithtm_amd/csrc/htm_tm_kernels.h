@@ -1,0 +1,676 @@
+// Temporal Memory roles and kernels: activation, the middle of the step (lists, allocation, classification),
+// learning and growth, the segment scan.
+// Part of the single translation unit htm_engine.hip (included there, in this order:
+// htm_dev.h, htm_sp_kernels.h, htm_tm_kernels.h, htm_pipeline.h).
+#ifndef BITHTM_HTM_TM_KERNELS_H
+#define BITHTM_HTM_TM_KERNELS_H
+
+// ------------------------------------------------------------------------------------------
+// Temporal Memory
+
+// stand-alone TM: take the active columns from the caller, clear the per-step words
+__global__ __launch_bounds__(256) void k_tm_load_active(Dev d, int p, const int *cols, int n) {
+    for (int c = blockIdx.x * 256 + threadIdx.x; c < d.C; c += gridDim.x * 256) {
+        d.act[p][c] = 0;
+        d.pred[p][c] = 0;
+        d.win[p][c] = 0;
+        if (c < n) d.active_cols[p][c] = cols[c];
+        if (c < d.colwords) d.colbits[p][c] = 0;
+    }
+}
+
+// stand-alone TM: per-column activation, one active column per half-wave
+__global__ __launch_bounds__(256) void k_tm_activate(Dev d, int p, int n_active, int want_winner) {
+    const int idx = (blockIdx.x * 256 + threadIdx.x) >> 5;
+    const bool ok = idx < n_active;
+    const int a = ok ? d.active_cols[p][idx] : 0;
+    if (ok && (threadIdx.x & 31) == 0) atomicOr(&d.colbits[p][a >> 5], 1u << (a & 31));
+    tm_activate_column(d, p, want_winner, ok, a, idx, ok ? d.pred[p ^ 1][a] : 0u);
+}
+
+// bind segment `seg` to winner cell `cell` (projections.py:275-281) and queue it for learning at
+// work-list slot `pos`; rows are packed, so clearing a recycled row (projections.py:82-85) is nsyn = 0
+// Sharded: every rank records the new owner (segment ids are global), but only the owner of a
+// cell keeps that cell's segment count, and only the new owner queues the segment; the others
+// note how many synapses it will grow (projections.py:114-127 on an empty row: min(sampling,
+// previous winners)), which is all they ever need to know about it.
+__device__ __forceinline__ bool col_is_local(const Dev &d, int cell) { const int col = cell >> 5; return col >= d.c0 && col < d.c1; }
+
+__device__ __forceinline__ void tm_bind_segment(const Dev &d, int seg, int cell, bool recycled, int pos, int grown) {
+    if (recycled) {
+        const int old = d.seg_cell[seg];
+        if (col_is_local(d, old)) atomicSub(&d.segcount[old], 1);
+    }
+    d.seg_cell[seg] = cell;
+    if (col_is_local(d, cell)) {
+        d.seg_nsyn[seg] = 0;
+        atomicAdd(&d.segcount[cell], 1);
+        if (pos < 0) pos = atomicAdd(&d.ctr->n_work, 1);
+        if (pos < d.work_cap) d.work[pos] = (uint32_t)seg; else atomicOr(&d.ctr->error, 4);
+    } else {
+        d.seg_nsyn[seg] = grown;
+    }
+}
+
+// DenseProjection.update (projections.py:23-24) on winner row ri, fused with the rebuild of that
+// row's connected mask, by TPR threads (t = 0..TPR-1): two float64 per lane (16-byte accesses); a
+// wave covers 128 consecutive elements = four mask words, assembled from the ballots of its even
+// and odd elements
+template <int TPR>
+// p: parity of the step the rows belong to; ahead = 1 when that step's index is not published yet
+// (the row update runs beside the previous step's scan): it is step[p ^ 1] + 1 then
+__device__ __forceinline__ void role_sp_row(const Dev &d, int p, const uint32_t *__restrict__ bank, int n_inputs, int ahead, int ri, int t) {
+    const uint32_t step = ahead ? d.ctr->step[p ^ 1] + 1u : d.ctr->step[p];
+    const uint32_t *in = bank + (size_t)(step % (uint32_t)n_inputs) * d.W;
+    const int row = d.active_cols[p][ri];
+    if (row < d.c0 || row >= d.c1) return;          // another rank's column
+    double *prow = d.perm + (size_t)row * d.Ipad;
+    uint32_t *mrow = d.mask + (size_t)row * d.W;
+    for (int i0 = 0; i0 < d.Ipad; i0 += 2 * TPR) {
+        const int e0 = i0 + 2 * t;                   // Ipad is a multiple of 128: e0 + 1 < Ipad whenever e0 < Ipad
+        bool c0 = false, c1 = false;
+        if (e0 < d.Ipad) {
+            double2 v = *(double2 *)(prow + e0);
+            const uint32_t bits = in[e0 >> 5] >> (e0 & 31);
+            if (e0 < d.I) { v.x = v.x + ((bits & 1u) ? d.sp_don : d.sp_doff); c0 = v.x >= d.sp_thr; }
+            if (e0 + 1 < d.I) { v.y = v.y + ((bits & 2u) ? d.sp_don : d.sp_doff); c1 = v.y >= d.sp_thr; }
+            *(double2 *)(prow + e0) = v;
+        }
+        const u64 b0 = __ballot(c0), b1 = __ballot(c1);
+        const int base = i0 + 2 * (t & ~63);
+        if (lane_id() == 0 && base < d.Ipad) {
+            u64 *mw = (u64 *)&mrow[base >> 5];
+            mw[0] = spread32((uint32_t)b0) | (spread32((uint32_t)b1) << 1);
+            mw[1] = spread32((uint32_t)(b0 >> 32)) | (spread32((uint32_t)(b1 >> 32)) << 1);
+        }
+    }
+}
+
+// The middle of TemporalMemory.process / PredictiveProjection.update, one launch:
+//   block 0      ordered lists of winner cells (networks.py:103-104) and of winners that need a new
+//                segment (projections.py:271-273); SparseProjection.add_output (projections.py:79-95):
+//                recycle the lowest-id segments with fewer than matching_threshold synapses, append
+//                the rest; bind them to the winners in ascending cell order (:275-281)
+//   blocks 1..   which previous matching segments learn, which are punished (projections.py:264-269;
+//                punishment mask built at networks.py:107-108,111)
+//   last n_sp_rows blocks   DenseProjection.update (projections.py:23-24) on one winner row each,
+//                fused with the rebuild of that row's connected mask: independent of the TM work and
+//                bandwidth-bound, it rides along with the latency-bound block 0
+// block 0 and the classify blocks 1..n_cls of the middle launch (below)
+template <int BS>
+__device__ __forceinline__ void role_mid(const Dev &d, int p, int n_active, int want_winner, int learning, int blk, int n_cls) {
+    Counters *c = d.ctr;
+    __shared__ int s_cnt, s_base;
+    if (blk > 0) {
+        if (!learning || !c->has_distal) return;
+        const int q = p ^ 1;
+        const int n = c->S;          // ids at or above the S of the last scan still hold info == 0
+        const int stride = n_cls * BS;
+        for (int i0 = (blk - 1) * BS; i0 < n; i0 += stride) {
+            const int seg = i0 + threadIdx.x;
+            bool learn = false, punish = false;
+            const uint32_t info = seg < n ? d.seg_info[seg] : 0u;
+            const int cell = seg < n ? d.seg_cell[seg] : 0;         // fetched with the info word, not after it
+            if (info & 0x40000000u) {
+                const int col = cell >> 5, bit = cell & 31;
+                const bool is_winner = (d.win[p][col] >> bit) & 1u;
+                const bool unpred = !((d.pred[q][col] >> bit) & 1u);                         // :266
+                const bool best = fabsf(d.seg_jit[seg] - __uint_as_float(d.cellmax[cell])) < EPS32;   // :267
+                learn = is_winner && ((info >> 31) || (unpred && best));                     // :268
+                punish = d.act[p][col] == 0;                                                 // :269
+            }
+            if (threadIdx.x == 0) s_cnt = 0;
+            __syncthreads();
+            const u64 ml = __ballot(learn), mp = __ballot(punish);
+            const int n_l = __popcll(ml), n_p = __popcll(mp);
+            int woff = 0;
+            if (lane_id() == 0 && n_l + n_p) woff = atomicAdd(&s_cnt, n_l + n_p);
+            woff = __shfl(woff, 0);
+            __syncthreads();
+            if (threadIdx.x == 0 && s_cnt) s_base = atomicAdd(&c->n_work, s_cnt);     // one reservation per block
+            __syncthreads();
+            const int base = s_base + woff;
+            if (learn) {
+                const int pos = base + __popcll(ml & lanemask_lt());
+                if (pos < d.work_cap) d.work[pos] = (uint32_t)seg; else atomicOr(&c->error, 4);
+            }
+            if (punish) {
+                const int pos = base + n_l + __popcll(mp & lanemask_lt());
+                if (pos < d.work_cap) d.work[pos] = (uint32_t)seg | 0x80000000u; else atomicOr(&c->error, 4);
+            }
+        }
+        return;
+    }
+    // ---- block 0
+    __shared__ uint32_t s_wave[16];
+    __shared__ uint32_t s_cells;
+    __shared__ int s_nneed;
+    if (threadIdx.x == 0) { s_cells = 0; s_nneed = 0; }
+    const int S = c->S, nb = (S + 1023) >> 10;
+    // first batch of the per-1024-segment recyclable counts: fetched with the column lists, not after them
+    const uint32_t recyc_first = (int)threadIdx.x < nb ? (uint32_t)d.recyc_cnt[threadIdx.x] : 0u;
+    uint32_t carry_w = 0, carry_u = 0, n_cells = 0;
+    // LPT consecutive columns per thread, one scan per pass: with 256 threads one pass covers 2048 winner
+    // columns, so every load of the lists is in flight at once (under the load of the row updates that
+    // share this launch a dependent round trip costs about 3 us)
+    constexpr int LPT = 8;
+    static_assert(LPT == 8, "the list pass loads 8 entries per thread");
+    for (int base = 0; base < n_active; base += LPT * BS) {
+        const int i0 = base + LPT * (int)threadIdx.x;
+        uint32_t v[LPT], ww[LPT], uw[LPT];
+        int a[LPT];
+        uint32_t vsum = 0;
+        if (i0 < n_active) {                       // 16-byte loads (the arrays are padded by 8 entries), masked below
+            const int4 a0 = *(const int4 *)(d.active_cols[p] + i0), a1 = *(const int4 *)(d.active_cols[p] + i0 + 4);
+            const uint4 w0 = *(const uint4 *)(d.winw_idx + i0), w1 = *(const uint4 *)(d.winw_idx + i0 + 4);
+            const uint4 u0 = *(const uint4 *)(d.unacc_word + i0), u1 = *(const uint4 *)(d.unacc_word + i0 + 4);
+            const u64 ac = *(const u64 *)(d.actcnt + i0);
+            a[0] = a0.x; a[1] = a0.y; a[2] = a0.z; a[3] = a0.w; a[4] = a1.x; a[5] = a1.y; a[6] = a1.z; a[7] = a1.w;
+            ww[0] = w0.x; ww[1] = w0.y; ww[2] = w0.z; ww[3] = w0.w; ww[4] = w1.x; ww[5] = w1.y; ww[6] = w1.z; ww[7] = w1.w;
+            uw[0] = u0.x; uw[1] = u0.y; uw[2] = u0.z; uw[3] = u0.w; uw[4] = u1.x; uw[5] = u1.y; uw[6] = u1.z; uw[7] = u1.w;
+#pragma unroll
+            for (int j = 0; j < LPT; ++j) {
+                const bool ok = i0 + j < n_active;
+                if (!ok) { ww[j] = 0; uw[j] = 0; }
+                n_cells += ok ? (uint32_t)((ac >> (8 * j)) & 0xFFu) : 0u;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < LPT; ++j) { a[j] = 0; ww[j] = 0; uw[j] = 0; }
+        }
+#pragma unroll
+        for (int j = 0; j < LPT; ++j) {
+            v[j] = want_winner ? (uint32_t)__popc(ww[j]) | ((uint32_t)__popc(uw[j]) << 16) : 0u;      // winners | needing a segment
+            vsum += v[j];
+        }
+        uint32_t total;
+        uint32_t run = block_excl_scan<BS>(vsum, s_wave, total);
+        if (want_winner) {
+#pragma unroll
+            for (int j = 0; j < LPT; ++j) {
+                int pw = carry_w + (run & 0xFFFFu), pu = carry_u + (run >> 16);
+                uint32_t w1 = ww[j], u1 = uw[j];
+                while (w1) { int b = __ffs(w1) - 1; w1 &= w1 - 1; d.winners[p][pw++] = a[j] * 32 + b; }
+                while (u1) { int b = __ffs(u1) - 1; u1 &= u1 - 1; d.unacc_list[pu++] = a[j] * 32 + b; }
+                run += v[j];
+            }
+        }
+        carry_w += total & 0xFFFFu;
+        carry_u += total >> 16;
+    }
+    for (int o = 32; o > 0; o >>= 1) n_cells += __shfl_xor(n_cells, o);
+    if (lane_id() == 0) atomicAdd(&s_cells, n_cells);
+    __syncthreads();
+    const int n_un = (learning && c->has_distal) ? (int)carry_u : 0;
+    if (threadIdx.x == 0) {
+        c->n_win[p] = want_winner ? (int)carry_w : 0;
+        c->has_winner[p] = want_winner;
+        c->n_un = n_un;
+        c->n_active_cells = (int)s_cells;
+        if (n_un == 0) c->n_bind = 0;
+    }
+    if (n_un == 0) return;
+    uint32_t carry = 0;                       // recyclable segments seen so far
+    for (int base = 0; base < nb; base += BS) {
+        const int b = base + threadIdx.x;
+        const uint32_t v = base == 0 ? recyc_first : (b < nb ? (uint32_t)d.recyc_cnt[b] : 0u);
+        uint32_t total;
+        const uint32_t ex = block_excl_scan<BS>(v, s_wave, total);
+        if (v > 0 && carry + ex < (uint32_t)n_un) {
+            const int slot = atomicAdd(&s_nneed, 1);
+            d.recyc_need[2 * slot] = b;
+            d.recyc_need[2 * slot + 1] = (int)(carry + ex);
+        }
+        carry += total;
+        if (carry >= (uint32_t)n_un) break;
+    }
+    __syncthreads();
+    const int n_r = min(n_un, (int)carry);
+    int n_new = n_un - n_r;
+    if (S + n_new > d.Scap) {
+        if (threadIdx.x == 0) atomicOr(&c->error, 1);
+        n_new = max(d.Scap - S, 0);
+    }
+    // the bound segments are queued from the back of the work array (no reservation to wait for);
+    // sharded: only the binds to own cells are queued, each with its own reservation at the front
+    const bool whole = d.world == 1;
+    __syncthreads();
+    const int wbase = d.work_cap - (n_r + n_new);
+    const int n_w = c->has_winner[p ^ 1] ? c->n_win[p ^ 1] : -1;
+    const int grown = n_w > 0 ? min(d.sample, n_w) : 0;
+    const int n_need = s_nneed;
+    for (int i = 0; i < n_need; ++i) {          // each needed 1024-block: rank its recyclable segments
+        const int b = d.recyc_need[2 * i], off = d.recyc_need[2 * i + 1];
+        constexpr int IPT = 1024 / BS;             // consecutive segments per thread
+        uint32_t fl[IPT], cnt = 0;
+#pragma unroll
+        for (int j = 0; j < IPT; ++j) {
+            const int seg = b * 1024 + (int)threadIdx.x * IPT + j;
+            fl[j] = (seg < S && d.seg_nsyn[seg] < d.match_thr) ? 1u : 0u;
+            cnt += fl[j];
+        }
+        uint32_t total;
+        int rank = off + (int)block_excl_scan<BS>(cnt, s_wave, total);
+#pragma unroll
+        for (int j = 0; j < IPT; ++j) {
+            const int seg = b * 1024 + (int)threadIdx.x * IPT + j;
+            if (fl[j] && rank < n_r) tm_bind_segment(d, seg, d.unacc_list[rank], true, whole ? wbase + rank : -1, grown);
+            rank += (int)fl[j];
+        }
+    }
+    for (int i = threadIdx.x; i < n_new; i += BS)
+        tm_bind_segment(d, S + i, d.unacc_list[n_r + i], false, whole ? wbase + n_r + i : -1, grown);
+    if (threadIdx.x == 0) {
+        c->n_recycled = n_r;
+        c->n_new = n_new;
+        c->n_bind = whole ? n_r + n_new : 0;
+        c->S_old = S;
+        c->S = S + n_new;
+    }
+}
+
+// SparseProjection.update_permanence (projections.py:97-109) and add_edge (:111-161) for one
+// work item per wave.  Permanences: float64 sum, float32 store, prune on the float64 value; the
+// surviving synapses are re-packed to the front of the row.  Growth: the n_add previous winner
+// cells with the smallest keyed priority that the segment does not have yet.
+template <int EPL, int BS>
+struct LearnShared { u64 cand[BS / 64][CAND_CAP]; int keep[BS / 64][EPL * 64]; };
+
+template <int EPL, int BS>
+__device__ __forceinline__ void role_learn(const Dev &d, int p, int blk, int nblk, LearnShared<EPL, BS> *sh) {
+    int (*s_keep)[EPL * 64] = sh->keep;
+    u64 (*s_cand)[CAND_CAP] = sh->cand;
+    Counters *c = d.ctr;
+    {   // forget the previous scan's per-cell maxima (sparse clear; every reader ran in an earlier
+        // launch) and reset what the coming scan accumulates
+        const int n = c->has_distal ? c->S : 0;
+        for (int i = blk * BS + threadIdx.x; i < n; i += nblk * BS)
+            if (d.seg_info[i] & 0x40000000u) d.cellmax[d.seg_cell[i]] = 0u;
+        const int nb = (c->S + 1023) >> 10;
+        for (int i = blk * BS + threadIdx.x; i < nb; i += nblk * BS) d.recyc_cnt[i] = 0;
+    }
+    const int wv = threadIdx.x >> 6, lane = lane_id();
+    const int n_front = min(c->n_work, d.work_cap), n_back = c->n_bind;
+    if (n_front + n_back > d.work_cap && blk == 0 && threadIdx.x == 0) atomicOr(&c->error, 4);
+    const int n_work = min(n_front + n_back, d.work_cap);
+    const uint32_t *act_prev = d.act[p ^ 1];
+    const int *winners = d.winners[p ^ 1];
+    const int n_w = c->has_winner[p ^ 1] ? c->n_win[p ^ 1] : -1;       // -1: winner_input is None
+    const uint32_t base2 = htm_stream_base(d.seed, HTM_STREAM_GROWTH, c->step[p]);
+    for (int item = blk * (BS / 64) + wv; item < n_work; item += nblk * (BS / 64)) {
+        const uint32_t w = d.work[item < n_front ? item : d.work_cap - n_back + (item - n_front)];
+        const int seg = (int)(w & 0x7FFFFFFFu), mode = (int)(w >> 31);
+        const double dA = mode ? d.pun_act : d.lrn_act, dI = mode ? d.pun_inact : d.lrn_inact;
+        const bool prune = mode ? d.pun_prune : d.lrn_prune;
+        const int n = d.seg_nsyn[seg];
+        int *prow = d.presyn + (size_t)seg * d.E;
+        float *mrow = d.sperm + (size_t)seg * d.E;
+        int n_keep = 0, n_active = 0;
+#pragma unroll
+        for (int jj = 0; jj < EPL; ++jj) {
+            const int idx = jj * 64 + lane;
+            const bool valid = idx < n;
+            int ps = 0;
+            float pm = 0.f;
+            if (valid) { ps = prow[idx]; pm = mrow[idx]; }
+            const bool a = valid && ((act_prev[ps >> 5] >> (ps & 31)) & 1u);
+            const double p64 = (double)pm + (a ? dA : dI);               // :102-103
+            const bool keep = valid && !(prune && p64 < 0.0);            // :105-108
+            const u64 mk = __ballot(keep);
+            if (keep) {
+                const int pos = n_keep + __popcll(mk & lanemask_lt());
+                prow[pos] = ps;
+                mrow[pos] = (float)p64;                                   // :104
+                s_keep[wv][pos] = ps;
+            }
+            n_keep += __popcll(mk);
+            n_active += __popcll(__ballot(keep && a));                    // :114
+        }
+        __builtin_amdgcn_wave_barrier();
+        int n_total = n_keep;
+        if (mode == 0 && n_w > 0) {
+            const int n_add = min(max(d.sample - n_active, 0), min(d.sample, n_w));     // :115
+            if (n_add > 0) {
+                // threshold T with n_add <= |{absent winners with priority < T}| <= CAND_CAP
+                uint32_t lo = 0, hi = 1u << 24, T = 1u << 24;
+                if (n_w > CAND_CAP) {
+                    u64 est = ((u64)(2 * n_add + 16) << 24) / (u64)max(n_w - n_active, 1);
+                    T = (uint32_t)min(est, (u64)(1u << 24));
+                }
+                // Each try stages every winner with priority < T, then drops the ones the segment already
+                // has: one lane per staged winner walks the kept synapses once.  (Testing membership
+                // inside the scan of the winner list made the whole wave walk them in every 64-winner
+                // chunk with a hit: 30 us for a full row.)
+                int found = 0;
+                for (int iter = 0; iter < 64; ++iter) {
+                    int staged = 0;
+                    for (int b0 = 0; b0 < n_w; b0 += 64) {
+                        const int i = b0 + lane;
+                        uint32_t pr = 0;
+                        bool take = false;
+                        if (i < n_w) {
+                            pr = htm_draw24(base2, (uint32_t)seg, enc_to_flat(winners[i], d.K));     // :120
+                            take = pr < T;
+                        }
+                        const u64 mt = __ballot(take);
+                        if (take) {
+                            const int pos = staged + __popcll(mt & lanemask_lt());
+                            if (pos < CAND_CAP) s_cand[wv][pos] = ((u64)pr << 32) | (uint32_t)i;
+                        }
+                        staged += __popcll(mt);
+                    }
+                    if (staged > CAND_CAP) {                      // too many for the staging area: lower T
+                        hi = T;
+                        if (hi - lo <= 1) { atomicOr(&c->error, 4); found = 0; break; }
+                        T = (lo + hi) / 2;
+                        continue;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    found = 0;
+                    for (int e0 = 0; e0 < staged; e0 += 64) {     // :121-123, compacting in place (pos <= e)
+                        const int e = e0 + lane;
+                        u64 key = 0;
+                        bool absent = false;
+                        if (e < staged) {
+                            key = s_cand[wv][e];
+                            const int cell = winners[(uint32_t)key];
+                            absent = true;
+                            for (int qq = 0; qq < n_keep; ++qq)
+                                if (s_keep[wv][qq] == cell) { absent = false; break; }
+                        }
+                        const u64 ma = __ballot(absent);
+                        __builtin_amdgcn_wave_barrier();
+                        if (absent) s_cand[wv][found + __popcll(ma & lanemask_lt())] = key;
+                        found += __popcll(ma);
+                    }
+                    if (found >= n_add || T == (1u << 24)) break; // enough, or fewer absent winners than n_add: take all
+                    lo = T;
+                    T = (hi == (1u << 24)) ? (uint32_t)min((u64)T * 4u + 16u, (u64)hi) : (lo + hi + 1) / 2;
+                }
+                __builtin_amdgcn_wave_barrier();
+                const int n_c = min(found, CAND_CAP), take_n = min(n_add, n_c);        // :125-127
+                for (int e = lane; e < n_c; e += 64) {
+                    const u64 key = s_cand[wv][e];
+                    int rank = 0;
+                    for (int f = 0; f < n_c; ++f) rank += s_cand[wv][f] < key;
+                    if (rank < take_n) {
+                        const int slot = n_keep + rank;
+                        if (slot < d.E) {
+                            prow[slot] = winners[(uint32_t)key];
+                            mrow[slot] = d.perm_init;                                   // :149,158
+                        } else {
+                            atomicOr(&c->error, 2);
+                        }
+                    }
+                }
+                n_total = min(n_keep + take_n, d.E);                                    // :161
+            }
+        }
+        if (lane == 0) {
+            d.seg_nsyn[seg] = n_total;
+            if (d.world > 1 && n >= d.match_thr && n_total < d.match_thr) {       // tell the other ranks
+                const int slot = atomicAdd(&d.dead_list[0], 1);
+                if (slot < DEAD_CAP) d.dead_list[1 + slot] = seg; else atomicOr(&c->error, 8);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
+
+template <int EPL>
+__global__ __launch_bounds__(RB) void k_tm_learn(Dev d, int p) {
+    role_learn<EPL, RB>(d, p, blockIdx.x, gridDim.x, (LearnShared<EPL, RB> *)dyn_lds);
+}
+
+// PredictiveProjection.process (projections.py:245-255): per segment, potential = active
+// presynaptic cells; matching segments additionally count connected active synapses;
+// per-cell prediction and max jittered potential (:229-239).  8 lanes per segment, 16-byte
+// loads of the packed row, two segments in flight per lane group; a block owns SCAN_SEGS
+// consecutive segment ids and also counts the recyclable ones among them (per 1024 ids) for the
+// next step's add_output.  The last duty of a timestep: publish the next step index.
+// use_lds: the bitmap of active columns is staged in LDS and consulted first, so that only the
+// ~2 % of synapses whose presynaptic column is active touch the per-column cell words in L2.
+// Branch-free: lanes whose column is inactive read act[0] instead (one shared cache line), so all
+// LDS reads and then all global reads of a lane can be in flight together.
+// use_lds: the bitmap of active columns is consulted in LDS first; only the ~2 % of synapses whose
+// presynaptic column is active then read that column's cell word (lanes of inactive columns read
+// act[0], one shared cache line, so the access stays branch-free).  Measured alternatives: a
+// global gather for every synapse moves 64 B per bit; an LDS-only lookup (bitmap + prefix counts +
+// active words) costs three bank-conflicted LDS reads per synapse and was 1.6x slower.
+struct ScanLds { const uint32_t *colbits; };
+__device__ __forceinline__ uint32_t scan_cell_active(const uint32_t *act, const ScanLds &L, int enc, bool valid, bool use_lds) {
+    const int col = enc >> 5;
+    uint32_t maybe = valid ? 1u : 0u;
+    if (use_lds) maybe &= (L.colbits[col >> 5] >> (col & 31));
+    uint32_t aw = 0;
+    if (maybe) aw = act[col];          // exec-masked: only lanes of active columns issue a request
+    return maybe & (aw >> (enc & 31));
+}
+
+// LDS: word 0 = recyclable counter; from word 4: column bitmap [colwords]
+template <int BS, bool use_lds>
+__device__ __forceinline__ void role_scan(const Dev &d, int p, int blk, int nblk, int n_spec, uint32_t *lds) {
+    constexpr int SEGS = BS / 4;                   // segments per block iteration: BS/8 lane groups x 2 in flight
+    int &s_recyc = *(int *)lds;
+    uint32_t *s_colbits = lds + 4;
+    const ScanLds L{s_colbits};
+    Counters *c = d.ctr;
+    const int S = c->S;
+    if (blk == 0 && threadIdx.x == 0) {
+        c->step[p ^ 1] = c->step[p] + 1;
+        c->has_distal = 1;
+        c->n_work_last = c->n_work + c->n_bind;
+        c->n_work = 0;
+        c->n_bind = 0;
+    }
+    const uint32_t *act = d.act[p];
+    const uint32_t base3 = htm_stream_base(d.seed, HTM_STREAM_SEGMENT_JITTER, c->step[p]);
+    // 8 lanes per segment, 16 bytes per lane: one 128-byte chunk = 32 synapse slots.  Packed rows
+    // rarely exceed one chunk (growth tops a segment up to 32 active synapses), so a typical row
+    // costs exactly 128 bytes of presynaptic ids.
+    const int g = threadIdx.x >> 3, l = threadIdx.x & 7;
+    constexpr int NG = BS / 8;                     // lane groups per block
+    constexpr int U = SEGS / NG;                   // segments in flight per lane group
+    bool staged = false;
+    // In the first n_spec blocks (the ones that had segments when the host last saw the segment count)
+    // the loads of the first batch do not wait for the count: rows up to the pool's capacity exist, so they
+    // are fetched for ids clamped to it and masked once S has arrived: one dependent round trip less.
+    for (int b = blk;; b += nblk) {
+        const bool speculative = b == blk && blk < n_spec;
+        if (!speculative && b * SEGS >= S) break;
+        int seg[U], n[U], pot[U], conn[U], n_true[U], cellu[U];
+        u64 bits[U];
+        int4 ps[U], ps2[U];
+        bool mine[U];
+        // round trip 1: synapse count, owner cell and the first chunk of each row, all unconditional
+        // (rows of other ranks' segments exist in the replicated address space; they are masked below)
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            seg[u] = min(b * SEGS + u * NG + g, d.Scap - 1);
+            n[u] = d.seg_nsyn[seg[u]];
+            cellu[u] = d.seg_cell[seg[u]];
+            ps[u] = *(const int4 *)(d.presyn + (size_t)seg[u] * d.E + l * 4);
+        }
+        if (!staged) {                               // the bitmap staging overlaps with those loads
+            if (use_lds)
+                for (int i = threadIdx.x; i < d.colwords; i += BS) s_colbits[i] = d.colbits[p][i];
+            staged = true;
+        }
+        if (threadIdx.x == 0) s_recyc = 0;
+        __syncthreads();
+        if (speculative && b * SEGS >= S) break;     // (uniform in the block)
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool ok = b * SEGS + u * NG + g < S;
+            mine[u] = d.world == 1 || col_is_local(d, cellu[u]);
+            n_true[u] = ok ? n[u] : 0x7FFFFFFF;      // for the recyclable count (all ranks, all segments)
+            if (!ok || !mine[u]) n[u] = 0;
+            seg[u] = ok ? seg[u] : S;
+        }
+        // round trip 2 (only rows longer than one chunk): second chunk, in flight during the lookups of the first
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            ps2[u] = make_int4(0, 0, 0, 0);
+            if (n[u] > 32) ps2[u] = *(const int4 *)(d.presyn + (size_t)seg[u] * d.E + 32 + l * 4);
+        }
+        // chunk 1: all LDS lookups, then all cell-word reads, each as one batch
+        {
+            int e[U][4];
+            uint32_t on[U][4], aw[U][4];
+#pragma unroll
+            for (int u = 0; u < U; ++u) { e[u][0] = ps[u].x; e[u][1] = ps[u].y; e[u][2] = ps[u].z; e[u][3] = ps[u].w; }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) {
+                    const int col = e[u][qq] >> 5;
+                    on[u][qq] = use_lds ? (s_colbits[col >> 5] >> (col & 31)) & 1u : 1u;
+                }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) {
+                    if (l * 4 + qq >= n[u]) on[u][qq] = 0;
+                    aw[u][qq] = act[on[u][qq] ? (e[u][qq] >> 5) : 0];     // inactive columns: one shared line
+                }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                u64 bb = 0;
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) bb |= (u64)(on[u][qq] & (aw[u][qq] >> (e[u][qq] & 31))) << qq;
+                bits[u] = bb;
+            }
+        }
+        // chunk 2, same shape (skipped by waves in which no row is that long)
+        bool any_long = false;
+#pragma unroll
+        for (int u = 0; u < U; ++u) any_long |= n[u] > 32;
+        if (__any(any_long)) {
+            int e[U][4];
+            uint32_t on[U][4], aw[U][4];
+#pragma unroll
+            for (int u = 0; u < U; ++u) { e[u][0] = ps2[u].x; e[u][1] = ps2[u].y; e[u][2] = ps2[u].z; e[u][3] = ps2[u].w; }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) {
+                    const int col = e[u][qq] >> 5;
+                    on[u][qq] = use_lds ? (s_colbits[col >> 5] >> (col & 31)) & 1u : 1u;
+                }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) {
+                    if (32 + l * 4 + qq >= n[u]) on[u][qq] = 0;
+                    aw[u][qq] = act[on[u][qq] ? (e[u][qq] >> 5) : 0];
+                }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) bits[u] |= (u64)(on[u][qq] & (aw[u][qq] >> (e[u][qq] & 31))) << (4 + qq);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (n[u] > 64) {                         // rare: rows longer than two chunks
+                const int *prow = d.presyn + (size_t)seg[u] * d.E;
+                for (int i = 64 + l * 4, ch = 2; i < n[u]; i += 32, ++ch) {
+                    const int4 pv = *(const int4 *)(prow + i);
+                    const int e[4] = {pv.x, pv.y, pv.z, pv.w};
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq)
+                        bits[u] |= (u64)scan_cell_active(act, L, e[qq], i + qq < n[u], use_lds) << (ch * 4 + qq);
+                }
+            }
+            int v = __popcll(bits[u]);
+            for (int o = 4; o > 0; o >>= 1) v += __shfl_xor(v, o);
+            pot[u] = v;
+        }
+        {   // connected active synapses of the matching segments (:171-172): the permanences of the first two
+            // chunks of every matching row are fetched in one batch (one round trip, not one per chunk and row)
+            float4 pm[U][2];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const bool matching = pot[u] >= d.match_thr;                         // :247
+                const float *mrow = d.sperm + (size_t)seg[u] * d.E;
+#pragma unroll
+                for (int ch = 0; ch < 2; ++ch)
+                    pm[u][ch] = (matching && ch * 32 + l * 4 < n[u]) ? *(const float4 *)(mrow + ch * 32 + l * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                int cn = 0;
+#pragma unroll
+                for (int ch = 0; ch < 2; ++ch) {
+                    const float e[4] = {pm[u][ch].x, pm[u][ch].y, pm[u][ch].z, pm[u][ch].w};
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq)
+                        cn += ((bits[u] >> (ch * 4 + qq)) & 1ull) && (e[qq] >= d.perm_thr);
+                }
+                if (pot[u] >= d.match_thr && n[u] > 64) {                            // rare: longer rows
+                    const float *mrow = d.sperm + (size_t)seg[u] * d.E;
+                    for (int i = 64 + l * 4, ch = 2; i < n[u]; i += 32, ++ch) {
+                        const float4 pv = *(const float4 *)(mrow + i);
+                        const float e[4] = {pv.x, pv.y, pv.z, pv.w};
+#pragma unroll
+                        for (int qq = 0; qq < 4; ++qq)
+                            cn += ((bits[u] >> (ch * 4 + qq)) & 1ull) && (e[qq] >= d.perm_thr);
+                    }
+                }
+                for (int o = 4; o > 0; o >>= 1) cn += __shfl_xor(cn, o);
+                conn[u] = cn;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (l == 0 && seg[u] < S) {
+                if (n_true[u] < d.match_thr) atomicAdd(&s_recyc, 1);
+                if (!mine[u]) continue;
+                const bool matching = pot[u] >= d.match_thr;
+                uint32_t info = (uint32_t)pot[u];
+                if (matching) {
+                    const bool active = conn[u] >= d.act_thr;                         // :250
+                    const int cell = cellu[u];
+                    const float jit = htm_jitter((float)pot[u], htm_draw24(base3, (uint32_t)seg[u], 0u));   // :234-235
+                    atomicMax(&d.cellmax[cell], __float_as_uint(jit));               // :237
+                    if (active) atomicOr(&d.pred[p][cell >> 5], 1u << (cell & 31));   // :251, networks.py:122
+                    info |= ((uint32_t)conn[u] << 12) | 0x40000000u | (active ? 0x80000000u : 0u);
+                    d.seg_jit[seg[u]] = jit;
+                }
+                d.seg_info[seg[u]] = info;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0 && s_recyc) atomicAdd(&d.recyc_cnt[(b * SEGS) >> 10], s_recyc);
+    }
+}
+
+// use_lds is a compile-time switch: as a run-time flag it put a branch and a wait around every
+// single LDS lookup, which serialised them
+// MINW = 6 caps the kernel at 80 registers so that 6 blocks fit a CU and a pool of up to ~98 k
+// segments is scanned by blocks that are all resident at once (the latency-bound regime of the bench
+// workload); large pools are bandwidth-bound and run faster without the cap (MINW = 1).
+template <bool use_lds, int MINW>
+__global__ __launch_bounds__(256, MINW) void k_tm_scan(Dev d, int p, int n_spec) {
+    role_scan<256, use_lds>(d, p, blockIdx.x, gridDim.x, n_spec, (uint32_t *)dyn_lds);
+}
+
+// recount recyclable segments after a state import
+__global__ __launch_bounds__(256) void k_tm_recount(Dev d) {
+    __shared__ int s_recyc;
+    const int S = d.ctr->S, b = blockIdx.x;
+    if (b * 1024 >= S) return;
+    if (threadIdx.x == 0) s_recyc = 0;
+    __syncthreads();
+    int v = 0;
+    for (int q = 0; q < 4; ++q) {
+        int s = b * 1024 + threadIdx.x * 4 + q;
+        v += (s < S && d.seg_nsyn[s] < d.match_thr) ? 1 : 0;
+    }
+    if (v) atomicAdd(&s_recyc, v);
+    __syncthreads();
+    if (threadIdx.x == 0) d.recyc_cnt[b] = s_recyc;
+}
+
+#endif
