@@ -648,9 +648,10 @@ extern "C" int htm_shard_begin(htm_handle *h, const uint32_t *device_inputs, int
     Dev &d = h->d;
     const int p = (int)(h->step_host & 1);
     const int cl = d.c1 - d.c0;
-    LAUNCH(h, "sp_overlap", k_sp_overlap, h->sp_blocks, RB, d, h->shard_bank, h->shard_n_inputs, h->G, p, p, 0);
-    LAUNCH(h, "shard_pack_clear", k_shard_pack_clear, 1, 256, d, (unsigned char *)send_device);
-    LAUNCH(h, "shard_pack", k_shard_pack, (cl * 32 + 255) / 256, 256, d, p, (unsigned char *)send_device);
+    const int rows_per_block = 4 * 4 * (64 / h->G);                 // 256 threads: 4 waves x 4 row groups in flight
+    const int n_ov = std::max(1, std::min((cl + rows_per_block - 1) / rows_per_block, 1024));
+    LAUNCH(h, "shard_begin", k_shard_begin, n_ov + (cl + 7) / 8, 256, d, h->shard_bank, h->shard_n_inputs, h->G, p,
+           (unsigned char *)send_device, n_ov);
     h->shard_open = true;
     (void)learning;
     return HTM_OK;

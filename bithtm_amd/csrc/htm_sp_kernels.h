@@ -32,7 +32,8 @@ __global__ __launch_bounds__(256) void k_sp_build_mask(Dev d, int row_begin, int
 // sp = parity buffer of the SP step being computed; step_offset = that step minus the current one.
 template <int BS>
 __device__ __forceinline__ void role_overlap(const Dev &d, const uint32_t *__restrict__ bank, int n_inputs, int G,
-                                             int p, int sp, int step_offset, int blk, int nblk, uint32_t *h) {
+                                             int p, int sp, int step_offset, int blk, int nblk, uint32_t *h,
+                                             double *shard_boosted = nullptr) {      // sharded: also into the exchange record
     const int gtid = blk * BS + threadIdx.x;
     const int nthreads = nblk * BS;
     const bool do_hist = d.world == 1;
@@ -86,6 +87,7 @@ __device__ __forceinline__ void role_overlap(const Dev &d, const uint32_t *__res
                 const float f = htm_exp_f32(d.coef * dty[u]);          // float32 product, documented exp
                 const double bo = (double)f * (double)cn;              // exact (24-bit x <= 16-bit)
                 d.boosted[sp][row] = bo;
+                if (shard_boosted) shard_boosted[row - d.c0] = bo;
                 key = (u64)__double_as_longlong(bo);
                 d.key[sp][row] = key;
             }
@@ -310,35 +312,40 @@ __host__ __device__ __forceinline__ size_t shard_record_bytes(int cl) {
 // before the exchange: what each OWN column would look like if it became active (this only
 // needs the rank's own previous predictions, segment maxima and segment counts), its boosted
 // overlap, and the segments that died during the previous step's learning
-__global__ __launch_bounds__(256) void k_shard_pack(Dev d, int p, unsigned char *send) {
+// One launch: blocks [0, n_overlap_blocks) compute overlap + boost of the own columns, straight into the
+// record; the others pack eight own columns each (one per half-wave); the first of them also reports
+// the segments that died while learning.
+__global__ __launch_bounds__(256) void k_shard_begin(Dev d, const uint32_t *__restrict__ bank, int n_inputs, int G, int p,
+                                                      unsigned char *send, int n_overlap_blocks) {
     const int cl = d.c1 - d.c0;
-    double *r_boost = (double *)send;
+    if ((int)blockIdx.x < n_overlap_blocks) {
+        role_overlap<256>(d, bank, n_inputs, G, p, p, 0, blockIdx.x, n_overlap_blocks, nullptr, (double *)send);
+        return;
+    }
+    __shared__ uint32_t s_burst;
+    const int pb = (int)blockIdx.x - n_overlap_blocks;
     uint32_t *r_act = (uint32_t *)(send + (size_t)cl * 8);
     uint32_t *r_win = r_act + cl, *r_unacc = r_win + cl, *r_burst = r_unacc + cl;
     uint32_t *r_dead = r_burst + (cl + 31) / 32;
-    const int i = (blockIdx.x * 256 + threadIdx.x) >> 5;           // local column, one per half-wave
+    if (threadIdx.x == 0) s_burst = 0;
+    __syncthreads();
+    const int i = (pb * 256 + (int)threadIdx.x) >> 5;               // local column, one per half-wave
     const bool ok = i < cl;
     const int a = d.c0 + (ok ? i : 0);
     const ColumnWords w = tm_column_words(d, p, 1, ok, a, ok ? d.pred[p ^ 1][a] : 0u);
-    // bursting bits: one 32-bit word per 32 columns = 16 consecutive waves' halves; use atomics
     if (ok && (lane_id() & 31) == 0) {
-        r_boost[i] = d.boosted[p][a];
         r_act[i] = w.act;
         r_win[i] = w.winner;
         r_unacc[i] = w.unacc;
-        if (w.burst) atomicOr(&r_burst[i >> 5], 1u << (i & 31));
+        if (w.burst) atomicOr(&s_burst, 1u << (i & 7));
     }
-    if (blockIdx.x == 0) {
+    __syncthreads();
+    if (threadIdx.x == 0 && pb * 8 < cl) ((unsigned char *)r_burst)[pb] = (unsigned char)s_burst;   // 8 columns = one byte of the bit words
+    if (pb == 0) {
         const int n = min(d.dead_list[0], DEAD_CAP);
         if (threadIdx.x == 0) r_dead[0] = (uint32_t)n;
         for (int j = threadIdx.x; j < n; j += 256) r_dead[1 + j] = (uint32_t)d.dead_list[1 + j];
     }
-}
-
-__global__ __launch_bounds__(256) void k_shard_pack_clear(Dev d, unsigned char *send) {
-    const int cl = d.c1 - d.c0;
-    uint32_t *r_burst = (uint32_t *)(send + (size_t)cl * 20);
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < (cl + 31) / 32; i += gridDim.x * 256) r_burst[i] = 0;
 }
 
 // after the exchange: the keys and speculative words of ALL columns in global column order, the
