@@ -416,7 +416,7 @@ __global__ __launch_bounds__(1024) void k_shard_unpack(Dev d, const unsigned cha
 // bucket keys (or more than CAND_MAX in total) switches ALL blocks, consistently, to an exact
 // fallback: the remaining digits are resolved block-redundantly from the key array and the
 // per-block counts are exchanged in a second tagged round.
-#define CAND_D 8              // distinct bucket keys one block can publish
+#define CAND_D 15             // distinct bucket keys one block can publish (head + 15 granules = its 128-byte record)
 #define CAND_RAW 64           // ... and collect from its waves before merging duplicates
 #define CAND_MAX 2048         // bucket entries a block can merge
 #define CAND_OTHERS 160         // ... after folding the copies of one key, if at most this many others remain
@@ -549,7 +549,7 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
         __syncthreads();
         if (tid < nraw && first != tid) atomicAdd(&s_bc[first], my_cnt);
         __syncthreads();
-        // record = up to 8 self-validating 64-bit granules (form R2: every granule carries the epoch, one
+        // record = up to 16 self-validating 64-bit granules (form R2: every granule carries the epoch, one
         // aligned 8-byte write-through store each, so no separate tag and no drain):
         //   [0]      epoch:12 | overflow:1 | pairs:4 | keys above the bucket:9 | multiplicity:9 | key bits:29
         //   [j >= 1] epoch:12 | multiplicity:12 | low 40 key bits   (the high bits are the bucket's)
@@ -594,7 +594,7 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
             int np = (g[0] >> 52) == epoch ? (int)((g[0] >> 47) & 0xFu) : 0;
             for (int spins = 0; np > 1; ++spins) {
 #pragma unroll
-                for (int j = 1; j < CAND_D; ++j) g[j] = __hip_atomic_load(rr + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int j = 1; j < CAND_D; ++j) g[j] = j < np ? __hip_atomic_load(rr + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
                 bool ok = true;
 #pragma unroll
                 for (int j = 1; j < CAND_D; ++j) ok = ok && (j >= np || (g[j] >> 52) == epoch);
