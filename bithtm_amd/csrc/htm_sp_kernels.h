@@ -64,13 +64,13 @@ __device__ __forceinline__ void role_overlap(const Dev &d, const uint32_t *__res
             dty[u] = (l == 0 && row < d.c1) ? d.duty[row] : 0.f;
         }
         for (int j = l; j < d.W4; j += G) {
-            const uint4 x = in4[j];
-            uint4 m[U];
+            uint4 m[U];                            // the mask rows first: they do not wait for the step counter
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int row = row0 + u * rpw + sub;
                 m[u] = row < d.c1 ? mask4[(size_t)row * d.W4 + j] : make_uint4(0, 0, 0, 0);
             }
+            const uint4 x = in4[j];
 #pragma unroll
             for (int u = 0; u < U; ++u)
                 cnt[u] += __popc(m[u].x & x.x) + __popc(m[u].y & x.y) + __popc(m[u].z & x.z) + __popc(m[u].w & x.w);

@@ -338,9 +338,13 @@ __device__ __forceinline__ void role_learn(const Dev &d, int p, int blk, int nbl
                     T = (uint32_t)min(est, (u64)(1u << 24));
                 }
                 // Each try stages every winner with priority < T, then drops the ones the segment already
-                // has: one lane per staged winner walks the kept synapses once.  (Testing membership
-                // inside the scan of the winner list made the whole wave walk them in every 64-winner
-                // chunk with a hit: 30 us for a full row.)
+                // has.  The kept synapses sit in registers, EPL per lane; the staged winners are broadcast
+                // one at a time and compared by the whole wave.  (Testing membership inside the scan of the
+                // winner list made the wave walk the kept synapses in every 64-winner chunk with a hit:
+                // 30 us for a full row; one lane per staged winner walking them took 4 us per 64 staged.)
+                int kept[EPL];
+#pragma unroll
+                for (int jj = 0; jj < EPL; ++jj) kept[jj] = jj * 64 + lane < n_keep ? s_keep[wv][jj * 64 + lane] : -1;
                 int found = 0;
                 for (int iter = 0; iter < 64; ++iter) {
                     int staged = 0;
@@ -369,15 +373,19 @@ __device__ __forceinline__ void role_learn(const Dev &d, int p, int blk, int nbl
                     found = 0;
                     for (int e0 = 0; e0 < staged; e0 += 64) {     // :121-123, compacting in place (pos <= e)
                         const int e = e0 + lane;
-                        u64 key = 0;
-                        bool absent = false;
-                        if (e < staged) {
-                            key = s_cand[wv][e];
-                            const int cell = winners[(uint32_t)key];
-                            absent = true;
-                            for (int qq = 0; qq < n_keep; ++qq)
-                                if (s_keep[wv][qq] == cell) { absent = false; break; }
+                        const u64 key = e < staged ? s_cand[wv][e] : 0ull;
+                        const int cell = e < staged ? winners[(uint32_t)key] : -2;
+                        bool present = false;
+                        const int n_here = min(64, staged - e0);
+                        for (int t = 0; t < n_here; ++t) {        // (t is uniform: a lane read, not a shuffle)
+                            const int ct = __builtin_amdgcn_readlane(cell, t);
+                            bool hit = false;
+#pragma unroll
+                            for (int jj = 0; jj < EPL; ++jj) hit |= kept[jj] == ct;
+                            const bool any = __ballot(hit) != 0;
+                            if (lane == t) present = any;
                         }
+                        const bool absent = e < staged && !present;
                         const u64 ma = __ballot(absent);
                         __builtin_amdgcn_wave_barrier();
                         if (absent) s_cand[wv][found + __popcll(ma & lanemask_lt())] = key;
