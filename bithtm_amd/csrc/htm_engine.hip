@@ -53,6 +53,7 @@ struct htm_handle {
     bool shard_open;
     int G;                                // lanes per SP row
     int graph_steps;                      // steady-state steps per captured graph (BITHTM_GRAPH_STEPS)
+    bool emit_fused, emit_fused_open;     // the emit grid is resident at once in k_sp_emit / in k_open_emit
     int seg_hint;                         // a lower bound of the segment count (see scan_spec_blocks)
     int *seg_pinned;                      // pinned word the end of each htm_run copies the count into
     int sp_blocks, sel_blocks, c256_blocks, s1024_blocks, scan_blocks;
@@ -176,7 +177,7 @@ static void enqueue_sp_front(htm_handle *h, const uint32_t *bank, int n_inputs, 
 // its own (handles without a Temporal Memory, and the first step of a pipelined run).
 static void enqueue_sp_back(htm_handle *h, const uint32_t *bank, int n_inputs, int p, int want_winner, int mode, bool sp_learn) {
     Dev &d = h->d;
-    const int fused = h->c256_blocks <= 1024;      // all blocks co-resident: count inside emit
+    const int fused = h->emit_fused;               // all blocks co-resident: count inside emit
     if (!fused) LAUNCH(h, "sp_count", k_sp_count, h->c256_blocks, 256, d, p);
     LAUNCH(h, "sp_emit", k_sp_emit, h->c256_blocks, 256, d, p, want_winner, fused, mode);
     // (a forked graph branch for this independent update was measured at +17..29 us per step on
@@ -209,7 +210,7 @@ struct StepPlan { bool sp_done, next_sp, next_front; };
 // the pipelined schedule needs the select finished inside one co-resident emit grid after two
 // launched digits
 static bool can_pipeline(const htm_handle *h) {
-    return h->cfg.enable_sp && h->cfg.enable_tm && h->world == 1 && h->c256_blocks <= 1024 && h->d.sel_passes == 2;
+    return h->cfg.enable_sp && h->cfg.enable_tm && h->world == 1 && h->emit_fused_open && h->d.sel_passes == 2;
 }
 
 // the four launches of a pipelined step (see the kernels): step p's Temporal Memory beside SP work of
@@ -460,8 +461,26 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
         const int informative = std::min(64, 64 - (29 - B));
         d.sel_passes = std::max(1, std::min(SEL_MAX_PASSES, (informative + SEL_DIGIT - 1) / SEL_DIGIT));
         d.low_zero = 64 - informative;            // key bits [0, low_zero) are zero in every key
-        // grids of at most 1024 emit blocks finish the select inside k_sp_emit: two digits by launches
-        if ((d.C + 255) / 256 <= 1024) d.sel_passes = std::min(d.sel_passes, 2);
+        // Emit grids whose blocks are all resident at once finish the select inside k_sp_emit (two digits
+        // by launches, the rest through the record exchange, in which blocks wait for each other).  What
+        // fits is asked of the runtime, kernel by kernel, not assumed.
+        {
+            const int c256 = (d.C + 255) / 256;
+            hipDeviceProp_t prop;
+            int per_cu_emit = 0, per_cu_open = 0;
+            if (hipGetDeviceProperties(&prop, h->device) == hipSuccess &&
+                hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_emit, (const void *)k_sp_emit, 256, 0) == hipSuccess &&
+                hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_open, (const void *)k_open_emit, 256, sizeof(EmitShared)) == hipSuccess) {
+                const int cus = prop.multiProcessorCount;
+                h->emit_fused = c256 <= std::min(1024, per_cu_emit * cus);
+                // the pipelined launch puts the activation blocks of the current step behind the emit blocks
+                h->emit_fused_open = h->emit_fused && c256 + (d.k * 32 + 255) / 256 <= std::min(1024, per_cu_open * cus);
+            } else {
+                (void)hipGetLastError();
+                h->emit_fused = h->emit_fused_open = false;
+            }
+        }
+        if (h->emit_fused) d.sel_passes = std::min(d.sel_passes, 2);
         // test knobs: more launched digits (smaller buckets); fewer record slots (forces the fallback)
         if (const char *e = getenv("BITHTM_SEL_LAUNCH_DIGITS")) d.sel_passes = std::max(2, std::min(d.sel_passes, atoi(e)));
         d.cand_d = CAND_D;
@@ -666,7 +685,7 @@ extern "C" int htm_shard_finish(htm_handle *h, const void *recv_device, int32_t 
     learning = learning ? 1 : 0;
     LAUNCH(h, "shard_unpack", k_shard_unpack, h->sel_blocks, 1024, d, (const unsigned char *)recv_device, h->rank, p);
     for (int pass = 1; pass < d.sel_passes; ++pass) LAUNCH(h, "sp_select", k_sel_pass, h->sel_blocks, RB, d, pass, p);
-    const int fused = h->c256_blocks <= 1024;
+    const int fused = h->emit_fused;
     if (!fused) LAUNCH(h, "sp_count", k_sp_count, h->c256_blocks, 256, d, p);
     LAUNCH(h, "sp_emit", k_sp_emit, h->c256_blocks, 256, d, p, 1, fused, EMIT_ALL);
     enqueue_tm(h, d.k, learning, 1, p, h->shard_bank, h->shard_n_inputs, true);

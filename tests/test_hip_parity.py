@@ -156,3 +156,29 @@ def test_more_than_1024_column_blocks_uses_separate_count_kernel():
     from hip_impl import lockstep_vs_oracle
     lockstep_vs_oracle(seed=8, input_dim=96, column_dim=327680, cell_dim=4, patterns=5, density=0.1,
                        noise=0.01, steps=22, store_every=21, segment_capacity=1 << 20)
+
+
+def test_emit_grid_too_large_for_the_pipelined_launch_falls_back():
+    """204 800 columns = 800 emit blocks: they fit k_sp_emit (select finished in-kernel) but not
+    k_open_emit together with the activation blocks, so a batched run must not use the pipelined
+    schedule -- the engine asks the runtime what is resident at once instead of assuming it.  The
+    result has to be the oracle's either way."""
+    from hip_impl import make_htm, compare_store_with_oracle
+    from oracle import HTMOracle
+    I, C, K, P, steps = 64, 204800, 4, 6, 20
+    k = round(C * 0.02)
+    np.random.seed(23)
+    ora = HTMOracle(I, C, K, active_columns=k, seed=23)
+    htm = make_htm(I, C, K, k, 23, ora.spatial_pooler.permanence.copy(), None, None, segment_capacity=1 << 19)
+    bank = np.random.RandomState(24).rand(P, I) < 0.12
+    for t in range(steps):
+        o_sp, _ = ora.step(bank[t % P])
+    htm.run(bank, steps - 4)
+    htm.engine.profile(True)                        # the launches of a (requested) pipelined run, by name
+    htm.run(bank, 4, use_graph=False, pipeline=True)
+    names = set(htm.engine.profile_read())
+    htm.engine.profile(False)
+    assert "sp_emit" in names and "tm_activate+sp_emit" not in names, names
+    assert np.array_equal(htm.engine.read_sp_fields()["active_column"], o_sp.active_column)
+    compare_store_with_oracle(steps - 1, ora, htm)
+    htm.engine.check_capacity()
