@@ -29,30 +29,48 @@ __global__ void k_big(u64 *stamps, int kidx, int maxblk, float *data, size_t n_r
     for (int i = 0; i < 60; ++i) s += b.a[i];
     body(stamps, kidx, maxblk, data, n_read, n_write, s);
 }
+__global__ void k_ptr(u64 *stamps, int kidx, int maxblk, float *data, size_t n_read, size_t n_write, const Big *b) {
+    long long s = 0;
+    for (int i = 0; i < 60; ++i) s += b->a[i];
+    body(stamps, kidx, maxblk, data, n_read, n_write, s);
+}
+__global__ void k_scratch(u64 *stamps, int kidx, int maxblk, float *data, size_t n_read, size_t n_write) {
+    volatile int spill[12];                        // private (scratch) memory: what a register-capped kernel gets when it spills
+    for (int i = 0; i < 12; ++i) spill[i] = (int)threadIdx.x + i;
+    long long s = 0;
+    for (int i = 0; i < 12; ++i) s += spill[(i * 5 + kidx) % 12];
+    body(stamps, kidx, maxblk, data, n_read, n_write, s);
+}
 int main() {
     hipStream_t s; CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     const int N = 20, MAXBLK = 4096;
     u64 *stamps; CK(hipMalloc(&stamps, (size_t)N * MAXBLK * 16));
     float *data; CK(hipMalloc(&data, (size_t)1 << 28)); CK(hipMemset(data, 0, (size_t)1 << 28));
     Big big{};
-    struct V { const char *name; int blocks, lds; bool bigarg; size_t rd, wr; };
+    Big *dbig; CK(hipMalloc(&dbig, sizeof(Big))); CK(hipMemset(dbig, 0, sizeof(Big)));
+    struct V { const char *name; int blocks, lds; int bigarg; size_t rd, wr; };
     const V vs[] = {
-        {"256 blocks, 8-byte args", 256, 0, false, 0, 0},
-        {"  + 480-byte by-value arg", 256, 0, true, 0, 0},
-        {"  + 20 KB dynamic LDS", 256, 20480, false, 0, 0},
-        {"3000 blocks", 3000, 0, false, 0, 0},
-        {"256 blocks, reads 8 MB", 256, 0, false, 2 << 20, 0},
-        {"256 blocks, writes 1 MB", 256, 0, false, 0, 1 << 18},
-        {"256 blocks, writes 8 MB", 256, 0, false, 0, 2 << 20},
-        {"1024 blocks, writes 32 MB", 1024, 0, false, 0, 8 << 20},
-        {"3000 blocks, all of it, w 8 MB", 3000, 20480, true, 2 << 20, 2 << 20},
+        {"256 blocks, 8-byte args", 256, 0, 0, 0, 0},
+        {"  + 480-byte by-value arg", 256, 0, 1, 0, 0},
+        {"  the same 480 bytes behind a pointer", 256, 0, 2, 0, 0},
+        {"  + 20 KB dynamic LDS", 256, 20480, 0, 0, 0},
+        {"  + 48 bytes of scratch per lane", 256, 0, 3, 0, 0},
+        {"3000 blocks, scratch", 3000, 0, 3, 0, 0},
+        {"3000 blocks", 3000, 0, 0, 0, 0},
+        {"256 blocks, reads 8 MB", 256, 0, 0, 2 << 20, 0},
+        {"256 blocks, writes 1 MB", 256, 0, 0, 0, 1 << 18},
+        {"256 blocks, writes 8 MB", 256, 0, 0, 0, 2 << 20},
+        {"1024 blocks, writes 32 MB", 1024, 0, 0, 0, 8 << 20},
+        {"3000 blocks, all of it, w 8 MB", 3000, 20480, 1, 2 << 20, 2 << 20},
     };
     printf("%-34s %10s %10s %10s %10s\n", "variant", "step us", "in-kernel", "gap", "start skew");
     for (const V &v : vs) {
         hipGraph_t g; hipGraphExec_t ge;
         CK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
         for (int i = 0; i < N; ++i) {
-            if (v.bigarg) hipLaunchKernelGGL(k_big, dim3(v.blocks), dim3(256), v.lds, s, stamps, i, MAXBLK, data, v.rd, v.wr, big);
+            if (v.bigarg == 3) hipLaunchKernelGGL(k_scratch, dim3(v.blocks), dim3(256), v.lds, s, stamps, i, MAXBLK, data, v.rd, v.wr);
+            else if (v.bigarg == 2) hipLaunchKernelGGL(k_ptr, dim3(v.blocks), dim3(256), v.lds, s, stamps, i, MAXBLK, data, v.rd, v.wr, (const Big *)dbig);
+            else if (v.bigarg) hipLaunchKernelGGL(k_big, dim3(v.blocks), dim3(256), v.lds, s, stamps, i, MAXBLK, data, v.rd, v.wr, big);
             else hipLaunchKernelGGL(k_small, dim3(v.blocks), dim3(256), v.lds, s, stamps, i, MAXBLK, data, v.rd, v.wr);
         }
         CK(hipStreamEndCapture(s, &g));
