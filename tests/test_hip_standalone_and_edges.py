@@ -175,6 +175,34 @@ def test_batched_run_equals_step_by_step():
             assert np.array_equal(a, b)
 
 
+def test_batched_run_with_learning_switched_off_and_on():
+    """The pipelined schedule with learning=False (no SP rows, no classification, no learning launches
+    doing work) between learning runs == the same schedule of flags through process()."""
+    import bithtm_amd as B
+    rng = np.random.RandomState(13)
+    bank = rng.rand(25, 160) < 0.1
+    plan = ((22, True), (1, False), (19, False), (2, True), (40, True), (18, False), (21, True))
+    outs = []
+    for mode in ("graph", "eager", "process"):
+        np.random.seed(14)
+        htm = B.HierarchicalTemporalMemory(160, 2048, 8)
+        t = 0
+        for n, learning in plan:
+            if mode == "process":
+                for _ in range(n):
+                    htm.process(bank[t % 25], learning=learning)
+                    t += 1
+            else:
+                htm.run(bank, n, learning=learning, use_graph=(mode == "graph"))
+                t += n
+        st = htm.engine.read_store()
+        outs.append((htm.engine.read_sp_fields()["active_column"], st["seg_cell"], st["seg_nsyn"], st["perm"], st["presyn"],
+                     htm.temporal_memory.last_state.cell_prediction, htm.engine.read_duty_cycle(), htm.engine.get_permanence()))
+    for o in outs[:-1]:
+        for a, b in zip(outs[-1], o):
+            assert np.array_equal(a, b)
+
+
 @pytest.mark.parametrize("digits,slots,pairwise,others", [("2", "8", "160", "128"), ("3", "8", "160", "128"), ("2", "0", "160", "128"),
                                                           ("2", "1", "160", "128"), ("2", "8", "0", "128"), ("2", "8", "0", "4"), ("2", "8", "0", "0")])
 def test_select_is_exact_on_the_record_path_and_on_the_fallback(digits, slots, pairwise, others, monkeypatch):
