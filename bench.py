@@ -134,7 +134,11 @@ def run_single(args):
     bank = eng.upload_bank(noisy)
     n_bank = noisy.shape[0]
     log(f"[bench] setup {time.perf_counter() - t_setup:.1f}s; warm-up {args.warmup} steps")
-    use_graph = not args.no_graph
+    # rocprofv3 crashes inside hipGraph replay on this image: under the profiler, launch eagerly
+    under_profiler = "ROCP_TOOL_LIBRARIES" in os.environ
+    if under_profiler and not args.no_graph:
+        log("[bench] rocprofv3 detected: hipGraph replay switched off (eager launches of the same schedule)")
+    use_graph = not args.no_graph and not under_profiler
     pipeline = not args.no_pipeline
     eng.run(bank, n_bank, args.warmup, learning=True, use_graph=use_graph, pipeline=pipeline)
     eng.sync()
