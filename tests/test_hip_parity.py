@@ -42,7 +42,8 @@ def test_hip_small_slots_64():
 
 
 def test_harness_counters_match_reference():
-    """example.py:50-57 counters (bursting / correct / incorrect columns) over 600 steps."""
+    """example.py:50-57 counters (bursting / correct / incorrect columns) over 600 steps: equal to the
+    reference's, and showing its learning curve."""
     from hip_impl import make_htm
     z = np.load(os.path.join(GOLDEN, "harness_example.npz"))
     seed, I, C, K, P = int(z["seed"]), int(z["input_dim"]), int(z["column_dim"]), int(z["cell_dim"]), int(z["patterns"])
@@ -60,6 +61,12 @@ def test_harness_counters_match_reference():
         correct = int(prev_col_pred[sp_state.active_column].sum())
         got.append((burst, correct, int(prev_col_pred.sum() - correct)))
     assert np.array_equal(np.array(got, dtype=np.int32), z["counters"])
+    # the learning curve a user of example.py watches: everything bursts for four passes
+    # (0.21 + 3 x 0.1 reaches the 0.5 threshold), then the sequence is predicted
+    got = np.array(got).reshape(-1, P, 3).mean(axis=1)
+    k = round(C * 0.02)
+    assert (got[:4, 0] == k).all() and (got[:4, 1] == 0).all()
+    assert got[4, 0] < 0.15 * k and got[5, 0] < 0.05 * k and got[5, 1] > 0.95 * k and got[:, 2].max() < 0.5
 
 
 def test_full_size_65536x32_state_handoff_and_parity():
