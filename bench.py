@@ -177,6 +177,15 @@ def run_single(args):
                     bytes_per_launch=int(kb[dominant]), avg_launch_us=round(avg_us[dominant], 2),
                     whole_step_bytes=int(sum(kb[n] for n in ("sp_overlap", "sp_learn", "tm_scan", "sp_select", "sp_count", "sp_emit"))))
     roofline["whole_step_frac"] = round(roofline["whole_step_bytes"] * steps_per_s / 1e9 / HBM_PEAK_GBS, 4)
+    if dominant == "tm_scan":
+        # SURVEY.md section 8(d) prices the scan at 8 bytes per slot of every allocated segment (the reference's
+        # unpacked store, 64 slots at this state); the packed store above needs 4 bytes per VALID synapse and
+        # reads permanences only for matching segments.  Both are given; `achieved` is the smaller one.
+        S = int(len(store["seg_nsyn"]))
+        sb = 8 * S * 64
+        roofline["survey_formula"] = dict(bytes_per_launch=sb, achieved=round(sb / (avg_us[dominant] * 1e-6) / 1e9, 1),
+                                          frac=round(sb / (avg_us[dominant] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                          formula="8 * S * E with E = 64 (reference layout)")
     roofline.update(recorded_traffic(dominant))
 
     cpu = None
