@@ -632,31 +632,22 @@ __device__ __forceinline__ void role_scan(const Dev &d, int p, int blk, int nblk
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            uint32_t info = 0;
-            bool store = false;
             if (l == 0 && seg[u] < S) {
                 if (n_true[u] < d.match_thr) atomicAdd(&s_recyc, 1);
-                if (mine[u]) {
-                    const bool matching = pot[u] >= d.match_thr;
-                    info = (uint32_t)pot[u];
-                    store = true;
-                    if (matching) {
-                        const bool active = conn[u] >= d.act_thr;                         // :250
-                        const int cell = cellu[u];
-                        const float jit = htm_jitter((float)pot[u], htm_draw24(base3, (uint32_t)seg[u], 0u));   // :234-235
-                        atomicMax(&d.cellmax[cell], __float_as_uint(jit));               // :237
-                        if (active) atomicOr(&d.pred[p][cell >> 5], 1u << (cell & 31));   // :251, networks.py:122
-                        info |= ((uint32_t)conn[u] << 12) | 0x40000000u | (active ? 0x80000000u : 0u);
-                        d.seg_jit[seg[u]] = jit;
-                    }
+                if (!mine[u]) continue;
+                const bool matching = pot[u] >= d.match_thr;
+                uint32_t info = (uint32_t)pot[u];
+                if (matching) {
+                    const bool active = conn[u] >= d.act_thr;                         // :250
+                    const int cell = cellu[u];
+                    const float jit = htm_jitter((float)pot[u], htm_draw24(base3, (uint32_t)seg[u], 0u));   // :234-235
+                    atomicMax(&d.cellmax[cell], __float_as_uint(jit));               // :237
+                    if (active) atomicOr(&d.pred[p][cell >> 5], 1u << (cell & 31));   // :251, networks.py:122
+                    info |= ((uint32_t)conn[u] << 12) | 0x40000000u | (active ? 0x80000000u : 0u);
+                    d.seg_jit[seg[u]] = jit;
                 }
+                d.seg_info[seg[u]] = info;
             }
-            // the info words of a wave's eight segments go out as one 32-byte store from lanes 0..7 (from the
-            // group leaders, eight lanes apart, they were eight separate partial writes)
-            const int src = (lane_id() & 7) * 8;
-            const uint32_t info8 = __shfl(info, src);
-            const bool store8 = __shfl((int)store, src) != 0;
-            if (lane_id() < 8 && store8) d.seg_info[b * SEGS + u * NG + (g & ~7) + lane_id()] = info8;
         }
         __syncthreads();
         if (threadIdx.x == 0 && s_recyc) atomicAdd(&d.recyc_cnt[(b * SEGS) >> 10], s_recyc);
