@@ -521,7 +521,7 @@ __device__ __forceinline__ void role_scan(const Dev &d, int p, int blk, int nblk
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             ps2[u] = make_int4(0, 0, 0, 0);
-            if (32 + l * 4 < n[u]) ps2[u] = *(const int4 *)(d.presyn + (size_t)seg[u] * d.E + 32 + l * 4);   // only the lanes with valid slots: half a line is often enough
+            if (n[u] > 32) ps2[u] = *(const int4 *)(d.presyn + (size_t)seg[u] * d.E + 32 + l * 4);
         }
         // chunk 1: all LDS lookups, then all cell-word reads, each as one batch
         {
