@@ -683,7 +683,7 @@ extern "C" int htm_shard_finish(htm_handle *h, const void *recv_device, int32_t 
     Dev &d = h->d;
     const int p = (int)(h->step_host & 1);
     learning = learning ? 1 : 0;
-    LAUNCH(h, "shard_unpack", k_shard_unpack, h->sel_blocks, 1024, d, (const unsigned char *)recv_device, h->rank, p);
+    LAUNCH(h, "shard_unpack", k_shard_unpack, std::min(h->c256_blocks, 512), 256, d, (const unsigned char *)recv_device, h->rank, p);
     for (int pass = 1; pass < d.sel_passes; ++pass) LAUNCH(h, "sp_select", k_sel_pass, h->sel_blocks, RB, d, pass, p);
     const int fused = h->emit_fused;
     if (!fused) LAUNCH(h, "sp_count", k_sp_count, h->c256_blocks, 256, d, p);

@@ -352,7 +352,7 @@ __global__ __launch_bounds__(256) void k_shard_begin(Dev d, const uint32_t *__re
 // histogram of the top key digit (what k_sp_overlap does on an unsharded handle), and the deaths
 // the other ranks reported (only "fewer synapses than the matching threshold" matters here:
 // projections.py:80)
-__global__ __launch_bounds__(1024) void k_shard_unpack(Dev d, const unsigned char *recv, int rank, int sp) {
+__global__ __launch_bounds__(256) void k_shard_unpack(Dev d, const unsigned char *recv, int rank, int sp) {
     __shared__ uint32_t h[SEL_BINS];
     const int gtid = blockIdx.x * blockDim.x + threadIdx.x;
     const int nthreads = gridDim.x * blockDim.x;
@@ -360,14 +360,14 @@ __global__ __launch_bounds__(1024) void k_shard_unpack(Dev d, const unsigned cha
     const size_t rb = shard_record_bytes(cl);
     uint32_t *ghist = d.hist + sp * SEL_MAX_PASSES * SEL_BINS;
     for (int i = gtid; i < (d.sel_passes - 1) * SEL_BINS; i += nthreads) ghist[SEL_BINS + i] = 0;
-    for (int i = threadIdx.x; i < SEL_BINS; i += 1024) h[i] = 0;
+    for (int i = threadIdx.x; i < SEL_BINS; i += 256) h[i] = 0;
     if (gtid == 0) {
         d.ctr->sel_pass_prefix[sp][0] = 0;
         d.ctr->sel_pass_krem[sp][0] = (uint32_t)d.k;
         d.dead_list[0] = 0;                        // reported; start collecting this step's
     }
     __syncthreads();
-    for (int c0 = blockIdx.x * 1024 + (threadIdx.x & ~63); c0 < d.C; c0 += gridDim.x * 1024) {
+    for (int c0 = blockIdx.x * 256 + (threadIdx.x & ~63); c0 < d.C; c0 += gridDim.x * 256) {
         const int c = c0 + lane_id();
         u64 key = 0;
         if (c < d.C) {
@@ -389,14 +389,14 @@ __global__ __launch_bounds__(1024) void k_shard_unpack(Dev d, const unsigned cha
     }
     __syncthreads();
     uint32_t *g0 = d.hist0 + (size_t)(sp * HIST_REP + (blockIdx.x & (HIST_REP - 1))) * SEL_BINS;
-    for (int i = threadIdx.x; i < SEL_BINS; i += 1024)
+    for (int i = threadIdx.x; i < SEL_BINS; i += 256)
         if (h[i]) atomicAdd(&g0[i], h[i]);
     if (blockIdx.x == 0) {
         for (int r = 0; r < d.world; ++r) {
             if (r == rank) continue;
             const uint32_t *r_dead = (const uint32_t *)(recv + (size_t)r * rb + (size_t)cl * 20) + (cl + 31) / 32;
             const int n = min((int)r_dead[0], DEAD_CAP);
-            for (int j = threadIdx.x; j < n; j += 1024) {
+            for (int j = threadIdx.x; j < n; j += 256) {
                 const int seg = (int)r_dead[1 + j];
                 d.seg_nsyn[seg] = 0;
                 atomicAdd(&d.recyc_cnt[seg >> 10], 1);
