@@ -152,9 +152,12 @@ int htm_tm_step(htm_handle *h, const int32_t *active_column, int32_t n, int32_t 
 /* n_steps timesteps of htm_step over a bank of n_inputs packed inputs that is ALREADY IN
  * DEVICE MEMORY (words_per_row words each, see htm_info); step t reads input
  * (step_index % n_inputs).  Nothing is copied or synchronised: this is the loop
- * example.py:48-53 runs, with the input bank resident in HBM.  use_graph bit 0: replay a captured
- * hipGraph per step instead of issuing the launches one by one; bit 1: do NOT pipeline (by default
- * the next step's overlap / select launches share the current step's learn / scan launches). */
+ * example.py:48-53 runs, with the input bank resident in HBM.  use_graph bit 0: replay captured
+ * hipGraphs (one per step, or per 16 steady-state steps) instead of issuing the launches one by one;
+ * bit 1: do NOT pipeline.  By default the Spatial Pooler works ahead of the Temporal Memory inside the
+ * call -- its next steps share the four launches of the current TM step -- which includes its
+ * permanence and duty-cycle updates; it never looks past n_steps, so the state a call leaves behind
+ * is exactly that of n_steps htm_step calls. */
 int htm_run(htm_handle *h, const uint32_t *device_inputs, int32_t n_inputs, int32_t n_steps,
             int32_t learning, int32_t use_graph);
 
