@@ -127,3 +127,20 @@ def test_config3_65536_columns_eight_shards():
     """BASELINE.json configs[3]: 65 536 columns x 32 cells sharded 8-way (8 192 columns per shard),
     here with the 8 shards emulated on one GPU; every shard must agree with the unsharded oracle."""
     _run(8, I=1024, C=65536, K=32, P=12, density=0.02, noise=0.005, steps=60, jump=0.0, seed=0)
+
+
+def test_random_sharded_configurations():
+    """A seeded sample of shard counts, cell counts and thresholds (low thresholds make segments die and
+    get recycled across ranks early)."""
+    rng = np.random.RandomState(77)
+    for _ in range(6):
+        world = int(rng.choice([2, 4, 8]))
+        C = int(rng.choice([1024, 2048, 4096]))
+        K = int(rng.choice([4, 8, 16, 32]))
+        tmp = None
+        if rng.rand() < 0.6:
+            thr = int(rng.choice([3, 5]))
+            tmp = TMParams(segment_activation_threshold=thr, segment_matching_threshold=thr - int(rng.randint(0, 2)),
+                           segment_sampling_synapses=int(rng.choice([8, 16])), permanence_punishment=float(rng.choice([0.01, 0.3])))
+        _run(world, I=int(rng.choice([64, 200])), C=C, K=K, P=int(rng.choice([5, 12])), density=float(rng.choice([0.1, 0.3])),
+             noise=float(rng.choice([0.0, 0.02])), steps=60, jump=float(rng.choice([0.0, 0.2])), seed=int(rng.randint(1 << 16)), tmp=tmp)
