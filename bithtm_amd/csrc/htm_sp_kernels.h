@@ -91,7 +91,9 @@ __device__ __forceinline__ void role_overlap(const Dev &d, const uint32_t *__res
                 key = (u64)__double_as_longlong(bo);
                 d.key[sp][row] = key;
             }
-            if (do_hist) hist_add(h, (uint32_t)(key >> sel_shift(0)), owner);
+            // (plain LDS atomics: only the 64 / G row owners of the wave take part, and hist_add's loop over the
+            // distinct digits, a dependent shuffle + ballot + atomic each, cost 0.3 us per call here)
+            if (do_hist && owner) atomicAdd(&h[(uint32_t)(key >> sel_shift(0))], 1u);
         }
     }
     if (!do_hist) return;
@@ -195,7 +197,9 @@ __device__ __forceinline__ void role_sel_pass(const Dev &d, int pass, int sp, in
     for (int c0 = blk * BS + (tid & ~63); c0 < d.C; c0 += nblk * BS) {
         const int c = c0 + lane_id();
         const u64 key = c < d.C ? keys[c] : 0;
-        hist_add(sh->h, (uint32_t)(key >> shift) & (nb - 1), c < d.C && ((key ^ prefix) & himask) == 0);
+        // digits below the top one are spread over the bins: plain LDS atomics (hist_add's loop runs once per
+        // distinct digit of the wave, which here is most of its lanes)
+        if (c < d.C && ((key ^ prefix) & himask) == 0) atomicAdd(&sh->h[(uint32_t)(key >> shift) & (nb - 1)], 1u);
     }
     __syncthreads();
     uint32_t *gh = d.hist + (sp * SEL_MAX_PASSES + pass) * SEL_BINS;
