@@ -15,6 +15,8 @@ typedef unsigned long long u64;
 #define DEAD_CAP 256          // newly dead segment ids one rank can report per exchange
 #define CAND_CAP 256          // growth candidates staged per wave
 #define MAX_SLOTS 512
+#define SYN_CONNECTED 0x80000000u   // a presynaptic id carries `permanence >= threshold` in its top bit ...
+#define SYN_CELL 0x7FFFFFFF         // ... and the cell (column * 32 + cell) below it
 #define EPS32 1e-8f           // `epsilon=1e-8` against float32 arrays (weak Python scalar)
 
 // radix-select digit p covers key bits [shift, shift + bits): 12 bits from the top, the last one 4

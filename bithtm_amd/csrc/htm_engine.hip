@@ -838,7 +838,7 @@ extern "C" int64_t htm_read(htm_handle *h, int32_t field, void *dst, int64_t cou
             for (int64_t s = 0; s < S; ++s)
                 for (int64_t e = 0; e < E; ++e) {
                     const bool valid = e < nsyn[(size_t)s];
-                    if (field == HTM_F_SEG_PRESYN) { int *v = (int *)dst + s * E + e; *v = valid ? enc_flat(*v, (int)K) : -1; }
+                    if (field == HTM_F_SEG_PRESYN) { int *v = (int *)dst + s * E + e; *v = valid ? enc_flat(*v & SYN_CELL, (int)K) : -1; }   // (without the connected flag)
                     else if (!valid) ((float *)dst)[s * E + e] = -1.0f;
                 }
             return n;
@@ -962,6 +962,7 @@ extern "C" int htm_import_commit(htm_handle *h, int32_t segments, int32_t matchi
     HIPCHK(h, hipMemcpy(d.ctr, &c, sizeof(c), hipMemcpyHostToDevice));
     if (h->cfg.enable_tm) {
         hipLaunchKernelGGL(k_tm_recount, dim3(h->s1024_blocks), dim3(256), 0, h->stream, d);
+        hipLaunchKernelGGL(k_tm_flag_connected, dim3(std::min(4096, std::max(1, (int)(((long long)segments * d.E + 255) / 256)))), dim3(256), 0, h->stream, d);
         HIPCHK(h, hipStreamSynchronize(h->stream));
     }
     return HTM_OK;

@@ -312,15 +312,16 @@ __device__ __forceinline__ void role_learn(const Dev &d, int p, int blk, int nbl
             const bool valid = idx < n;
             int ps = 0;
             float pm = 0.f;
-            if (valid) { ps = prow[idx]; pm = mrow[idx]; }
+            if (valid) { ps = prow[idx] & SYN_CELL; pm = mrow[idx]; }
             const bool a = valid && ((act_prev[ps >> 5] >> (ps & 31)) & 1u);
             const double p64 = (double)pm + (a ? dA : dI);               // :102-103
             const bool keep = valid && !(prune && p64 < 0.0);            // :105-108
             const u64 mk = __ballot(keep);
             if (keep) {
                 const int pos = n_keep + __popcll(mk & lanemask_lt());
-                prow[pos] = ps;
-                mrow[pos] = (float)p64;                                   // :104
+                const float p32 = (float)p64;                              // :104
+                prow[pos] = ps | (p32 >= d.perm_thr ? (int)SYN_CONNECTED : 0);   // the scan's `permanence >= threshold`, kept with the id
+                mrow[pos] = p32;
                 s_keep[wv][pos] = ps;
             }
             n_keep += __popcll(mk);
@@ -404,7 +405,7 @@ __device__ __forceinline__ void role_learn(const Dev &d, int p, int blk, int nbl
                     if (rank < take_n) {
                         const int slot = n_keep + rank;
                         if (slot < d.E) {
-                            prow[slot] = winners[(uint32_t)key];
+                            prow[slot] = winners[(uint32_t)key] | (d.perm_init >= d.perm_thr ? (int)SYN_CONNECTED : 0);
                             mrow[slot] = d.perm_init;                                   // :149,158
                         } else {
                             atomicOr(&c->error, 2);
@@ -489,7 +490,6 @@ __device__ __forceinline__ void role_scan(const Dev &d, int p, int blk, int nblk
         const bool speculative = b == blk && blk < n_spec;
         if (!speculative && b * SEGS >= S) break;
         int seg[U], n[U], pot[U], conn[U], n_true[U], cellu[U];
-        u64 bits[U];
         int4 ps[U], ps2[U];
         bool mine[U];
         // round trip 1: synapse count, owner cell and the first chunk of each row, all unconditional
@@ -523,17 +523,20 @@ __device__ __forceinline__ void role_scan(const Dev &d, int p, int blk, int nblk
             ps2[u] = make_int4(0, 0, 0, 0);
             if (n[u] > 32) ps2[u] = *(const int4 *)(d.presyn + (size_t)seg[u] * d.E + 32 + l * 4);
         }
-        // chunk 1: all LDS lookups, then all cell-word reads, each as one batch
+        // chunk 1: all LDS lookups, then all cell-word reads, each as one batch.  An active synapse counts
+        // towards the potential (:247); if its id carries the connected flag, also towards the activation
+        // (:171-172: `permanence >= threshold`, maintained by the learning role where permanences change).
+        int pl[U], cl[U];                            // this lane's share of potential / connected-active count
         {
-            int e[U][4];
+            uint32_t e[U][4];
             uint32_t on[U][4], aw[U][4];
 #pragma unroll
-            for (int u = 0; u < U; ++u) { e[u][0] = ps[u].x; e[u][1] = ps[u].y; e[u][2] = ps[u].z; e[u][3] = ps[u].w; }
+            for (int u = 0; u < U; ++u) { e[u][0] = (uint32_t)ps[u].x; e[u][1] = (uint32_t)ps[u].y; e[u][2] = (uint32_t)ps[u].z; e[u][3] = (uint32_t)ps[u].w; }
 #pragma unroll
             for (int u = 0; u < U; ++u)
 #pragma unroll
                 for (int qq = 0; qq < 4; ++qq) {
-                    const int col = e[u][qq] >> 5;
+                    const uint32_t col = (e[u][qq] & SYN_CELL) >> 5;
                     on[u][qq] = use_lds ? (s_colbits[col >> 5] >> (col & 31)) & 1u : 1u;
                 }
 #pragma unroll
@@ -541,14 +544,19 @@ __device__ __forceinline__ void role_scan(const Dev &d, int p, int blk, int nblk
 #pragma unroll
                 for (int qq = 0; qq < 4; ++qq) {
                     if (l * 4 + qq >= n[u]) on[u][qq] = 0;
-                    aw[u][qq] = act[on[u][qq] ? (e[u][qq] >> 5) : 0];     // inactive columns: one shared line
+                    aw[u][qq] = act[on[u][qq] ? (e[u][qq] & SYN_CELL) >> 5 : 0];     // inactive columns: one shared line
                 }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                u64 bb = 0;
+                int p1 = 0, c1 = 0;
 #pragma unroll
-                for (int qq = 0; qq < 4; ++qq) bb |= (u64)(on[u][qq] & (aw[u][qq] >> (e[u][qq] & 31))) << qq;
-                bits[u] = bb;
+                for (int qq = 0; qq < 4; ++qq) {
+                    const uint32_t a = on[u][qq] & (aw[u][qq] >> (e[u][qq] & 31));
+                    p1 += (int)a;
+                    c1 += (int)(a & (e[u][qq] >> 31));
+                }
+                pl[u] = p1;
+                cl[u] = c1;
             }
         }
         // chunk 2, same shape (skipped by waves in which no row is that long)
@@ -556,15 +564,15 @@ __device__ __forceinline__ void role_scan(const Dev &d, int p, int blk, int nblk
 #pragma unroll
         for (int u = 0; u < U; ++u) any_long |= n[u] > 32;
         if (__any(any_long)) {
-            int e[U][4];
+            uint32_t e[U][4];
             uint32_t on[U][4], aw[U][4];
 #pragma unroll
-            for (int u = 0; u < U; ++u) { e[u][0] = ps2[u].x; e[u][1] = ps2[u].y; e[u][2] = ps2[u].z; e[u][3] = ps2[u].w; }
+            for (int u = 0; u < U; ++u) { e[u][0] = (uint32_t)ps2[u].x; e[u][1] = (uint32_t)ps2[u].y; e[u][2] = (uint32_t)ps2[u].z; e[u][3] = (uint32_t)ps2[u].w; }
 #pragma unroll
             for (int u = 0; u < U; ++u)
 #pragma unroll
                 for (int qq = 0; qq < 4; ++qq) {
-                    const int col = e[u][qq] >> 5;
+                    const uint32_t col = (e[u][qq] & SYN_CELL) >> 5;
                     on[u][qq] = use_lds ? (s_colbits[col >> 5] >> (col & 31)) & 1u : 1u;
                 }
 #pragma unroll
@@ -572,63 +580,36 @@ __device__ __forceinline__ void role_scan(const Dev &d, int p, int blk, int nblk
 #pragma unroll
                 for (int qq = 0; qq < 4; ++qq) {
                     if (32 + l * 4 + qq >= n[u]) on[u][qq] = 0;
-                    aw[u][qq] = act[on[u][qq] ? (e[u][qq] >> 5) : 0];
+                    aw[u][qq] = act[on[u][qq] ? (e[u][qq] & SYN_CELL) >> 5 : 0];
                 }
 #pragma unroll
             for (int u = 0; u < U; ++u)
 #pragma unroll
-                for (int qq = 0; qq < 4; ++qq) bits[u] |= (u64)(on[u][qq] & (aw[u][qq] >> (e[u][qq] & 31))) << (4 + qq);
+                for (int qq = 0; qq < 4; ++qq) {
+                    const uint32_t a = on[u][qq] & (aw[u][qq] >> (e[u][qq] & 31));
+                    pl[u] += (int)a;
+                    cl[u] += (int)(a & (e[u][qq] >> 31));
+                }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (n[u] > 64) {                         // rare: rows longer than two chunks
                 const int *prow = d.presyn + (size_t)seg[u] * d.E;
-                for (int i = 64 + l * 4, ch = 2; i < n[u]; i += 32, ++ch) {
+                for (int i = 64 + l * 4; i < n[u]; i += 32) {
                     const int4 pv = *(const int4 *)(prow + i);
-                    const int e[4] = {pv.x, pv.y, pv.z, pv.w};
+                    const uint32_t e[4] = {(uint32_t)pv.x, (uint32_t)pv.y, (uint32_t)pv.z, (uint32_t)pv.w};
 #pragma unroll
-                    for (int qq = 0; qq < 4; ++qq)
-                        bits[u] |= (u64)scan_cell_active(act, L, e[qq], i + qq < n[u], use_lds) << (ch * 4 + qq);
-                }
-            }
-            int v = __popcll(bits[u]);
-            for (int o = 4; o > 0; o >>= 1) v += __shfl_xor(v, o);
-            pot[u] = v;
-        }
-        {   // connected active synapses of the matching segments (:171-172): the permanences of the first two
-            // chunks of every matching row are fetched in one batch (one round trip, not one per chunk and row)
-            float4 pm[U][2];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const bool matching = pot[u] >= d.match_thr;                         // :247
-                const float *mrow = d.sperm + (size_t)seg[u] * d.E;
-#pragma unroll
-                for (int ch = 0; ch < 2; ++ch)
-                    pm[u][ch] = (matching && ch * 32 + l * 4 < n[u]) ? *(const float4 *)(mrow + ch * 32 + l * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                int cn = 0;
-#pragma unroll
-                for (int ch = 0; ch < 2; ++ch) {
-                    const float e[4] = {pm[u][ch].x, pm[u][ch].y, pm[u][ch].z, pm[u][ch].w};
-#pragma unroll
-                    for (int qq = 0; qq < 4; ++qq)
-                        cn += ((bits[u] >> (ch * 4 + qq)) & 1ull) && (e[qq] >= d.perm_thr);
-                }
-                if (pot[u] >= d.match_thr && n[u] > 64) {                            // rare: longer rows
-                    const float *mrow = d.sperm + (size_t)seg[u] * d.E;
-                    for (int i = 64 + l * 4, ch = 2; i < n[u]; i += 32, ++ch) {
-                        const float4 pv = *(const float4 *)(mrow + i);
-                        const float e[4] = {pv.x, pv.y, pv.z, pv.w};
-#pragma unroll
-                        for (int qq = 0; qq < 4; ++qq)
-                            cn += ((bits[u] >> (ch * 4 + qq)) & 1ull) && (e[qq] >= d.perm_thr);
+                    for (int qq = 0; qq < 4; ++qq) {
+                        const uint32_t a = scan_cell_active(act, L, (int)(e[qq] & SYN_CELL), i + qq < n[u], use_lds);
+                        pl[u] += (int)a;
+                        cl[u] += (int)(a & (e[qq] >> 31));
                     }
                 }
-                for (int o = 4; o > 0; o >>= 1) cn += __shfl_xor(cn, o);
-                conn[u] = cn;
             }
+            int v = pl[u], w = cl[u];
+            for (int o = 4; o > 0; o >>= 1) { v += __shfl_xor(v, o); w += __shfl_xor(w, o); }
+            pot[u] = v;
+            conn[u] = w;
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -662,6 +643,18 @@ __device__ __forceinline__ void role_scan(const Dev &d, int p, int blk, int nblk
 template <bool use_lds, int MINW>
 __global__ __launch_bounds__(256, MINW) void k_tm_scan(Dev d, int p, int n_spec) {
     role_scan<256, use_lds>(d, p, blockIdx.x, gridDim.x, n_spec, (uint32_t *)dyn_lds);
+}
+
+// after a state import: derive the connected flag of every valid synapse from its permanence
+// (the scan reads the flag instead of the permanence row)
+__global__ __launch_bounds__(256) void k_tm_flag_connected(Dev d) {
+    const int S = d.ctr->S;
+    const long long total = (long long)S * d.E;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int seg = (int)(i / d.E), slot = (int)(i % d.E);
+        if (slot < d.seg_nsyn[seg])
+            d.presyn[i] = (d.presyn[i] & SYN_CELL) | (d.sperm[i] >= d.perm_thr ? (int)SYN_CONNECTED : 0);
+    }
 }
 
 // recount recyclable segments after a state import
