@@ -157,7 +157,7 @@ __device__ __forceinline__ void role_mid(const Dev &d, int p, int n_active, int 
     static_assert(LPT == 8, "the list pass loads 8 entries per thread");
     for (int base = 0; base < n_active; base += LPT * BS) {
         const int i0 = base + LPT * (int)threadIdx.x;
-        uint32_t v[LPT], ww[LPT], uw[LPT];
+        uint32_t ww[LPT], uw[LPT];                 // (counts are recomputed from the words: the launch is capped at 64 registers)
         int a[LPT];
         uint32_t vsum = 0;
         if (i0 < n_active) {                       // 16-byte loads (the arrays are padded by 8 entries), masked below
@@ -180,8 +180,7 @@ __device__ __forceinline__ void role_mid(const Dev &d, int p, int n_active, int 
         }
 #pragma unroll
         for (int j = 0; j < LPT; ++j) {
-            v[j] = want_winner ? (uint32_t)__popc(ww[j]) | ((uint32_t)__popc(uw[j]) << 16) : 0u;      // winners | needing a segment
-            vsum += v[j];
+            vsum += want_winner ? (uint32_t)__popc(ww[j]) | ((uint32_t)__popc(uw[j]) << 16) : 0u;    // winners | needing a segment
         }
         uint32_t total;
         uint32_t run = block_excl_scan<BS>(vsum, s_wave, total);
@@ -192,7 +191,7 @@ __device__ __forceinline__ void role_mid(const Dev &d, int p, int n_active, int 
                 uint32_t w1 = ww[j], u1 = uw[j];
                 while (w1) { int b = __ffs(w1) - 1; w1 &= w1 - 1; d.winners[p][pw++] = a[j] * 32 + b; }
                 while (u1) { int b = __ffs(u1) - 1; u1 &= u1 - 1; d.unacc_list[pu++] = a[j] * 32 + b; }
-                run += v[j];
+                run += (uint32_t)__popc(ww[j]) | ((uint32_t)__popc(uw[j]) << 16);
             }
         }
         carry_w += total & 0xFFFFu;
