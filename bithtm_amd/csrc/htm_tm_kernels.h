@@ -74,7 +74,13 @@ __device__ __forceinline__ void role_sp_row(const Dev &d, int p, const uint32_t 
             const uint32_t bits = in[e0 >> 5] >> (e0 & 31);
             if (e0 < d.I) { v.x = v.x + ((bits & 1u) ? d.sp_don : d.sp_doff); c0 = v.x >= d.sp_thr; }
             if (e0 + 1 < d.I) { v.y = v.y + ((bits & 2u) ? d.sp_don : d.sp_doff); c1 = v.y >= d.sp_thr; }
-            *(double2 *)(prow + e0) = v;
+            {   // 16-byte write-through store (sc0 sc1): nothing of the rows stays dirty in L2 for the kernel-end release
+                typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+                union { double2 d2; u32x4 u4; } cvt;
+                cvt.d2 = v;
+                double *dst = prow + e0;
+                asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(cvt.u4) : "memory");
+            }
         }
         const u64 b0 = __ballot(c0), b1 = __ballot(c1);
         const int base = i0 + 2 * (t & ~63);
