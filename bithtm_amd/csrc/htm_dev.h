@@ -9,7 +9,7 @@ typedef unsigned long long u64;
 #define SEL_MAX_PASSES 6
 #define SEL_DIGIT 12
 #define SEL_BINS 4096         // 1 << SEL_DIGIT
-#define HIST_REP 8            // copies of the digit-0 histogram (its few hot bins take one atomic per block)
+#define HIST_REP 4            // copies of the digit-0 histogram (its few hot bins take one atomic per block; 8 and 2 measured no better)
 #define RB 512                // threads per block of the role kernels (overlap, select, learn, scan)
 #define SCAN_SEGS 64          // segments per 256-thread block iteration of the segment scan
 #define DEAD_CAP 256          // newly dead segment ids one rank can report per exchange
