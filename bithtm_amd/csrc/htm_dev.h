@@ -110,15 +110,37 @@ struct Dev {
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ u64 lanemask_lt() { return (1ull << lane_id()) - 1ull; }
 
+// Inclusive prefix sum over the 64 lanes with DPP row shifts and broadcasts (seven dependent VALU ops;
+// the __shfl_up loop compiles to six ds_bpermute round trips through the LDS crossbar).
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+    uint32_t t = v;
+    t += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    t += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    t += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x113, 0xf, 0xf, false);   // row_shr:3
+    t += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t, 0x114, 0xf, 0xe, false);   // row_shr:4 bank_mask:0xe
+    t += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t, 0x118, 0xf, 0xc, false);   // row_shr:8 bank_mask:0xc
+    t += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t, 0x142, 0xa, 0xf, false);   // row_bcast:15 row_mask:0xa
+    t += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t, 0x143, 0xc, 0xf, false);   // row_bcast:31 row_mask:0xc
+    return t;
+}
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(v), 63); }
+
+// Sum over each aligned group of 8 lanes, valid in the group's FIRST lane only (row_shl:1,2,3 then 4:
+// four VALU ops instead of three ds_bpermute round trips).
+__device__ __forceinline__ int group8_sum_first(int v) {
+    int t = v;
+    t += __builtin_amdgcn_update_dpp(0, v, 0x101, 0xf, 0xf, false);
+    t += __builtin_amdgcn_update_dpp(0, v, 0x102, 0xf, 0xf, false);
+    t += __builtin_amdgcn_update_dpp(0, v, 0x103, 0xf, 0xf, false);
+    t += __builtin_amdgcn_update_dpp(0, t, 0x104, 0xf, 0xf, false);
+    return t;
+}
+
 template <int BS>
 __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *s_wave, uint32_t &total) {
     const int lane = lane_id(), wv = threadIdx.x >> 6;
-    uint32_t x = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        uint32_t y = __shfl_up(x, o);
-        if (lane >= o) x += y;
-    }
+    const uint32_t x = wave_incl_scan(v);
     if (lane == 63) s_wave[wv] = x;
     __syncthreads();
     uint32_t woff = 0, tot = 0;

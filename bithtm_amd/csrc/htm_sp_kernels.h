@@ -78,7 +78,8 @@ __device__ __forceinline__ void role_overlap(const Dev &d, const uint32_t *__res
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             int cn = cnt[u];
-            for (int o = G >> 1; o > 0; o >>= 1) cn += __shfl_xor(cn, o);
+            if (G == 8) cn = group8_sum_first(cn);                     // (only the row's first lane uses the sum)
+            else for (int o = G >> 1; o > 0; o >>= 1) cn += __shfl_xor(cn, o);
             const int row = row0 + u * rpw + sub;
             const bool owner = l == 0 && row < d.c1;
             u64 key = 0;
@@ -150,15 +151,11 @@ __device__ __forceinline__ void sel_resolve(const Dev &d, int sp, int prev, uint
         const uint4 v = *(const uint4 *)(h + tid * PER + 4 * j);
         cs += v.x + v.y + v.z + v.w;
     }
-    uint32_t x = cs;                              // inclusive suffix sum inside the wave
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t y = __shfl_down(x, o);
-        if (lane + o < 64) x += y;
-    }
-    if (lane == 0) s_wave[wv] = x;                // wave total
+    const uint32_t pre = wave_incl_scan(cs);      // inclusive prefix inside the wave; suffixes follow from the total
+    const uint32_t wtot = (uint32_t)__builtin_amdgcn_readlane((int)pre, 63);
+    if (lane == 0) s_wave[wv] = wtot;             // wave total
     __syncthreads();
-    uint32_t above = x - cs;                      // keys in bins above my chunk, inside my wave ...
+    uint32_t above = wtot - pre;                  // keys in bins above my chunk, inside my wave ...
     for (int w = wv + 1; w < BS / 64; ++w) above += s_wave[w];      // ... plus the higher waves
     if (above < krem && krem <= above + cs) {     // exactly one thread
         for (int b = min((tid + 1) * PER, nb) - 1; b >= tid * PER; --b) {
@@ -439,15 +436,11 @@ __device__ __forceinline__ void sel_pick(const uint32_t *h, int nb, uint32_t kre
         const int b = tid * PER + j;
         cs += b < nb ? h[b] : 0u;
     }
-    uint32_t x = cs;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t y = __shfl_down(x, o);
-        if (lane + o < 64) x += y;
-    }
-    if (lane == 0) s_wave[wv] = x;
+    const uint32_t pre = wave_incl_scan(cs);
+    const uint32_t wtot = (uint32_t)__builtin_amdgcn_readlane((int)pre, 63);
+    if (lane == 0) s_wave[wv] = wtot;
     __syncthreads();
-    uint32_t above = x - cs;
+    uint32_t above = wtot - pre;
     for (int w = wv + 1; w < BS / 64; ++w) above += s_wave[w];
     if (above < krem && krem <= above + cs) {
         for (int b = min((tid + 1) * PER, nb) - 1; b >= tid * PER; --b) {
@@ -655,7 +648,7 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
                         if (pos < CAND_OTHERS) { sh->ok[pos] = ke; sh->oc[pos] = s_ec[e]; }
                     }
                 }
-                for (int o = 32; o > 0; o >>= 1) c0 += __shfl_xor(c0, o);
+                c0 = wave_sum(c0);
                 if (lane == 0 && c0) atomicAdd(&sh->c0, c0);
                 __syncthreads();
                 const int no = sh->n_others;
@@ -709,7 +702,8 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
                     if (s_ek[e] > T) g += s_ec[e];
                     else if (s_ek[e] == T) e2 += s_ec[e];
                 }
-            for (int o = 32; o > 0; o >>= 1) { g += __shfl_xor(g, o); e2 += __shfl_xor(e2, o); }
+            g = wave_sum(g);
+            e2 = wave_sum(e2);
             if (lane == 0) { atomicAdd(&s_gt, g); atomicAdd(&s_eq, e2); }
         } else {
             // exact fallback: resolve the remaining digits from the key array, redundantly per block
@@ -778,7 +772,8 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
                 e += v >> 16;
             }
         }
-        for (int o = 32; o > 0; o >>= 1) { g += __shfl_xor(g, o); e += __shfl_xor(e, o); }
+        g = wave_sum(g);
+        e = wave_sum(e);
         if (lane == 0) { atomicAdd(&s_gt, g); atomicAdd(&s_eq, e); }
     }
     __syncthreads();

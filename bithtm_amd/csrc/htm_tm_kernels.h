@@ -203,7 +203,7 @@ __device__ __forceinline__ void role_mid(const Dev &d, int p, int n_active, int 
         carry_w += total & 0xFFFFu;
         carry_u += total >> 16;
     }
-    for (int o = 32; o > 0; o >>= 1) n_cells += __shfl_xor(n_cells, o);
+    n_cells = wave_sum(n_cells);
     if (lane_id() == 0) atomicAdd(&s_cells, n_cells);
     __syncthreads();
     const int n_un = (learning && c->has_distal) ? (int)carry_u : 0;
@@ -611,10 +611,8 @@ __device__ __forceinline__ void role_scan(const Dev &d, int p, int blk, int nblk
                     }
                 }
             }
-            int v = pl[u], w = cl[u];
-            for (int o = 4; o > 0; o >>= 1) { v += __shfl_xor(v, o); w += __shfl_xor(w, o); }
-            pot[u] = v;
-            conn[u] = w;
+            pot[u] = group8_sum_first(pl[u]);        // (used by the segment's first lane only)
+            conn[u] = group8_sum_first(cl[u]);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
