@@ -513,8 +513,7 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
     if (fused) {
         u64 P;
         uint32_t krem;
-        sel_resolve<256>(d, p, d.sel_passes - 1, h, s_wave, &P, &krem, &s_prefix, &s_krem);
-        __syncthreads();
+        sel_resolve<256>(d, p, d.sel_passes - 1, h, s_wave, &P, &krem, &s_prefix, &s_krem);    // (ends behind a barrier)
         const int lowbits = sel_shift(d.sel_passes - 1);        // key bits not resolved by launches
         const u64 hiP = P >> lowbits, hi = my_key >> lowbits;
         const bool c_gt = c < d.C && hi > hiP, c_cand = c < d.C && hi == hiP;
@@ -539,13 +538,17 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
         const uint32_t my_gt_hi = s_gt;
         int first = -1;                              // merge duplicates that came from different waves
         uint32_t my_cnt = 0;
-        if (tid < nraw) {
-            my_cnt = s_bc[tid];
-            for (first = 0; s_bk[first] != s_bk[tid]; ++first) {}
+        if (nraw > 1) {                              // (uniform in the block; most blocks have at most one bucket key)
+            if (tid < nraw) {
+                my_cnt = s_bc[tid];
+                for (first = 0; s_bk[first] != s_bk[tid]; ++first) {}
+            }
+            __syncthreads();
+            if (tid < nraw && first != tid) atomicAdd(&s_bc[first], my_cnt);
+            __syncthreads();
+        } else if (tid < nraw) {
+            first = tid;
         }
-        __syncthreads();
-        if (tid < nraw && first != tid) atomicAdd(&s_bc[first], my_cnt);
-        __syncthreads();
         // record = up to 16 self-validating 64-bit granules (form R2: every granule carries the epoch, one
         // aligned 8-byte write-through store each, so no separate tag and no drain):
         //   [0]      epoch:12 | overflow:1 | pairs:4 | keys above the bucket:9 | multiplicity:9 | key bits:29
