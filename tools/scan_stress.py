@@ -35,9 +35,11 @@ def main():
         distal = B.PredictiveProjection(N, segment_capacity=S, segment_slots=E)
         eng = Engine(0, C, K, k, distal=distal, seed=0)
         presyn = np.full((S, E), -1, dtype=np.int32)
-        presyn[:, :n_syn] = rng.randint(0, N, size=(S, n_syn), dtype=np.int32)
         perm = np.full((S, E), -1.0, dtype=np.float32)
-        perm[:, :n_syn] = rng.uniform(0.3, 0.7, size=(S, n_syn)).astype(np.float32)
+        for s0 in range(0, S, 1 << 20):              # in slices: the float64 intermediates stay small
+            s1 = min(S, s0 + (1 << 20))
+            presyn[s0:s1, :n_syn] = rng.randint(0, N, size=(s1 - s0, n_syn), dtype=np.int32)
+            perm[s0:s1, :n_syn] = rng.uniform(0.3, 0.7, size=(s1 - s0, n_syn)).astype(np.float32)
         seg_cell = rng.randint(0, N, size=S).astype(np.int32)
         st = dict(S=S, slots=E, step_index=0, seg_cell=seg_cell, seg_nsyn=np.full(S, n_syn, np.int32), presyn=presyn, perm=perm,
                   segcount=np.bincount(seg_cell, minlength=N).astype(np.int32),
