@@ -404,8 +404,10 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
         rc |= dalloc(h, &d.win[0], C);
         rc |= dalloc(h, &d.win[1], C);
         d.colwords = (int)((C + 63) / 64) * 2;
-        rc |= dalloc(h, &d.colbits[0], (size_t)d.colwords);
-        rc |= dalloc(h, &d.colbits[1], (size_t)d.colwords);
+        // (the emit blocks write the bitmap words of whole 256-column blocks)
+        const size_t colwords_padded = (size_t)((C + 255) / 256) * 8;
+        rc |= dalloc(h, &d.colbits[0], colwords_padded);
+        rc |= dalloc(h, &d.colbits[1], colwords_padded);
         rc |= dalloc(h, &d.bursting, k);
         rc |= dalloc(h, &d.winw_idx, k + 8);
         rc |= dalloc(h, &d.actcnt, k + 8);

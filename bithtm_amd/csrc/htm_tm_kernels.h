@@ -614,10 +614,15 @@ __device__ __forceinline__ void role_scan(const Dev &d, int p, int blk, int nblk
             pot[u] = group8_sum_first(pl[u]);        // (used by the segment's first lane only)
             conn[u] = group8_sum_first(cl[u]);
         }
+        {                                            // recyclable rows: one LDS atomic per wave (same-address atomics serialise)
+            int n_recyc = 0;
+#pragma unroll
+            for (int u = 0; u < U; ++u) n_recyc += __popcll(__ballot(l == 0 && seg[u] < S && n_true[u] < d.match_thr));
+            if (lane_id() == 0 && n_recyc) atomicAdd(&s_recyc, n_recyc);
+        }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (l == 0 && seg[u] < S) {
-                if (n_true[u] < d.match_thr) atomicAdd(&s_recyc, 1);
                 if (!mine[u]) continue;
                 const bool matching = pot[u] >= d.match_thr;
                 uint32_t info = (uint32_t)pot[u];
