@@ -1,8 +1,9 @@
 #!/bin/bash
 # Run on the GPU box (via gpurun) from the repo root: bench line, rocprofv3 kernel stats, PMC
 # passes (each counter in its own run, kernel-trace only), scan stress, PCIe-inclusive rate, the
-# device-clock timeline of the pipelined step and the launch-boundary micro-benchmark
-# (tools/launch_anatomy: build it first with hipcc --offload-arch=gfx950 -O3 -o tools/launch_anatomy tools/launch_anatomy.hip).
+# device-clock timeline of the pipelined step and the micro-benchmarks (launch boundary, attainable
+# read bandwidth, cost of a vector-memory instruction; build them first:
+# for t in launch_anatomy hbm_read ta_rate; do hipcc --offload-arch=gfx950 -O3 -o tools/$t tools/$t.hip; done).
 # Everything lands in gpurun_out/profile_<tag>/; copy what should be judged into profiles/.
 set -u
 TAG=${1:-r01}
@@ -13,7 +14,9 @@ timeout -k 10 400 python bench.py > $OUT/bench.json 2> $OUT/bench.log; echo "ben
 timeout -k 10 300 python tools/pcie_rate.py > $OUT/pcie_rate.txt 2>&1
 timeout -k 10 200 python tools/step_timeline.py > $OUT/step_timeline.txt 2>&1
 [ -x tools/launch_anatomy ] && timeout -k 10 120 ./tools/launch_anatomy > $OUT/launch_anatomy.txt 2>&1
-timeout -k 10 600 python tools/scan_stress.py --segments 250000 1000000 4000000 --slots 64 > $OUT/scan_stress.jsonl 2> $OUT/scan_stress.log
+[ -x tools/hbm_read ] && timeout -k 10 120 ./tools/hbm_read 1024 > $OUT/hbm_read.txt 2>&1
+[ -x tools/ta_rate ] && timeout -k 10 120 ./tools/ta_rate > $OUT/ta_rate.txt 2>&1
+timeout -k 10 600 python tools/scan_stress.py --segments 250000 1000000 4000000 16000000 --slots 64 > $OUT/scan_stress.jsonl 2> $OUT/scan_stress.log
 timeout -k 10 600 python tools/scan_stress.py --segments 1000000 --slots 128 >> $OUT/scan_stress.jsonl 2>> $OUT/scan_stress.log
 cd /tmp && export TMPDIR=/tmp
 # (a) one role per launch: the kernels the roofline line names, standalone
