@@ -7,6 +7,7 @@
 //          2 dword, ~2 % of the lanes a random line of a 256 KB table, the others one shared word (the scan's lookup)
 //          3 as 2, but only the ~2 % lanes active (exec-masked)
 //          4 dwordx4, lanes consecutive (1 KB per wave), 64 KB working set per block (L2 hits)
+//          5 the same as non-temporal loads (do streaming loads take another path?)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
@@ -30,10 +31,16 @@ __global__ __launch_bounds__(256) void k_ta(const unsigned *__restrict__ table, 
             if (KIND == 1) v[j] = table[((it * 8 + j) * 64 + (threadIdx.x & 63)) & 0xFFFF];
             if (KIND == 2) v[j] = table[on ? far : 0];
             if (KIND == 3) { v[j] = 0; if (on) v[j] = table[far]; }
-            if (KIND == 4) w[j] = *(const uint4 *)(table + ((((blockIdx.x * 8 + j) * 256 + threadIdx.x) * 4 + it * 64) & 0xFFFC));
+            const unsigned *src = table + ((((blockIdx.x * 8 + j) * 256 + threadIdx.x) * 4 + it * 64) & 0xFFFC);
+            if (KIND == 4) w[j] = *(const uint4 *)src;
+            if (KIND == 5) {                                      // compiler-managed streaming load (nt bit)
+                typedef unsigned v4u __attribute__((ext_vector_type(4)));
+                const v4u t = __builtin_nontemporal_load((const v4u *)src);
+                w[j] = make_uint4(t.x, t.y, t.z, t.w);
+            }
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc += KIND == 4 ? w[j].x ^ w[j].w : v[j];
+        for (int j = 0; j < 8; ++j) acc += KIND >= 4 ? w[j].x ^ w[j].w : v[j];
     }
     if (acc == 0x12345u) out[tid] = acc;
 }
@@ -43,14 +50,15 @@ int main() {
     CK(hipMalloc(&table, 1 << 18)); CK(hipMemset(table, 0, 1 << 18)); CK(hipMalloc(&out, 1 << 22));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const int blocks = 1536;
-    const char *names[] = {"dword, one address", "dword, consecutive lanes", "dword, 2% lanes scattered + shared word", "dword, only the 2% lanes (exec-masked)", "dwordx4, consecutive lanes"};
-    for (int kind = 0; kind < 5; ++kind) {
+    const char *names[] = {"dword, one address", "dword, consecutive lanes", "dword, 2% lanes scattered + shared word", "dword, only the 2% lanes (exec-masked)", "dwordx4, consecutive lanes", "dwordx4, consecutive lanes, non-temporal"};
+    for (int kind = 0; kind < 6; ++kind) {
         auto launch = [&] {
             if (kind == 0) hipLaunchKernelGGL(k_ta<0>, dim3(blocks), dim3(256), 0, 0, table, out);
             if (kind == 1) hipLaunchKernelGGL(k_ta<1>, dim3(blocks), dim3(256), 0, 0, table, out);
             if (kind == 2) hipLaunchKernelGGL(k_ta<2>, dim3(blocks), dim3(256), 0, 0, table, out);
             if (kind == 3) hipLaunchKernelGGL(k_ta<3>, dim3(blocks), dim3(256), 0, 0, table, out);
             if (kind == 4) hipLaunchKernelGGL(k_ta<4>, dim3(blocks), dim3(256), 0, 0, table, out);
+            if (kind == 5) hipLaunchKernelGGL(k_ta<5>, dim3(blocks), dim3(256), 0, 0, table, out);
         };
         launch(); CK(hipDeviceSynchronize());
         CK(hipEventRecord(e0, 0));
