@@ -60,7 +60,7 @@ def main():
         us = 1e3 * ms / n
         algo = 4 * S * n_syn + 8 * S
         info = eng.info()
-        print(json.dumps(dict(segments=S, slots=E, synapses_per_segment=n_syn, scan_us=round(us, 2),
+        print(json.dumps(dict(columns=C, cells=K, segments=S, slots=E, synapses_per_segment=n_syn, scan_us=round(us, 2),
                               algorithmic_bytes=algo, achieved_GBps=round(algo / us / 1e3, 1),
                               frac_of_8TBps=round(algo / us / 1e3 / 8000.0, 4), matching_segments=info.matching_segments)),
               flush=True)
