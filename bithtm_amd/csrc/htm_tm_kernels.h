@@ -549,7 +549,8 @@ __device__ __forceinline__ void role_scan(const Dev &d, int p, int blk, int nblk
 #pragma unroll
                 for (int qq = 0; qq < 4; ++qq) {
                     if (l * 4 + qq >= n[u]) on[u][qq] = 0;
-                    aw[u][qq] = act[on[u][qq] ? (e[u][qq] & SYN_CELL) >> 5 : 0];     // inactive columns: one shared line
+                    aw[u][qq] = 0;                   // a lookup no lane of the wave needs is not issued at all
+                    if (__any(on[u][qq])) aw[u][qq] = act[on[u][qq] ? (e[u][qq] & SYN_CELL) >> 5 : 0];     // inactive columns: one shared line
                 }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -585,7 +586,8 @@ __device__ __forceinline__ void role_scan(const Dev &d, int p, int blk, int nblk
 #pragma unroll
                 for (int qq = 0; qq < 4; ++qq) {
                     if (32 + l * 4 + qq >= n[u]) on[u][qq] = 0;
-                    aw[u][qq] = act[on[u][qq] ? (e[u][qq] & SYN_CELL) >> 5 : 0];
+                    aw[u][qq] = 0;
+                    if (__any(on[u][qq])) aw[u][qq] = act[on[u][qq] ? (e[u][qq] & SYN_CELL) >> 5 : 0];
                 }
 #pragma unroll
             for (int u = 0; u < U; ++u)
