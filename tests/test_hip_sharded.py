@@ -2,6 +2,8 @@
 box (the all-gather becomes device copies), and every rank's share of every result must equal the
 unsharded oracle bit for bit -- the same check tests/test_sharded_gloo.py makes on the CPU protocol."""
 
+import os
+
 import numpy as np
 import pytest
 
@@ -132,8 +134,8 @@ def test_config3_65536_columns_eight_shards():
 def test_random_sharded_configurations():
     """A seeded sample of shard counts, cell counts and thresholds (low thresholds make segments die and
     get recycled across ranks early)."""
-    rng = np.random.RandomState(77)
-    for _ in range(6):
+    rng = np.random.RandomState(int(os.environ.get("BITHTM_SHARD_FUZZ_SEED", "77")))      # (a longer manual sweep: set seed and count)
+    for _ in range(int(os.environ.get("BITHTM_SHARD_FUZZ_CONFIGS", "6"))):
         world = int(rng.choice([2, 4, 8]))
         C = int(rng.choice([1024, 2048, 4096]))
         K = int(rng.choice([4, 8, 16, 32]))
