@@ -19,6 +19,17 @@ typedef unsigned long long u64;
 #define SYN_CELL 0x7FFFFFFF         // ... and the cell (column * 32 + cell) below it
 #define EPS32 1e-8f           // `epsilon=1e-8` against float32 arrays (weak Python scalar)
 
+// Select key of a boosted overlap: an order-preserving image of the double's bits that spends 8 bits on the
+// exponent instead of 12 on sign + exponent.  boosted = (float32 factor) x (overlap <= input_dim <= 2^17) is 0 or
+// lies in [2^-149, 2^17], 167 exponents, so the exponent field minus (1023 - 150) fits 8 bits and the whole key
+// moves up by 3: two launched 12-bit digits then resolve 3 more mantissa bits, and the bucket the select
+// finishes in-kernel is 8 times narrower (a crowded bucket is what makes `emit` slow).
+#define KEY_SHIFT 3
+__device__ __forceinline__ u64 select_key(double boosted) {
+    const u64 bits = (u64)__double_as_longlong(boosted);
+    return bits ? (bits - ((u64)(1023 - 150) << 52)) << KEY_SHIFT : 0ull;
+}
+
 // radix-select digit p covers key bits [shift, shift + bits): 12 bits from the top, the last one 4
 __host__ __device__ __forceinline__ int sel_shift(int pass) { return pass < 5 ? 52 - SEL_DIGIT * pass : 0; }
 __host__ __device__ __forceinline__ int sel_bits(int pass) { return pass < 5 ? SEL_DIGIT : 4; }

@@ -460,7 +460,7 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
     {
         int B = 0;
         while ((1ll << B) <= (long long)d.I) ++B;
-        const int informative = std::min(64, 64 - (29 - B));
+        const int informative = std::min(64, 64 - (29 - B) - KEY_SHIFT);      // (select_key moves the bits up by KEY_SHIFT)
         d.sel_passes = std::max(1, std::min(SEL_MAX_PASSES, (informative + SEL_DIGIT - 1) / SEL_DIGIT));
         d.low_zero = 64 - informative;            // key bits [0, low_zero) are zero in every key
         // Emit grids whose blocks are all resident at once finish the select inside k_sp_emit (two digits

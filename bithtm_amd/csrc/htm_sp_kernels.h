@@ -89,7 +89,7 @@ __device__ __forceinline__ void role_overlap(const Dev &d, const uint32_t *__res
                 const double bo = (double)f * (double)cn;              // exact (24-bit x <= 16-bit)
                 d.boosted[sp][row] = bo;
                 if (shard_boosted) shard_boosted[row - d.c0] = bo;
-                key = (u64)__double_as_longlong(bo);
+                key = select_key(bo);
                 d.key[sp][row] = key;
             }
             // (plain LDS atomics: only the 64 / G row owners of the wave take part, and hist_add's loop over the
@@ -376,7 +376,7 @@ __global__ __launch_bounds__(256) void k_shard_unpack(Dev d, const unsigned char
             const unsigned char *rec = recv + (size_t)r * rb;
             const double bo = ((const double *)rec)[i];
             const uint32_t *r_act = (const uint32_t *)(rec + (size_t)cl * 8);
-            key = (u64)__double_as_longlong(bo);
+            key = select_key(bo);
             d.boosted[sp][c] = bo;
             d.key[sp][c] = key;
             d.spec_act[c] = r_act[i];
