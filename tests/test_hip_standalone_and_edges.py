@@ -4,7 +4,7 @@ learning / return_winner_cell switches, edge-case inputs and the loud failure mo
 import numpy as np
 import pytest
 
-from oracle import SpatialPoolerOracle, TemporalMemoryOracle, HTMOracle, canonical_synapses
+from oracle import SpatialPoolerOracle, TemporalMemoryOracle, HTMOracle, SPParams, canonical_synapses
 
 pytestmark = pytest.mark.gpu
 
@@ -27,6 +27,36 @@ def test_standalone_spatial_pooler_matches_oracle():
         assert np.array_equal(got.boosted_overlaps.view(np.int64), want.boosted_overlaps.view(np.int64)), t
     assert np.array_equal(sp.proximal_projection.permanence.view(np.int64), ora.permanence.view(np.int64))
     assert np.array_equal(sp.boosting.duty_cycle.view(np.int32), ora.duty_cycle.view(np.int32))
+
+
+def test_select_keys_stay_exact_for_extreme_boost_factors():
+    """The select works on `select_key(boosted)`, the double's bits with the exponent packed into 8 bits.  That is
+    exact for every value a float32 factor times an integer overlap can take -- down to denormal factors and
+    factors that underflow to zero.  Boost intensity 4 at 2 % density makes exp(-200 x duty): duty cycles written
+    between 0 and 1.2 put the factors anywhere from 1 through the float32 denormals to 0."""
+    import bithtm_amd as B
+    I, C, k = 300, 4096, 82
+    spp = SPParams(boost_intensity=4.0)
+    np.random.seed(5)
+    sp = B.SpatialPooler(I, C, k, boosting=B.ExponentialBoosting(C, k, intensity=spp.boost_intensity, momentum=spp.boost_momentum))
+    ora = SpatialPoolerOracle(I, C, k, params=spp, permanence=sp.proximal_projection.permanence.copy())
+    rng = np.random.RandomState(6)
+    x = rng.rand(I) < 0.2
+    sp.process(x)                                     # creates the engine
+    ora.step(x)
+    duty = (rng.rand(C) * 1.2).astype(np.float32)
+    duty[rng.rand(C) < 0.3] = 0.0                     # plenty of factors of exactly 1 as well
+    ora.duty_cycle = duty.copy()
+    sp._engine.write(4, duty, np.float32)             # HTM_F_DUTY_CYCLE
+    factors = set()
+    for t in range(40):
+        x = rng.rand(I) < 0.2
+        got, want = sp.process(x), ora.step(x)
+        assert np.array_equal(got.active_column, want.active_column), t
+        assert np.array_equal(got.boosted_overlaps.view(np.int64), want.boosted_overlaps.view(np.int64)), t
+        nz = want.boosted_overlaps[want.overlaps > 0] / want.overlaps[want.overlaps > 0]
+        factors.update(np.frexp(nz[nz > 0])[1].tolist())
+    assert min(factors) < -126 and max(factors) >= 0, (min(factors), max(factors))      # denormal factors were in play
 
 
 def test_standalone_temporal_memory_matches_oracle_with_unsorted_columns():
