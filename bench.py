@@ -29,7 +29,6 @@ sys.path.insert(0, ROOT)
 
 WORKLOAD = dict(input_dim=1024, column_dim=65536, cell_dim=32, patterns=50, density=0.02, noise=0.005,
                 noisy_copies=20, segment_slots=128)
-PIPELINED_LAUNCHES = ("tm_activate+sp_emit", "tm_mid+sp_learn", "tm_learn+sp_overlap", "tm_scan+sp_select")
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 
 
@@ -65,39 +64,58 @@ def build_htm(w, perm, device, column_range=None):
     return B.HierarchicalTemporalMemory(I, C, K, active_columns=k, spatial_pooler=sp, temporal_memory=tm, device=device)
 
 
-def kernel_bytes(w, k, store):
-    """Algorithmic HBM bytes per launch of each kernel ('Kernels and rooflines')."""
+LAUNCH_KERNEL = {"tm_activate+sp_emit": "k_open_emit", "tm_mid+sp_learn": "k_mid_rows",
+                 "tm_learn+sp_overlap": "k_learn_overlap", "tm_scan+sp_select": "k_scan_sel"}
+LAUNCH_ROLES = {"tm_activate+sp_emit": ("tm_activate", "sp_emit"), "tm_mid+sp_learn": ("tm_mid", "sp_rows"),
+                "tm_learn+sp_overlap": ("tm_learn", "sp_overlap"), "tm_scan+sp_select": ("tm_scan", "sp_select", "tm_clear")}
+
+
+def role_bytes(w, k, seg_nsyn, n_work, n_match):
+    """Algorithmic HBM bytes per timestep of every role ('Kernels and rooflines'):
+    what the role has to read and write once, whatever the kernel actually fetches."""
     C, I = w["column_dim"], w["input_dim"]
-    W = ((I + 127) // 128) * 4
-    nsyn = store["seg_nsyn"].astype(np.int64)
-    S = len(nsyn)
-    syn = int(nsyn.sum())
+    W = ((I + 127) // 128) * 4                     # packed words per SP row
+    nsyn = seg_nsyn.astype(np.int64)
+    S, syn = len(nsyn), int(nsyn.sum())
+    mean_syn = syn / max(S, 1)
     return {
-        # mask read + input + duty read + overlap/boosted/key writes
+        # mask rows + input + duty read + overlap / boosted / key writes
         "sp_overlap": C * W * 4 + W * 4 + C * 4 + C * (4 + 8 + 8),
-        # k winner rows: float64 read + write, mask row rewrite
-        "sp_learn": 2 * 8 * k * I + k * W * 4,
-        # packed presynaptic ids of every segment + per-segment nsyn read and potential write
+        # digit 1: the keys once + the digit-0 histogram copies
+        "sp_select": C * 8 + 4 * 4096 * 4,
+        # select finish + winner list: keys, per-block records (write + read), column bitmap, list
+        "sp_emit": C * 8 + 2 * 128 * ((C + 255) // 256) + C // 8 + 4 * k,
+        # k winner rows: float64 read + write, mask row rewrite; duty cycle read + write, column bitmap
+        "sp_rows": 2 * 8 * k * I + k * W * 4 + 2 * 4 * C + C // 8,
+        # per winner column: previous prediction word, 32 x (cell maximum + segment count), six result words
+        "tm_activate": k * (4 + 32 * 8 + 24),
+        # lists of block 0 + classification: info word and owner cell of every segment, jitter / maximum / words of matching ones
+        "tm_mid": 13 * k + 8 * S + 12 * n_match,
+        # learning / punished rows: presynaptic ids + permanences, read and written; the info words for the sparse clear
+        "tm_learn": int(16 * mean_syn * n_work) + 4 * S,
+        # packed presynaptic ids of every segment + synapse count read and info word written per segment
         "tm_scan": 4 * syn + 8 * S,
-        "sp_select": 6 * C * 8, "sp_count": C * 8, "sp_emit": C * (8 + 4 + 4 + 12),
+        # dense per-column words of the coming step
+        "tm_clear": 12 * C,
     }
 
 
 def recorded_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r01_pmc_summary.json:
-    rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs of this same workload; KB units;
-    FETCH_SIZE doubled as MI355X_MICROARCH.md section HBM prescribes for gfx950).  PMC counters cannot be
-    read from inside this process, so this is a recorded value, not a live one."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
-    name = {"tm_scan": "k_tm_scan", "sp_overlap": "k_sp_overlap", "sp_learn": "k_tm_mid"}.get(kernel)
-    try:
-        d = json.load(open(path))
-        key = next(k for k in d["FETCH_SIZE"] if name in k)          # template kernels: "void k_tm_scan<true, 6>"
-        f = d["FETCH_SIZE"][key]["mean_last150_KB"]
-        wr = d["WRITE_SIZE"][key]["mean_last150_KB"]
-        return dict(traffic=int((2 * f + wr) * 1024), traffic_source="profiles/r01_pmc_summary.json (recorded PMC pass)")
-    except Exception:
-        return dict(traffic=None)
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r02_pmc_summary.json:
+    rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs of this same workload and schedule; KB
+    units; FETCH_SIZE doubled as MI355X_MICROARCH.md section HBM prescribes for gfx950).  PMC counters cannot
+    be read from inside this process, so this is a recorded value, not a live one."""
+    for name in ("r02_pmc_summary.json", "r01_pmc_summary.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        try:
+            d = json.load(open(path))
+            key = next(k for k in d["FETCH_SIZE"] if kernel in k)          # template kernels: "void k_scan_sel<true, 6>"
+            f = d["FETCH_SIZE"][key]["mean_last150_KB"]
+            wr = d["WRITE_SIZE"][key]["mean_last150_KB"]
+            return dict(traffic=int((2 * f + wr) * 1024), traffic_source=f"profiles/{name} (recorded PMC pass, 2*FETCH_SIZE + WRITE_SIZE)")
+        except Exception:
+            continue
+    return dict(traffic=None)
 
 
 def cpu_baseline(w, htm, noisy, start_step, sample_steps):
@@ -133,60 +151,78 @@ def run_single(args):
     k = htm.active_columns
     bank = eng.upload_bank(noisy)
     n_bank = noisy.shape[0]
-    log(f"[bench] setup {time.perf_counter() - t_setup:.1f}s; warm-up {args.warmup} steps")
     # rocprofv3 crashes inside hipGraph replay on this image: under the profiler, launch eagerly
     under_profiler = "ROCP_TOOL_LIBRARIES" in os.environ
     if under_profiler and not args.no_graph:
         log("[bench] rocprofv3 detected: hipGraph replay switched off (eager launches of the same schedule)")
     use_graph = not args.no_graph and not under_profiler
     pipeline = not args.no_pipeline
-    eng.run(bank, n_bank, args.warmup, learning=True, use_graph=use_graph, pipeline=pipeline)
+    run = dict(learning=True, use_graph=use_graph, pipeline=pipeline)
+    # Untimed setup: bring the model to the learned state the metric is quoted on (warm-up of
+    # at least 10 passes over the pattern bank; predictions appear after four).  The W warm-up steps of the
+    # command line come on top of it, before every timed repetition.
+    pretrain = args.pretrain if args.pretrain >= 0 else 10 * w["patterns"]
+    eng.run(bank, n_bank, pretrain, **run)
     eng.sync()
     eng.check_capacity()
-    t0 = time.perf_counter()
-    eng.run(bank, n_bank, args.steps, learning=True, use_graph=use_graph, pipeline=pipeline)
-    eng.sync()
-    dt = time.perf_counter() - t0
+    log(f"[bench] setup {time.perf_counter() - t_setup:.1f}s incl. {pretrain} untimed pre-training steps; "
+        f"S={eng.info().segments} segments")
+    # R repetitions of [W warm-up steps, exactly K timed steps]; `value` is the median repetition
+    reps = args.reps if args.reps > 0 else max(3, min(15, -(-4000 // max(args.steps, 1))))
+    rates = []
+    for r in range(reps):
+        eng.run(bank, n_bank, args.warmup, **run)
+        eng.prepare(bank, n_bank, args.steps, **run)     # every graph the timed call replays exists before the clock starts
+        eng.sync()
+        t0 = time.perf_counter()
+        eng.run(bank, n_bank, args.steps, **run)
+        eng.sync()
+        rates.append(args.steps / (time.perf_counter() - t0))
     info = eng.check_capacity()
-    steps_per_s = args.steps / dt
-    log(f"[bench] {args.steps} steps in {dt:.3f}s = {steps_per_s:.0f} timesteps/s; S={info.segments}; "
+    steps_per_s = float(np.median(rates))
+    log(f"[bench] {reps} x {args.steps} timed steps: median {steps_per_s:.0f} timesteps/s "
+        f"(min {min(rates):.0f}, max {max(rates):.0f}); S={info.segments}; "
         f"select fallbacks so far: {info.select_fallbacks} of {info.step_index} steps")
 
-    # per-kernel device time (HIP events on the engine's stream), same workload, profiled replay
-    prof_steps = min(args.steps, 300)
+    # per-launch device time (HIP events on the engine's stream) of the TIMED schedule, then of the same
+    # workload with one role per launch; both eager (events cannot be read out of a graph replay)
+    prof_steps = max(min(args.steps, 300), 50)
     eng.profile(True)
-    eng.run(bank, n_bank, prof_steps, learning=True, use_graph=False, pipeline=False)     # one role per launch
-    prof = eng.profile_read()
-    eng.run(bank, n_bank, prof_steps, learning=True, use_graph=False, pipeline=True)      # the launches of the timed run
-    prof_pipe = {n: v for n, v in eng.profile_read().items() if n in PIPELINED_LAUNCHES}
+    eng.run(bank, n_bank, prof_steps, learning=True, use_graph=False, pipeline=pipeline)
+    prof_timed = eng.profile_read()
+    eng.run(bank, n_bank, prof_steps, learning=True, use_graph=False, pipeline=False)
+    prof_roles = eng.profile_read()
     eng.profile(False)
+    info = eng.check_capacity()
     store = eng.read_store()
-    kb = kernel_bytes(w, k, store)
-    per_step_us = {name: 1e3 * ms / prof_steps for name, (ms, n) in prof.items()}
-    avg_us = {name: 1e3 * ms / max(n, 1) for name, (ms, n) in prof.items()}
-    dominant = max((n for n in per_step_us if n in ("sp_overlap", "sp_learn", "tm_scan")), key=lambda n: per_step_us[n])
-    achieved = kb[dominant] / (avg_us[dominant] * 1e-6) / 1e9
-    per_step_us = {n: v for n, v in per_step_us.items() if n not in PIPELINED_LAUNCHES}
-    log("[bench] per-step device time by kernel, one role per launch (us): " +
-        ", ".join(f"{n}={v:.1f}" for n, v in sorted(per_step_us.items(), key=lambda kv: -kv[1])))
-    pipe_us = {n: 1e3 * ms / max(cnt, 1) for n, (ms, cnt) in prof_pipe.items()}
-    log("[bench] pipelined launches (us): " + ", ".join(f"{n}={pipe_us.get(n, 0):.1f}" for n in PIPELINED_LAUNCHES) +
-        f"; sum {sum(pipe_us.values()):.1f} of {1e6 / steps_per_s:.1f} us per step")
-    roofline = dict(bound="hbm", kernel=dominant, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
-                    bytes_per_launch=int(kb[dominant]), avg_launch_us=round(avg_us[dominant], 2),
-                    whole_step_bytes=int(sum(kb[n] for n in ("sp_overlap", "sp_learn", "tm_scan", "sp_select", "sp_count", "sp_emit"))))
-    roofline["whole_step_frac"] = round(roofline["whole_step_bytes"] * steps_per_s / 1e9 / HBM_PEAK_GBS, 4)
-    if dominant == "tm_scan":
-        # SURVEY.md section 8(d) prices the scan at 8 bytes per slot of every allocated segment (the reference's
-        # unpacked store, 64 slots at this state); the packed store above needs 4 bytes per VALID synapse and
-        # reads permanences only for matching segments.  Both are given; `achieved` is the smaller one.
-        S = int(len(store["seg_nsyn"]))
-        sb = 8 * S * 64
-        roofline["survey_formula"] = dict(bytes_per_launch=sb, achieved=round(sb / (avg_us[dominant] * 1e-6) / 1e9, 1),
-                                          frac=round(sb / (avg_us[dominant] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-                                          formula="8 * S * E with E = 64 (reference layout)")
-    roofline.update(recorded_traffic(dominant))
+    rb = role_bytes(w, k, store["seg_nsyn"], info.work_items, info.matching_segments)
+    role_us = {n: 1e3 * ms / max(cnt, 1) for n, (ms, cnt) in prof_roles.items()}
+    log("[bench] one role per launch, average launch (us): " +
+        ", ".join(f"{n}={v:.1f}" for n, v in sorted(role_us.items(), key=lambda kv: -kv[1])))
+    if pipeline and all(n in prof_timed for n in LAUNCH_ROLES):
+        launch_us = {n: 1e3 * prof_timed[n][0] / max(prof_timed[n][1], 1) for n in LAUNCH_ROLES}
+        launch_bytes = {n: sum(rb[r] for r in roles) for n, roles in LAUNCH_ROLES.items()}
+        kernel_of = LAUNCH_KERNEL
+    else:                                             # --no-pipeline (or a grid too large to pipeline): the roles ARE the launches
+        per_role = {"sp_overlap": ("sp_overlap",), "sp_select": ("sp_select",), "sp_emit": ("sp_emit", "tm_activate", "tm_clear"),
+                    "tm_mid": ("tm_mid", "sp_rows"), "tm_learn": ("tm_learn",), "tm_scan": ("tm_scan",)}
+        launch_us = {n: v for n, v in role_us.items() if n in per_role}
+        launch_bytes = {n: sum(rb[r] for r in per_role[n]) for n in launch_us}
+        kernel_of = {"sp_overlap": "k_sp_overlap", "sp_select": "k_sel_pass", "sp_emit": "k_sp_emit", "tm_mid": "k_mid_rows",
+                     "tm_learn": "k_tm_learn", "tm_scan": "k_tm_scan"}
+    log("[bench] launches of the timed schedule (us): " + ", ".join(f"{n}={v:.1f}" for n, v in launch_us.items()) +
+        f"; sum {sum(launch_us.values()):.1f} of {1e6 / steps_per_s:.1f} us per step")
+    dominant = max(launch_us, key=lambda n: launch_us[n])
+    achieved = launch_bytes[dominant] / (launch_us[dominant] * 1e-6) / 1e9
+    whole = int(sum(rb.values()))
+    roofline = dict(bound="hbm", kernel=f"{kernel_of[dominant]} ({dominant})", achieved=round(achieved, 1), peak=HBM_PEAK_GBS,
+                    unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
+                    bytes_per_launch=int(launch_bytes[dominant]), avg_launch_us=round(launch_us[dominant], 2),
+                    whole_step_bytes=whole, whole_step_frac=round(whole * steps_per_s / 1e9 / HBM_PEAK_GBS, 4),
+                    launches={n: dict(kernel=kernel_of[n], us=round(launch_us[n], 2), bytes=int(launch_bytes[n]),
+                                      frac=round(launch_bytes[n] / (launch_us[n] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4))
+                              for n in launch_us})
+    roofline.update(recorded_traffic(kernel_of[dominant]))
 
     cpu = None
     if not args.no_cpu_baseline:
@@ -195,17 +231,18 @@ def run_single(args):
 
     return dict(
         metric="HTM timesteps/sec (SP + TM, learning on), 65536 cols x 32 cells", value=round(steps_per_s, 1),
-        unit="timesteps/s", n_gpus=1, steps=args.steps, warmup=args.warmup, ms_per_step=round(1e3 * dt / args.steps, 5),
+        unit="timesteps/s", n_gpus=1, steps=args.steps, warmup=args.warmup, ms_per_step=round(1e3 / steps_per_s, 5),
         higher_is_better=True, scaling="strong", vs_baseline=None, dtype="u32 bit-packed / f64 + f32 permanences",
         data="synthetic",
         config=dict(workload="configs[2]: 65536 columns x 32 cells, SP + TM learning on, 1 MI355X",
                     input_dim=w["input_dim"], column_dim=w["column_dim"], cell_dim=w["cell_dim"], active_columns=k,
                     patterns=w["patterns"], input_density=w["density"], flip_noise=w["noise"],
-                    segments=int(info.segments), segment_slots=w["segment_slots"], hip_graph=use_graph,
-                    pipelined=pipeline),
+                    pretrain_steps=pretrain, segments=int(info.segments), segment_slots=w["segment_slots"],
+                    hip_graph=use_graph, pipelined=pipeline, repetitions=reps),
+        repetitions=[round(r, 1) for r in rates],
         roofline=roofline, cpu_baseline=cpu,
-        kernel_us_per_step={n: round(v, 2) for n, v in per_step_us.items()},
-        pipelined_launch_us={n: round(v, 2) for n, v in pipe_us.items()})
+        role_us_one_per_launch={n: round(v, 2) for n, v in role_us.items()},
+        role_bytes={n: int(v) for n, v in rb.items()})
 
 
 def main():
@@ -214,6 +251,8 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=500)
     ap.add_argument("--columns", type=int, default=0, help="override column_dim (debugging)")
+    ap.add_argument("--pretrain", type=int, default=-1, help="untimed pre-training steps (default: 10 passes over the pattern bank)")
+    ap.add_argument("--reps", type=int, default=0, help="timed repetitions (default: enough for about 4000 timed steps, 3..15)")
     ap.add_argument("--cpu-steps", type=int, default=40)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")

@@ -54,6 +54,7 @@ EXPORTS = {
     "htm_sp_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     "htm_tm_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
     "htm_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "htm_prepare": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "htm_bank_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]),
     "htm_shard_record_bytes": (C.c_int64, [C.c_void_p]),
     "htm_shard_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),

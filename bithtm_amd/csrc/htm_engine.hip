@@ -19,6 +19,7 @@
 #include <string.h>
 #include <algorithm>
 #include <map>
+#include <mutex>
 #include <string>
 #include <tuple>
 #include <vector>
@@ -53,7 +54,9 @@ struct htm_handle {
     bool shard_open;
     int G;                                // lanes per SP row
     int graph_steps;                      // steady-state steps per captured graph (BITHTM_GRAPH_STEPS)
-    bool emit_fused, emit_fused_open;     // the emit grid is resident at once in k_sp_emit / in k_open_emit
+    bool emit_fused, emit_fused_open;     // the emit grid is resident at once in k_sp_emit / in k_open_emit (refreshed per call)
+    bool emit_fits, emit_fits_open;       // ... as far as this handle's own grids go (fixed at creation)
+    int sel_passes_fused, sel_passes_full; // launched select digits with / without the in-kernel finish
     int seg_hint;                         // a lower bound of the segment count (see scan_spec_blocks)
     int *seg_pinned;                      // pinned word the end of each htm_run copies the count into
     int sp_blocks, sel_blocks, c256_blocks, s1024_blocks, scan_blocks;
@@ -72,6 +75,26 @@ struct htm_handle {
     std::vector<double> prof_ms;
     std::vector<long long> prof_n;
 };
+
+// Live handles, per process.  The in-kernel select finish (k_sp_emit / k_open_emit) makes the blocks of one grid
+// wait for each other, which is only safe while nothing else can hold the CU slots that grid needs: kernels of
+// one stream run one after the other, kernels of another handle's stream do not.  A handle therefore uses the
+// in-kernel finish only while every other live handle on its device enqueues on the same stream; otherwise it
+// launches all select digits and the separate count kernel (slower, no waiting between blocks, same result).
+static std::mutex g_registry_mutex;
+static std::vector<htm_handle *> g_registry;
+
+static void refresh_exchange_mode(htm_handle *h) {
+    bool solo = true;
+    {
+        std::lock_guard<std::mutex> lock(g_registry_mutex);
+        for (const htm_handle *o : g_registry)
+            if (o != h && o->device == h->device && o->stream != h->stream) solo = false;
+    }
+    h->emit_fused = h->emit_fits && solo;
+    h->emit_fused_open = h->emit_fits_open && solo;
+    h->d.sel_passes = h->emit_fused ? h->sel_passes_fused : h->sel_passes_full;
+}
 
 #define HIPCHK(h, call)                                                                          \
     do {                                                                                         \
@@ -284,6 +307,10 @@ extern "C" const char *htm_last_error(const htm_handle *h) { return h ? h->err.c
 
 extern "C" void htm_destroy(htm_handle *h) {
     if (!h) return;
+    {
+        std::lock_guard<std::mutex> lock(g_registry_mutex);
+        g_registry.erase(std::remove(g_registry.begin(), g_registry.end(), h), g_registry.end());
+    }
     hipSetDevice(h->device);
     hipStreamSynchronize(h->stream);
     for (auto &kv : h->graphs) hipGraphExecDestroy(kv.second);
@@ -474,17 +501,18 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
                 hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_emit, (const void *)k_sp_emit, 256, 0) == hipSuccess &&
                 hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_open, (const void *)k_open_emit, 256, sizeof(EmitShared)) == hipSuccess) {
                 const int cus = prop.multiProcessorCount;
-                h->emit_fused = c256 <= std::min(1024, per_cu_emit * cus);
+                h->emit_fits = c256 <= std::min(1024, per_cu_emit * cus);
                 // the pipelined launch puts the activation blocks of the current step behind the emit blocks
-                h->emit_fused_open = h->emit_fused && c256 + (d.k * 32 + 255) / 256 <= std::min(1024, per_cu_open * cus);
+                h->emit_fits_open = h->emit_fits && c256 + (d.k * 32 + 255) / 256 <= std::min(1024, per_cu_open * cus);
             } else {
                 (void)hipGetLastError();
-                h->emit_fused = h->emit_fused_open = false;
+                h->emit_fits = h->emit_fits_open = false;
             }
         }
-        if (h->emit_fused) d.sel_passes = std::min(d.sel_passes, 2);
+        h->sel_passes_full = d.sel_passes;
+        h->sel_passes_fused = std::min(d.sel_passes, 2);
         // test knobs: more launched digits (smaller buckets); fewer record slots (forces the fallback)
-        if (const char *e = getenv("BITHTM_SEL_LAUNCH_DIGITS")) d.sel_passes = std::max(2, std::min(d.sel_passes, atoi(e)));
+        if (const char *e = getenv("BITHTM_SEL_LAUNCH_DIGITS")) h->sel_passes_fused = std::max(2, std::min(d.sel_passes, atoi(e)));
         d.cand_d = CAND_D;
         if (const char *e = getenv("BITHTM_CAND_D")) d.cand_d = std::max(0, std::min(CAND_D, atoi(e)));
         d.cand_pairwise = CAND_PAIRWISE;
@@ -494,6 +522,11 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
     }
     e = hipStreamSynchronize(h->stream);
     if (e != hipSuccess) return fail_create(h, std::string("hipStreamSynchronize: ") + hipGetErrorString(e), HTM_ERR_HIP);
+    {
+        std::lock_guard<std::mutex> lock(g_registry_mutex);
+        g_registry.push_back(h);
+    }
+    refresh_exchange_mode(h);
     *out = h;
     return HTM_OK;
 }
@@ -554,6 +587,7 @@ extern "C" int htm_step(htm_handle *h, const uint32_t *packed_input, int32_t lea
     if (!h->cfg.enable_sp || !h->cfg.enable_tm) { h->err = "htm_step needs a handle with SP and TM"; return HTM_ERR_STATE; }
     if (h->world > 1) { h->err = "sharded handle: use htm_shard_begin / htm_shard_finish"; return HTM_ERR_STATE; }
     HIPCHK(h, hipSetDevice(h->device));
+    refresh_exchange_mode(h);
     int rc = stage_input(h, packed_input);
     if (rc) return rc;
     return enqueue_step(h, h->d.input_stage, 1, learning ? 1 : 0, StepPlan{false, false, false});
@@ -562,7 +596,11 @@ extern "C" int htm_step(htm_handle *h, const uint32_t *packed_input, int32_t lea
 extern "C" int htm_sp_step(htm_handle *h, const uint32_t *packed_input, int32_t learning) {
     if (!h || !packed_input) return HTM_ERR_ARGUMENT;
     if (!h->cfg.enable_sp) { h->err = "handle has no Spatial Pooler"; return HTM_ERR_STATE; }
+    // a handle that also owns a Temporal Memory steps both layers together: an SP-only step would skip the SP
+    // learning that rides in the TM's middle launch and leave the TM's parity buffers one step behind
+    if (h->cfg.enable_tm) { h->err = "htm_sp_step: the handle also has a Temporal Memory; use htm_step"; return HTM_ERR_STATE; }
     HIPCHK(h, hipSetDevice(h->device));
+    refresh_exchange_mode(h);
     int rc = stage_input(h, packed_input);
     if (rc) return rc;
     const int p = (int)(h->step_host & 1);
@@ -593,14 +631,18 @@ extern "C" int htm_tm_step(htm_handle *h, const int32_t *active_column, int32_t 
     return HTM_OK;
 }
 
-extern "C" int htm_run(htm_handle *h, const uint32_t *device_inputs, int32_t n_inputs, int32_t n_steps, int32_t learning, int32_t use_graph) {
+// htm_run, or (dry) only the capture + instantiation of every hipGraph that htm_run call would replay
+static int run_or_prepare(htm_handle *h, const uint32_t *device_inputs, int32_t n_inputs, int32_t n_steps, int32_t learning,
+                          int32_t use_graph, bool dry) {
     if (!h || !device_inputs || n_inputs < 1 || n_steps < 0) return HTM_ERR_ARGUMENT;
     if (!h->cfg.enable_sp || !h->cfg.enable_tm) { h->err = "htm_run needs a handle with SP and TM"; return HTM_ERR_STATE; }
     if (h->world > 1) { h->err = "sharded handle: use htm_shard_begin / htm_shard_finish"; return HTM_ERR_STATE; }
     HIPCHK(h, hipSetDevice(h->device));
+    refresh_exchange_mode(h);
     learning = learning ? 1 : 0;
     const bool graph = (use_graph & 1) && !h->profile;
     const bool pipeline = !(use_graph & 2) && can_pipeline(h);
+    if (dry && !graph) return HTM_OK;
     // Graphs hold the launches of one step, or of kGraphSteps consecutive steady-state steps (a graph
     // launch boundary costs about 5 us more than a kernel boundary inside a graph: tools/step_timeline.py).
     // Nothing in a graph depends on the step index: kernels read it, and with it the bank row, from
@@ -608,6 +650,7 @@ extern "C" int htm_run(htm_handle *h, const uint32_t *device_inputs, int32_t n_i
     const int kGraphSteps = h->graph_steps;
     if (h->seg_pinned) { const int seen = *(volatile int *)h->seg_pinned; h->seg_hint = std::max(h->seg_hint, seen); }      // what the last run left
     bool sp_done = false;                           // the SP has already done the coming step
+    long long step = h->step_host;
     for (int t = 0; t < n_steps;) {
         const StepPlan plan{sp_done, pipeline && t + 1 < n_steps, pipeline && t + 2 < n_steps};
         sp_done = plan.next_sp;
@@ -617,12 +660,14 @@ extern "C" int htm_run(htm_handle *h, const uint32_t *device_inputs, int32_t n_i
             t += 1;
             continue;
         }
-        const int p = (int)(h->step_host & 1);
+        const int p = (int)(step & 1);
         // steady state: this and the next kGraphSteps - 1 steps all look ahead fully
         const int span = (plan.sp_done && plan.next_front && t + kGraphSteps + 1 < n_steps) ? kGraphSteps : 1;
-        if (!plan.sp_done && !plan.next_sp) enqueue_sp_front(h, device_inputs, n_inputs, p);    // eager
-        enqueue_cold_start(h, device_inputs, n_inputs, learning, plan);                         // eager: first step of a pipelined run
-        auto key = std::make_tuple(p, learning * 16 + (span > 1 ? 8 : 0) + (plan.sp_done ? 4 : 0) + (plan.next_sp ? 2 : 0) + (plan.next_front ? 1 : 0) + 32 * scan_spec_blocks(h) + (scan_pool_is_large(h) ? (1 << 20) : 0),
+        if (!dry) {
+            if (!plan.sp_done && !plan.next_sp) enqueue_sp_front(h, device_inputs, n_inputs, p);    // eager
+            enqueue_cold_start(h, device_inputs, n_inputs, learning, plan);                         // eager: first step of a pipelined run
+        }
+        auto key = std::make_tuple(p, learning * 16 + (span > 1 ? 8 : 0) + (plan.sp_done ? 4 : 0) + (plan.next_sp ? 2 : 0) + (plan.next_front ? 1 : 0) + 32 * scan_spec_blocks(h) + (scan_pool_is_large(h) ? (1 << 20) : 0) + (h->emit_fused ? (1 << 21) : 0),
                                    (const void *)device_inputs, n_inputs);
         auto it = h->graphs.find(key);
         if (it == h->graphs.end()) {
@@ -636,13 +681,24 @@ extern "C" int htm_run(htm_handle *h, const uint32_t *device_inputs, int32_t n_i
             hipGraphDestroy(graph_obj);
             it = h->graphs.emplace(key, exec).first;
         }
-        HIPCHK(h, hipGraphLaunch(it->second, h->stream));
-        h->step_host += span;
+        if (!dry) {
+            HIPCHK(h, hipGraphLaunch(it->second, h->stream));
+            h->step_host += span;
+        }
+        step += span;
         t += span;
     }
     // leave the segment count where the next call finds it (no wait: it may see the one before)
-    if (h->seg_pinned && n_steps > 0) HIPCHK(h, hipMemcpyAsync(h->seg_pinned, &h->d.ctr->S, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    if (!dry && h->seg_pinned && n_steps > 0) HIPCHK(h, hipMemcpyAsync(h->seg_pinned, &h->d.ctr->S, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     return HTM_OK;
+}
+
+extern "C" int htm_run(htm_handle *h, const uint32_t *device_inputs, int32_t n_inputs, int32_t n_steps, int32_t learning, int32_t use_graph) {
+    return run_or_prepare(h, device_inputs, n_inputs, n_steps, learning, use_graph, false);
+}
+
+extern "C" int htm_prepare(htm_handle *h, const uint32_t *device_inputs, int32_t n_inputs, int32_t n_steps, int32_t learning, int32_t use_graph) {
+    return run_or_prepare(h, device_inputs, n_inputs, n_steps, learning, use_graph, true);
 }
 
 extern "C" int64_t htm_shard_record_bytes(htm_handle *h) {
@@ -656,6 +712,7 @@ extern "C" int htm_shard_begin(htm_handle *h, const uint32_t *device_inputs, int
     if (h->world < 2) { h->err = "htm_shard_begin: handle is not sharded"; return HTM_ERR_STATE; }
     if (h->shard_open) { h->err = "htm_shard_begin: previous step not finished"; return HTM_ERR_STATE; }
     HIPCHK(h, hipSetDevice(h->device));
+    refresh_exchange_mode(h);
     if (packed_input) {
         int rc = stage_input(h, packed_input);
         if (rc) return rc;
@@ -954,6 +1011,12 @@ extern "C" int htm_import_commit(htm_handle *h, int32_t segments, int32_t matchi
         if (segments) {
             HIPCHK(h, hipMemcpy(d.seg_info, info.data(), info.size() * 4, hipMemcpyHostToDevice));
             HIPCHK(h, hipMemcpy(d.seg_jit, jit.data(), jit.size() * 4, hipMemcpyHostToDevice));
+        }
+        // the import is the one place where the segment count can shrink (rollback to an earlier checkpoint):
+        // ids at or above it must read "no info" again, as the classification and the binding assume
+        if (segments < d.Scap) {
+            HIPCHK(h, hipMemset(d.seg_info + segments, 0, (size_t)(d.Scap - segments) * 4));
+            HIPCHK(h, hipMemset(d.seg_jit + segments, 0, (size_t)(d.Scap - segments) * 4));
         }
         h->imp_pot.clear(); h->imp_match_seg.clear(); h->imp_match_info.clear(); h->imp_match_jit.clear();
     }

@@ -187,6 +187,12 @@ class Engine:
                                      flags), "htm_run")
         self.steps += n_steps
 
+    def prepare(self, device_bank, n_inputs, n_steps, learning=True, use_graph=True, pipeline=True):
+        """Build (capture + instantiate) the hipGraphs the run() call with these arguments will replay."""
+        flags = (1 if use_graph else 0) | (0 if pipeline else 2)
+        self._check(self.lib.htm_prepare(self.h, C.c_void_p(device_bank), int(n_inputs), int(n_steps), int(bool(learning)),
+                                         flags), "htm_prepare")
+
     # ---- column-sharded stepping (shard_world > 1): begin -> all-gather by the caller -> finish
     def shard_record_bytes(self):
         return int(self._check(self.lib.htm_shard_record_bytes(self.h), "htm_shard_record_bytes"))

@@ -88,8 +88,9 @@ typedef struct htm_info {
     int32_t active_cells;               /* len(active_cell[0]) of the last step */
     int32_t has_distal_state;           /* last_state.distal_state is not None */
     int32_t has_winner_cells;           /* last_state.winner_cell is not None */
-    int32_t capacity_error;             /* sticky: 1 = segment pool, 2 = synapse slots, 4 = work list,
-                                           8 = dead-segment report of a sharded handle */
+    int32_t capacity_error;             /* sticky: 1 = segment pool, 2 = synapse slots, 4 = work list / growth staging,
+                                           8 = dead-segment report of a sharded handle, 16 = (internal) a block of the
+                                           in-kernel select exchange never arrived: the step's result is invalid */
     int32_t words_per_row;              /* packed input words per SP row (input_dim padded to 128 bits) */
     int32_t new_segment_requests;       /* last step: winners without a matching segment (projections.py:271) */
     int32_t recycled_segments;          /* last step: of those, served by recycling (projections.py:80-85) */
@@ -160,6 +161,12 @@ int htm_tm_step(htm_handle *h, const int32_t *active_column, int32_t n, int32_t 
  * is exactly that of n_steps htm_step calls. */
 int htm_run(htm_handle *h, const uint32_t *device_inputs, int32_t n_inputs, int32_t n_steps,
             int32_t learning, int32_t use_graph);
+
+/* Capture and instantiate, without running anything, every hipGraph the htm_run call with the same
+ * arguments will replay when it comes next (graphs are otherwise built lazily inside htm_run, the first
+ * time a launch pattern is met).  Latency-sensitive callers invoke it once after their warm-up. */
+int htm_prepare(htm_handle *h, const uint32_t *device_inputs, int32_t n_inputs, int32_t n_steps,
+                int32_t learning, int32_t use_graph);
 
 /* Convenience for callers without their own device allocator: copy n_inputs packed inputs
  * (ceil(input_dim/32) host words each, as for htm_step) into a handle-owned device bank laid out

@@ -130,6 +130,61 @@ def test_full_size_65536x32_state_handoff_and_parity():
         assert u.shape == v.shape and np.array_equal(u, v), f"import round trip: {key}"
 
 
+@pytest.fixture(scope="module")
+def full_size_oracle():
+    """The NumPy oracle stepped 260 times FROM THE SEED at BASELINE.json configs[2] (65 536 x 32, bench.py's
+    workload and input stream): an independent reference for the state the timed path must reach."""
+    import bench
+    from oracle import HTMOracle
+    w = dict(bench.WORKLOAD)
+    noisy, perm = bench.make_inputs(w)
+    ora = HTMOracle(w["input_dim"], w["column_dim"], w["cell_dim"], seed=0, permanence=perm)
+    n = 260                                                      # > 5 passes over the 50 patterns: bursting, then predicted
+    for t in range(n):
+        o_sp, o_tm = ora.step(noisy[t % len(noisy)])
+    return dict(w=w, noisy=noisy, ora=ora, o_sp=o_sp, o_tm=o_tm, n=n)
+
+
+@pytest.mark.parametrize("use_graph,pipeline", [(True, True), (False, True), (False, False)],
+                         ids=["graph-pipelined", "eager-pipelined", "one-role-per-launch"])
+def test_full_size_timed_path_equals_from_scratch_oracle(full_size_oracle, use_graph, pipeline):
+    """The schedule bench.py times (pipelined launches, 16-step hipGraphs) and its two plainer forms, each run from
+    scratch at the full size and compared with the from-scratch oracle: last step's outputs and the whole state."""
+    import bench
+    from hip_impl import compare_store_with_oracle, step_outputs
+    f = full_size_oracle
+    w, noisy, ora, n = f["w"], f["noisy"], f["ora"], f["n"]
+    K = w["cell_dim"]
+    _, perm = bench.make_inputs(w)
+    htm = bench.build_htm(w, perm, 0)
+    del perm
+    htm.run(noisy, n, learning=True, use_graph=use_graph, pipeline=pipeline)
+    eng = htm.engine
+    info = eng.check_capacity()
+    assert info.step_index == n and info.select_fallbacks == 0
+    sp_state = type(htm.spatial_pooler).State(eng, eng.steps)
+    tm_state = htm.temporal_memory.last_state
+    got = step_outputs(sp_state, tm_state, K)
+    o_sp, o_tm = f["o_sp"], f["o_tm"]
+    od = o_tm.distal_state
+    want = dict(active_column=o_sp.active_column, overlaps=o_sp.overlaps, boosted=o_sp.boosted_overlaps,
+                bursting=o_tm.active_column_bursting[:, 0],
+                act_bits=np.packbits(o_tm.cell_activation.reshape(-1), bitorder="little"),
+                pred_bits=np.packbits(o_tm.cell_prediction.reshape(-1), bitorder="little"),
+                winner=o_tm.winner_cell[0] * K + o_tm.winner_cell[1], matching=od.matching_segment,
+                match_pot=od.segment_potential[od.matching_segment], match_act=od.matching_segment_activation,
+                match_active=od.matching_segment_active, S=len(od.segment_potential))
+    for key in gr.FIELDS:
+        a, b = np.asarray(got[key]), np.asarray(want[key])
+        if key == "boosted":
+            a, b = a.view(np.int64), b.view(np.int64)
+        assert a.shape == b.shape and np.array_equal(a, b), f"{key} after {n} steps"
+    d = tm_state.distal_state
+    assert np.array_equal(d.segment_potential, od.segment_potential)
+    assert np.array_equal(d.max_jittered_potential.view(np.int32), od.max_jittered_potential.view(np.int32))
+    compare_store_with_oracle(n - 1, ora, htm)       # seg_cell, seg_nsyn, segcount, synapses + permanence bits, SP permanence, duty
+
+
 def test_config1_16384_columns_sp_only():
     """BASELINE.json configs[1]: 16 384 columns, 2 % input sparsity, SpatialPooler only."""
     import bithtm_amd as B

@@ -8,6 +8,7 @@
 set -u
 TAG=${1:-r01}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/profile_$TAG
+export OUT
 mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
 timeout -k 10 400 python bench.py > $OUT/bench.json 2> $OUT/bench.log; echo "bench exit=$?"
