@@ -14,6 +14,7 @@ typedef unsigned long long u64;
 #define SCAN_SEGS 64          // segments per 256-thread block iteration of the segment scan
 #define DEAD_CAP 256          // newly dead segment ids one rank can report per exchange
 #define CAND_CAP 256          // growth candidates staged per wave
+#define WIN_LDS 4096          // previous winner cells the learning role keeps in LDS (more are read from global memory)
 #define MAX_SLOTS 512
 #define SYN_CONNECTED 0x80000000u   // a presynaptic id carries `permanence >= threshold` in its top bit ...
 #define SYN_CELL 0x7FFFFFFF         // ... and the cell (column * 32 + cell) below it

@@ -22,6 +22,7 @@
 #include <mutex>
 #include <string>
 #include <tuple>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/bithtm_hip.h"
@@ -149,7 +150,7 @@ static int prof_slot(htm_handle *h, const char *name) {
     } while (0)
 #define LAUNCH(h, name, kernel, grid, block, ...) LAUNCH_ON(h, (h)->stream, 0, name, kernel, grid, block, __VA_ARGS__)
 
-static size_t learn_lds(int epl, int bs = RB) { return (size_t)(bs / 64) * CAND_CAP * 8 + (size_t)(bs / 64) * epl * 64 * 4; }
+static size_t learn_lds(int epl, int bs = RB) { return (size_t)(bs / 64) * CAND_CAP * 8 + (size_t)(bs / 64) * epl * 64 * 4 + (size_t)WIN_LDS * 4; }
 static int learn_epl(const Dev &d) { const int e = d.E / 64; return e <= 1 ? 1 : e == 2 ? 2 : e <= 4 ? 4 : 8; }
 static size_t scan_lds(const Dev &d, int use_lds) { return 16 + (use_lds ? (size_t)d.colwords * 4 : 0); }
 static const int kClassifyBlocks = 384;           // x 256 segments per pass of the learn / punish classification

@@ -279,7 +279,18 @@ __device__ __forceinline__ void role_mid(const Dev &d, int p, int n_active, int 
 // surviving synapses are re-packed to the front of the row.  Growth: the n_add previous winner
 // cells with the smallest keyed priority that the segment does not have yet.
 template <int EPL, int BS>
-struct LearnShared { u64 cand[BS / 64][CAND_CAP]; int keep[BS / 64][EPL * 64]; };
+struct LearnShared { u64 cand[BS / 64][CAND_CAP]; int keep[BS / 64][EPL * 64]; int win[WIN_LDS]; };
+static_assert(CAND_CAP == 4 * 64, "the growth path holds the staged winners four per lane");
+
+// diagnostic build (-DBITHTM_LEARN_STAMPS, handle created under BITHTM_TRACE=1): cycles per phase of the learning
+// role, summed over all waves into the first words of the trace buffer (tools/learn_phases.py)
+#ifdef BITHTM_LEARN_STAMPS
+#define LSTAMP(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); acc_[i] += now_ - stamp_; stamp_ = now_; } while (0)
+#define LCOUNT(i, v) do { acc_[i] += (unsigned long long)(v); } while (0)
+#else
+#define LSTAMP(i) do { } while (0)
+#define LCOUNT(i, v) do { } while (0)
+#endif
 
 template <int EPL, int BS>
 __device__ __forceinline__ void role_learn(const Dev &d, int p, int blk, int nblk, LearnShared<EPL, BS> *sh) {
@@ -302,7 +313,18 @@ __device__ __forceinline__ void role_learn(const Dev &d, int p, int blk, int nbl
     const int *winners = d.winners[p ^ 1];
     const int n_w = c->has_winner[p ^ 1] ? c->n_win[p ^ 1] : -1;       // -1: winner_input is None
     const uint32_t base2 = htm_stream_base(d.seed, HTM_STREAM_GROWTH, c->step[p]);
+    // the previous winners, the population every growing segment samples from: once per block into LDS
+    // (the staging pass of a growing segment otherwise waits for one global load per 64 winners)
+    int *s_win = sh->win;
+    for (int i = threadIdx.x; i < min(n_w, WIN_LDS); i += BS) s_win[i] = winners[i];
+    __syncthreads();
+    auto winner_at = [&](int i) -> int { return i < WIN_LDS ? s_win[i] : winners[i]; };
+#ifdef BITHTM_LEARN_STAMPS
+    unsigned long long acc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};      // per wave, in registers; written once below
+    unsigned long long stamp_ = __builtin_readcyclecounter();
+#endif
     for (int item = blk * (BS / 64) + wv; item < n_work; item += nblk * (BS / 64)) {
+        LSTAMP(0);
         const uint32_t w = d.work[item < n_front ? item : d.work_cap - n_back + (item - n_front)];
         const int seg = (int)(w & 0x7FFFFFFFu), mode = (int)(w >> 31);
         const double dA = mode ? d.pun_act : d.lrn_act, dI = mode ? d.pun_inact : d.lrn_inact;
@@ -333,6 +355,8 @@ __device__ __forceinline__ void role_learn(const Dev &d, int p, int blk, int nbl
             n_active += __popcll(__ballot(keep && a));                    // :114
         }
         __builtin_amdgcn_wave_barrier();
+        LSTAMP(1);
+        LCOUNT(8, 1);
         int n_total = n_keep;
         if (mode == 0 && n_w > 0) {
             const int n_add = min(max(d.sample - n_active, 0), min(d.sample, n_w));     // :115
@@ -340,34 +364,41 @@ __device__ __forceinline__ void role_learn(const Dev &d, int p, int blk, int nbl
                 // threshold T with n_add <= |{absent winners with priority < T}| <= CAND_CAP
                 uint32_t lo = 0, hi = 1u << 24, T = 1u << 24;
                 if (n_w > CAND_CAP) {
-                    u64 est = ((u64)(2 * n_add + 16) << 24) / (u64)max(n_w - n_active, 1);
+                    // expected number staged: 1.5 n_add + 12 (60 of them for a whole sample of 32: they fit one
+                    // register slot per lane below, and fewer than n_add turn up about once in 10^4 tries)
+                    u64 est = ((u64)(3 * n_add / 2 + 12) << 24) / (u64)max(n_w - n_active, 1);
                     T = (uint32_t)min(est, (u64)(1u << 24));
                 }
-                // Each try stages every winner with priority < T, then drops the ones the segment already
-                // has.  The kept synapses sit in registers, EPL per lane; the staged winners are broadcast
-                // one at a time and compared by the whole wave.  (Testing membership inside the scan of the
-                // winner list made the wave walk the kept synapses in every 64-winner chunk with a hit:
-                // 30 us for a full row; one lane per staged winner walking them took 4 us per 64 staged.)
-                int kept[EPL];
-#pragma unroll
-                for (int jj = 0; jj < EPL; ++jj) kept[jj] = jj * 64 + lane < n_keep ? s_keep[wv][jj * 64 + lane] : -1;
+                // Each try stages every winner with priority < T (four 64-winner chunks per pass: the list sits in
+                // LDS and the four hash chains are independent), then drops the ones the segment already has:
+                // the staged winners sit in registers, up to four per lane, and the kept synapses are broadcast
+                // from LDS one after the other.  An empty row (a new or recycled segment, every growing segment
+                // of the first steps) has nothing to drop.
                 int found = 0;
+                LCOUNT(9, 1);
                 for (int iter = 0; iter < 64; ++iter) {
+                    LCOUNT(10, 1);
+                    LSTAMP(2);
                     int staged = 0;
-                    for (int b0 = 0; b0 < n_w; b0 += 64) {
-                        const int i = b0 + lane;
-                        uint32_t pr = 0;
-                        bool take = false;
-                        if (i < n_w) {
-                            pr = htm_draw24(base2, (uint32_t)seg, enc_to_flat(winners[i], d.K));     // :120
-                            take = pr < T;
+                    for (int b0 = 0; b0 < n_w; b0 += 4 * 64) {
+                        uint32_t pr[4];
+                        bool take[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int i = b0 + j * 64 + lane;
+                            const int wcell = i < n_w ? winner_at(i) : 0;
+                            pr[j] = htm_draw24(base2, (uint32_t)seg, enc_to_flat(wcell, d.K));       // :120
+                            take[j] = i < n_w && pr[j] < T;
                         }
-                        const u64 mt = __ballot(take);
-                        if (take) {
-                            const int pos = staged + __popcll(mt & lanemask_lt());
-                            if (pos < CAND_CAP) s_cand[wv][pos] = ((u64)pr << 32) | (uint32_t)i;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const u64 mt = __ballot(take[j]);
+                            if (take[j]) {
+                                const int pos = staged + __popcll(mt & lanemask_lt());
+                                if (pos < CAND_CAP) s_cand[wv][pos] = ((u64)pr[j] << 32) | (uint32_t)(b0 + j * 64 + lane);
+                            }
+                            staged += __popcll(mt);
                         }
-                        staged += __popcll(mt);
                     }
                     if (staged > CAND_CAP) {                      // too many for the staging area: lower T
                         hi = T;
@@ -376,48 +407,79 @@ __device__ __forceinline__ void role_learn(const Dev &d, int p, int blk, int nbl
                         continue;
                     }
                     __builtin_amdgcn_wave_barrier();
-                    found = 0;
-                    for (int e0 = 0; e0 < staged; e0 += 64) {     // :121-123, compacting in place (pos <= e)
-                        const int e = e0 + lane;
-                        const u64 key = e < staged ? s_cand[wv][e] : 0ull;
-                        const int cell = e < staged ? winners[(uint32_t)key] : -2;
-                        bool present = false;
-                        const int n_here = min(64, staged - e0);
-                        for (int t = 0; t < n_here; ++t) {        // (t is uniform: a lane read, not a shuffle)
-                            const int ct = __builtin_amdgcn_readlane(cell, t);
-                            bool hit = false;
+                    LSTAMP(3);
+                    LCOUNT(11, staged);
+                    found = staged;
+                    if (n_keep > 0) {                             // :121-123
+                        u64 key[4];
+                        int cell[4];
+                        bool present[4];
 #pragma unroll
-                            for (int jj = 0; jj < EPL; ++jj) hit |= kept[jj] == ct;
-                            const bool any = __ballot(hit) != 0;
-                            if (lane == t) present = any;
+                        for (int j = 0; j < 4; ++j) {
+                            const int e = j * 64 + lane;
+                            key[j] = e < staged ? s_cand[wv][e] : 0ull;
+                            cell[j] = e < staged ? winner_at((int)(uint32_t)key[j]) : -2;
+                            present[j] = false;
                         }
-                        const bool absent = e < staged && !present;
-                        const u64 ma = __ballot(absent);
+#pragma unroll 4
+                        for (int f = 0; f < n_keep; ++f) {
+                            const int kf = s_keep[wv][f];         // (one address for the wave: a broadcast read)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) present[j] |= cell[j] == kf;
+                        }
+                        __builtin_amdgcn_wave_barrier();          // every lane holds its entries: compact in place
+                        found = 0;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const bool absent = j * 64 + lane < staged && !present[j];
+                            const u64 ma = __ballot(absent);
+                            if (absent) s_cand[wv][found + __popcll(ma & lanemask_lt())] = key[j];
+                            found += __popcll(ma);
+                        }
                         __builtin_amdgcn_wave_barrier();
-                        if (absent) s_cand[wv][found + __popcll(ma & lanemask_lt())] = key;
-                        found += __popcll(ma);
                     }
+                    LSTAMP(4);
                     if (found >= n_add || T == (1u << 24)) break; // enough, or fewer absent winners than n_add: take all
                     lo = T;
                     T = (hi == (1u << 24)) ? (uint32_t)min((u64)T * 4u + 16u, (u64)hi) : (lo + hi + 1) / 2;
                 }
-                __builtin_amdgcn_wave_barrier();
+                // the n_add smallest (priority, position) keys: each lane ranks its up to four candidates against the
+                // list (broadcast reads again).  Only the chosen SET matters -- slots have no meaning, the reference
+                // fills its free slots with the chosen cells in ascending order (:129-160) -- so the rank serves as slot
                 const int n_c = min(found, CAND_CAP), take_n = min(n_add, n_c);        // :125-127
-                for (int e = lane; e < n_c; e += 64) {
-                    const u64 key = s_cand[wv][e];
-                    int rank = 0;
-                    for (int f = 0; f < n_c; ++f) rank += s_cand[wv][f] < key;
-                    if (rank < take_n) {
-                        const int slot = n_keep + rank;
-                        if (slot < d.E) {
-                            prow[slot] = winners[(uint32_t)key] | (d.perm_init >= d.perm_thr ? (int)SYN_CONNECTED : 0);
-                            mrow[slot] = d.perm_init;                                   // :149,158
-                        } else {
-                            atomicOr(&c->error, 2);
+                auto rank_and_write = [&](auto slots_tag) {
+                    constexpr int SL = decltype(slots_tag)::value;      // register slots in use: ceil(n_c / 64)
+                    u64 key[SL];
+                    int rank[SL];
+#pragma unroll
+                    for (int j = 0; j < SL; ++j) {
+                        key[j] = j * 64 + lane < n_c ? s_cand[wv][j * 64 + lane] : ~0ull;
+                        rank[j] = 0;
+                    }
+#pragma unroll 4
+                    for (int f = 0; f < n_c; ++f) {
+                        const u64 kf = s_cand[wv][f];
+#pragma unroll
+                        for (int j = 0; j < SL; ++j) rank[j] += kf < key[j];
+                    }
+#pragma unroll
+                    for (int j = 0; j < SL; ++j) {
+                        if (j * 64 + lane < n_c && rank[j] < take_n) {
+                            const int slot = n_keep + rank[j];
+                            if (slot < d.E) {
+                                prow[slot] = winner_at((int)(uint32_t)key[j]) | (d.perm_init >= d.perm_thr ? (int)SYN_CONNECTED : 0);
+                                mrow[slot] = d.perm_init;                               // :149,158
+                            } else {
+                                atomicOr(&c->error, 2);
+                            }
                         }
                     }
-                }
+                };
+                if (n_c <= 64) rank_and_write(std::integral_constant<int, 1>());
+                else if (n_c <= 128) rank_and_write(std::integral_constant<int, 2>());
+                else rank_and_write(std::integral_constant<int, 4>());
                 n_total = min(n_keep + take_n, d.E);                                    // :161
+                LSTAMP(5);
             }
         }
         if (lane == 0) {
@@ -429,6 +491,10 @@ __device__ __forceinline__ void role_learn(const Dev &d, int p, int blk, int nbl
         }
         __builtin_amdgcn_wave_barrier();
     }
+#ifdef BITHTM_LEARN_STAMPS
+    if (lane == 0 && d.trace)
+        for (int i = 0; i < 12; ++i) d.trace[(size_t)(blk * (BS / 64) + wv) * 16 + i] += acc_[i];
+#endif
 }
 
 extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
