@@ -102,7 +102,8 @@ struct Dev {
     float *sperm;             // [Scap][E] float32 permanence
     int *segcount;            // [C*32] segments per cell
     uint32_t *cellmax;        // [C*32] float bits of max jittered potential per cell (0 = none)
-    uint32_t *seg_info;       // [Scap] last scan: potential | activation << 12 | matching << 30 | active << 31
+    uint32_t *match_bits;     // [ceil(Scap/32)] last scan: segment is matching (projections.py:247); whole words are written
+    uint32_t *seg_info;       // [Scap] last scan, MATCHING segments only: potential | activation << 12 | 1 << 30 | active << 31
     float *seg_jit;           // [Scap] jittered potential of the matching segments
     uint32_t *work;           // [work_cap] segment | mode << 31 (0 = learn + grow, 1 = punish)
     int *recyc_cnt;           // [ceil(Scap/1024)] recyclable segments per 1024-segment block

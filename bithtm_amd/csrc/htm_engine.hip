@@ -174,7 +174,11 @@ static void launch_learn(htm_handle *h, int p) {
 static int scan_spec_blocks(const htm_handle *h) { return std::min(h->seg_hint / SCAN_SEGS, h->scan_blocks) & ~63; }
 
 // more segments than three rounds of resident blocks: the scan is bandwidth-bound (see k_tm_scan)
-static bool scan_pool_is_large(const htm_handle *h) { return h->seg_hint > 3 * 1536 * SCAN_SEGS; }
+static bool scan_pool_is_large(const htm_handle *h) {
+    static const int force = getenv("BITHTM_SCAN_LARGE") ? atoi(getenv("BITHTM_SCAN_LARGE")) : -1;      // tuning knob
+    if (force >= 0) return h->world == 1 && force != 0;
+    return h->world == 1 && h->seg_hint > 3 * 1536 * SCAN_SEGS;
+}
 
 static void launch_scan(htm_handle *h, int p, int use_lds) {
     Dev &d = h->d;
@@ -447,6 +451,7 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
         rc |= dalloc(h, &d.sperm, S * E);
         rc |= dalloc(h, &d.segcount, C * 32);
         rc |= dalloc(h, &d.cellmax, C * 32);
+        rc |= dalloc(h, &d.match_bits, (S + 63) / 64 * 2);
         rc |= dalloc(h, &d.seg_info, S);
         rc |= dalloc(h, &d.seg_jit, S);
         rc |= dalloc(h, &d.work, (size_t)d.work_cap);
@@ -791,9 +796,9 @@ extern "C" int htm_get_info(htm_handle *h, htm_info *out) {
     out->segments = c.S;
     out->matching_segments = 0;
     if (c.has_distal && c.S > 0) {
-        std::vector<uint32_t> info((size_t)c.S);
-        HIPCHK(h, hipMemcpy(info.data(), h->d.seg_info, info.size() * 4, hipMemcpyDeviceToHost));
-        for (uint32_t v : info) out->matching_segments += (v >> 30) & 1u;
+        std::vector<uint32_t> bits(((size_t)c.S + 31) / 32);
+        HIPCHK(h, hipMemcpy(bits.data(), h->d.match_bits, bits.size() * 4, hipMemcpyDeviceToHost));
+        for (int i = 0; i < c.S; ++i) out->matching_segments += (bits[(size_t)i >> 5] >> (i & 31)) & 1u;
     }
     out->winner_cells = c.n_win[q];
     out->active_cells = c.n_active_cells;
@@ -856,23 +861,36 @@ extern "C" int64_t htm_read(htm_handle *h, int32_t field, void *dst, int64_t cou
             // the device keeps one info word per segment; the matching-segment lists of
             // PredictiveProjection.State (ascending ids, projections.py:247) are its non-zero part
             if (!tm) { h->err = "htm_read: field not available on this handle"; return HTM_ERR_STATE; }
-            std::vector<uint32_t> info((size_t)S);
-            std::vector<float> jit((size_t)S);
-            if (S && (hipMemcpy(info.data(), d.seg_info, (size_t)S * 4, hipMemcpyDeviceToHost) != hipSuccess ||
-                      hipMemcpy(jit.data(), d.seg_jit, (size_t)S * 4, hipMemcpyDeviceToHost) != hipSuccess)) { h->err = "htm_read: hipMemcpy failed"; return HTM_ERR_HIP; }
-            if (!c.has_distal) std::fill(info.begin(), info.end(), 0u);
-            int64_t m = 0;
             if (field == HTM_F_SEG_POTENTIAL) {
+                // the device keeps the potential of matching segments only: recompute all of them from the
+                // last step's activation (same definition, projections.py:175-178 / :246)
                 if ((n = need(true, S)) < 0) return n;
-                for (int64_t i = 0; i < S; ++i) ((int *)dst)[i] = (int)(info[(size_t)i] & 0xFFFu);
+                if (S == 0) return 0;
+                if (!c.has_distal) { memset(dst, 0, (size_t)S * 4); return S; }
+                int *tmp = nullptr;
+                if (hipMalloc((void **)&tmp, (size_t)S * 4) != hipSuccess) { h->err = "htm_read: hipMalloc failed"; return HTM_ERR_HIP; }
+                hipLaunchKernelGGL(k_tm_potentials, dim3((unsigned)std::min<int64_t>((S * 8 + 255) / 256, 8192)), dim3(256), 0, h->stream, d, q, tmp);
+                const bool ok = hipStreamSynchronize(h->stream) == hipSuccess && hipMemcpy(dst, tmp, (size_t)S * 4, hipMemcpyDeviceToHost) == hipSuccess;
+                hipFree(tmp);
+                if (!ok) { h->err = "htm_read: potentials kernel failed"; return HTM_ERR_HIP; }
                 return S;
             }
-            for (int64_t i = 0; i < S; ++i) m += (info[(size_t)i] >> 30) & 1u;
+            // one bit per segment says whether it is matching; info word and jitter exist for those only.  The
+            // matching-segment lists of PredictiveProjection.State (ascending ids, projections.py:247):
+            std::vector<uint32_t> bits(((size_t)S + 31) / 32, 0u);
+            std::vector<uint32_t> info((size_t)S);
+            std::vector<float> jit((size_t)S);
+            if (S && c.has_distal && (hipMemcpy(bits.data(), d.match_bits, bits.size() * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+                                      hipMemcpy(info.data(), d.seg_info, (size_t)S * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+                                      hipMemcpy(jit.data(), d.seg_jit, (size_t)S * 4, hipMemcpyDeviceToHost) != hipSuccess)) { h->err = "htm_read: hipMemcpy failed"; return HTM_ERR_HIP; }
+            auto is_matching = [&](int64_t i) { return (bits[(size_t)i >> 5] >> (i & 31)) & 1u; };
+            int64_t m = 0;
+            for (int64_t i = 0; i < S; ++i) m += is_matching(i);
             if ((n = need(true, m)) < 0) return n;
             m = 0;
             for (int64_t i = 0; i < S; ++i) {
+                if (!is_matching(i)) continue;
                 const uint32_t v = info[(size_t)i];
-                if (!((v >> 30) & 1u)) continue;
                 if (field == HTM_F_MATCH_SEGMENT) ((int *)dst)[m] = (int)i;
                 else if (field == HTM_F_MATCH_INFO) ((uint32_t *)dst)[m] = v & ~0x40000000u;
                 else ((float *)dst)[m] = jit[(size_t)i];
@@ -998,27 +1016,24 @@ extern "C" int htm_import_commit(htm_handle *h, int32_t segments, int32_t matchi
             h->err = "htm_import_commit: SEG_POTENTIAL / MATCH_* fields missing or of the wrong length";
             return HTM_ERR_ARGUMENT;
         }
-        std::vector<uint32_t> info((size_t)segments, 0u);
+        std::vector<uint32_t> info((size_t)segments, 0u), bits((size_t)(d.Scap + 63) / 64 * 2, 0u);
         std::vector<float> jit((size_t)segments, 0.f);
         if (has_distal_state) {
-            for (size_t i = 0; i < (size_t)segments; ++i) info[i] = (uint32_t)h->imp_pot[i] & 0xFFFu;
             for (size_t i = 0; i < M; ++i) {
                 const int sgm = h->imp_match_seg[i];
                 if (sgm < 0 || sgm >= segments) { h->err = "htm_import_commit: matching segment id out of range"; return HTM_ERR_ARGUMENT; }
                 info[(size_t)sgm] = (h->imp_match_info[i] & ~0x40000000u) | 0x40000000u;
                 jit[(size_t)sgm] = h->imp_match_jit[i];
+                bits[(size_t)sgm >> 5] |= 1u << (sgm & 31);
             }
         }
         if (segments) {
             HIPCHK(h, hipMemcpy(d.seg_info, info.data(), info.size() * 4, hipMemcpyHostToDevice));
             HIPCHK(h, hipMemcpy(d.seg_jit, jit.data(), jit.size() * 4, hipMemcpyHostToDevice));
         }
-        // the import is the one place where the segment count can shrink (rollback to an earlier checkpoint):
-        // ids at or above it must read "no info" again, as the classification and the binding assume
-        if (segments < d.Scap) {
-            HIPCHK(h, hipMemset(d.seg_info + segments, 0, (size_t)(d.Scap - segments) * 4));
-            HIPCHK(h, hipMemset(d.seg_jit + segments, 0, (size_t)(d.Scap - segments) * 4));
-        }
+        // all of the bitmap: the import is the one place where the segment count can shrink (rollback to an
+        // earlier checkpoint), and ids at or above it must read "not matching", as the classification assumes
+        HIPCHK(h, hipMemcpy(d.match_bits, bits.data(), bits.size() * 4, hipMemcpyHostToDevice));
         h->imp_pot.clear(); h->imp_match_seg.clear(); h->imp_match_info.clear(); h->imp_match_jit.clear();
     }
     c.n_win[q] = winner_cells;

@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256, MINW) void k_scan_sel(Dev d, int p, int n_sel_
         return;
     }
     b -= n_clear_blocks;
-    role_scan<256, use_lds>(d, p, b, gridDim.x - n_sel_blocks - n_clear_blocks, n_spec, (uint32_t *)dyn_lds);
+    role_scan<256, use_lds, MINW == 1>(d, p, b, gridDim.x - n_sel_blocks - n_clear_blocks, n_spec, (uint32_t *)dyn_lds);
 }
 
 #endif

@@ -42,12 +42,18 @@ __device__ __forceinline__ void tm_bind_segment(const Dev &d, int seg, int cell,
         if (col_is_local(d, old)) atomicSub(&d.segcount[old], 1);
     }
     d.seg_cell[seg] = cell;
+    // recyclable count of the id's 1024-block: a recycled id was counted and still is (its row is empty until the
+    // learning role has grown it, which then takes it off the count); a fresh id enters as an empty row.  A rank
+    // that does not own the cell only ever learns the size the row will have after that growth.
     if (col_is_local(d, cell)) {
+        if (!recycled) atomicAdd(&d.recyc_cnt[seg >> 10], 1);
         d.seg_nsyn[seg] = 0;
         atomicAdd(&d.segcount[cell], 1);
         if (pos < 0) pos = atomicAdd(&d.ctr->n_work, 1);
         if (pos < d.work_cap) d.work[pos] = (uint32_t)seg; else atomicOr(&d.ctr->error, 4);
     } else {
+        if (recycled && grown >= d.match_thr) atomicSub(&d.recyc_cnt[seg >> 10], 1);
+        if (!recycled && grown < d.match_thr) atomicAdd(&d.recyc_cnt[seg >> 10], 1);
         d.seg_nsyn[seg] = grown;
     }
 }
@@ -115,9 +121,11 @@ __device__ __forceinline__ void role_mid(const Dev &d, int p, int n_active, int 
         for (int i0 = (blk - 1) * BS; i0 < n; i0 += stride) {
             const int seg = i0 + threadIdx.x;
             bool learn = false, punish = false;
-            const uint32_t info = seg < n ? d.seg_info[seg] : 0u;
-            const int cell = seg < n ? d.seg_cell[seg] : 0;         // fetched with the info word, not after it
-            if (info & 0x40000000u) {
+            // the scan leaves one bit per segment (matching or not) and an info word for the matching ones only
+            const bool was_matching = seg < n && ((d.match_bits[seg >> 5] >> (seg & 31)) & 1u);
+            const uint32_t info = was_matching ? d.seg_info[seg] : 0u;
+            const int cell = was_matching ? d.seg_cell[seg] : 0;     // fetched with the info word, not after it
+            if (was_matching) {
                 const int col = cell >> 5, bit = cell & 31;
                 const bool is_winner = (d.win[p][col] >> bit) & 1u;
                 const bool unpred = !((d.pred[q][col] >> bit) & 1u);                         // :266
@@ -301,9 +309,7 @@ __device__ __forceinline__ void role_learn(const Dev &d, int p, int blk, int nbl
         // launch) and reset what the coming scan accumulates
         const int n = c->has_distal ? c->S : 0;
         for (int i = blk * BS + threadIdx.x; i < n; i += nblk * BS)
-            if (d.seg_info[i] & 0x40000000u) d.cellmax[d.seg_cell[i]] = 0u;
-        const int nb = (c->S + 1023) >> 10;
-        for (int i = blk * BS + threadIdx.x; i < nb; i += nblk * BS) d.recyc_cnt[i] = 0;
+            if ((d.match_bits[i >> 5] >> (i & 31)) & 1u) d.cellmax[d.seg_cell[i]] = 0u;
     }
     const int wv = threadIdx.x >> 6, lane = lane_id();
     const int n_front = min(c->n_work, d.work_cap), n_back = c->n_bind;
@@ -484,7 +490,10 @@ __device__ __forceinline__ void role_learn(const Dev &d, int p, int blk, int nbl
         }
         if (lane == 0) {
             d.seg_nsyn[seg] = n_total;
-            if (d.world > 1 && n >= d.match_thr && n_total < d.match_thr) {       // tell the other ranks
+            // recyclable segments (fewer synapses than the matching threshold, projections.py:80) per 1024 ids
+            const bool was_dead = n < d.match_thr, is_dead = n_total < d.match_thr;
+            if (was_dead != is_dead) atomicAdd(&d.recyc_cnt[seg >> 10], is_dead ? 1 : -1);
+            if (d.world > 1 && !was_dead && is_dead) {                            // tell the other ranks
                 const int slot = atomicAdd(&d.dead_list[0], 1);
                 if (slot < DEAD_CAP) d.dead_list[1 + slot] = seg; else atomicOr(&c->error, 8);
             }
@@ -504,21 +513,34 @@ __global__ __launch_bounds__(RB) void k_tm_learn(Dev d, int p) {
     role_learn<EPL, RB>(d, p, blockIdx.x, gridDim.x, (LearnShared<EPL, RB> *)dyn_lds);
 }
 
-// PredictiveProjection.process (projections.py:245-255): per segment, potential = active
-// presynaptic cells; matching segments additionally count connected active synapses;
-// per-cell prediction and max jittered potential (:229-239).  8 lanes per segment, 16-byte
-// loads of the packed row, two segments in flight per lane group; a block owns SCAN_SEGS
-// consecutive segment ids and also counts the recyclable ones among them (per 1024 ids) for the
-// next step's add_output.  The last duty of a timestep: publish the next step index.
-// use_lds: the bitmap of active columns is staged in LDS and consulted first, so that only the
-// ~2 % of synapses whose presynaptic column is active touch the per-column cell words in L2.
-// Branch-free: lanes whose column is inactive read act[0] instead (one shared cache line), so all
-// LDS reads and then all global reads of a lane can be in flight together.
-// use_lds: the bitmap of active columns is consulted in LDS first; only the ~2 % of synapses whose
-// presynaptic column is active then read that column's cell word (lanes of inactive columns read
-// act[0], one shared cache line, so the access stays branch-free).  Measured alternatives: a
-// global gather for every synapse moves 64 B per bit; an LDS-only lookup (bitmap + prefix counts +
-// active words) costs three bank-conflicted LDS reads per synapse and was 1.6x slower.
+// PredictiveProjection.process (projections.py:245-255): per segment, potential = active presynaptic cells;
+// matching segments additionally count connected active synapses; per-cell prediction and max jittered
+// potential (:229-239).  The last duty of a timestep: publish the next step index.
+//
+// Shape: 8 lanes per segment, 16-byte loads of the packed row (one 128-byte chunk = 32 synapse slots; growth tops
+// a segment up to 32 active synapses, so rows rarely exceed one chunk), two segments in flight per lane group.
+// A wave owns 16 consecutive segment ids per iteration, a 256-thread block 64; nothing is shared between the
+// waves of a block after the bitmap of active columns has been staged in LDS, so the loop has no barrier.
+//
+// Per synapse the scan does as little as it can: the column bit is looked up in LDS and packed into an 8-bit hit
+// mask per lane (two shifts, an and, one LDS read, a bit-field extract, a shift-or).  About 2 % of the synapses
+// hit an active column; only those go on to read that column's cell word, in a loop that handles one hit per lane
+// and pass -- one or two passes per wave instead of one guarded gather per slot -- and accumulates the potential
+// and, from the connected flag kept in the id's top bit (`permanence >= threshold`, maintained by the learning
+// role where permanences change: no permanence loads, no bit arrays), the connected-active count.
+//
+// Per segment the scan leaves ONE BIT (matching or not: d.match_bits, 16 bits per wave and iteration) and, for the
+// few matching segments only, the info word and the jittered potential: a result word per segment cost 15-20 % of
+// the stream on large pools.  The potentials of the other segments (PredictiveProjection.State.segment_potential,
+// projections.py:246) are recomputed when somebody reads them (k_tm_potentials).  Recyclable segments are not
+// counted here: the counts per 1024 ids are kept up to date where a row changes (role_learn, tm_bind_segment).
+// LARGE: pools that are bandwidth-bound: the owner cell is fetched for matching segments only (small pools are
+// latency-bound and fetch it with the synapse count, a dependent round trip earlier).
+//
+// Measured alternatives: a global gather for every synapse moves 64 B per bit; an LDS-only lookup (bitmap +
+// prefix counts + active words) costs three bank-conflicted LDS reads per synapse and was 1.6x slower; one
+// guarded cell-word gather per slot (sixteen per wave and iteration, most of them for a single lane) left the
+// kernel issue-bound at ~400 vector instructions per wave and iteration.
 struct ScanLds { const uint32_t *colbits; };
 __device__ __forceinline__ uint32_t scan_cell_active(const uint32_t *act, const ScanLds &L, int enc, bool valid, bool use_lds) {
     const int col = enc >> 5;
@@ -529,12 +551,84 @@ __device__ __forceinline__ uint32_t scan_cell_active(const uint32_t *act, const 
     return maybe & (aw >> (enc & 31));
 }
 
-// LDS: word 0 = recyclable counter; from word 4: column bitmap [colwords]
-template <int BS, bool use_lds>
+// One 128-byte chunk of two rows, 8 slots per lane: e[u * 4 + qq] = slot `first + l * 4 + qq` of row u, of which
+// row u has n[u] valid ones.  chunk_issue builds the lane's hit mask and issues the cell-word reads of its first
+// two hits (lanes without a hit read act[0], one shared line: no branch, so the reads of several chunks and the
+// row loads of the next iteration can all be in flight before anything is waited for); chunk_finish adds
+// potential | connected-active << 16  of the lane's slots to acc[u] and loops over third and later hits (rare).
+struct ChunkHits { uint32_t m_rest, e1, e2, aw1, aw2; int j1, j2; };
+
+__device__ __forceinline__ uint32_t select8(const uint32_t (&e)[8], int j) {
+    const uint32_t t0 = (j & 1) ? e[1] : e[0], t1 = (j & 1) ? e[3] : e[2], t2 = (j & 1) ? e[5] : e[4], t3 = (j & 1) ? e[7] : e[6];
+    const uint32_t u0 = (j & 2) ? t1 : t0, u1 = (j & 2) ? t3 : t2;
+    return (j & 4) ? u1 : u0;
+}
+
+template <bool use_lds>
+__device__ __forceinline__ ChunkHits chunk_issue(const uint32_t *__restrict__ act, const uint32_t *s_colbits, const uint32_t (&e)[8],
+                                                 int first, int l, const int (&n)[2]) {
+    uint32_t m = 0;                                  // bit i: slot i of this lane is valid and its column is active
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        uint32_t on = 1u;
+        if (use_lds) {
+            const uint32_t w = s_colbits[(e[i] & SYN_CELL) >> 10];
+            on = (w >> ((e[i] >> 5) & 31)) & 1u;
+        }
+        m |= on << i;
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {                    // rows are packed: slots [0, n) are the valid ones
+        const int nv = min(max(n[u] - first - l * 4, 0), 4);
+        m &= ~(((0xFu << nv) & 0xFu) << (4 * u));
+    }
+    ChunkHits h;
+    h.j1 = __ffs(m) - 1;                             // (-1 in lanes without a hit)
+    const uint32_t m1 = m & (m - 1);
+    h.j2 = __ffs(m1) - 1;
+    h.m_rest = m1 & (m1 - 1);
+    h.e1 = m ? select8(e, h.j1) : 0u;                // (id 0: column 0's word, bit 0 -- masked in chunk_finish)
+    h.e2 = m1 ? select8(e, h.j2) : 0u;
+    h.aw1 = act[(h.e1 & SYN_CELL) >> 5];
+    h.aw2 = act[(h.e2 & SYN_CELL) >> 5];
+    return h;
+}
+
+__device__ __forceinline__ void chunk_finish(const uint32_t *__restrict__ act, const uint32_t (&e)[8], const ChunkHits &h, uint32_t (&acc)[2]) {
+    {
+        const uint32_t a = h.j1 >= 0 ? (h.aw1 >> (h.e1 & 31)) & 1u : 0u;
+        const uint32_t add = a + ((a & (h.e1 >> 31)) << 16);
+        acc[0] += (h.j1 & 4) ? 0u : add;
+        acc[1] += (h.j1 & 4) ? add : 0u;
+    }
+    {
+        const uint32_t a = h.j2 >= 0 ? (h.aw2 >> (h.e2 & 31)) & 1u : 0u;
+        const uint32_t add = a + ((a & (h.e2 >> 31)) << 16);
+        acc[0] += (h.j2 & 4) ? 0u : add;
+        acc[1] += (h.j2 & 4) ? add : 0u;
+    }
+    uint32_t m = h.m_rest;
+    while (__any(m != 0)) {                          // a third hit among a lane's eight slots: one per pass
+        const int j = __ffs(m) - 1;
+        const uint32_t ej = select8(e, j);
+        uint32_t aw = 0;
+        if (m) aw = act[(ej & SYN_CELL) >> 5];
+        const uint32_t a = (aw >> (ej & 31)) & 1u;   // (aw = 0 without a hit)
+        const uint32_t add = a + ((a & (ej >> 31)) << 16);
+        acc[0] += (j & 4) ? 0u : add;
+        acc[1] += (j & 4) ? add : 0u;
+        m &= m - 1;
+    }
+}
+
+// LDS: from word 4: column bitmap [colwords] (words 0..3 unused)
+template <int BS, bool use_lds, bool LARGE>
 __device__ __forceinline__ void role_scan(const Dev &d, int p, int blk, int nblk, int n_spec, uint32_t *lds) {
-    constexpr int SEGS = BS / 4;                   // segments per block iteration: BS/8 lane groups x 2 in flight
-    int &s_recyc = *(int *)lds;
+    static_assert(BS == 256, "four waves of 16 segments");
+    constexpr int SEGS = 64;                       // segments per block iteration
+    constexpr int U = 2;                           // segments in flight per lane group
     uint32_t *s_colbits = lds + 4;
+    constexpr bool need_cell = !LARGE;             // (column-sharded handles filter by owner cell: never LARGE)
     const ScanLds L{s_colbits};
     Counters *c = d.ctr;
     const int S = c->S;
@@ -547,123 +641,67 @@ __device__ __forceinline__ void role_scan(const Dev &d, int p, int blk, int nblk
     }
     const uint32_t *act = d.act[p];
     const uint32_t base3 = htm_stream_base(d.seed, HTM_STREAM_SEGMENT_JITTER, c->step[p]);
-    // 8 lanes per segment, 16 bytes per lane: one 128-byte chunk = 32 synapse slots.  Packed rows
-    // rarely exceed one chunk (growth tops a segment up to 32 active synapses), so a typical row
-    // costs exactly 128 bytes of presynaptic ids.
-    const int g = threadIdx.x >> 3, l = threadIdx.x & 7;
-    constexpr int NG = BS / 8;                     // lane groups per block
-    constexpr int U = SEGS / NG;                   // segments in flight per lane group
-    bool staged = false;
+    const int wave = threadIdx.x >> 6, gi = (threadIdx.x & 63) >> 3, l = threadIdx.x & 7;
+    // round trip 1 of an iteration: synapse count, owner cell and the first chunk of each row, all unconditional
+    // (ids are clamped to the pool; rows of other ranks' segments exist in the replicated address space; both
+    // are masked once the segment count is known)
+    struct Batch { int seg[U], n[U], cell[U]; int4 ps[U]; };
+    auto fetch = [&](int b) {
+        Batch t;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            t.seg[u] = min(b * SEGS + wave * 16 + u * 8 + gi, d.Scap - 1);
+            t.n[u] = d.seg_nsyn[t.seg[u]];
+            t.cell[u] = need_cell ? d.seg_cell[t.seg[u]] : 0;
+            t.ps[u] = *(const int4 *)(d.presyn + (size_t)t.seg[u] * d.E + l * 4);
+        }
+        return t;
+    };
     // In the first n_spec blocks (the ones that had segments when the host last saw the segment count)
-    // the loads of the first batch do not wait for the count: rows up to the pool's capacity exist, so they
-    // are fetched for ids clamped to it and masked once S has arrived: one dependent round trip less.
-    for (int b = blk;; b += nblk) {
-        const bool speculative = b == blk && blk < n_spec;
-        if (!speculative && b * SEGS >= S) break;
-        int seg[U], n[U], pot[U], conn[U], n_true[U], cellu[U];
-        int4 ps[U], ps2[U];
+    // the loads of the first batch do not wait for the count: one dependent round trip less.
+    const bool speculative = blk < n_spec;
+    if (!speculative && blk * SEGS >= S) return;
+    Batch cur = fetch(blk);
+    if (use_lds)                                     // the bitmap staging overlaps with those loads
+        for (int i = threadIdx.x; i < d.colwords; i += BS) s_colbits[i] = d.colbits[p][i];
+    __syncthreads();                                 // the only barrier: from here on the waves share nothing
+    for (int b = blk; b * SEGS < S; b += nblk) {
+        int seg[U], n[U];
         bool mine[U];
-        // round trip 1: synapse count, owner cell and the first chunk of each row, all unconditional
-        // (rows of other ranks' segments exist in the replicated address space; they are masked below)
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            seg[u] = min(b * SEGS + u * NG + g, d.Scap - 1);
-            n[u] = d.seg_nsyn[seg[u]];
-            cellu[u] = d.seg_cell[seg[u]];
-            ps[u] = *(const int4 *)(d.presyn + (size_t)seg[u] * d.E + l * 4);
-        }
-        if (!staged) {                               // the bitmap staging overlaps with those loads
-            if (use_lds)
-                for (int i = threadIdx.x; i < d.colwords; i += BS) s_colbits[i] = d.colbits[p][i];
-            staged = true;
-        }
-        if (threadIdx.x == 0) s_recyc = 0;
-        __syncthreads();
-        if (speculative && b * SEGS >= S) break;     // (uniform in the block)
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const bool ok = b * SEGS + u * NG + g < S;
-            mine[u] = d.world == 1 || col_is_local(d, cellu[u]);
-            n_true[u] = ok ? n[u] : 0x7FFFFFFF;      // for the recyclable count (all ranks, all segments)
-            if (!ok || !mine[u]) n[u] = 0;
-            seg[u] = ok ? seg[u] : S;
+            const bool ok = b * SEGS + wave * 16 + u * 8 + gi < S;
+            mine[u] = d.world == 1 || col_is_local(d, cur.cell[u]);
+            n[u] = (ok && mine[u]) ? cur.n[u] : 0;
+            seg[u] = ok ? cur.seg[u] : S;
         }
         // round trip 2 (only rows longer than one chunk): second chunk, in flight during the lookups of the first
+        int4 ps2[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             ps2[u] = make_int4(0, 0, 0, 0);
             if (n[u] > 32) ps2[u] = *(const int4 *)(d.presyn + (size_t)seg[u] * d.E + 32 + l * 4);
         }
-        // chunk 1: all LDS lookups, then all cell-word reads, each as one batch.  An active synapse counts
-        // towards the potential (:247); if its id carries the connected flag, also towards the activation
-        // (:171-172: `permanence >= threshold`, maintained by the learning role where permanences change).
-        int pl[U], cl[U];                            // this lane's share of potential / connected-active count
-        {
-            uint32_t e[U][4];
-            uint32_t on[U][4], aw[U][4];
-#pragma unroll
-            for (int u = 0; u < U; ++u) { e[u][0] = (uint32_t)ps[u].x; e[u][1] = (uint32_t)ps[u].y; e[u][2] = (uint32_t)ps[u].z; e[u][3] = (uint32_t)ps[u].w; }
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-#pragma unroll
-                for (int qq = 0; qq < 4; ++qq) {
-                    const uint32_t col = (e[u][qq] & SYN_CELL) >> 5;
-                    on[u][qq] = use_lds ? (s_colbits[col >> 5] >> (col & 31)) & 1u : 1u;
-                }
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-#pragma unroll
-                for (int qq = 0; qq < 4; ++qq) {
-                    if (l * 4 + qq >= n[u]) on[u][qq] = 0;
-                    aw[u][qq] = 0;                   // a lookup no lane of the wave needs is not issued at all
-                    if (__any(on[u][qq])) aw[u][qq] = act[on[u][qq] ? (e[u][qq] & SYN_CELL) >> 5 : 0];     // inactive columns: one shared line
-                }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                int p1 = 0, c1 = 0;
-#pragma unroll
-                for (int qq = 0; qq < 4; ++qq) {
-                    const uint32_t a = on[u][qq] & (aw[u][qq] >> (e[u][qq] & 31));
-                    p1 += (int)a;
-                    c1 += (int)(a & (e[u][qq] >> 31));
-                }
-                pl[u] = p1;
-                cl[u] = c1;
-            }
+        uint32_t acc[U] = {0u, 0u};                  // this lane's share of potential (:247) | connected-active count << 16 (:171-172)
+        const uint32_t e1[8] = {(uint32_t)cur.ps[0].x, (uint32_t)cur.ps[0].y, (uint32_t)cur.ps[0].z, (uint32_t)cur.ps[0].w,
+                                (uint32_t)cur.ps[1].x, (uint32_t)cur.ps[1].y, (uint32_t)cur.ps[1].z, (uint32_t)cur.ps[1].w};
+        const ChunkHits h1 = chunk_issue<use_lds>(act, s_colbits, e1, 0, l, n);
+        // large pools: the next iteration's rows are requested now, behind this iteration's cell-word reads (loads
+        // return in issue order: requested earlier they would be waited for with those reads)
+        const int b_next = b + nblk;
+        const int cell_cur[U] = {cur.cell[0], cur.cell[1]};
+        // (unconditional -- past the last batch the clamped ids fetch a row nobody uses: a branch around the loads
+        // would make the compiler wait for them with everything else)
+        Batch nxt = cur;
+        if (LARGE) nxt = fetch(b_next);
+        chunk_finish(act, e1, h1, acc);
+        if (__any(n[0] > 32 || n[1] > 32)) {         // (skipped by waves in which no row is that long)
+            const uint32_t e2[8] = {(uint32_t)ps2[0].x, (uint32_t)ps2[0].y, (uint32_t)ps2[0].z, (uint32_t)ps2[0].w,
+                                    (uint32_t)ps2[1].x, (uint32_t)ps2[1].y, (uint32_t)ps2[1].z, (uint32_t)ps2[1].w};
+            const ChunkHits h2 = chunk_issue<use_lds>(act, s_colbits, e2, 32, l, n);
+            chunk_finish(act, e2, h2, acc);
         }
-        // chunk 2, same shape (skipped by waves in which no row is that long)
-        bool any_long = false;
-#pragma unroll
-        for (int u = 0; u < U; ++u) any_long |= n[u] > 32;
-        if (__any(any_long)) {
-            uint32_t e[U][4];
-            uint32_t on[U][4], aw[U][4];
-#pragma unroll
-            for (int u = 0; u < U; ++u) { e[u][0] = (uint32_t)ps2[u].x; e[u][1] = (uint32_t)ps2[u].y; e[u][2] = (uint32_t)ps2[u].z; e[u][3] = (uint32_t)ps2[u].w; }
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-#pragma unroll
-                for (int qq = 0; qq < 4; ++qq) {
-                    const uint32_t col = (e[u][qq] & SYN_CELL) >> 5;
-                    on[u][qq] = use_lds ? (s_colbits[col >> 5] >> (col & 31)) & 1u : 1u;
-                }
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-#pragma unroll
-                for (int qq = 0; qq < 4; ++qq) {
-                    if (32 + l * 4 + qq >= n[u]) on[u][qq] = 0;
-                    aw[u][qq] = 0;
-                    if (__any(on[u][qq])) aw[u][qq] = act[on[u][qq] ? (e[u][qq] & SYN_CELL) >> 5 : 0];
-                }
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-#pragma unroll
-                for (int qq = 0; qq < 4; ++qq) {
-                    const uint32_t a = on[u][qq] & (aw[u][qq] >> (e[u][qq] & 31));
-                    pl[u] += (int)a;
-                    cl[u] += (int)(a & (e[u][qq] >> 31));
-                }
-        }
+        bool matching[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (n[u] > 64) {                         // rare: rows longer than two chunks
@@ -674,40 +712,32 @@ __device__ __forceinline__ void role_scan(const Dev &d, int p, int blk, int nblk
 #pragma unroll
                     for (int qq = 0; qq < 4; ++qq) {
                         const uint32_t a = scan_cell_active(act, L, (int)(e[qq] & SYN_CELL), i + qq < n[u], use_lds);
-                        pl[u] += (int)a;
-                        cl[u] += (int)(a & (e[qq] >> 31));
+                        acc[u] += a + ((a & (e[qq] >> 31)) << 16);
                     }
                 }
             }
-            pot[u] = group8_sum_first(pl[u]);        // (used by the segment's first lane only)
-            conn[u] = group8_sum_first(cl[u]);
-        }
-        {                                            // recyclable rows: one LDS atomic per wave (same-address atomics serialise)
-            int n_recyc = 0;
-#pragma unroll
-            for (int u = 0; u < U; ++u) n_recyc += __popcll(__ballot(l == 0 && seg[u] < S && n_true[u] < d.match_thr));
-            if (lane_id() == 0 && n_recyc) atomicAdd(&s_recyc, n_recyc);
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (l == 0 && seg[u] < S) {
-                if (!mine[u]) continue;
-                const bool matching = pot[u] >= d.match_thr;
-                uint32_t info = (uint32_t)pot[u];
-                if (matching) {
-                    const bool active = conn[u] >= d.act_thr;                         // :250
-                    const int cell = cellu[u];
-                    const float jit = htm_jitter((float)pot[u], htm_draw24(base3, (uint32_t)seg[u], 0u));   // :234-235
-                    atomicMax(&d.cellmax[cell], __float_as_uint(jit));               // :237
-                    if (active) atomicOr(&d.pred[p][cell >> 5], 1u << (cell & 31));   // :251, networks.py:122
-                    info |= ((uint32_t)conn[u] << 12) | 0x40000000u | (active ? 0x80000000u : 0u);
-                    d.seg_jit[seg[u]] = jit;
-                }
-                d.seg_info[seg[u]] = info;
+            const uint32_t sum = (uint32_t)group8_sum_first((int)acc[u]);     // (valid in the segment's first lane only)
+            const int pot = (int)(sum & 0xFFFFu), conn = (int)(sum >> 16);
+            matching[u] = l == 0 && seg[u] < S && mine[u] && pot >= d.match_thr;      // :247
+            if (matching[u]) {
+                const bool active = conn >= d.act_thr;                                // :250
+                const int cell = need_cell ? cell_cur[u] : d.seg_cell[seg[u]];
+                const float jit = htm_jitter((float)pot, htm_draw24(base3, (uint32_t)seg[u], 0u));   // :234-235
+                atomicMax(&d.cellmax[cell], __float_as_uint(jit));                   // :237
+                if (active) atomicOr(&d.pred[p][cell >> 5], 1u << (cell & 31));       // :251, networks.py:122
+                d.seg_info[seg[u]] = (uint32_t)pot | ((uint32_t)conn << 12) | 0x40000000u | (active ? 0x80000000u : 0u);
+                d.seg_jit[seg[u]] = jit;
             }
         }
-        __syncthreads();
-        if (threadIdx.x == 0 && s_recyc) atomicAdd(&d.recyc_cnt[(b * SEGS) >> 10], s_recyc);
+        {   // the wave's 16 match bits: the ballots hold one bit per lane group at lane 8 * gi; a multiplication
+            // gathers those eight bits into the top byte (all partial products fall on different bit positions)
+            const u64 m0 = __ballot(matching[0]), m1 = __ballot(matching[1]);
+            const uint32_t b0 = (uint32_t)(((m0 & 0x0101010101010101ull) * 0x0102040810204080ull) >> 56);
+            const uint32_t b1 = (uint32_t)(((m1 & 0x0101010101010101ull) * 0x0102040810204080ull) >> 56);
+            if ((threadIdx.x & 63) == 0) ((uint16_t *)d.match_bits)[b * 4 + wave] = (uint16_t)(b0 | (b1 << 8));
+        }
+        if (b_next * SEGS >= S) break;
+        cur = LARGE ? nxt : fetch(b_next);
     }
 }
 
@@ -718,7 +748,26 @@ __device__ __forceinline__ void role_scan(const Dev &d, int p, int blk, int nblk
 // workload); large pools are bandwidth-bound and run faster without the cap (MINW = 1).
 template <bool use_lds, int MINW>
 __global__ __launch_bounds__(256, MINW) void k_tm_scan(Dev d, int p, int n_spec) {
-    role_scan<256, use_lds>(d, p, blockIdx.x, gridDim.x, n_spec, (uint32_t *)dyn_lds);
+    role_scan<256, use_lds, MINW == 1>(d, p, blockIdx.x, gridDim.x, n_spec, (uint32_t *)dyn_lds);
+}
+
+// State.segment_potential (projections.py:246) for every segment, on demand: active presynaptic cells of the last
+// completed step (parity p), 8 lanes per segment.  Segments of other ranks read 0.
+__global__ __launch_bounds__(256) void k_tm_potentials(Dev d, int p, int *out) {
+    const int S = d.ctr->S;
+    const uint32_t *act = d.act[p];
+    const int l = threadIdx.x & 7;
+    for (int seg = (blockIdx.x * 256 + threadIdx.x) >> 3; seg < S; seg += (gridDim.x * 256) >> 3) {
+        const int n = (d.world == 1 || col_is_local(d, d.seg_cell[seg])) ? d.seg_nsyn[seg] : 0;
+        const int *prow = d.presyn + (size_t)seg * d.E;
+        int pot = 0;
+        for (int i = l; i < n; i += 8) {
+            const int e = prow[i] & SYN_CELL;
+            pot += (int)((act[e >> 5] >> (e & 31)) & 1u);
+        }
+        pot = group8_sum_first(pot);
+        if (l == 0) out[seg] = pot;
+    }
 }
 
 // after a state import: derive the connected flag of every valid synapse from its permanence
