@@ -6,7 +6,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libbithtm_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class HtmConfig(C.Structure):
@@ -22,7 +22,7 @@ class HtmConfig(C.Structure):
         ("tm_permanence_initial", C.c_float), ("tm_permanence_threshold", C.c_float),
         ("segment_activation_threshold", C.c_int32), ("segment_matching_threshold", C.c_int32),
         ("segment_sampling_synapses", C.c_int32),
-        ("segment_capacity", C.c_int32), ("segment_slots", C.c_int32),
+        ("segment_capacity", C.c_int32), ("segment_capacity_local", C.c_int32), ("segment_slots", C.c_int32),
         ("seed", C.c_uint32), ("shard_rank", C.c_int32), ("shard_world", C.c_int32), ("use_caller_stream", C.c_int32),
         ("stream", C.c_void_p),
     ]
@@ -30,7 +30,7 @@ class HtmConfig(C.Structure):
 
 class HtmInfo(C.Structure):
     _fields_ = [
-        ("step_index", C.c_int64), ("segments", C.c_int32), ("matching_segments", C.c_int32),
+        ("step_index", C.c_int64), ("segments", C.c_int32), ("local_segments", C.c_int32), ("matching_segments", C.c_int32),
         ("winner_cells", C.c_int32), ("active_cells", C.c_int32), ("has_distal_state", C.c_int32),
         ("has_winner_cells", C.c_int32), ("capacity_error", C.c_int32), ("words_per_row", C.c_int32),
         ("new_segment_requests", C.c_int32), ("recycled_segments", C.c_int32), ("appended_segments", C.c_int32),
@@ -42,6 +42,7 @@ class HtmInfo(C.Structure):
 F_ACTIVE_COLUMN, F_OVERLAPS, F_BOOSTED, F_DUTY_CYCLE, F_CELL_ACTIVATION, F_CELL_PREDICTION = 1, 2, 3, 4, 5, 6
 F_WINNER_WORDS, F_BURSTING, F_WINNER_CELL, F_SEG_CELL, F_SEG_NSYN, F_SEG_PRESYN, F_SEG_PERM = 7, 8, 9, 10, 11, 12, 13
 F_SEGCOUNT, F_SEG_POTENTIAL, F_MATCH_SEGMENT, F_MATCH_INFO, F_MATCH_JITTER, F_CELL_MAX_JITTER = 14, 15, 16, 17, 18, 19
+F_SEG_GID = 20
 
 EXPORTS = {
     "htm_abi_version": (C.c_int, []),
@@ -59,6 +60,10 @@ EXPORTS = {
     "htm_shard_record_bytes": (C.c_int64, [C.c_void_p]),
     "htm_shard_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
     "htm_shard_finish": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
+    "htm_shard_unique_id": (C.c_int, [C.c_void_p]),
+    "htm_shard_comm_init": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "htm_shard_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]),
+    "htm_populate": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_uint32]),
     "htm_sync": (C.c_int, [C.c_void_p]),
     "htm_get_info": (C.c_int, [C.c_void_p, C.POINTER(HtmInfo)]),
     "htm_read": (C.c_int64, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]),

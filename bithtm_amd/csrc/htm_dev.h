@@ -52,6 +52,8 @@ struct Counters {
     uint32_t emit_epoch;      // bumped by every overlap launch: tags the records k_sp_emit's blocks exchange
     int32_t n_un;             // winners needing a new segment
     int32_t n_recycled, n_new, S_old;
+    int32_t L;                // column-sharded handles: local rows in use are [0, L) (unsharded: local row = segment id, L = S)
+    int32_t n_lfree;          // ... and the stack of free local rows below L (rows whose segment was recycled by another rank)
     int32_t error;            // sticky capacity flags
     // Spatial Pooler select state, double-buffered by the parity of the step it belongs to (the
     // pipelined schedule computes step t+1's overlap / select digits while step t's TM runs)
@@ -64,6 +66,9 @@ struct Counters {
 struct Dev {
     int I, W, W4, Ipad, C, K, k, E, Scap, work_cap, sel_passes, colwords, low_zero, cand_d, cand_pairwise, cand_others;
     int world, c0, c1;        // this rank owns columns [c0, c1) (world == 1: everything)
+    int sel_lo, sel_hi, sel_k; // the select works on the keys of columns [sel_lo, sel_hi) and finds their sel_k largest
+                              // (unsharded: all columns, k; a shard selects its own candidates: [c0, c1), min(k, c1 - c0))
+    int Lcap, n_cand;         // sharded: local row capacity; candidates per rank in the exchange record = sel_k
     double sp_thr, sp_don, sp_doff;
     float coef, mom, dinc;
     double lrn_act, lrn_inact, pun_act, pun_inact;
@@ -108,10 +113,18 @@ struct Dev {
     uint32_t *work;           // [work_cap] segment | mode << 31 (0 = learn + grow, 1 = punish)
     int *recyc_cnt;           // [ceil(Scap/1024)] recyclable segments per 1024-segment block
     int *recyc_need;          // [2*k*32] (block, first rank) pairs of the blocks add_output draws from
-    // column sharding (world > 1): speculative per-column words of ALL columns after the exchange,
-    // and the ids of owned segments that fell below the matching threshold while learning
-    uint32_t *spec_act, *spec_win, *spec_unacc, *spec_burst;      // [C] [C] [C] [ceil(C/32)]
-    int *dead_list;           // [1 + DEAD_CAP]: count, ids
+    // Column sharding (world > 1).  Segment ids are global (they key the random draws and order the recycling, and
+    // must be what an unsharded run would assign), rows are local: a rank stores only the segments of its own
+    // cells, in local rows, and keeps for the whole id space only one bit per id (fewer synapses than the matching
+    // threshold: what the recycling rule of projections.py:80-81 looks at) and the row of the ids it owns.
+    int *seg_gid;             // [Lcap]  global id of a local row, -1 = free (null on unsharded handles: row == id)
+    int *g2l;                 // [Scap]  local row of an owned id, -1 otherwise
+    uint32_t *dead_bits;      // [Scap/32] replicated on every rank, changed only by identical decisions
+    int *lfree;               // [Lcap]  stack of free local rows
+    int *asg_gid;             // [k*32]  ids assigned to this step's new segment requests, in request order
+    int *cand_cols;           // [sel_k] own candidate columns of this step, ascending
+    int *dead_list;           // [1 + DEAD_CAP]: count, global ids of own segments that died while learning
+    unsigned char *send;      // this step's exchange record (set per call)
     Counters *ctr;
     unsigned long long *trace;    // [8][4096][2] BITHTM_TRACE=1: device clock at the start / end of every block of the
                                   // pipelined launches (slot = launch + 4 * step parity), else null

@@ -14,6 +14,7 @@
 
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
+#include <dlfcn.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -37,7 +38,10 @@
 // ------------------------------------------------------------------------------------------
 // host side
 
+struct ncclUniqueIdBytes { char internal[128]; };      // ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES), passed by value
+
 static thread_local std::string g_create_error;
+static int (*g_rccl_destroy)(void *) = nullptr;        // ncclCommDestroy once RCCL is loaded
 
 struct htm_handle {
     htm_config cfg;
@@ -53,6 +57,8 @@ struct htm_handle {
     const uint32_t *shard_bank;           // input of the step between htm_shard_begin and _finish
     int shard_n_inputs;
     bool shard_open;
+    void *rccl_comm;                      // ncclComm_t of htm_shard_comm_init (the exchange of htm_shard_step)
+    unsigned char *shard_send, *shard_recv;   // ... and its device buffers
     int G;                                // lanes per SP row
     int graph_steps;                      // steady-state steps per captured graph (BITHTM_GRAPH_STEPS)
     bool emit_fused, emit_fused_open;     // the emit grid is resident at once in k_sp_emit / in k_open_emit (refreshed per call)
@@ -60,7 +66,7 @@ struct htm_handle {
     int sel_passes_fused, sel_passes_full; // launched select digits with / without the in-kernel finish
     int seg_hint;                         // a lower bound of the segment count (see scan_spec_blocks)
     int *seg_pinned;                      // pinned word the end of each htm_run copies the count into
-    int sp_blocks, sel_blocks, c256_blocks, s1024_blocks, scan_blocks;
+    int sp_blocks, sel_blocks, c256_blocks, s1024_blocks, scan_blocks, cus;
     // graphs keyed by (parity, learning, bank, n_inputs)
     std::map<std::tuple<int, int, const void *, int>, hipGraphExec_t> graphs;
     // state import staging (htm_write of the MATCH_* / SEG_POTENTIAL fields, applied at commit)
@@ -176,13 +182,19 @@ static int scan_spec_blocks(const htm_handle *h) { return std::min(h->seg_hint /
 // more segments than three rounds of resident blocks: the scan is bandwidth-bound (see k_tm_scan)
 static bool scan_pool_is_large(const htm_handle *h) {
     static const int force = getenv("BITHTM_SCAN_LARGE") ? atoi(getenv("BITHTM_SCAN_LARGE")) : -1;      // tuning knob
-    if (force >= 0) return h->world == 1 && force != 0;
-    return h->world == 1 && h->seg_hint > 3 * 1536 * SCAN_SEGS;
+    if (force >= 0) return force != 0;
+    return h->seg_hint > 3 * 1536 * SCAN_SEGS;
 }
 
 static void launch_scan(htm_handle *h, int p, int use_lds) {
     Dev &d = h->d;
     const int spec = scan_spec_blocks(h);
+    if (scan_pool_is_large(h) && use_lds && scan_lds(d, 1) > 16 * 1024) {
+        // a big column bitmap (32 KB at 262 144 columns): one copy per 1024-thread block, two blocks per CU
+        const int blocks = std::max(1, std::min((d.Lcap + 255) / 256, 2 * h->cus));
+        LAUNCH_ON(h, h->stream, scan_lds(d, 1), "tm_scan", (k_tm_scan_wide<true>), blocks, 1024, d, p, 0);
+        return;
+    }
     if (scan_pool_is_large(h)) {
         if (use_lds) LAUNCH_ON(h, h->stream, scan_lds(d, 1), "tm_scan", (k_tm_scan<true, 1>), h->scan_blocks, 256, d, p, spec);
         else LAUNCH_ON(h, h->stream, scan_lds(d, 0), "tm_scan", (k_tm_scan<false, 1>), h->scan_blocks, 256, d, p, spec);
@@ -220,7 +232,8 @@ static void enqueue_tm(htm_handle *h, int n_active, int learning, int want_winne
     Dev &d = h->d;
     const int n_cls = learning ? kClassifyBlocks : 0;
     const int n_sp_rows = (sp_rows && learning && h->cfg.enable_sp) ? d.k : 0;
-    LAUNCH(h, "tm_mid", k_mid_rows, 1 + n_cls + n_sp_rows, 256, d, p, n_active, want_winner, learning, n_cls, bank, n_inputs, n_sp_rows, 0, 0);
+    const int n_duty = h->world > 1 ? (d.c1 - d.c0 + 255) / 256 : 0;      // (unsharded: the emit role updates the duty cycle)
+    LAUNCH(h, "tm_mid", k_mid_rows, 1 + n_cls + n_sp_rows + n_duty, 256, d, p, n_active, want_winner, learning, n_cls, bank, n_inputs, n_sp_rows, 0, n_duty);
     launch_learn(h, p);
     launch_scan(h, p, scan_lds(d, 1) <= 64 * 1024);
 }
@@ -322,6 +335,7 @@ extern "C" void htm_destroy(htm_handle *h) {
     for (auto &v : h->prof_events)
         for (auto &pr : v) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     for (hipEvent_t e : h->prof_all) hipEventDestroy(e);
+    if (h->rccl_comm && g_rccl_destroy) g_rccl_destroy(h->rccl_comm);
     for (void *p : h->allocs) hipFree(p);
     if (h->seg_pinned) hipHostFree(h->seg_pinned);
     if (h->own_stream) hipStreamDestroy(h->stream);
@@ -371,6 +385,8 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
     h->shard_bank = nullptr;
     h->shard_n_inputs = 1;
     h->shard_open = false;
+    h->rccl_comm = nullptr;
+    h->shard_send = h->shard_recv = nullptr;
     hipError_t e = hipSetDevice(cfg->device);
     if (e != hipSuccess) return fail_create(h, std::string("hipSetDevice: ") + hipGetErrorString(e), HTM_ERR_HIP);
     if (cfg->use_caller_stream) {
@@ -395,7 +411,15 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
     d.k = cfg->active_columns;
     d.E = cfg->enable_tm ? cfg->segment_slots : 64;
     d.Scap = cfg->enable_tm ? cfg->segment_capacity : 0;
-    d.work_cap = d.Scap + d.k * 32;
+    d.Lcap = d.Scap;
+    if (world > 1) {
+        const long long dflt = std::min<long long>(d.Scap, 2LL * d.Scap / world + 1024);
+        d.Lcap = cfg->segment_capacity_local > 0 ? std::min(cfg->segment_capacity_local, cfg->segment_capacity) : (int)dflt;
+    }
+    d.work_cap = d.Lcap + d.k * 32;
+    // the select: all columns and their k largest; a shard selects its own candidates for the exchange
+    d.sel_lo = d.c0; d.sel_hi = d.c1;
+    d.sel_k = d.n_cand = std::min(d.k, d.c1 - d.c0);
     d.sp_thr = cfg->sp_permanence_threshold; d.sp_don = cfg->sp_delta_on; d.sp_doff = cfg->sp_delta_off;
     d.coef = cfg->boost_coefficient; d.mom = cfg->duty_momentum; d.dinc = cfg->duty_increment;
     d.lrn_act = cfg->tm_learn_active; d.lrn_inact = cfg->tm_learn_inactive;
@@ -427,7 +451,7 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
         rc |= dalloc(h, &d.input_stage, (size_t)d.W);
     }
     if (cfg->enable_tm) {
-        const size_t S = d.Scap, E = d.E;
+        const size_t S = d.Lcap, E = d.E, G = d.Scap;        // local rows (= ids on an unsharded handle), slots, segment ids
         for (int q = 0; q < 2; ++q) {
             rc |= dalloc(h, &d.act[q], C);
             rc |= dalloc(h, &d.pred[q], C);
@@ -451,18 +475,22 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
         rc |= dalloc(h, &d.sperm, S * E);
         rc |= dalloc(h, &d.segcount, C * 32);
         rc |= dalloc(h, &d.cellmax, C * 32);
-        rc |= dalloc(h, &d.match_bits, (S + 63) / 64 * 2);
+        rc |= dalloc(h, &d.match_bits, (S + 255) / 256 * 8);
         rc |= dalloc(h, &d.seg_info, S);
         rc |= dalloc(h, &d.seg_jit, S);
         rc |= dalloc(h, &d.work, (size_t)d.work_cap);
-        rc |= dalloc(h, &d.recyc_cnt, (S + 1023) / 1024);
+        rc |= dalloc(h, &d.recyc_cnt, (G + 1023) / 1024);
         rc |= dalloc(h, &d.recyc_need, 2 * k * 32);
         rc |= dalloc(h, &d.dead_list, (size_t)1 + DEAD_CAP);
         if (world > 1) {
-            rc |= dalloc(h, &d.spec_act, C);
-            rc |= dalloc(h, &d.spec_win, C);
-            rc |= dalloc(h, &d.spec_unacc, C);
-            rc |= dalloc(h, &d.spec_burst, (C + 31) / 32);
+            rc |= dalloc(h, &d.seg_gid, S);
+            rc |= dalloc(h, &d.g2l, G);
+            rc |= dalloc(h, &d.dead_bits, (G + 31) / 32 + 32);
+            rc |= dalloc(h, &d.lfree, S);
+            rc |= dalloc(h, &d.asg_gid, k * 32);
+            rc |= dalloc(h, &d.cand_cols, (size_t)d.n_cand + 8);
+            if (!rc && (hipMemsetAsync(d.seg_gid, 0xFF, S * 4, h->stream) != hipSuccess ||
+                        hipMemsetAsync(d.g2l, 0xFF, G * 4, h->stream) != hipSuccess)) { h->err = "hipMemsetAsync failed"; rc = HTM_ERR_HIP; }
         }
         rc |= dalloc(h, &h->d_cols_stage, k);
     }
@@ -482,10 +510,14 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
     d.trace = nullptr;
     if (getenv("BITHTM_TRACE")) rc |= dalloc(h, &d.trace, (size_t)8 * 4096 * 2);
     d.trace_until = getenv("BITHTM_TRACE_UNTIL") ? (uint32_t)strtoul(getenv("BITHTM_TRACE_UNTIL"), nullptr, 10) : 0xFFFFFFFFu;
-    h->sel_blocks = std::max(1, std::min((d.C + RB - 1) / RB, 128));
-    h->c256_blocks = (d.C + 255) / 256;
+    h->sel_blocks = std::max(1, std::min((d.sel_hi - d.sel_lo + RB - 1) / RB, 128));
+    h->c256_blocks = (d.sel_hi - d.sel_lo + 255) / 256;        // blocks of the emit role: 256 columns of the select's range each
     h->s1024_blocks = std::max(1, (d.Scap + 1023) / 1024);
-    h->scan_blocks = std::max(1, std::min((d.Scap + SCAN_SEGS - 1) / SCAN_SEGS, 2048));
+    h->scan_blocks = std::max(1, std::min((d.Lcap + SCAN_SEGS - 1) / SCAN_SEGS, 2048));
+    {
+        hipDeviceProp_t prop;
+        h->cus = hipGetDeviceProperties(&prop, h->device) == hipSuccess ? prop.multiProcessorCount : 256;
+    }
     if (const char *e = getenv("BITHTM_SCAN_BLOCKS")) h->scan_blocks = std::max(1, atoi(e));      // tuning knob
     // boosted = float32 factor x integer overlap <= input_dim has at most 24 + bit_length(I)
     // significant bits, so the low 53 - 24 - bit_length(I) bits of every key are zero and the
@@ -500,7 +532,7 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
         // by launches, the rest through the record exchange, in which blocks wait for each other).  What
         // fits is asked of the runtime, kernel by kernel, not assumed.
         {
-            const int c256 = (d.C + 255) / 256;
+            const int c256 = (d.sel_hi - d.sel_lo + 255) / 256;
             hipDeviceProp_t prop;
             int per_cu_emit = 0, per_cu_open = 0;
             if (hipGetDeviceProperties(&prop, h->device) == hipSuccess &&
@@ -707,9 +739,35 @@ extern "C" int htm_prepare(htm_handle *h, const uint32_t *device_inputs, int32_t
     return run_or_prepare(h, device_inputs, n_inputs, n_steps, learning, use_graph, true);
 }
 
+static int read_counters(htm_handle *h, Counters *out);
+
 extern "C" int64_t htm_shard_record_bytes(htm_handle *h) {
     if (!h) return HTM_ERR_ARGUMENT;
-    return (int64_t)shard_record_bytes(h->d.c1 - h->d.c0);
+    return (int64_t)shard_record_bytes(h->d.n_cand);
+}
+
+static int shard_enqueue_begin(htm_handle *h, const uint32_t *bank, int n_inputs, void *send_device) {
+    Dev &d = h->d;
+    if (!h->emit_fused) { h->err = "sharded handle: another handle with its own stream is live on this device"; return HTM_ERR_STATE; }
+    const int p = (int)(h->step_host & 1);
+    d.send = (unsigned char *)send_device;
+    // own columns: overlap + boost + top digit, and the zeroing of the step's dense words; digit 1; local select finish
+    // + speculative cell words of the candidates, packed into the record
+    LAUNCH(h, "shard_overlap", k_shard_overlap, h->sp_blocks + std::min((d.C + RB - 1) / RB, 64), RB, d, bank, n_inputs, h->G, p, h->sp_blocks);
+    for (int pass = 1; pass < d.sel_passes; ++pass) LAUNCH(h, "sp_select", k_sel_pass, h->sel_blocks, RB, d, pass, p);
+    LAUNCH(h, "shard_candidates", k_sp_emit, h->c256_blocks, 256, d, p, 1, 1, EMIT_LOCAL);
+    return 0;
+}
+
+static int shard_enqueue_finish(htm_handle *h, const uint32_t *bank, int n_inputs, const void *recv_device, int learning) {
+    Dev &d = h->d;
+    const int p = (int)(h->step_host & 1);
+    LAUNCH(h, "shard_select", k_shard_select, h->world, 1024, d, (const unsigned char *)recv_device, p);
+    enqueue_tm(h, d.k, learning, 1, p, bank, n_inputs, true);
+    h->step_host += 1;
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { h->err = std::string("kernel launch: ") + hipGetErrorString(e); return HTM_ERR_HIP; }
+    return 0;
 }
 
 extern "C" int htm_shard_begin(htm_handle *h, const uint32_t *device_inputs, int32_t n_inputs, const uint32_t *packed_input,
@@ -729,13 +787,8 @@ extern "C" int htm_shard_begin(htm_handle *h, const uint32_t *device_inputs, int
         h->shard_bank = device_inputs;
         h->shard_n_inputs = n_inputs;
     }
-    Dev &d = h->d;
-    const int p = (int)(h->step_host & 1);
-    const int cl = d.c1 - d.c0;
-    const int rows_per_block = 4 * 4 * (64 / h->G);                 // 256 threads: 4 waves x 4 row groups in flight
-    const int n_ov = std::max(1, std::min((cl + rows_per_block - 1) / rows_per_block, 1024));
-    LAUNCH(h, "shard_begin", k_shard_begin, n_ov + (cl + 7) / 8, 256, d, h->shard_bank, h->shard_n_inputs, h->G, p,
-           (unsigned char *)send_device, n_ov);
+    int rc = shard_enqueue_begin(h, h->shard_bank, h->shard_n_inputs, send_device);
+    if (rc) return rc;
     h->shard_open = true;
     (void)learning;
     return HTM_OK;
@@ -745,19 +798,129 @@ extern "C" int htm_shard_finish(htm_handle *h, const void *recv_device, int32_t 
     if (!h || !recv_device) return HTM_ERR_ARGUMENT;
     if (h->world < 2 || !h->shard_open) { h->err = "htm_shard_finish: no step in progress"; return HTM_ERR_STATE; }
     HIPCHK(h, hipSetDevice(h->device));
-    Dev &d = h->d;
-    const int p = (int)(h->step_host & 1);
-    learning = learning ? 1 : 0;
-    LAUNCH(h, "shard_unpack", k_shard_unpack, std::min(h->c256_blocks, 512), 256, d, (const unsigned char *)recv_device, h->rank, p);
-    for (int pass = 1; pass < d.sel_passes; ++pass) LAUNCH(h, "sp_select", k_sel_pass, h->sel_blocks, RB, d, pass, p);
-    const int fused = h->emit_fused;
-    if (!fused) LAUNCH(h, "sp_count", k_sp_count, h->c256_blocks, 256, d, p);
-    LAUNCH(h, "sp_emit", k_sp_emit, h->c256_blocks, 256, d, p, 1, fused, EMIT_ALL);
-    enqueue_tm(h, d.k, learning, 1, p, h->shard_bank, h->shard_n_inputs, true);
-    h->step_host += 1;
     h->shard_open = false;
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) { h->err = std::string("kernel launch: ") + hipGetErrorString(e); return HTM_ERR_HIP; }
+    return shard_enqueue_finish(h, h->shard_bank, h->shard_n_inputs, recv_device, learning ? 1 : 0);
+}
+
+// ---- the exchange inside the library: RCCL, loaded at run time (a handle that is never sharded needs no RCCL) ----
+namespace {
+struct RcclApi {
+    void *lib = nullptr;
+    int (*get_unique_id)(void *) = nullptr;
+    int (*comm_init_rank)(void **, int, ncclUniqueIdBytes, int) = nullptr;
+    int (*all_gather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+    int (*comm_destroy)(void *) = nullptr;
+    const char *(*get_error_string)(int) = nullptr;
+};
+RcclApi g_rccl;
+std::mutex g_rccl_mutex;
+
+const char *load_rccl() {
+    std::lock_guard<std::mutex> lock(g_rccl_mutex);
+    if (g_rccl.lib) return nullptr;
+    void *lib = nullptr;
+    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+        if ((lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!lib) return "cannot load librccl.so";
+    RcclApi api;
+    api.lib = lib;
+    api.get_unique_id = (int (*)(void *))dlsym(lib, "ncclGetUniqueId");
+    api.comm_init_rank = (int (*)(void **, int, ncclUniqueIdBytes, int))dlsym(lib, "ncclCommInitRank");
+    api.all_gather = (int (*)(const void *, void *, size_t, int, void *, hipStream_t))dlsym(lib, "ncclAllGather");
+    api.comm_destroy = (int (*)(void *))dlsym(lib, "ncclCommDestroy");
+    api.get_error_string = (const char *(*)(int))dlsym(lib, "ncclGetErrorString");
+    if (!api.get_unique_id || !api.comm_init_rank || !api.all_gather || !api.comm_destroy) return "librccl.so lacks an expected symbol";
+    g_rccl = api;
+    g_rccl_destroy = api.comm_destroy;
+    return nullptr;
+}
+}  // namespace
+
+extern "C" int htm_shard_unique_id(void *out128) {
+    if (!out128) return HTM_ERR_ARGUMENT;
+    if (const char *err = load_rccl()) { g_create_error = err; return HTM_ERR_HIP; }
+    ncclUniqueIdBytes id;
+    if (g_rccl.get_unique_id(&id) != 0) { g_create_error = "ncclGetUniqueId failed"; return HTM_ERR_HIP; }
+    memcpy(out128, &id, sizeof(id));
+    return HTM_OK;
+}
+
+extern "C" int htm_shard_comm_init(htm_handle *h, const void *unique_id128) {
+    if (!h || !unique_id128) return HTM_ERR_ARGUMENT;
+    if (h->world < 2) { h->err = "htm_shard_comm_init: handle is not sharded"; return HTM_ERR_STATE; }
+    if (h->rccl_comm) { h->err = "htm_shard_comm_init: already initialised"; return HTM_ERR_STATE; }
+    if (const char *err = load_rccl()) { h->err = err; return HTM_ERR_HIP; }
+    HIPCHK(h, hipSetDevice(h->device));
+    ncclUniqueIdBytes id;
+    memcpy(&id, unique_id128, sizeof(id));
+    void *comm = nullptr;
+    const int rc = g_rccl.comm_init_rank(&comm, h->world, id, h->rank);
+    if (rc != 0) { h->err = std::string("ncclCommInitRank: ") + (g_rccl.get_error_string ? g_rccl.get_error_string(rc) : "failed"); return HTM_ERR_HIP; }
+    h->rccl_comm = comm;
+    const size_t rb = shard_record_bytes(h->d.n_cand);
+    int rc2 = dalloc(h, &h->shard_send, rb);
+    rc2 |= dalloc(h, &h->shard_recv, rb * (size_t)h->world);
+    if (rc2) return rc2;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return HTM_OK;
+}
+
+extern "C" int htm_shard_step(htm_handle *h, const uint32_t *device_inputs, int32_t n_inputs, const uint32_t *packed_input, int32_t learning) {
+    if (!h || (!device_inputs == !packed_input)) return HTM_ERR_ARGUMENT;
+    if (h->world < 2 || !h->rccl_comm) { h->err = "htm_shard_step: needs a sharded handle after htm_shard_comm_init"; return HTM_ERR_STATE; }
+    if (h->shard_open) { h->err = "htm_shard_step: a step opened with htm_shard_begin is not finished"; return HTM_ERR_STATE; }
+    HIPCHK(h, hipSetDevice(h->device));
+    refresh_exchange_mode(h);
+    const uint32_t *bank = device_inputs;
+    if (packed_input) {
+        int rc = stage_input(h, packed_input);
+        if (rc) return rc;
+        bank = h->d.input_stage;
+        n_inputs = 1;
+    } else if (n_inputs < 1) {
+        return HTM_ERR_ARGUMENT;
+    }
+    int rc = shard_enqueue_begin(h, bank, n_inputs, h->shard_send);
+    if (rc) return rc;
+    const size_t rb = shard_record_bytes(h->d.n_cand);
+    const int nrc = g_rccl.all_gather(h->shard_send, h->shard_recv, rb, /* ncclChar */ 0, h->rccl_comm, h->stream);
+    if (nrc != 0) { h->err = std::string("ncclAllGather: ") + (g_rccl.get_error_string ? g_rccl.get_error_string(nrc) : "failed"); return HTM_ERR_HIP; }
+    return shard_enqueue_finish(h, bank, n_inputs, h->shard_recv, learning ? 1 : 0);
+}
+
+// Pre-populated pool (BASELINE.json configs[4]: a pure scan stress, not a learned state): every cell with flat id in
+// [cell_begin, cell_end) gets segments_per_cell segments of `synapses` synapses to keyed-random presynaptic cells
+// (no two alike within a segment), permanences keyed-uniform in [perm_lo, perm_hi).  Segment ids are cell-major:
+// (cell - cell_begin) * segments_per_cell + j.  Generated on the device (oracle twin: TemporalMemoryOracle.populate);
+// a column-sharded handle generates the rows of its own cells only, every handle of the group is given the same range.
+extern "C" int htm_populate(htm_handle *h, int64_t cell_begin, int64_t cell_end, int32_t segments_per_cell, int32_t synapses,
+                            double perm_lo, double perm_hi, uint32_t seed) {
+    if (!h) return HTM_ERR_ARGUMENT;
+    if (!h->cfg.enable_tm) { h->err = "handle has no Temporal Memory"; return HTM_ERR_STATE; }
+    Dev &d = h->d;
+    const int64_t N = (int64_t)d.C * d.K;
+    if (cell_begin < 0 || cell_end > N || cell_begin > cell_end || segments_per_cell < 1 || synapses < d.match_thr || synapses > 64 ||
+        synapses > d.E || synapses > N || !(perm_lo >= 0.0) || !(perm_hi >= perm_lo)) { h->err = "htm_populate: bad arguments"; return HTM_ERR_ARGUMENT; }
+    Counters c;
+    int rc = read_counters(h, &c);
+    if (rc) return rc;
+    if (c.S != 0 || h->step_host != 0) { h->err = "htm_populate: the handle must be fresh"; return HTM_ERR_STATE; }
+    const int64_t total = (cell_end - cell_begin) * segments_per_cell;
+    const int64_t own_lo = std::max<int64_t>(cell_begin, (int64_t)d.c0 * d.K), own_hi = std::min<int64_t>(cell_end, (int64_t)d.c1 * d.K);
+    const int64_t own = std::max<int64_t>(own_hi - own_lo, 0) * segments_per_cell;
+    if (total > d.Scap || own > d.Lcap) { h->err = "htm_populate: pool too small (segment_capacity / segment_capacity_local)"; return HTM_ERR_CAPACITY; }
+    if (own > 0) {
+        const int64_t blocks = std::min<int64_t>((own + 3) / 4, (int64_t)h->cus * 64);
+        hipLaunchKernelGGL(k_tm_populate, dim3((unsigned)blocks), dim3(256), 0, h->stream, d, (long long)cell_begin, (long long)own_lo, (long long)own,
+                           segments_per_cell, synapses, perm_lo, perm_hi, seed);
+    }
+    c.S = (int32_t)total;
+    c.L = (int32_t)own;
+    HIPCHK(h, hipMemcpyAsync(&d.ctr->S, &c.S, sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(&d.ctr->L, &c.L, sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->seg_hint = (int)(h->world > 1 ? own : total);
+    if (h->seg_pinned) *h->seg_pinned = h->seg_hint;
     return HTM_OK;
 }
 
@@ -781,8 +944,8 @@ static int read_counters(htm_handle *h, Counters *out) {
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipMemcpy(out, h->d.ctr, sizeof(Counters), hipMemcpyDeviceToHost));
-    h->seg_hint = out->S;                           // exact: the stream is idle
-    if (h->seg_pinned) *h->seg_pinned = out->S;
+    h->seg_hint = h->world > 1 ? out->L : out->S;   // exact: the stream is idle (rows the scan covers)
+    if (h->seg_pinned) *h->seg_pinned = h->seg_hint;
     return 0;
 }
 
@@ -792,13 +955,15 @@ extern "C" int htm_get_info(htm_handle *h, htm_info *out) {
     int rc = read_counters(h, &c);
     if (rc) return rc;
     const int q = (int)((h->step_host + 1) & 1);          // parity of the last completed step
+    const int rows = h->world > 1 ? c.L : c.S;
     out->step_index = h->step_host;
     out->segments = c.S;
+    out->local_segments = rows;
     out->matching_segments = 0;
-    if (c.has_distal && c.S > 0) {
-        std::vector<uint32_t> bits(((size_t)c.S + 31) / 32);
+    if (c.has_distal && rows > 0) {
+        std::vector<uint32_t> bits(((size_t)rows + 31) / 32);
         HIPCHK(h, hipMemcpy(bits.data(), h->d.match_bits, bits.size() * 4, hipMemcpyDeviceToHost));
-        for (int i = 0; i < c.S; ++i) out->matching_segments += (bits[(size_t)i >> 5] >> (i & 31)) & 1u;
+        for (int i = 0; i < rows; ++i) out->matching_segments += (bits[(size_t)i >> 5] >> (i & 31)) & 1u;
     }
     out->winner_cells = c.n_win[q];
     out->active_cells = c.n_active_cells;
@@ -833,7 +998,7 @@ extern "C" int64_t htm_read(htm_handle *h, int32_t field, void *dst, int64_t cou
     Dev &d = h->d;
     const int q = (int)((h->step_host + 1) & 1);
     const bool sp = h->cfg.enable_sp, tm = h->cfg.enable_tm;
-    const int64_t C = d.C, K = d.K, S = c.S, E = d.E;
+    const int64_t C = d.C, K = d.K, S = h->world > 1 ? c.L : c.S, E = d.E;      // S: rows of the per-segment fields
     auto need = [&](bool ok, int64_t n) -> int64_t {
         if (!ok) { h->err = "htm_read: field not available on this handle"; return HTM_ERR_STATE; }
         if (count < n) { h->err = "htm_read: buffer too small"; return HTM_ERR_ARGUMENT; }
@@ -932,6 +1097,12 @@ extern "C" int64_t htm_read(htm_handle *h, int32_t field, void *dst, int64_t cou
                 for (int64_t j = 0; j < K; ++j) v[col * K + j] = tmp[(size_t)col * 32 + j];
             return n;
         }
+        case HTM_F_SEG_GID: {
+            if ((n = need(tm, S)) < 0) return n;
+            if (d.seg_gid) return copy(d.seg_gid, n, 4);
+            for (int64_t i = 0; i < n; ++i) ((int *)dst)[i] = (int)i;
+            return n;
+        }
         default: h->err = "htm_read: unknown field"; return HTM_ERR_ARGUMENT;
     }
 }
@@ -987,6 +1158,7 @@ extern "C" int htm_write(htm_handle *h, int32_t field, const void *src, int64_t 
 
 extern "C" int htm_import_begin(htm_handle *h, int64_t step_index) {
     if (!h || step_index < 0) return HTM_ERR_ARGUMENT;
+    if (h->world > 1) { h->err = "state import is not available on a column-sharded handle"; return HTM_ERR_STATE; }
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->step_host = step_index;
@@ -1016,7 +1188,7 @@ extern "C" int htm_import_commit(htm_handle *h, int32_t segments, int32_t matchi
             h->err = "htm_import_commit: SEG_POTENTIAL / MATCH_* fields missing or of the wrong length";
             return HTM_ERR_ARGUMENT;
         }
-        std::vector<uint32_t> info((size_t)segments, 0u), bits((size_t)(d.Scap + 63) / 64 * 2, 0u);
+        std::vector<uint32_t> info((size_t)segments, 0u), bits((size_t)(d.Lcap + 255) / 256 * 8, 0u);
         std::vector<float> jit((size_t)segments, 0.f);
         if (has_distal_state) {
             for (size_t i = 0; i < M; ++i) {

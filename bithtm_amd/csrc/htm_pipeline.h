@@ -70,10 +70,10 @@ __global__ __launch_bounds__(256, 8) void k_mid_rows(Dev d, int p, int n_active,
         return;
     }
     b -= n_rows;
-    const int c = b * 256 + (int)threadIdx.x;
-    if (b < n_duty_blocks && c < d.C) {
+    const int c = d.c0 + b * 256 + (int)threadIdx.x;              // (own columns)
+    if (b < n_duty_blocks && c < d.c1) {
         float dc = d.duty[c] * d.mom;
-        if ((d.colbits[q][c >> 5] >> (c & 31)) & 1u) dc = dc + d.dinc;
+        if ((d.colbits[rows_ahead ? q : p][c >> 5] >> (c & 31)) & 1u) dc = dc + d.dinc;
         d.duty[c] = dc;
     }
 }

@@ -13,6 +13,8 @@
 #define HTM_STREAM_LEAST_USED 1u
 #define HTM_STREAM_GROWTH 2u
 #define HTM_STREAM_SEGMENT_JITTER 3u
+#define HTM_STREAM_POPULATE_CELL 4u      // pre-populated pools (htm_populate): a = segment id, b = synapse index
+#define HTM_STREAM_POPULATE_PERM 5u
 
 __host__ __device__ __forceinline__ uint32_t htm_mix32(uint32_t x) {   // "lowbias32"
     x ^= x >> 16;
@@ -30,6 +32,11 @@ __host__ __device__ __forceinline__ uint32_t htm_stream_base(uint32_t seed, uint
 
 __host__ __device__ __forceinline__ uint32_t htm_draw24(uint32_t base, uint32_t a, uint32_t b) {
     return htm_mix32(htm_mix32(base ^ a) ^ b) >> 8;
+}
+
+// the same hash, all 32 bits (htm_populate: presynaptic cell = (draw32 * cells) >> 32)
+__host__ __device__ __forceinline__ uint32_t htm_draw32(uint32_t base, uint32_t a, uint32_t b) {
+    return htm_mix32(htm_mix32(base ^ a) ^ b);
 }
 
 // float32(float64(count) + u): the in-place `float32 += float64` of networks.py:87 and

@@ -25,18 +25,16 @@ __global__ __launch_bounds__(256) void k_sp_build_mask(Dev d, int row_begin, int
 
 // DenseProjection.process (projections.py:18-21) + ExponentialBoosting.process
 // (regularizations.py:15-17).  G lanes share one row (G = power of two, W4 16-byte chunks per row).
-// Sharded handles run it on their own rows only and leave the histogram to k_shard_unpack, which
-// sees the keys of all columns.
+// Sharded handles run it on their own rows only: the select that follows picks their own candidates.
 // Roles are written against (blk, nblk) instead of blockIdx / gridDim so that two independent
 // roles can share one launch (pipelined schedule: step t's TM work beside step t+1's SP work).
 // sp = parity buffer of the SP step being computed; step_offset = that step minus the current one.
 template <int BS>
 __device__ __forceinline__ void role_overlap(const Dev &d, const uint32_t *__restrict__ bank, int n_inputs, int G,
-                                             int p, int sp, int step_offset, int blk, int nblk, uint32_t *h,
-                                             double *shard_boosted = nullptr) {      // sharded: also into the exchange record
+                                             int p, int sp, int step_offset, int blk, int nblk, uint32_t *h) {
     const int gtid = blk * BS + threadIdx.x;
     const int nthreads = nblk * BS;
-    const bool do_hist = d.world == 1;
+    const bool do_hist = true;
     uint32_t *ghist = d.hist + sp * SEL_MAX_PASSES * SEL_BINS;
     if (gtid == 0) d.ctr->emit_epoch += 1;          // a new generation of k_sp_emit records
     if (do_hist) {
@@ -44,7 +42,7 @@ __device__ __forceinline__ void role_overlap(const Dev &d, const uint32_t *__res
         for (int i = threadIdx.x; i < SEL_BINS; i += BS) h[i] = 0;
         if (gtid == 0) {
             d.ctr->sel_pass_prefix[sp][0] = 0;
-            d.ctr->sel_pass_krem[sp][0] = (uint32_t)d.k;
+            d.ctr->sel_pass_krem[sp][0] = (uint32_t)d.sel_k;
         }
         __syncthreads();
     }
@@ -88,7 +86,6 @@ __device__ __forceinline__ void role_overlap(const Dev &d, const uint32_t *__res
                 const float f = htm_exp_f32(d.coef * dty[u]);          // float32 product, documented exp
                 const double bo = (double)f * (double)cn;              // exact (24-bit x <= 16-bit)
                 d.boosted[sp][row] = bo;
-                if (shard_boosted) shard_boosted[row - d.c0] = bo;
                 key = select_key(bo);
                 d.key[sp][row] = key;
             }
@@ -191,12 +188,12 @@ __device__ __forceinline__ void role_sel_pass(const Dev &d, int pass, int sp, in
     for (int i = tid; i < nb; i += BS) sh->h[i] = 0;
     __syncthreads();
     const u64 *keys = d.key[sp];
-    for (int c0 = blk * BS + (tid & ~63); c0 < d.C; c0 += nblk * BS) {
+    for (int c0 = d.sel_lo + blk * BS + (tid & ~63); c0 < d.sel_hi; c0 += nblk * BS) {
         const int c = c0 + lane_id();
-        const u64 key = c < d.C ? keys[c] : 0;
+        const u64 key = c < d.sel_hi ? keys[c] : 0;
         // digits below the top one are spread over the bins: plain LDS atomics (hist_add's loop runs once per
         // distinct digit of the wave, which here is most of its lanes)
-        if (c < d.C && ((key ^ prefix) & himask) == 0) atomicAdd(&sh->h[(uint32_t)(key >> shift) & (nb - 1)], 1u);
+        if (c < d.sel_hi && ((key ^ prefix) & himask) == 0) atomicAdd(&sh->h[(uint32_t)(key >> shift) & (nb - 1)], 1u);
     }
     __syncthreads();
     uint32_t *gh = d.hist + (sp * SEL_MAX_PASSES + pass) * SEL_BINS;
@@ -225,9 +222,9 @@ __global__ __launch_bounds__(256) void k_sp_count(Dev d, int sp) {
     }
     if (d.sel_passes > 1)                       // pass-0 histogram is consumed: clear it for its next use
         for (int i = blockIdx.x * 256 + threadIdx.x; i < HIST_REP * SEL_BINS; i += gridDim.x * 256) d.hist0[(size_t)sp * HIST_REP * SEL_BINS + i] = 0;
-    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int c = d.sel_lo + blockIdx.x * 256 + threadIdx.x;
     uint32_t v = 0;
-    if (c < d.C) {
+    if (c < d.sel_hi) {
         u64 key = d.key[sp][c];
         v = (key > T) ? 1u : ((key == T) ? 0x10000u : 0u);
     }
@@ -287,123 +284,21 @@ __device__ __forceinline__ void tm_store_column(const Dev &d, int p, bool col_ok
 }
 
 __device__ __forceinline__ void tm_activate_column(const Dev &d, int p, int want_winner, bool col_ok, int a, int idx, uint32_t pw) {
-    if (d.world == 1) {
-        tm_store_column(d, p, col_ok, a, idx, tm_column_words(d, p, want_winner, col_ok, a, pw));
-    } else {          // the owner computed the words before the exchange
-        ColumnWords w{0, 0, 0, false};
-        if (col_ok) {
-            w.act = d.spec_act[a];
-            w.winner = want_winner ? d.spec_win[a] : 0u;
-            w.unacc = want_winner ? d.spec_unacc[a] : 0u;
-            w.burst = (d.spec_burst[a >> 5] >> (a & 31)) & 1u;
-        }
-        tm_store_column(d, p, col_ok, a, idx, w);
-    }
+    tm_store_column(d, p, col_ok, a, idx, tm_column_words(d, p, want_winner, col_ok, a, pw));
 }
 
-// ---- column sharding: the two kernels around the exchange ---------------------------------
-// wire format of one rank's record (oracle/sharded.py record_nbytes):
-//   [boosted f64 x Cl][act u32 x Cl][win u32 x Cl][unacc u32 x Cl][bursting bits u32 x ceil(Cl/32)]
+// ---- column sharding: the exchange record ----------------------------------------------------
+// One fixed-size record per rank and timestep (oracle/sharded.py record_nbytes): the rank's own
+// top-min(k, own columns) candidates, in ascending column order, each with the cell words the column WOULD have if
+// it became active (they only depend on the owner's previous predictions, segment maxima and segment counts), and
+// the global ids of own segments that fell below the matching threshold while learning (the lowest-id-first
+// recycling rule of projections.py:80-81 is global).  KL = candidates per rank:
+//   [boosted f64 x KL][column | bursting << 31  u32 x KL][winner word u32 x KL][needs-a-segment word u32 x KL]
 //   [n_dead u32][dead ids u32 x DEAD_CAP], padded to 16 bytes
-__host__ __device__ __forceinline__ size_t shard_record_bytes(int cl) {
-    size_t n = (size_t)cl * 20 + 4 * (size_t)((cl + 31) / 32) + 4 + 4 * DEAD_CAP;
+// (the active-cell word is not sent: it is all cells of a bursting column and the winner word otherwise)
+__host__ __device__ __forceinline__ size_t shard_record_bytes(int n_cand) {
+    size_t n = (size_t)n_cand * 20 + 4 + 4 * DEAD_CAP;
     return (n + 15) / 16 * 16;
-}
-
-// before the exchange: what each OWN column would look like if it became active (this only
-// needs the rank's own previous predictions, segment maxima and segment counts), its boosted
-// overlap, and the segments that died during the previous step's learning
-// One launch: blocks [0, n_overlap_blocks) compute overlap + boost of the own columns, straight into the
-// record; the others pack eight own columns each (one per half-wave); the first of them also reports
-// the segments that died while learning.
-__global__ __launch_bounds__(256) void k_shard_begin(Dev d, const uint32_t *__restrict__ bank, int n_inputs, int G, int p,
-                                                      unsigned char *send, int n_overlap_blocks) {
-    const int cl = d.c1 - d.c0;
-    if ((int)blockIdx.x < n_overlap_blocks) {
-        role_overlap<256>(d, bank, n_inputs, G, p, p, 0, blockIdx.x, n_overlap_blocks, nullptr, (double *)send);
-        return;
-    }
-    __shared__ uint32_t s_burst;
-    const int pb = (int)blockIdx.x - n_overlap_blocks;
-    uint32_t *r_act = (uint32_t *)(send + (size_t)cl * 8);
-    uint32_t *r_win = r_act + cl, *r_unacc = r_win + cl, *r_burst = r_unacc + cl;
-    uint32_t *r_dead = r_burst + (cl + 31) / 32;
-    if (threadIdx.x == 0) s_burst = 0;
-    __syncthreads();
-    const int i = (pb * 256 + (int)threadIdx.x) >> 5;               // local column, one per half-wave
-    const bool ok = i < cl;
-    const int a = d.c0 + (ok ? i : 0);
-    const ColumnWords w = tm_column_words(d, p, 1, ok, a, ok ? d.pred[p ^ 1][a] : 0u);
-    if (ok && (lane_id() & 31) == 0) {
-        r_act[i] = w.act;
-        r_win[i] = w.winner;
-        r_unacc[i] = w.unacc;
-        if (w.burst) atomicOr(&s_burst, 1u << (i & 7));
-    }
-    __syncthreads();
-    if (threadIdx.x == 0 && pb * 8 < cl) ((unsigned char *)r_burst)[pb] = (unsigned char)s_burst;   // 8 columns = one byte of the bit words
-    if (pb == 0) {
-        const int n = min(d.dead_list[0], DEAD_CAP);
-        if (threadIdx.x == 0) r_dead[0] = (uint32_t)n;
-        for (int j = threadIdx.x; j < n; j += 256) r_dead[1 + j] = (uint32_t)d.dead_list[1 + j];
-    }
-}
-
-// after the exchange: the keys and speculative words of ALL columns in global column order, the
-// histogram of the top key digit (what k_sp_overlap does on an unsharded handle), and the deaths
-// the other ranks reported (only "fewer synapses than the matching threshold" matters here:
-// projections.py:80)
-__global__ __launch_bounds__(256) void k_shard_unpack(Dev d, const unsigned char *recv, int rank, int sp) {
-    __shared__ uint32_t h[SEL_BINS];
-    const int gtid = blockIdx.x * blockDim.x + threadIdx.x;
-    const int nthreads = gridDim.x * blockDim.x;
-    const int cl = d.c1 - d.c0;
-    const size_t rb = shard_record_bytes(cl);
-    uint32_t *ghist = d.hist + sp * SEL_MAX_PASSES * SEL_BINS;
-    for (int i = gtid; i < (d.sel_passes - 1) * SEL_BINS; i += nthreads) ghist[SEL_BINS + i] = 0;
-    for (int i = threadIdx.x; i < SEL_BINS; i += 256) h[i] = 0;
-    if (gtid == 0) {
-        d.ctr->sel_pass_prefix[sp][0] = 0;
-        d.ctr->sel_pass_krem[sp][0] = (uint32_t)d.k;
-        d.dead_list[0] = 0;                        // reported; start collecting this step's
-    }
-    __syncthreads();
-    for (int c0 = blockIdx.x * 256 + (threadIdx.x & ~63); c0 < d.C; c0 += gridDim.x * 256) {
-        const int c = c0 + lane_id();
-        u64 key = 0;
-        if (c < d.C) {
-            const int r = c / cl, i = c - r * cl;
-            const unsigned char *rec = recv + (size_t)r * rb;
-            const double bo = ((const double *)rec)[i];
-            const uint32_t *r_act = (const uint32_t *)(rec + (size_t)cl * 8);
-            key = select_key(bo);
-            d.boosted[sp][c] = bo;
-            d.key[sp][c] = key;
-            d.spec_act[c] = r_act[i];
-            d.spec_win[c] = r_act[cl + i];
-            d.spec_unacc[c] = r_act[2 * cl + i];
-            if ((c & 31) == 0) {                   // cl is a multiple of 32: words do not straddle ranks
-                d.spec_burst[c >> 5] = r_act[3 * cl + (i >> 5)];
-            }
-        }
-        hist_add(h, (uint32_t)(key >> sel_shift(0)), c < d.C);
-    }
-    __syncthreads();
-    uint32_t *g0 = d.hist0 + (size_t)(sp * HIST_REP + (blockIdx.x & (HIST_REP - 1))) * SEL_BINS;
-    for (int i = threadIdx.x; i < SEL_BINS; i += 256)
-        if (h[i]) atomicAdd(&g0[i], h[i]);
-    if (blockIdx.x == 0) {
-        for (int r = 0; r < d.world; ++r) {
-            if (r == rank) continue;
-            const uint32_t *r_dead = (const uint32_t *)(recv + (size_t)r * rb + (size_t)cl * 20) + (cl + 31) / 32;
-            const int n = min((int)r_dead[0], DEAD_CAP);
-            for (int j = threadIdx.x; j < n; j += 256) {
-                const int seg = (int)r_dead[1 + j];
-                d.seg_nsyn[seg] = 0;
-                atomicAdd(&d.recyc_cnt[seg >> 10], 1);
-            }
-        }
-    }
 }
 
 // ---- finishing the select inside k_sp_emit ---------------------------------------------------
@@ -467,6 +362,8 @@ __device__ __forceinline__ void sel_pick(const uint32_t *h, int nb, uint32_t kre
 #define EMIT_ACTIVATE 2
 #define EMIT_CLEAR 4
 #define EMIT_ALL 7
+#define EMIT_LOCAL 8            // a shard's own candidates: the list goes to cand_cols and, with each candidate's speculative
+                                // cell words, into the exchange record (send); nothing else is touched
 struct EmitShared {
     uint32_t h[SEL_BINS];
     u64 prefix, T;
@@ -499,13 +396,14 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
     static_assert(2 * CAND_MAX <= SEL_BINS, "bucket keys must fit the histogram");
     const int tid = threadIdx.x, lane = lane_id();
     if (tid == 0) { s_gt = 0; s_eq = 0; s_n = 0; s_nraw = 0; s_ne = 0; s_flags = 0; }
-    const int c = b * 256 + tid;
+    const int cbase = d.sel_lo + b * 256, c = cbase + tid;      // the select covers columns [sel_lo, sel_hi)
+    const bool local = mode & EMIT_LOCAL;
     // independent of everything below: in flight while the select state is resolved
-    const u64 my_key = c < d.C ? d.key[p][c] : 0;
-    const bool own_col = c < d.C && c >= d.c0 && c < d.c1;
+    const u64 my_key = c < d.sel_hi ? d.key[p][c] : 0;
+    const bool own_col = c < d.sel_hi && c >= d.c0 && c < d.c1;
     const float my_duty = (own_col && (mode & EMIT_DUTY)) ? d.duty[c] : 0.f;
     const bool tm_here = d.act[0] && (mode & EMIT_ACTIVATE);
-    s_predw[tid] = (c < d.C && tm_here && d.world == 1) ? d.pred[p ^ 1][c] : 0u;
+    s_predw[tid] = (c < d.sel_hi && (tm_here || local)) ? d.pred[p ^ 1][c] : 0u;
     u64 T;
     uint32_t r;                                     // how many of the keys == T are selected
     bool second_round = false;                      // per-block counts still to be exchanged
@@ -516,7 +414,7 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
         sel_resolve<256>(d, p, d.sel_passes - 1, h, s_wave, &P, &krem, &s_prefix, &s_krem);    // (ends behind a barrier)
         const int lowbits = sel_shift(d.sel_passes - 1);        // key bits not resolved by launches
         const u64 hiP = P >> lowbits, hi = my_key >> lowbits;
-        const bool c_gt = c < d.C && hi > hiP, c_cand = c < d.C && hi == hiP;
+        const bool c_gt = c < d.sel_hi && hi > hiP, c_cand = c < d.sel_hi && hi == hiP;
         // ---- this block's record
         {
             const u64 mg = __ballot(c_gt);
@@ -717,10 +615,10 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
                 const int bits = min(SEL_DIGIT, top), shift = top - bits, nb = 1 << bits;
                 for (int i = tid; i < nb; i += 256) h[i] = 0;
                 __syncthreads();
-                for (int c0 = (tid & ~63); c0 < d.C; c0 += 256) {
+                for (int c0 = d.sel_lo + (tid & ~63); c0 < d.sel_hi; c0 += 256) {
                     const int cc = c0 + lane;
-                    const u64 kk = cc < d.C ? keys[cc] : 0;
-                    hist_add(h, (uint32_t)(kk >> shift) & (nb - 1), cc < d.C && ((kk ^ P2) >> top) == 0);
+                    const u64 kk = cc < d.sel_hi ? keys[cc] : 0;
+                    hist_add(h, (uint32_t)(kk >> shift) & (nb - 1), cc < d.sel_hi && ((kk ^ P2) >> top) == 0);
                 }
                 __syncthreads();
                 uint32_t bucket, above;
@@ -746,7 +644,7 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
     }
     __syncthreads();
     uint32_t flag = 0;
-    if (c < d.C) flag = (my_key > T) ? 1u : ((my_key == T) ? 0x10000u : 0u);
+    if (c < d.sel_hi) flag = (my_key > T) ? 1u : ((my_key == T) ? 0x10000u : 0u);
     uint32_t total;
     const uint32_t ex = block_excl_scan<256>(flag, s_wave, total);
     if (second_round || !fused) {
@@ -783,12 +681,12 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
     const uint32_t gt_before = s_gt, eq_before = s_eq;
     const uint32_t g_run = gt_before + (ex & 0xFFFFu), e_run = eq_before + (ex >> 16);
     const int first_pos = (int)(gt_before + min(eq_before, r));
-    const bool sel_any = c < d.C && ((flag & 1u) || ((flag >> 16) && e_run < r));
-    if (d.act[0]) {
+    const bool sel_any = c < d.sel_hi && ((flag & 1u) || ((flag >> 16) && e_run < r));
+    if (d.act[0] && !local) {
         const u64 mcol = __ballot(sel_any);
-        if (lane_id() == 0) *(u64 *)&d.colbits[p][(b * 256 + (tid & ~63)) >> 5] = mcol;
+        if (lane_id() == 0) *(u64 *)&d.colbits[p][(cbase + (tid & ~63)) >> 5] = mcol;
     }
-    if (c < d.C) {
+    if (c < d.sel_hi) {
         const bool sel = sel_any;
         if (own_col && (mode & EMIT_DUTY)) {
             float dc = my_duty * d.mom;
@@ -797,7 +695,7 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
         }
         if (sel) {
             const int pos = (int)(g_run + min(e_run, r));
-            d.active_cols[p][pos] = c;
+            (local ? d.cand_cols : d.active_cols[p])[pos] = c;
             s_col[pos - first_pos] = c;
             atomicAdd(&s_n, 1);
         }
@@ -807,14 +705,38 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
         }
     }
     if (b == 0 && tid == 0 && !d.act[0]) d.ctr->step[p ^ 1] = d.ctr->step[p] + 1;   // SP-only handle
-    if (!tm_here) return;
+    if (!tm_here && !local) return;
     __syncthreads();
     const int n_sel = s_n;
+    if (local) {                                   // this block's candidates into the exchange record
+        double *r_boost = (double *)d.send;
+        uint32_t *r_col = (uint32_t *)(d.send + (size_t)d.n_cand * 8), *r_win = r_col + d.n_cand, *r_unacc = r_win + d.n_cand;
+        for (int i0 = 0; i0 < n_sel; i0 += 8) {    // 8 half-waves
+            const int i = i0 + (tid >> 5);
+            const bool ok = i < n_sel;
+            const int a = ok ? s_col[i] : d.sel_lo;
+            const ColumnWords w = tm_column_words(d, p, 1, ok, a, ok ? s_predw[a - cbase] : 0u);
+            if (ok && (lane_id() & 31) == 0) {
+                const int pos = first_pos + i;
+                r_boost[pos] = d.boosted[p][a];
+                r_col[pos] = (uint32_t)a | (w.burst ? 0x80000000u : 0u);
+                r_win[pos] = w.winner;
+                r_unacc[pos] = w.unacc;
+            }
+        }
+        if (b == 0) {                              // and the segments that died while the previous step learned
+            uint32_t *r_dead = r_unacc + d.n_cand;
+            const int n = min(d.dead_list[0], DEAD_CAP);
+            if (tid == 0) r_dead[0] = (uint32_t)n;
+            for (int j = tid; j < n; j += 256) r_dead[1 + j] = (uint32_t)d.dead_list[1 + j];
+        }
+        return;
+    }
     for (int i0 = 0; i0 < n_sel; i0 += 8) {        // 8 half-waves
         const int i = i0 + (tid >> 5);
         const bool ok = i < n_sel;
         const int a = ok ? s_col[i] : 0;
-        tm_activate_column(d, p, want_winner, ok, a, first_pos + i, ok ? s_predw[a - b * 256] : 0u);
+        tm_activate_column(d, p, want_winner, ok, a, first_pos + i, ok ? s_predw[a - cbase] : 0u);
     }
 }
 
@@ -841,6 +763,115 @@ __global__ __launch_bounds__(256) void k_sp_learn(Dev d, const uint32_t *__restr
         }
         u64 m = __ballot(conn);
         if (lane_id() == 0 && i < d.Ipad) *(u64 *)&mrow[i >> 5] = m;
+    }
+}
+
+// ---- column sharding: the kernels on either side of the exchange -----------------------------
+// before the exchange, first launch: overlap + boost + top key digit of the OWN columns, and the zeroing of the
+// step's dense per-column words (the winners' words are written after the exchange)
+__global__ __launch_bounds__(RB) void k_shard_overlap(Dev d, const uint32_t *__restrict__ bank, int n_inputs, int G, int p, int n_overlap_blocks) {
+    __shared__ uint32_t h[SEL_BINS];
+    if ((int)blockIdx.x < n_overlap_blocks) {
+        role_overlap<RB>(d, bank, n_inputs, G, p, p, 0, blockIdx.x, n_overlap_blocks, h);
+        return;
+    }
+    const int nb = (int)gridDim.x - n_overlap_blocks, b = (int)blockIdx.x - n_overlap_blocks;
+    for (int c = b * RB + (int)threadIdx.x; c < d.C; c += nb * RB) {
+        d.act[p][c] = 0;
+        d.win[p][c] = 0;
+        d.pred[p][c] = 0;
+        if (c < d.colwords) d.colbits[p][c] = 0;
+    }
+}
+
+// after the exchange: the exact global top-k over the world x KL candidates, computed by every block for itself
+// (a radix select in LDS: the candidate keys are few and L2-resident), then block b emits rank b's winners into the
+// ascending winner list -- the records are in rank order and each is in ascending column order, so the candidates
+// ARE in ascending column order and the tie rule (lower column first) is their order -- together with the cell
+// words the owner computed.  Block 0 also applies every rank's death reports to the replicated dead bits.
+__global__ __launch_bounds__(1024) void k_shard_select(Dev d, const unsigned char *__restrict__ recv, int p) {
+    __shared__ uint32_t h[SEL_BINS];
+    __shared__ uint32_t s_wave[16], s_out[2], s_cnt[2];
+    const int tid = threadIdx.x, lane = lane_id();
+    const int KL = d.n_cand, n_tot = d.world * KL;
+    const size_t rb = shard_record_bytes(KL);
+    auto key_at = [&](int i) -> u64 {
+        const int r = i / KL, j = i - r * KL;
+        return select_key(((const double *)(recv + (size_t)r * rb))[j]);
+    };
+    u64 P = 0;
+    uint32_t krem = (uint32_t)d.k;
+    for (int top = 64; top > d.low_zero;) {
+        const int bits = min(SEL_DIGIT, top - d.low_zero < SEL_DIGIT ? top - d.low_zero : SEL_DIGIT), shift = top - bits, nb = 1 << bits;
+        for (int i = tid; i < nb; i += 1024) h[i] = 0;
+        __syncthreads();
+        for (int i = tid; i < n_tot; i += 1024) {
+            const u64 kk = key_at(i);
+            if (top == 64 || ((kk ^ P) >> top) == 0) atomicAdd(&h[(uint32_t)(kk >> shift) & (nb - 1)], 1u);
+        }
+        __syncthreads();
+        uint32_t bucket, above;
+        sel_pick<1024>(h, nb, krem, s_wave, s_out, &bucket, &above);
+        P |= (u64)bucket << shift;
+        krem -= above;
+        top = shift;
+        __syncthreads();
+    }
+    const u64 T = P;                               // the k-th largest key; krem of the keys equal to it win
+    const int b = blockIdx.x, lo = b * KL;
+    if (tid < 2) s_cnt[tid] = 0;
+    __syncthreads();
+    {   // winners among the candidates of the ranks before this one
+        uint32_t g = 0, e = 0;
+        for (int i = tid; i < lo; i += 1024) {
+            const u64 kk = key_at(i);
+            g += kk > T;
+            e += kk == T;
+        }
+        g = wave_sum(g);
+        e = wave_sum(e);
+        if (lane == 0) { atomicAdd(&s_cnt[0], g); atomicAdd(&s_cnt[1], e); }
+    }
+    __syncthreads();
+    uint32_t gt_run = s_cnt[0], eq_run = s_cnt[1];
+    const unsigned char *rec = recv + (size_t)b * rb;
+    const uint32_t *r_col = (const uint32_t *)(rec + (size_t)KL * 8), *r_win = r_col + KL, *r_unacc = r_win + KL;
+    for (int j0 = 0; j0 < KL; j0 += 1024) {
+        const int j = j0 + tid;
+        const u64 kk = j < KL ? key_at(lo + j) : 0;
+        const uint32_t flag = j < KL ? ((kk > T) ? 1u : ((kk == T) ? 0x10000u : 0u)) : 0u;
+        uint32_t total;
+        const uint32_t ex = block_excl_scan<1024>(flag, s_wave, total);
+        const uint32_t g = gt_run + (ex & 0xFFFFu), e = eq_run + (ex >> 16);
+        if ((flag & 1u) || ((flag >> 16) && e < krem)) {
+            const int pos = (int)(g + min(e, krem));
+            const uint32_t cw = r_col[j], wn = r_win[j];
+            const int col = (int)(cw & 0x7FFFFFFFu);
+            const bool burst = cw >> 31;
+            const uint32_t act = burst ? cell_mask(d.K) : wn;                   // networks.py:115
+            d.active_cols[p][pos] = col;
+            atomicOr(&d.colbits[p][col >> 5], 1u << (col & 31));
+            d.act[p][col] = act;
+            d.win[p][col] = wn;
+            d.bursting[pos] = burst ? 1 : 0;
+            d.unacc_word[pos] = r_unacc[j];
+            d.winw_idx[pos] = wn;
+            d.actcnt[pos] = (uint8_t)__popc(act);
+        }
+        gt_run += total & 0xFFFFu;
+        eq_run += total >> 16;
+    }
+    if (b == 0) {
+        for (int r = 0; r < d.world; ++r) {
+            const uint32_t *r_dead = (const uint32_t *)(recv + (size_t)r * rb + (size_t)KL * 20);
+            const int n = min((int)r_dead[0], DEAD_CAP);
+            for (int j = tid; j < n; j += 1024) {
+                const int gid = (int)r_dead[1 + j];
+                const uint32_t old = atomicOr(&d.dead_bits[gid >> 5], 1u << (gid & 31));
+                if (!((old >> (gid & 31)) & 1u)) atomicAdd(&d.recyc_cnt[gid >> 10], 1);
+            }
+        }
+        if (tid == 0) d.dead_list[0] = 0;          // reported; the coming learning role collects this step's
     }
 }
 

@@ -28,34 +28,69 @@ __global__ __launch_bounds__(256) void k_tm_activate(Dev d, int p, int n_active,
     tm_activate_column(d, p, want_winner, ok, a, idx, ok ? d.pred[p ^ 1][a] : 0u);
 }
 
-// bind segment `seg` to winner cell `cell` (projections.py:275-281) and queue it for learning at
-// work-list slot `pos`; rows are packed, so clearing a recycled row (projections.py:82-85) is nsyn = 0
-// Sharded: every rank records the new owner (segment ids are global), but only the owner of a
-// cell keeps that cell's segment count, and only the new owner queues the segment; the others
-// note how many synapses it will grow (projections.py:114-127 on an empty row: min(sampling,
-// previous winners)), which is all they ever need to know about it.
 __device__ __forceinline__ bool col_is_local(const Dev &d, int cell) { const int col = cell >> 5; return col >= d.c0 && col < d.c1; }
 
-__device__ __forceinline__ void tm_bind_segment(const Dev &d, int seg, int cell, bool recycled, int pos, int grown) {
-    if (recycled) {
-        const int old = d.seg_cell[seg];
-        if (col_is_local(d, old)) atomicSub(&d.segcount[old], 1);
-    }
-    d.seg_cell[seg] = cell;
+// the global id of a local row (unsharded handles: the row IS the id)
+__device__ __forceinline__ int seg_gid_of(const Dev &d, int row) { return d.seg_gid ? d.seg_gid[row] : row; }
+
+// bind segment `seg` to winner cell `cell` (projections.py:275-281) and queue it for learning at
+// work-list slot `pos`; rows are packed, so clearing a recycled row (projections.py:82-85) is nsyn = 0.
+// Unsharded handles (row == id).
+__device__ __forceinline__ void tm_bind_segment(const Dev &d, int seg, int cell, bool recycled, int pos) {
+    if (recycled) atomicSub(&d.segcount[d.seg_cell[seg]], 1);
     // recyclable count of the id's 1024-block: a recycled id was counted and still is (its row is empty until the
-    // learning role has grown it, which then takes it off the count); a fresh id enters as an empty row.  A rank
-    // that does not own the cell only ever learns the size the row will have after that growth.
-    if (col_is_local(d, cell)) {
-        if (!recycled) atomicAdd(&d.recyc_cnt[seg >> 10], 1);
-        d.seg_nsyn[seg] = 0;
-        atomicAdd(&d.segcount[cell], 1);
-        if (pos < 0) pos = atomicAdd(&d.ctr->n_work, 1);
-        if (pos < d.work_cap) d.work[pos] = (uint32_t)seg; else atomicOr(&d.ctr->error, 4);
-    } else {
-        if (recycled && grown >= d.match_thr) atomicSub(&d.recyc_cnt[seg >> 10], 1);
-        if (!recycled && grown < d.match_thr) atomicAdd(&d.recyc_cnt[seg >> 10], 1);
-        d.seg_nsyn[seg] = grown;
+    // learning role has grown it, which then takes it off the count); a fresh id enters as an empty row
+    else atomicAdd(&d.recyc_cnt[seg >> 10], 1);
+    d.seg_cell[seg] = cell;
+    d.seg_nsyn[seg] = 0;
+    atomicAdd(&d.segcount[cell], 1);
+    if (pos < d.work_cap) d.work[pos] = (uint32_t)seg; else atomicOr(&d.ctr->error, 4);
+}
+
+// Column-sharded handles: request `rank` of this step gets global id `gid` (recycled: an id whose dead bit is set).
+// Every rank takes the identical decision and keeps the replicated dead bits / counts in step; the rank that owns
+// the id's old row gives it up, the rank that owns `cell` takes a local row for it and queues that row for the
+// learning role.  `grown`: the synapses the row will have once that role has run (projections.py:114-127 on an
+// empty row: min(sampling, previous winners)) -- known everywhere, so the bits can be set now.
+// pass 0: give up rows (pushes on the free stack); pass 1: take rows (pops) -- the two are separated by a barrier.
+__device__ __forceinline__ void shard_bind(const Dev &d, int gid, int cell, bool recycled, int grown, int pass) {
+    Counters *c = d.ctr;
+    const bool to_me = col_is_local(d, cell);
+    const int old_row = recycled ? d.g2l[gid] : -1;                 // >= 0: the id was mine
+    if (pass == 0) {
+        const bool alive = grown >= d.match_thr;
+        if (recycled && alive) { atomicAnd(&d.dead_bits[gid >> 5], ~(1u << (gid & 31))); atomicSub(&d.recyc_cnt[gid >> 10], 1); }
+        if (!recycled && !alive) { atomicOr(&d.dead_bits[gid >> 5], 1u << (gid & 31)); atomicAdd(&d.recyc_cnt[gid >> 10], 1); }
+        if (old_row >= 0) {
+            atomicSub(&d.segcount[d.seg_cell[old_row]], 1);
+            if (!to_me) {                                           // the id moves to another rank: free the row
+                d.seg_gid[old_row] = -1;
+                d.seg_nsyn[old_row] = 0;
+                d.g2l[gid] = -1;
+                d.lfree[atomicAdd(&c->n_lfree, 1)] = old_row;
+            }
+        }
+        return;
     }
+    if (!to_me) return;
+    int row = old_row;
+    if (row < 0) {
+        const int top = atomicSub(&c->n_lfree, 1) - 1;              // a freed row if there is one, else a fresh one
+        if (top >= 0) {
+            row = d.lfree[top];
+        } else {
+            atomicAdd(&c->n_lfree, 1);
+            row = atomicAdd(&c->L, 1);
+        }
+        if (row >= d.Lcap) { atomicOr(&c->error, 1); return; }
+        d.seg_gid[row] = gid;
+        d.g2l[gid] = row;
+    }
+    d.seg_cell[row] = cell;
+    d.seg_nsyn[row] = 0;
+    atomicAdd(&d.segcount[cell], 1);
+    const int pos = atomicAdd(&c->n_work, 1);
+    if (pos < d.work_cap) d.work[pos] = (uint32_t)row; else atomicOr(&c->error, 4);
 }
 
 // DenseProjection.update (projections.py:23-24) on winner row ri, fused with the rebuild of that
@@ -116,7 +151,7 @@ __device__ __forceinline__ void role_mid(const Dev &d, int p, int n_active, int 
     if (blk > 0) {
         if (!learning || !c->has_distal) return;
         const int q = p ^ 1;
-        const int n = c->S;          // ids at or above the S of the last scan still hold info == 0
+        const int n = d.world > 1 ? c->L : c->S;     // rows at or above the count of the last scan are not matching
         const int stride = n_cls * BS;
         for (int i0 = (blk - 1) * BS; i0 < n; i0 += stride) {
             const int seg = i0 + threadIdx.x;
@@ -259,7 +294,8 @@ __device__ __forceinline__ void role_mid(const Dev &d, int p, int n_active, int 
 #pragma unroll
         for (int j = 0; j < IPT; ++j) {
             const int seg = b * 1024 + (int)threadIdx.x * IPT + j;
-            fl[j] = (seg < S && d.seg_nsyn[seg] < d.match_thr) ? 1u : 0u;
+            const bool dead = whole ? d.seg_nsyn[min(seg, d.Scap - 1)] < d.match_thr : (d.dead_bits[seg >> 5] >> (seg & 31)) & 1u;
+            fl[j] = (seg < S && dead) ? 1u : 0u;
             cnt += fl[j];
         }
         uint32_t total;
@@ -267,12 +303,23 @@ __device__ __forceinline__ void role_mid(const Dev &d, int p, int n_active, int 
 #pragma unroll
         for (int j = 0; j < IPT; ++j) {
             const int seg = b * 1024 + (int)threadIdx.x * IPT + j;
-            if (fl[j] && rank < n_r) tm_bind_segment(d, seg, d.unacc_list[rank], true, whole ? wbase + rank : -1, grown);
+            if (fl[j] && rank < n_r) {
+                if (whole) tm_bind_segment(d, seg, d.unacc_list[rank], true, wbase + rank);
+                else d.asg_gid[rank] = seg;
+            }
             rank += (int)fl[j];
         }
     }
-    for (int i = threadIdx.x; i < n_new; i += BS)
-        tm_bind_segment(d, S + i, d.unacc_list[n_r + i], false, whole ? wbase + n_r + i : -1, grown);
+    if (whole) {
+        for (int i = threadIdx.x; i < n_new; i += BS) tm_bind_segment(d, S + i, d.unacc_list[n_r + i], false, wbase + n_r + i);
+    } else {                                    // sharded: ids first, then rows given up, then rows taken
+        __syncthreads();
+        for (int pass = 0; pass < 2; ++pass) {
+            for (int i = threadIdx.x; i < n_r + n_new; i += BS)
+                shard_bind(d, i < n_r ? d.asg_gid[i] : S + (i - n_r), d.unacc_list[i], i < n_r, grown, pass);
+            __syncthreads();
+        }
+    }
     if (threadIdx.x == 0) {
         c->n_recycled = n_r;
         c->n_new = n_new;
@@ -307,7 +354,7 @@ __device__ __forceinline__ void role_learn(const Dev &d, int p, int blk, int nbl
     Counters *c = d.ctr;
     {   // forget the previous scan's per-cell maxima (sparse clear; every reader ran in an earlier
         // launch) and reset what the coming scan accumulates
-        const int n = c->has_distal ? c->S : 0;
+        const int n = c->has_distal ? (d.world > 1 ? c->L : c->S) : 0;
         for (int i = blk * BS + threadIdx.x; i < n; i += nblk * BS)
             if ((d.match_bits[i >> 5] >> (i & 31)) & 1u) d.cellmax[d.seg_cell[i]] = 0u;
     }
@@ -332,7 +379,8 @@ __device__ __forceinline__ void role_learn(const Dev &d, int p, int blk, int nbl
     for (int item = blk * (BS / 64) + wv; item < n_work; item += nblk * (BS / 64)) {
         LSTAMP(0);
         const uint32_t w = d.work[item < n_front ? item : d.work_cap - n_back + (item - n_front)];
-        const int seg = (int)(w & 0x7FFFFFFFu), mode = (int)(w >> 31);
+        const int seg = (int)(w & 0x7FFFFFFFu), mode = (int)(w >> 31);        // (a local row)
+        const uint32_t gid = (uint32_t)seg_gid_of(d, seg);                    // the random draws are keyed by the global id
         const double dA = mode ? d.pun_act : d.lrn_act, dI = mode ? d.pun_inact : d.lrn_inact;
         const bool prune = mode ? d.pun_prune : d.lrn_prune;
         const int n = d.seg_nsyn[seg];
@@ -393,7 +441,7 @@ __device__ __forceinline__ void role_learn(const Dev &d, int p, int blk, int nbl
                         for (int j = 0; j < 4; ++j) {
                             const int i = b0 + j * 64 + lane;
                             const int wcell = i < n_w ? winner_at(i) : 0;
-                            pr[j] = htm_draw24(base2, (uint32_t)seg, enc_to_flat(wcell, d.K));       // :120
+                            pr[j] = htm_draw24(base2, gid, enc_to_flat(wcell, d.K));       // :120
                             take[j] = i < n_w && pr[j] < T;
                         }
 #pragma unroll
@@ -490,12 +538,15 @@ __device__ __forceinline__ void role_learn(const Dev &d, int p, int blk, int nbl
         }
         if (lane == 0) {
             d.seg_nsyn[seg] = n_total;
-            // recyclable segments (fewer synapses than the matching threshold, projections.py:80) per 1024 ids
+            // recyclable segments (fewer synapses than the matching threshold, projections.py:80) per 1024 ids.
+            // Sharded: a death is reported with the next exchange and every rank, this one included, applies it
+            // then; what becomes of a row bound this step every rank knew when it was bound (shard_bind).
             const bool was_dead = n < d.match_thr, is_dead = n_total < d.match_thr;
-            if (was_dead != is_dead) atomicAdd(&d.recyc_cnt[seg >> 10], is_dead ? 1 : -1);
-            if (d.world > 1 && !was_dead && is_dead) {                            // tell the other ranks
+            if (d.world == 1) {
+                if (was_dead != is_dead) atomicAdd(&d.recyc_cnt[seg >> 10], is_dead ? 1 : -1);
+            } else if (!was_dead && is_dead) {
                 const int slot = atomicAdd(&d.dead_list[0], 1);
-                if (slot < DEAD_CAP) d.dead_list[1 + slot] = seg; else atomicOr(&c->error, 8);
+                if (slot < DEAD_CAP) d.dead_list[1 + slot] = (int)gid; else atomicOr(&c->error, 8);
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -624,14 +675,14 @@ __device__ __forceinline__ void chunk_finish(const uint32_t *__restrict__ act, c
 // LDS: from word 4: column bitmap [colwords] (words 0..3 unused)
 template <int BS, bool use_lds, bool LARGE>
 __device__ __forceinline__ void role_scan(const Dev &d, int p, int blk, int nblk, int n_spec, uint32_t *lds) {
-    static_assert(BS == 256, "four waves of 16 segments");
-    constexpr int SEGS = 64;                       // segments per block iteration
+    static_assert(BS % 64 == 0, "whole waves of 16 segments");
+    constexpr int SEGS = BS / 4;                   // segments per block iteration: 16 per wave
     constexpr int U = 2;                           // segments in flight per lane group
     uint32_t *s_colbits = lds + 4;
-    constexpr bool need_cell = !LARGE;             // (column-sharded handles filter by owner cell: never LARGE)
+    constexpr bool need_cell = !LARGE;
     const ScanLds L{s_colbits};
     Counters *c = d.ctr;
-    const int S = c->S;
+    const int S = d.world > 1 ? c->L : c->S;         // rows to scan (a shard scans its local rows; a free row is empty)
     if (blk == 0 && threadIdx.x == 0) {
         c->step[p ^ 1] = c->step[p] + 1;
         c->has_distal = 1;
@@ -643,14 +694,13 @@ __device__ __forceinline__ void role_scan(const Dev &d, int p, int blk, int nblk
     const uint32_t base3 = htm_stream_base(d.seed, HTM_STREAM_SEGMENT_JITTER, c->step[p]);
     const int wave = threadIdx.x >> 6, gi = (threadIdx.x & 63) >> 3, l = threadIdx.x & 7;
     // round trip 1 of an iteration: synapse count, owner cell and the first chunk of each row, all unconditional
-    // (ids are clamped to the pool; rows of other ranks' segments exist in the replicated address space; both
-    // are masked once the segment count is known)
+    // (rows are clamped to the pool and masked once the row count is known)
     struct Batch { int seg[U], n[U], cell[U]; int4 ps[U]; };
     auto fetch = [&](int b) {
         Batch t;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            t.seg[u] = min(b * SEGS + wave * 16 + u * 8 + gi, d.Scap - 1);
+            t.seg[u] = min(b * SEGS + wave * 16 + u * 8 + gi, d.Lcap - 1);
             t.n[u] = d.seg_nsyn[t.seg[u]];
             t.cell[u] = need_cell ? d.seg_cell[t.seg[u]] : 0;
             t.ps[u] = *(const int4 *)(d.presyn + (size_t)t.seg[u] * d.E + l * 4);
@@ -667,12 +717,10 @@ __device__ __forceinline__ void role_scan(const Dev &d, int p, int blk, int nblk
     __syncthreads();                                 // the only barrier: from here on the waves share nothing
     for (int b = blk; b * SEGS < S; b += nblk) {
         int seg[U], n[U];
-        bool mine[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const bool ok = b * SEGS + wave * 16 + u * 8 + gi < S;
-            mine[u] = d.world == 1 || col_is_local(d, cur.cell[u]);
-            n[u] = (ok && mine[u]) ? cur.n[u] : 0;
+            n[u] = ok ? cur.n[u] : 0;
             seg[u] = ok ? cur.seg[u] : S;
         }
         // round trip 2 (only rows longer than one chunk): second chunk, in flight during the lookups of the first
@@ -718,11 +766,11 @@ __device__ __forceinline__ void role_scan(const Dev &d, int p, int blk, int nblk
             }
             const uint32_t sum = (uint32_t)group8_sum_first((int)acc[u]);     // (valid in the segment's first lane only)
             const int pot = (int)(sum & 0xFFFFu), conn = (int)(sum >> 16);
-            matching[u] = l == 0 && seg[u] < S && mine[u] && pot >= d.match_thr;      // :247
+            matching[u] = l == 0 && seg[u] < S && pot >= d.match_thr;                 // :247
             if (matching[u]) {
                 const bool active = conn >= d.act_thr;                                // :250
                 const int cell = need_cell ? cell_cur[u] : d.seg_cell[seg[u]];
-                const float jit = htm_jitter((float)pot, htm_draw24(base3, (uint32_t)seg[u], 0u));   // :234-235
+                const float jit = htm_jitter((float)pot, htm_draw24(base3, (uint32_t)seg_gid_of(d, seg[u]), 0u));   // :234-235
                 atomicMax(&d.cellmax[cell], __float_as_uint(jit));                   // :237
                 if (active) atomicOr(&d.pred[p][cell >> 5], 1u << (cell & 31));       // :251, networks.py:122
                 d.seg_info[seg[u]] = (uint32_t)pot | ((uint32_t)conn << 12) | 0x40000000u | (active ? 0x80000000u : 0u);
@@ -734,7 +782,7 @@ __device__ __forceinline__ void role_scan(const Dev &d, int p, int blk, int nblk
             const u64 m0 = __ballot(matching[0]), m1 = __ballot(matching[1]);
             const uint32_t b0 = (uint32_t)(((m0 & 0x0101010101010101ull) * 0x0102040810204080ull) >> 56);
             const uint32_t b1 = (uint32_t)(((m1 & 0x0101010101010101ull) * 0x0102040810204080ull) >> 56);
-            if ((threadIdx.x & 63) == 0) ((uint16_t *)d.match_bits)[b * 4 + wave] = (uint16_t)(b0 | (b1 << 8));
+            if ((threadIdx.x & 63) == 0) ((uint16_t *)d.match_bits)[b * (SEGS / 16) + wave] = (uint16_t)(b0 | (b1 << 8));
         }
         if (b_next * SEGS >= S) break;
         cur = LARGE ? nxt : fetch(b_next);
@@ -751,14 +799,64 @@ __global__ __launch_bounds__(256, MINW) void k_tm_scan(Dev d, int p, int n_spec)
     role_scan<256, use_lds, MINW == 1>(d, p, blockIdx.x, gridDim.x, n_spec, (uint32_t *)dyn_lds);
 }
 
+// the same for large pools under a big column bitmap: 1024-thread blocks (16 waves share one copy of the bitmap), two per CU
+template <bool use_lds>
+__global__ __launch_bounds__(1024, 8) void k_tm_scan_wide(Dev d, int p, int n_spec) {
+    role_scan<1024, use_lds, true>(d, p, blockIdx.x, gridDim.x, n_spec, (uint32_t *)dyn_lds);
+}
+
+// htm_populate: one wave per segment, lane i = synapse i.  Row q of the rank's own range: cell own_lo + q / spc,
+// segment id (cell - cell_begin) * spc + q % spc.  Presynaptic cells: (draw32 * N) >> 32, made distinct within the
+// segment in synapse order (a cell already taken by an earlier synapse moves on to the next free cell id, mod N).
+__global__ __launch_bounds__(256) void k_tm_populate(Dev d, long long cell_begin, long long own_lo, long long own_rows, int spc, int n_syn,
+                                                     double perm_lo, double perm_hi, uint32_t seed) {
+    const int lane = lane_id();
+    const uint32_t N = (uint32_t)d.C * (uint32_t)d.K;
+    const uint32_t base_c = htm_stream_base(seed, HTM_STREAM_POPULATE_CELL, 0u), base_p = htm_stream_base(seed, HTM_STREAM_POPULATE_PERM, 0u);
+    for (long long q = ((long long)blockIdx.x * 256 + threadIdx.x) >> 6; q < own_rows; q += ((long long)gridDim.x * 256) >> 6) {
+        const long long flat = own_lo + q / spc;
+        const int j = (int)(q % spc);
+        const uint32_t gid = (uint32_t)((flat - cell_begin) * spc + j);
+        const int row = d.world > 1 ? (int)q : (int)gid;
+        const bool on = lane < n_syn;
+        uint32_t cell = on ? (uint32_t)(((u64)htm_draw32(base_c, gid, (uint32_t)lane) * N) >> 32) : 0xFFFFFFFFu;
+        bool dup = false;                           // an earlier synapse drew the same cell?
+        for (int t = 0; t < n_syn; ++t) {
+            const uint32_t ct = (uint32_t)__builtin_amdgcn_readlane((int)cell, t);
+            dup |= on && lane > t && cell == ct;
+        }
+        if (__any(dup)) {                           // rare (about n_syn^2 / 2N of the segments): settle them in synapse order
+            for (int i = 1; i < n_syn; ++i) {
+                uint32_t ci = (uint32_t)__builtin_amdgcn_readlane((int)cell, i);
+                while (__any(on && lane < i && cell == ci)) ci = ci + 1u == N ? 0u : ci + 1u;
+                if (lane == i) cell = ci;
+            }
+        }
+        if (on) {
+            const uint32_t u = htm_draw24(base_p, gid, (uint32_t)lane);
+            const float perm = (float)(perm_lo + (perm_hi - perm_lo) * ((double)u * (1.0 / 16777216.0)));
+            const int enc = (int)((cell / (uint32_t)d.K) * 32u + cell % (uint32_t)d.K);
+            d.presyn[(size_t)row * d.E + lane] = enc | (perm >= d.perm_thr ? (int)SYN_CONNECTED : 0);
+            d.sperm[(size_t)row * d.E + lane] = perm;
+        }
+        if (lane == 0) {
+            const int owner = (int)((flat / d.K) * 32 + flat % d.K);
+            d.seg_cell[row] = owner;
+            d.seg_nsyn[row] = n_syn;
+            if (d.seg_gid) { d.seg_gid[row] = (int)gid; d.g2l[gid] = row; }
+            if (j == 0) d.segcount[owner] = spc;
+        }
+    }
+}
+
 // State.segment_potential (projections.py:246) for every segment, on demand: active presynaptic cells of the last
-// completed step (parity p), 8 lanes per segment.  Segments of other ranks read 0.
+// completed step (parity p), 8 lanes per segment (sharded handles: per local row).
 __global__ __launch_bounds__(256) void k_tm_potentials(Dev d, int p, int *out) {
-    const int S = d.ctr->S;
+    const int S = d.world > 1 ? d.ctr->L : d.ctr->S;
     const uint32_t *act = d.act[p];
     const int l = threadIdx.x & 7;
     for (int seg = (blockIdx.x * 256 + threadIdx.x) >> 3; seg < S; seg += (gridDim.x * 256) >> 3) {
-        const int n = (d.world == 1 || col_is_local(d, d.seg_cell[seg])) ? d.seg_nsyn[seg] : 0;
+        const int n = d.seg_nsyn[seg];
         const int *prow = d.presyn + (size_t)seg * d.E;
         int pot = 0;
         for (int i = l; i < n; i += 8) {

@@ -1,9 +1,10 @@
 """Column-sharded HierarchicalTemporalMemory: one process per GPU, one all-gather per timestep.
 
 Each rank owns a contiguous block of mini-columns (their Spatial Pooler rows, their cells and the
-distal segments of those cells) and runs its own engine handle; the only exchange is an all-gather
-of one fixed-size record per rank and step (DESIGN.md "Multi-GPU"; the protocol is pinned by
-oracle/sharded.py and tests/test_sharded_gloo.py).  torch is used for what it is here for: device
+distal segments of those cells, in rows of its own) and runs its own engine handle; the only exchange is an
+all-gather of one fixed-size record per rank and step -- the rank's top-k candidate columns with their cell
+words, 20 bytes each (DESIGN.md "Multi-GPU"; the protocol is pinned by oracle/sharded.py and
+tests/test_sharded_gloo.py).  torch is used for what it is here for: device
 buffers, the current stream, and torch.distributed (backend "nccl" = RCCL over xGMI).
 """
 
@@ -29,8 +30,13 @@ def env_rank_world():
 
 
 class ShardedHTM:
-    """The reference's HierarchicalTemporalMemory.process (networks.py:146-149) over `world`
-    GPUs.  `all_gather(recv, send)` defaults to torch.distributed.all_gather_into_tensor."""
+    """The reference's HierarchicalTemporalMemory.process (networks.py:146-149) over `world` GPUs.
+
+    `all_gather=None` (production): the exchange happens inside the library -- one C call per timestep
+    (`htm_shard_step`), RCCL `ncclAllGather` on the engine's stream; the communicator is created here from a
+    unique id that rank 0 hands to the others through torch.distributed (any backend).  `all_gather(recv, send)`
+    given: the step is split around that callable (`htm_shard_begin` / `htm_shard_finish`): rehearsals over gloo,
+    and several shards inside one process (LocalGroup)."""
 
     def __init__(self, input_dim, column_dim, cell_dim, rank, world, active_columns=None, permanence=None,
                  proximal=None, boosting=None, distal=None, seed=0, device=0, all_gather=None):
@@ -54,16 +60,22 @@ class ShardedHTM:
         self.engine = Engine(input_dim, column_dim, cell_dim, active_columns, proximal=proximal, boosting=boosting,
                              distal=distal, seed=seed, device=device, stream=self.stream.cuda_stream,
                              shard_rank=rank, shard_world=world)
-        nbytes = self.engine.shard_record_bytes()
-        self.send = torch.zeros(nbytes, dtype=torch.uint8, device=f"cuda:{device}")
-        self.recv = torch.zeros(nbytes * world, dtype=torch.uint8, device=f"cuda:{device}")
+        self.all_gather = all_gather
+        self.record_bytes = self.engine.shard_record_bytes()
         if all_gather is None:
             import torch.distributed as dist
-            all_gather = dist.all_gather_into_tensor
-        self.all_gather = all_gather
+            ids = [self.engine.shard_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            self.engine.shard_comm_init(ids[0])
+        else:
+            self.send = torch.zeros(self.record_bytes, dtype=torch.uint8, device=f"cuda:{device}")
+            self.recv = torch.zeros(self.record_bytes * world, dtype=torch.uint8, device=f"cuda:{device}")
 
     def process(self, input_bits, learning=True):
         eng = self.engine
+        if self.all_gather is None:
+            eng.shard_step(input_bits=input_bits, learning=learning)
+            return
         eng.shard_begin(self.send.data_ptr(), input_bits=input_bits, learning=learning)
         self.all_gather(self.recv, self.send)
         eng.shard_finish(self.recv.data_ptr(), learning=learning)
@@ -72,6 +84,10 @@ class ShardedHTM:
 
     def run(self, device_bank, n_inputs, steps, learning=True):
         eng = self.engine
+        if self.all_gather is None:
+            for _ in range(steps):
+                eng.shard_step(device_bank=device_bank, n_inputs=n_inputs, learning=learning)
+            return
         send, recv = self.send.data_ptr(), self.recv.data_ptr()
         for _ in range(steps):
             eng.shard_begin(send, device_bank=device_bank, n_inputs=n_inputs, learning=learning)

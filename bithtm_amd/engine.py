@@ -76,6 +76,7 @@ class Engine:
             cap = distal.segment_capacity
             cfg.segment_capacity = int(cap) if cap is not None else max(4096, 512 * self.active_columns)
             cfg.segment_slots = int(distal.segment_slots)
+            cfg.segment_capacity_local = int(getattr(distal, "segment_capacity_local", None) or 0)
         cfg.seed = int(seed) & 0xFFFFFFFF
         cfg.shard_rank, cfg.shard_world = int(shard_rank), int(shard_world)
         cfg.use_caller_stream = int(stream is not None)
@@ -209,6 +210,35 @@ class Engine:
         self._check(self.lib.htm_shard_finish(self.h, C.c_void_p(recv_ptr), int(bool(learning))), "htm_shard_finish")
         self.steps += 1
 
+    def shard_unique_id(self):
+        """128-byte id for shard_comm_init (rank 0 creates it, the caller hands it to the other ranks)."""
+        buf = C.create_string_buffer(128)
+        rc = self.lib.htm_shard_unique_id(buf)
+        if rc < 0:
+            raise HtmError(f"htm_shard_unique_id failed ({rc}): {self.lib.htm_last_error(None).decode()}")
+        return buf.raw
+
+    def shard_comm_init(self, unique_id):
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        self._check(self.lib.htm_shard_comm_init(self.h, buf), "htm_shard_comm_init")
+
+    def shard_step(self, input_bits=None, device_bank=None, n_inputs=1, learning=True):
+        """One column-sharded timestep with the exchange (RCCL) inside the library."""
+        if input_bits is not None:
+            packed = pack_bits(input_bits, self.words)
+            rc = self.lib.htm_shard_step(self.h, None, 1, packed.ctypes.data_as(C.c_void_p), int(bool(learning)))
+        else:
+            rc = self.lib.htm_shard_step(self.h, C.c_void_p(device_bank), int(n_inputs), None, int(bool(learning)))
+        self._check(rc, "htm_shard_step")
+        self.steps += 1
+
+    def populate(self, segments_per_cell, synapses=32, perm_lo=0.3, perm_hi=0.7, seed=0, cell_begin=0, cell_end=None):
+        """Pre-populated pool generated on the device (htm_populate; BASELINE.json configs[4])."""
+        if cell_end is None:
+            cell_end = self.column_dim * self.cell_dim
+        self._check(self.lib.htm_populate(self.h, int(cell_begin), int(cell_end), int(segments_per_cell), int(synapses),
+                                          float(perm_lo), float(perm_hi), int(seed) & 0xFFFFFFFF), "htm_populate")
+
     def profile(self, enable):
         self._check(self.lib.htm_profile(self.h, int(bool(enable))), "htm_profile")
 
@@ -234,10 +264,12 @@ class Engine:
             boosted_overlaps=self.read(L.F_BOOSTED, np.float64, self.column_dim))
 
     def read_store(self):
+        """The segment store.  On a column-sharded handle the per-segment arrays have one row per LOCAL row (the
+        segments of the rank's own cells); `seg_gid` gives each row's global id (-1 = free row)."""
         info = self.info()
-        S, E = info.segments, self.segment_slots
+        S, E = info.local_segments, self.segment_slots
         return dict(
-            S=S, slots=E,
+            S=info.segments, rows=S, slots=E, seg_gid=self.read(L.F_SEG_GID, np.int32, S),
             seg_cell=self.read(L.F_SEG_CELL, np.int32, S), seg_nsyn=self.read(L.F_SEG_NSYN, np.int32, S),
             presyn=self.read(L.F_SEG_PRESYN, np.int32, S * E).reshape(S, E),
             perm=self.read(L.F_SEG_PERM, np.float32, S * E).reshape(S, E),
@@ -249,7 +281,7 @@ class Engine:
         info = self.info()
         if not info.has_distal_state:
             return None
-        S, M, N = info.segments, info.matching_segments, self.column_dim * self.cell_dim
+        S, M, N = info.local_segments, info.matching_segments, self.column_dim * self.cell_dim
         seg = self.read(L.F_MATCH_SEGMENT, np.int32, M).astype(np.int64)
         minfo = self.read(L.F_MATCH_INFO, np.uint32, M)
         jit = self.read(L.F_MATCH_JITTER, np.float32, M)

@@ -54,7 +54,8 @@ class PredictiveProjection:
     def __init__(self, output_dim, permanence_initial=0.21, permanence_threshold=0.5, permanence_increment=0.1,
                  permanence_decrement=0.1, permanence_punishment=0.01, segment_activation_threshold=15,
                  segment_matching_threshold=15, segment_sampling_synapses=32,
-                 segment_bundle_growth_exponential=True, segment_capacity=None, segment_slots=128):
+                 segment_bundle_growth_exponential=True, segment_capacity=None, segment_slots=128,
+                 segment_capacity_local=None):
         assert segment_activation_threshold >= segment_matching_threshold      # projections.py:211
         self.output_dim = output_dim
         self.permanence_initial = permanence_initial
@@ -67,6 +68,7 @@ class PredictiveProjection:
         self.segment_sampling_synapses = segment_sampling_synapses
         self.segment_capacity = segment_capacity
         self.segment_slots = segment_slots
+        self.segment_capacity_local = segment_capacity_local      # column-sharded engines: rows for the rank's own segments
         self._engine = None
 
     # state views (copy_custom-style consumers: reference_implementations.py:51-66)

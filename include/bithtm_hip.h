@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define BITHTM_ABI_VERSION 1
+#define BITHTM_ABI_VERSION 2
 
 typedef struct htm_handle htm_handle;
 
@@ -70,7 +70,9 @@ typedef struct htm_config {
     int32_t segment_matching_threshold;     /* (:222) */
     int32_t segment_sampling_synapses;      /* (:223), 1..64 */
     /* fixed-capacity pool replacing DynamicArray2D growth (utils.py:79-135) */
-    int32_t segment_capacity;           /* max segments; overflow => HTM_ERR_CAPACITY */
+    int32_t segment_capacity;           /* max segment ids (of the whole model); overflow => HTM_ERR_CAPACITY */
+    int32_t segment_capacity_local;     /* column-sharded handles: rows for the segments of this rank's own cells
+                                           (0 = 2 * segment_capacity / shard_world, at most segment_capacity) */
     int32_t segment_slots;              /* synapse slots per segment, multiple of 64, <= 512 */
     uint32_t seed;                      /* keyed random draws, see bithtm_amd/csrc/htm_rng.h */
     int32_t shard_rank;                 /* column sharding: this handle owns columns               */
@@ -83,6 +85,8 @@ typedef struct htm_config {
 typedef struct htm_info {
     int64_t step_index;                 /* timesteps processed */
     int32_t segments;                   /* S: allocated segment ids (len(segment_bundle)) */
+    int32_t local_segments;             /* rows in use on this handle: = segments, except on a column-sharded handle
+                                           (rows of the segments its own cells own, some of them free) */
     int32_t matching_segments;          /* len(distal_state.matching_segment) of the last step */
     int32_t winner_cells;               /* len(winner_cell[0]) of the last step */
     int32_t active_cells;               /* len(active_cell[0]) of the last step */
@@ -122,7 +126,10 @@ typedef enum htm_field {
     HTM_F_MATCH_SEGMENT = 16,  /* int32[M]   State.matching_segment, UNORDERED (projections.py:247) */
     HTM_F_MATCH_INFO = 17,     /* uint32[M]  potential | activation<<12 | active<<31, same order */
     HTM_F_MATCH_JITTER = 18,   /* float[M]   matching_segment_jittered_potential, same order */
-    HTM_F_CELL_MAX_JITTER = 19 /* float[N]   State.max_jittered_potential (projections.py:236-238) */
+    HTM_F_CELL_MAX_JITTER = 19,/* float[N]   State.max_jittered_potential (projections.py:236-238) */
+    HTM_F_SEG_GID = 20         /* int32[S]   global segment id of each row: 0..S-1, except on a column-sharded handle,
+                                             where the per-segment fields above have htm_info.local_segments rows
+                                             (the segments of the rank's own cells; -1 = free row) */
 } htm_field;
 
 /* Construction: HierarchicalTemporalMemory.__init__ / SpatialPooler.__init__ /
@@ -190,6 +197,25 @@ int64_t htm_shard_record_bytes(htm_handle *h);
 int htm_shard_begin(htm_handle *h, const uint32_t *device_inputs, int32_t n_inputs, const uint32_t *packed_input,
                     int32_t learning, void *send_device);
 int htm_shard_finish(htm_handle *h, const void *recv_device, int32_t learning);
+
+/* The same timestep as ONE call, with the exchange done inside the library by RCCL (ncclAllGather on the
+ * handle's stream, device to device over xGMI; librccl is loaded when first needed).  One process per GPU:
+ *   rank 0:     htm_shard_unique_id(id)          128 bytes, handed to the other ranks by the caller
+ *   every rank: htm_shard_comm_init(h, id)       collective (ncclCommInitRank); allocates the record buffers
+ *   every rank: htm_shard_step(h, ...)           per timestep; the input as for htm_shard_begin */
+int htm_shard_unique_id(void *out128);
+int htm_shard_comm_init(htm_handle *h, const void *unique_id128);
+int htm_shard_step(htm_handle *h, const uint32_t *device_inputs, int32_t n_inputs, const uint32_t *packed_input,
+                   int32_t learning);
+
+/* Pre-populated segment pool, generated on the device (BASELINE.json configs[4]: 255 segments per cell, a pure
+ * scan stress): every cell with flat id in [cell_begin, cell_end) gets segments_per_cell segments of `synapses`
+ * synapses (>= the matching threshold, <= 64) to keyed-random distinct presynaptic cells with permanences keyed-
+ * uniform in [perm_lo, perm_hi); segment ids are (cell - cell_begin) * segments_per_cell + j.  Fresh handles only.
+ * On a column-sharded handle only the rows of its own cells are generated; give every handle of the group the
+ * same range.  (The reference grows its store step by step, projections.py:226; it has no counterpart.) */
+int htm_populate(htm_handle *h, int64_t cell_begin, int64_t cell_end, int32_t segments_per_cell, int32_t synapses,
+                 double perm_lo, double perm_hi, uint32_t seed);
 
 int htm_sync(htm_handle *h);
 int htm_get_info(htm_handle *h, htm_info *out);      /* synchronises; HTM_ERR_CAPACITY (with *out filled

@@ -23,8 +23,8 @@ from types import SimpleNamespace
 import numpy as np
 
 from .fexp import exp_f32
-from .keyed_rng import (draw24, draw_unit, STREAM_LEAST_USED, STREAM_GROWTH,
-                        STREAM_SEGMENT_JITTER)
+from .keyed_rng import (draw24, draw32, draw_unit, STREAM_LEAST_USED, STREAM_GROWTH,
+                        STREAM_SEGMENT_JITTER, STREAM_POPULATE_CELL, STREAM_POPULATE_PERM)
 
 EPS32 = np.float32(1e-8)     # `epsilon=1e-8` compared against float32 arrays (weak scalar)
 
@@ -209,6 +209,41 @@ class TemporalMemoryOracle:
         ps = self.presyn[segs]
         valid = ps >= 0
         return ps, valid, np.where(valid, ps, self.N)
+
+    # ---- synthetic pre-populated pool (twin of htm_populate / k_tm_populate; BASELINE.json configs[4])
+    def populate(self, segments_per_cell, synapses=32, perm_lo=0.3, perm_hi=0.7, seed=0, cell_begin=0, cell_end=None):
+        """Every cell in [cell_begin, cell_end) gets `segments_per_cell` segments of `synapses` synapses to keyed-random
+        presynaptic cells, distinct within a segment (in synapse order, a cell already taken moves on to the next
+        free cell id, mod N), permanences keyed-uniform in [perm_lo, perm_hi).  Segment ids are cell-major.  The
+        reference has no counterpart (it grows its store step by step, projections.py:226); this is the scan
+        stress SURVEY section 8(d) describes."""
+        assert self.S == 0 and self.step_index == 0
+        N = self.N
+        cell_end = N if cell_end is None else cell_end
+        spc, n = int(segments_per_cell), int(synapses)
+        S = (cell_end - cell_begin) * spc
+        gid = np.arange(S, dtype=np.int64)
+        self._ensure_slots(n)
+        self.seg_cell = (cell_begin + gid // spc).astype(np.int32)
+        self.seg_nsyn = np.full(S, n, dtype=np.int32)
+        self.presyn = np.full((S, self.slots), -1, dtype=np.int32)
+        self.perm = np.full((S, self.slots), -1.0, dtype=np.float32)
+        idx = np.arange(n)
+        for lo in range(0, S, 1 << 18):                 # in slices: the intermediates stay small
+            g = gid[lo:lo + (1 << 18)]
+            cells = ((draw32(seed, STREAM_POPULATE_CELL, 0, g[:, None], idx[None, :]).astype(np.uint64) * np.uint64(N))
+                     >> np.uint64(32)).astype(np.int64)
+            srt = np.sort(cells, axis=1)
+            for r in np.flatnonzero((srt[:, 1:] == srt[:, :-1]).any(axis=1)):      # rare: settle in synapse order
+                row = cells[r]
+                for i in range(1, n):
+                    while row[i] in row[:i]:
+                        row[i] = (row[i] + 1) % N
+            u = draw24(seed, STREAM_POPULATE_PERM, 0, g[:, None], idx[None, :]).astype(np.float64) * (1.0 / 16777216.0)
+            self.presyn[lo:lo + len(g), :n] = cells
+            self.perm[lo:lo + len(g), :n] = (perm_lo + (perm_hi - perm_lo) * u).astype(np.float32)
+        self.segcount[cell_begin:cell_end] = spc
+        self.S = S
 
     # ---- learning pieces
     def _update_permanence(self, segs, act_pad, d_active, d_inactive, prune):

@@ -28,6 +28,8 @@ import numpy as np
 STREAM_LEAST_USED = 1
 STREAM_GROWTH = 2
 STREAM_SEGMENT_JITTER = 3
+STREAM_POPULATE_CELL = 4      # pre-populated pools (populate): a = segment id, b = synapse index
+STREAM_POPULATE_PERM = 5
 
 _M1 = np.uint32(0x7FEB352D)
 _M2 = np.uint32(0x846CA68B)
@@ -62,6 +64,15 @@ def draw24(seed, stream, step, a, b=0):
         h = mix32(h0 ^ a)
         h = mix32(h ^ b)
     return h >> np.uint32(8)
+
+
+def draw32(seed, stream, step, a, b=0):
+    """The same hash, all 32 bits (device twin: htm_draw32)."""
+    with np.errstate(over="ignore"):
+        h0 = stream_base(seed, stream, step)
+        a = np.asarray(a).astype(np.uint32)
+        b = np.asarray(b).astype(np.uint32)
+        return mix32(mix32(h0 ^ a) ^ b)
 
 
 def draw_unit(seed, stream, step, a, b=0):

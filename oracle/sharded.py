@@ -1,24 +1,24 @@
 """Column-sharded form of the oracle timestep.  TEST INFRASTRUCTURE ONLY.
 
-This file pins the multi-GPU protocol the HIP engine implements (DESIGN.md, "Multi-GPU"):
-rank r of R owns the contiguous columns [c0, c1) -- their Spatial Pooler rows and duty cycles,
-their cells, and every distal segment whose owning cell is one of those cells.  All arrays keep
-the global index space ("replicated address space"): segment ids, cell ids and column ids mean
-the same thing on every rank; a rank simply never touches rows it does not own.
+This file pins the multi-GPU protocol the HIP engine implements (DESIGN.md, "Multi-GPU"; SURVEY section 8e):
+rank r of R owns the contiguous columns [c0, c1) -- their Spatial Pooler rows and duty cycles, their cells, and
+every distal segment whose owning cell is one of those cells.  Segment ids are GLOBAL (what an unsharded run would
+assign: they key the random draws and order the recycling); every rank keeps, for the whole id space, only whether
+an id has fewer synapses than the matching threshold (`dead`, what projections.py:80-81 looks at).
 
 One exchange per timestep (an all-gather of fixed-size per-rank records):
 
-    boosted[C_local]      float64 boosted overlaps of the rank's columns
-    act/win/unacc[C_local] the cell words each local column WOULD have if it became active
-                          (computable before the global top-k: they depend only on the
-                          rank's own previous predictions / segment maxima / segment counts)
-    dead[]                ids of owned segments that dropped below the matching threshold
-                          during the previous step's learning (needed by the global
-                          lowest-id-first recycling rule, projections.py:80-81)
+    candidates[KL]   the rank's own top-min(k, own columns) columns by (boosted desc, column asc), in ascending
+                     column order, each with its boosted overlap (f64), its bursting bit and the winner-cell and
+                     needs-a-new-segment words the column WOULD have if it became active (computable before the
+                     global top-k: they depend only on the rank's own previous predictions / segment maxima /
+                     segment counts; the active word is all cells when bursting, the winner word otherwise)
+    dead[]           ids of own segments that dropped below the matching threshold during the previous step's
+                     learning (the lowest-id-first recycling rule, projections.py:80-81, is global)
 
-After the gather every rank performs the identical global top-k and the identical segment-id
-allocation, so no further communication is needed and the R-way result equals the 1-way result
-bit for bit.  `all_gather` is injected: torch.distributed (gloo) in tests/test_sharded_gloo.py.
+After the gather every rank performs the identical global top-k over the R x KL candidates and the identical
+segment-id allocation, so no further communication is needed and the R-way result equals the 1-way result bit for
+bit.  `all_gather` is injected: torch.distributed (gloo) in tests/test_sharded_gloo.py.
 """
 
 from types import SimpleNamespace
@@ -46,13 +46,15 @@ class ShardedHTMOracle:
         self.rank, self.world = rank, world
         self.input_dim, self.column_dim, self.cell_dim, self.k = input_dim, column_dim, cell_dim, active_columns
         self.c0, self.c1 = shard_range(rank, world, column_dim)
+        self.n_cand = min(self.k, self.c1 - self.c0)
         self.spp = sp_params or SPParams()
         self.d_sp = sp_derived(self.spp, column_dim, active_columns)
         assert permanence is not None and permanence.shape == (column_dim, input_dim)
         self.permanence = np.array(permanence[self.c0:self.c1], dtype=np.float64)      # own rows only
         self.duty = np.zeros(self.c1 - self.c0, dtype=np.float32)
-        # the TM store keeps the global index space; rows of segments owned elsewhere stay untouched
+        # the TM store is indexed by global id; a rank only ever touches the rows of segments it owns
         self.tm = TemporalMemoryOracle(column_dim, cell_dim, tm_params, seed)
+        self.dead = np.zeros(0, dtype=np.bool_)           # replicated: id has fewer synapses than the matching threshold
         self.dead_out = np.zeros(0, dtype=np.int64)       # reported with the next exchange
 
     # ---- ownership
@@ -60,13 +62,21 @@ class ShardedHTMOracle:
         col = np.asarray(flat) // self.cell_dim
         return (col >= self.c0) & (col < self.c1)
 
+    def owned_segments(self):
+        return self.owns_cell(self.tm.seg_cell[:self.tm.S])
+
+    def _ensure_dead(self, n):
+        if len(self.dead) < n:
+            self.dead = np.concatenate([self.dead, np.zeros(max(n, 2 * len(self.dead)) - len(self.dead), dtype=np.bool_)])
+
     # ---- phase A: everything that needs only this rank's own state
     def local_record(self, input_bits):
         tm, K = self.tm, self.cell_dim
         connected = self.permanence >= self.spp.permanence_threshold
         overlaps = (connected & input_bits).sum(axis=1)
         boosted = exp_f32(self.d_sp.coef32 * self.duty).astype(np.float64) * overlaps
-        cols = np.arange(self.c0, self.c1)
+        cand = stable_topk(boosted, self.n_cand)           # own candidates, ascending (local) column
+        cols = cand + self.c0
         predicted = tm.prev_prediction[cols]
         bursting = ~predicted.any(axis=1)
         flat = cols[:, None] * K + np.arange(K)
@@ -85,27 +95,28 @@ class ShardedHTMOracle:
         jittered = (count.astype(np.float64) + u).astype(np.float32)
         least = np.abs(jittered - jittered.min(axis=1, keepdims=True)) < EPS32
         winner = predicted | (bursting[:, None] & np.where(column_matching[:, None], best, least))
-        act = predicted | bursting[:, None]
         unacc = winner & ~has_match if tm.prev_distal is not None else np.zeros_like(winner)
-        rec = SimpleNamespace(overlaps=overlaps, boosted=boosted, act=act, win=winner, unacc=unacc,
-                              bursting=bursting, dead=self.dead_out.copy())
-        return rec
+        return SimpleNamespace(overlaps=overlaps, boosted_all=boosted, boosted=boosted[cand], col=cols.astype(np.int64),
+                               bursting=bursting, win=winner, unacc=unacc, dead=self.dead_out.copy())
 
     # ---- phase B: identical global decisions + this rank's share of the work
     def finish_step(self, input_bits, records, learning=True):
         tm, K, C = self.tm, self.cell_dim, self.column_dim
         p, d = tm.params, tm.d
         t = tm.step_index
-        boosted = np.concatenate([r.boosted for r in records])
-        act_spec = np.concatenate([r.act for r in records])
+        boosted = np.concatenate([r.boosted for r in records])       # R x KL candidates, ascending column overall
+        col = np.concatenate([r.col for r in records])
         win_spec = np.concatenate([r.win for r in records])
         unacc_spec = np.concatenate([r.unacc for r in records])
         burst_spec = np.concatenate([r.bursting for r in records])
-        active = stable_topk(boosted, self.k)                                  # identical everywhere
-        # dead segments reported by the other ranks: only the "< threshold" fact matters here
-        for r, rec in enumerate(records):
-            if r != self.rank and len(rec.dead):
-                tm.seg_nsyn[rec.dead] = 0
+        assert np.all(np.diff(col) > 0)
+        chosen = stable_topk(boosted, self.k)                           # value desc, then candidate order = column asc
+        active = col[chosen]                                            # identical everywhere, ascending
+        # deaths every rank reported (this one's own included): recyclable from now on
+        self._ensure_dead(tm.S)
+        for rec in records:
+            if len(rec.dead):
+                self.dead[rec.dead] = True
         # SP learning and duty cycle on the own rows
         mine = active[(active >= self.c0) & (active < self.c1)] - self.c0
         if learning:
@@ -113,10 +124,13 @@ class ShardedHTMOracle:
         self.duty *= self.d_sp.momentum32
         self.duty[mine] += self.d_sp.increment32
 
+        bursting = burst_spec[chosen]
+        win = win_spec[chosen]
+        act = np.where(bursting[:, None], True, win)                    # networks.py:115
         flat = active[:, None] * K + np.arange(K)
-        winner_flat = flat[win_spec[active]]
+        winner_flat = flat[win]
         activation = np.zeros((C, K), dtype=np.bool_)
-        activation[active] = act_spec[active]
+        activation[active] = act
         dead_out = []
         if learning and tm.prev_distal is not None:
             dd = tm.prev_distal
@@ -131,35 +145,36 @@ class ShardedHTMOracle:
             column_active[active] = True
             punished = m[~column_active[mcell // K]]
             # allocation: every rank takes the same decision (projections.py:79-95, 271-281)
-            unaccounted = flat[unacc_spec[active]]
+            unaccounted = flat[unacc_spec[chosen]]
             n_w = -1 if tm.prev_winner is None else len(tm.prev_winner)
             if len(unaccounted):
-                recycled = np.flatnonzero(tm.seg_nsyn[:tm.S] < p.segment_matching_threshold)[:len(unaccounted)]
+                recycled = np.flatnonzero(self.dead[:tm.S])[:len(unaccounted)]
                 n_r = len(recycled)
                 n_new = len(unaccounted) - n_r
                 fresh = np.arange(tm.S, tm.S + n_new)
                 tm._ensure_rows(tm.S + n_new)
+                self._ensure_dead(tm.S + n_new)
                 old_cells = tm.seg_cell[recycled]
                 own_old = self.owns_cell(old_cells)
                 np.subtract.at(tm.segcount, old_cells[own_old], 1)
                 ids = np.concatenate([recycled, fresh]).astype(np.int64)
-                tm.seg_cell[ids] = unaccounted
+                tm.seg_cell[ids] = unaccounted          # (the assignment is a replicated decision: every rank knows it)
                 own_new = self.owns_cell(unaccounted)
                 tm.segcount[unaccounted[own_new]] += 1
-                tm.presyn[ids[own_new]] = -1
-                tm.perm[ids[own_new]] = -1.0
+                tm.presyn[ids] = -1                     # rows given up / taken: empty either way
+                tm.perm[ids] = -1.0
                 tm.seg_nsyn[ids] = 0
-                # segments bound elsewhere: remember only whether they end up below the threshold
+                # what becomes of the row once its owner has grown it is known everywhere
                 grown = min(p.segment_sampling_synapses, n_w) if n_w > 0 else 0
-                tm.seg_nsyn[ids[~own_new]] = grown
+                self.dead[ids] = grown < p.segment_matching_threshold
                 tm.S += n_new
                 learning_seg = np.concatenate([learning_seg, ids[own_new]])
             act_pad = tm._padded(tm.prev_activation)
+            thr = p.segment_matching_threshold
             before = tm.seg_nsyn[learning_seg].copy()
             tm._update_permanence(learning_seg, act_pad, d.learn_active, d.learn_inactive, d.learn_prune)
             if tm.prev_winner is not None:
                 tm._grow(learning_seg.astype(np.int64), act_pad, tm.prev_winner, t)
-            thr = p.segment_matching_threshold
             dead_out.append(learning_seg[(before >= thr) & (tm.seg_nsyn[learning_seg] < thr)])
             before = tm.seg_nsyn[punished].copy()
             tm._update_permanence(punished, act_pad, d.punish_active, d.punish_inactive, d.punish_prune)
@@ -172,9 +187,9 @@ class ShardedHTMOracle:
         tm.prev_winner = winner_flat
         tm.prev_distal = distal
         tm.step_index += 1
-        return SimpleNamespace(active_column=active, boosted_overlaps=boosted, winner_flat=winner_flat,
-                               cell_activation=activation, cell_prediction=prediction,     # own columns only
-                               bursting=burst_spec[active], distal_state=distal)
+        return SimpleNamespace(active_column=active, winner_flat=winner_flat,
+                               cell_activation=activation, cell_prediction=prediction,     # prediction: own columns only
+                               bursting=bursting, distal_state=distal)
 
     def _scan_owned(self, activation, step):
         """PredictiveProjection.process restricted to the segments this rank owns."""
@@ -212,30 +227,24 @@ class ShardedHTMOracle:
 DEAD_CAP = 256
 
 
-def burst_words(c_local):
-    return (c_local + 31) // 32
-
-
-def record_nbytes(c_local):
-    """[boosted f64 x C_local][act u32 x C_local][win u32 x C_local][unacc u32 x C_local]
-    [bursting bits u32 x ceil(C_local/32)][n_dead u32][dead ids u32 x DEAD_CAP][pad to 16 bytes]"""
-    n = c_local * (8 + 4 + 4 + 4) + 4 * burst_words(c_local) + 4 + 4 * DEAD_CAP
+def record_nbytes(n_cand):
+    """[boosted f64 x KL][column | bursting << 31  u32 x KL][winner word u32 x KL][needs-a-segment word u32 x KL]
+    [n_dead u32][dead ids u32 x DEAD_CAP][pad to 16 bytes]"""
+    n = n_cand * (8 + 4 + 4 + 4) + 4 + 4 * DEAD_CAP
     return (n + 15) // 16 * 16
 
 
 def pack_record(rec, cell_dim):
-    c_local = len(rec.boosted)
-    buf = np.zeros(record_nbytes(c_local), dtype=np.uint8)
+    kl = len(rec.boosted)
+    buf = np.zeros(record_nbytes(kl), dtype=np.uint8)
     weights = (np.uint32(1) << np.arange(cell_dim, dtype=np.uint32))
     o = 0
-    buf[o:o + 8 * c_local] = rec.boosted.astype(np.float64).view(np.uint8); o += 8 * c_local
-    for mat in (rec.act, rec.win, rec.unacc):
-        buf[o:o + 4 * c_local] = (mat.astype(np.uint32) * weights).sum(axis=1).astype(np.uint32).view(np.uint8)
-        o += 4 * c_local
-    bw = burst_words(c_local)
-    bits = np.zeros(bw * 32, dtype=np.bool_)
-    bits[:c_local] = rec.bursting
-    buf[o:o + 4 * bw] = np.packbits(bits, bitorder="little"); o += 4 * bw
+    buf[o:o + 8 * kl] = rec.boosted.astype(np.float64).view(np.uint8); o += 8 * kl
+    colword = rec.col.astype(np.uint32) | (rec.bursting.astype(np.uint32) << np.uint32(31))
+    buf[o:o + 4 * kl] = colword.view(np.uint8); o += 4 * kl
+    for mat in (rec.win, rec.unacc):
+        buf[o:o + 4 * kl] = (mat.astype(np.uint32) * weights).sum(axis=1).astype(np.uint32).view(np.uint8)
+        o += 4 * kl
     if len(rec.dead) > DEAD_CAP:
         raise OverflowError("more newly dead segments than the exchange record holds")
     buf[o:o + 4] = np.array([len(rec.dead)], dtype=np.uint32).view(np.uint8); o += 4
@@ -243,15 +252,15 @@ def pack_record(rec, cell_dim):
     return buf
 
 
-def unpack_record(buf, c_local, cell_dim):
-    o = 0
-    boosted = buf[o:o + 8 * c_local].view(np.float64).copy(); o += 8 * c_local
+def unpack_record(buf, n_cand, cell_dim):
+    kl, o = n_cand, 0
+    boosted = buf[o:o + 8 * kl].view(np.float64).copy(); o += 8 * kl
+    colword = buf[o:o + 4 * kl].view(np.uint32); o += 4 * kl
     mats = []
-    for _ in range(3):
-        words = buf[o:o + 4 * c_local].view(np.uint32); o += 4 * c_local
+    for _ in range(2):
+        words = buf[o:o + 4 * kl].view(np.uint32); o += 4 * kl
         mats.append(((words[:, None] >> np.arange(cell_dim, dtype=np.uint32)) & 1).astype(np.bool_))
-    bw = burst_words(c_local)
-    bursting = np.unpackbits(buf[o:o + 4 * bw], bitorder="little")[:c_local].astype(np.bool_); o += 4 * bw
     n_dead = int(buf[o:o + 4].view(np.uint32)[0]); o += 4
     dead = buf[o:o + 4 * n_dead].view(np.uint32).astype(np.int64)
-    return SimpleNamespace(boosted=boosted, act=mats[0], win=mats[1], unacc=mats[2], dead=dead, bursting=bursting)
+    return SimpleNamespace(boosted=boosted, col=(colword & np.uint32(0x7FFFFFFF)).astype(np.int64),
+                           bursting=(colword >> np.uint32(31)).astype(np.bool_), win=mats[0], unacc=mats[1], dead=dead)

@@ -39,14 +39,14 @@ def main():
     full = HTMOracle(I, C, K, seed=seed, sp_params=spp, tm_params=tmp, permanence=perm)
     part = ShardedHTMOracle(rank, world, I, C, K, seed=seed, sp_params=spp, tm_params=tmp, permanence=perm)
     c0, c1 = part.c0, part.c1
-    c_local = c1 - c0
-    nbytes = record_nbytes(c_local)
+    n_cand = part.n_cand
+    nbytes = record_nbytes(n_cand)
 
     def all_gather(rec):
         send = torch.from_numpy(pack_record(rec, K))
         recv = [torch.empty(nbytes, dtype=torch.uint8) for _ in range(world)]
         dist.all_gather(recv, send)
-        return [unpack_record(r.numpy(), c_local, K) for r in recv]
+        return [unpack_record(r.numpy(), n_cand, K) for r in recv]
 
     rng = np.random.RandomState(seed + 1)
     bank = rng.rand(P, I) < density
@@ -63,7 +63,7 @@ def main():
         def eq(name, a, b):
             assert np.array_equal(np.asarray(a), np.asarray(b)), f"rank {rank} step {t}: {name}"
         eq("active_column", out.active_column, f_sp.active_column)
-        eq("boosted", out.boosted_overlaps.view(np.int64), f_sp.boosted_overlaps.view(np.int64))
+        eq("boosted (own)", rec.boosted_all.view(np.int64), f_sp.boosted_overlaps[c0:c1].view(np.int64))
         eq("overlaps (own)", rec.overlaps, f_sp.overlaps[c0:c1])
         eq("winner cells", out.winner_flat, f_tm.winner_cell[0] * K + f_tm.winner_cell[1])
         eq("activation", out.cell_activation, f_tm.cell_activation)
@@ -75,15 +75,14 @@ def main():
         eq("seg_cell", ptm.seg_cell[:S], ftm.seg_cell[:S])
         owned = part.owns_cell(ftm.seg_cell[:S])
         eq("nsyn (own)", ptm.seg_nsyn[:S][owned], ftm.seg_nsyn[:S][owned])
-        # deaths of this step travel with the NEXT exchange: until then the other ranks may still
-        # see those segments as alive; every other "< threshold" flag must already agree
+        # deaths of this step travel with the NEXT exchange (the owner applies its own then, too): until then
+        # those ids still read alive; every other "< threshold" flag must already agree, on every rank
         pending = [None] * world
         dist.all_gather_object(pending, part.dead_out.tolist())
         settled = np.ones(S, dtype=np.bool_)
-        for r, ids in enumerate(pending):
-            if r != rank:
-                settled[np.asarray(ids, dtype=np.int64)] = False
-        eq("dead flags (settled)", (ptm.seg_nsyn[:S] < thr)[settled], (ftm.seg_nsyn[:S] < thr)[settled])
+        for ids in pending:
+            settled[np.asarray(ids, dtype=np.int64)] = False
+        eq("dead flags (settled)", part.dead[:S][settled], (ftm.seg_nsyn[:S] < thr)[settled])
         fd, pd = f_tm.distal_state, out.distal_state
         mine = owned[fd.matching_segment]
         eq("matching (own)", pd.matching_segment, fd.matching_segment[mine])

@@ -54,16 +54,8 @@ def _run(world, I, C, K, P, density, noise, steps, jump, seed, spp=None, tmp=Non
             c0, c1 = m.column_range
             info = eng.check_capacity()
             tag = f"rank {m.rank}/{world} step {t}"
-            if info.segments != otm.S:
-                flags = eng.read(L.F_SEG_NSYN, np.int32, info.segments)
-                sc = eng.read(L.F_SEG_CELL, np.int32, info.segments)
-                n = min(info.segments, otm.S)
-                bad = np.flatnonzero((flags[:n] < thr) != (otm.seg_nsyn[:n] < thr))
-                raise AssertionError(
-                    f"{tag}: S {info.segments} vs {otm.S}; requests={info.new_segment_requests} recycled={info.recycled_segments} "
-                    f"appended={info.appended_segments}; oracle dead now={int((otm.seg_nsyn[:otm.S] < thr).sum())}; "
-                    f"flag mismatches at {bad[:10]} flags={flags[bad[:10]]} oracle={otm.seg_nsyn[bad[:10]]} "
-                    f"owners={(sc[bad[:10]] // K) // ((c1 - c0))} learning={learning}")
+            assert info.segments == otm.S, (f"{tag}: S {info.segments} vs {otm.S}; requests={info.new_segment_requests} "
+                                            f"recycled={info.recycled_segments} appended={info.appended_segments} learning={learning}")
             act_cols = eng.read(L.F_ACTIVE_COLUMN, np.int32, k)
             assert np.array_equal(act_cols, o_sp.active_column), f"{tag}: active columns"
             act = words_to_bool(eng.read(L.F_CELL_ACTIVATION, np.uint32, C), K)
@@ -75,26 +67,34 @@ def _run(world, I, C, K, P, density, noise, steps, jump, seed, spp=None, tmp=Non
             burst = eng.read(L.F_BURSTING, np.uint8, k).astype(bool)
             assert np.array_equal(burst, o_tm.active_column_bursting[:, 0]), f"{tag}: bursting"
             boosted = eng.read(L.F_BOOSTED, np.float64, C)
-            assert np.array_equal(boosted.view(np.int64), o_sp.boosted_overlaps.view(np.int64)), f"{tag}: boosted"
-            seg_cell = eng.read(L.F_SEG_CELL, np.int32, otm.S)
-            assert np.array_equal(seg_cell, otm.seg_cell[:otm.S]), f"{tag}: seg_cell"
-            owned = (seg_cell // K >= c0) & (seg_cell // K < c1)
-            nsyn = eng.read(L.F_SEG_NSYN, np.int32, otm.S)
-            assert np.array_equal(nsyn[owned], otm.seg_nsyn[:otm.S][owned]), f"{tag}: nsyn (own)"
+            assert np.array_equal(boosted[c0:c1].view(np.int64), o_sp.boosted_overlaps[c0:c1].view(np.int64)), f"{tag}: boosted (own)"
+            # the rank's rows hold exactly the segments its cells own, under their global ids
+            rows = info.local_segments
+            gid = eng.read(L.F_SEG_GID, np.int32, rows)
+            live = np.flatnonzero(gid >= 0)
+            owned = np.flatnonzero((otm.seg_cell[:otm.S] // K >= c0) & (otm.seg_cell[:otm.S] // K < c1))
+            assert np.array_equal(np.sort(gid[live]), owned), f"{tag}: ids of the own segments"
+            seg_cell = eng.read(L.F_SEG_CELL, np.int32, rows)
+            assert np.array_equal(seg_cell[live], otm.seg_cell[gid[live]]), f"{tag}: seg_cell (own)"
+            nsyn = eng.read(L.F_SEG_NSYN, np.int32, rows)
+            assert np.array_equal(nsyn[live], otm.seg_nsyn[gid[live]]), f"{tag}: nsyn (own)"
             od = o_tm.distal_state
-            mseg = eng.read(L.F_MATCH_SEGMENT, np.int32, otm.S)
-            mine = owned[od.matching_segment]
-            assert np.array_equal(mseg, od.matching_segment[mine]), f"{tag}: matching segments (own)"
-            minfo = eng.read(L.F_MATCH_INFO, np.uint32, otm.S)
-            assert np.array_equal((minfo >> 31).astype(bool), od.matching_segment_active[mine]), f"{tag}: active segments (own)"
+            mrow = eng.read(L.F_MATCH_SEGMENT, np.int32, rows)
+            minfo = eng.read(L.F_MATCH_INFO, np.uint32, rows)
+            order = np.argsort(gid[mrow], kind="stable")
+            mine = np.isin(od.matching_segment, owned)
+            assert np.array_equal(gid[mrow][order], od.matching_segment[mine]), f"{tag}: matching segments (own)"
+            assert np.array_equal((minfo[order] >> 31).astype(bool), od.matching_segment_active[mine]), f"{tag}: active segments (own)"
+            assert np.array_equal((minfo[order] & 0xFFF).astype(np.int64), od.segment_potential[od.matching_segment[mine]]), f"{tag}: potentials (own)"
             dead_seen += int((otm.seg_nsyn[:otm.S] < thr).sum() > 0)
             if check_store:
                 E = eng.segment_slots
-                presyn = eng.read(L.F_SEG_PRESYN, np.int32, otm.S * E).reshape(otm.S, E)
-                pm = eng.read(L.F_SEG_PERM, np.float32, otm.S * E).reshape(otm.S, E)
-                ids = np.flatnonzero(owned)
-                a = canonical_synapses(seg_cell[ids], presyn[ids], pm[ids])
-                b = canonical_synapses(otm.seg_cell[ids], otm.presyn[ids], otm.perm[ids])
+                presyn = eng.read(L.F_SEG_PRESYN, np.int32, rows * E).reshape(rows, E)
+                pm = eng.read(L.F_SEG_PERM, np.float32, rows * E).reshape(rows, E)
+                pot = eng.read(L.F_SEG_POTENTIAL, np.int32, rows)
+                assert np.array_equal(pot[live].astype(np.int64), od.segment_potential[gid[live]]), f"{tag}: all potentials (own)"
+                a = canonical_synapses(seg_cell[live], presyn[live], pm[live])
+                b = canonical_synapses(otm.seg_cell[gid[live]], otm.presyn[gid[live]], otm.perm[gid[live]])
                 for (ca, ia, pa), (cb, ib, pb) in zip(a, b):
                     assert ca == cb and np.array_equal(ia, ib) and np.array_equal(pa.view(np.int32), pb.view(np.int32)), \
                         f"{tag}: synapses of an owned segment"

@@ -53,15 +53,17 @@ def test_wire_format_round_trip():
     from types import SimpleNamespace
     from oracle.sharded import pack_record, unpack_record, record_nbytes, DEAD_CAP
     rng = np.random.RandomState(0)
-    c_local, K = 96, 12
-    rec = SimpleNamespace(boosted=rng.rand(c_local), act=rng.rand(c_local, K) < 0.5, win=rng.rand(c_local, K) < 0.2,
-                          unacc=rng.rand(c_local, K) < 0.1, bursting=rng.rand(c_local) < 0.5,
+    kl, K = 41, 12
+    rec = SimpleNamespace(boosted=rng.rand(kl), col=np.sort(rng.choice(5000, kl, replace=False)).astype(np.int64),
+                          bursting=rng.rand(kl) < 0.5, win=rng.rand(kl, K) < 0.2, unacc=rng.rand(kl, K) < 0.1,
                           dead=np.array([5, 77, 1234567], dtype=np.int64))
     buf = pack_record(rec, K)
-    assert len(buf) == record_nbytes(c_local) and len(buf) % 16 == 0
-    back = unpack_record(buf, c_local, K)
-    for f in ("boosted", "act", "win", "unacc", "bursting", "dead"):
+    assert len(buf) == record_nbytes(kl) and len(buf) % 16 == 0
+    back = unpack_record(buf, kl, K)
+    for f in ("boosted", "col", "bursting", "win", "unacc", "dead"):
         assert np.array_equal(getattr(back, f), getattr(rec, f)), f
     rec.dead = np.arange(DEAD_CAP + 1)
     with pytest.raises(OverflowError):
         pack_record(rec, K)
+    # 20 B per candidate; BASELINE.json configs[3] (65 536 columns, k = 1 311) sharded 8-way
+    assert record_nbytes(1311) <= 32 * 1024
