@@ -138,6 +138,71 @@ def cpu_baseline(w, htm, noisy, start_step, sample_steps):
                        f"(S={ora.temporal_memory.S} segments), single-threaded NumPy")
 
 
+STRESS = dict(input_dim=1024, column_dim=262144, cell_dim=16, world=8, segments_per_cell=255, synapses=32,
+              perm_lo=0.3, perm_hi=0.7, seed=0, segment_slots=64, patterns=8, density=0.02)
+
+
+class LazyPermanence:
+    """Rows [a, b) of a randn(C, I) * 0.1 matrix, generated when sliced (a rank only ever reads its own rows)."""
+
+    def __init__(self, columns, inputs, seed):
+        self.shape, self.seed = (columns, inputs), seed
+
+    def __getitem__(self, rows):
+        a, b, _ = rows.indices(self.shape[0])
+        return np.random.RandomState(self.seed + a).randn(b - a, self.shape[1]) * 0.1
+
+
+def stress_leg(steps=8, warmup=3):
+    """BASELINE.json configs[4] (262 144 columns x 16 cells, 255 segments per cell, 8 GPUs: the HBM-bound scan stress of
+    SURVEY section 8d) as far as one GPU can hold it: the whole 8-rank group runs in this process (bithtm_amd.distributed.
+    LocalGroup: every sharded kernel, the all-gather as device copies), with the pre-populated pool generated on the
+    device for rank 0's cells only -- exactly one rank's shard of the pool, 133.7 M segments x 32 synapses.  Reported:
+    rank 0's segment scan (the dominant kernel) against the HBM roofline, and rank 0's whole step."""
+    import bithtm_amd as B
+    from bithtm_amd.distributed import LocalGroup
+    s = STRESS
+    C, K, I, world, spc = s["column_dim"], s["cell_dim"], s["input_dim"], s["world"], s["segments_per_cell"]
+    k = round(C * 0.02)
+    own_cells = C // world * K
+    rows0 = own_cells * spc
+    growth = 64 * k                                   # ids for the segments the bursting columns grow meanwhile
+    perm = LazyPermanence(C, I, 12345)
+
+    def parts(r):
+        return dict(distal=B.PredictiveProjection(C * K, segment_capacity=rows0 + growth, segment_slots=s["segment_slots"],
+                                                  segment_capacity_local=(rows0 if r == 0 else 0) + growth))
+    t0 = time.perf_counter()
+    group = LocalGroup(world, I, C, K, active_columns=k, permanence=perm, make_parts=parts, seed=0)
+    for e in group.engines:                           # every rank is told the same range: rank 0's cells
+        e.populate(spc, synapses=s["synapses"], perm_lo=s["perm_lo"], perm_hi=s["perm_hi"], seed=s["seed"], cell_begin=0, cell_end=own_cells)
+    rng = np.random.RandomState(7)
+    group.upload_bank(rng.rand(s["patterns"], I) < s["density"])
+    group.run(warmup)
+    eng = group.engines[0]
+    eng.sync()
+    setup_s = time.perf_counter() - t0
+    eng.profile(True)
+    group.run(steps)
+    prof = {n: 1e3 * ms / cnt for n, (ms, cnt) in eng.profile_read().items() if cnt}
+    eng.profile(False)
+    info = eng.check_capacity()
+    rows = info.local_segments
+    scan_bytes = (4 * s["synapses"] + 8) * rows0 + (4 * s["synapses"] + 8) * (rows - rows0)     # 4 B per synapse + 8 B per segment
+    scan_us = prof["tm_scan"]
+    ach = scan_bytes / scan_us / 1e3
+    out = dict(workload=f"configs[4] on one GPU: rank 0 of {world} of {C} columns x {K} cells; its cells' {spc} segments x "
+                        f"{s['synapses']} synapses each ({rows0} segments, generated on the device); all {world} ranks run in this process",
+               kernel="k_tm_scan_wide (tm_scan of rank 0)", segments=int(rows), bytes_per_launch=int(scan_bytes),
+               avg_launch_us=round(scan_us, 1), achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4),
+               rank0_launch_us={n: round(v, 1) for n, v in prof.items()}, rank0_step_us=round(sum(prof.values()), 1),
+               exchange_bytes_per_rank=int(eng.shard_record_bytes()), setup_s=round(setup_s, 1))
+    log(f"[bench] configs[4] leg: rank 0 scans {rows} segments in {scan_us:.0f} us = {ach:.0f} GB/s ({ach / HBM_PEAK_GBS:.1%} of peak); "
+        f"its step {out['rank0_step_us']:.0f} us; setup {setup_s:.1f} s")
+    del group
+    return out
+
+
 def run_single(args):
     w = dict(WORKLOAD)
     if args.columns:
@@ -196,10 +261,10 @@ def run_single(args):
     info = eng.check_capacity()
     store = eng.read_store()
     rb = role_bytes(w, k, store["seg_nsyn"], info.work_items, info.matching_segments)
-    role_us = {n: 1e3 * ms / max(cnt, 1) for n, (ms, cnt) in prof_roles.items()}
+    role_us = {n: 1e3 * ms / cnt for n, (ms, cnt) in prof_roles.items() if cnt}
     log("[bench] one role per launch, average launch (us): " +
         ", ".join(f"{n}={v:.1f}" for n, v in sorted(role_us.items(), key=lambda kv: -kv[1])))
-    if pipeline and all(n in prof_timed for n in LAUNCH_ROLES):
+    if pipeline and all(prof_timed.get(n, (0, 0))[1] for n in LAUNCH_ROLES):
         launch_us = {n: 1e3 * prof_timed[n][0] / max(prof_timed[n][1], 1) for n in LAUNCH_ROLES}
         launch_bytes = {n: sum(rb[r] for r in roles) for n, roles in LAUNCH_ROLES.items()}
         kernel_of = LAUNCH_KERNEL
@@ -228,6 +293,17 @@ def run_single(args):
     if not args.no_cpu_baseline:
         cpu = cpu_baseline(w, htm, noisy, int(eng.info().step_index), args.cpu_steps)
         log(f"[bench] cpu baseline: {cpu['value']:.2f} timesteps/s")
+    step_index, segments = int(info.step_index), int(info.segments)
+    stress = None
+    if not args.no_stress and not args.columns:
+        del eng, htm, bank, store                       # the leg needs the device to itself (memory, and CU slots: see DESIGN.md)
+        import gc
+        gc.collect()
+        try:
+            stress = stress_leg()
+        except Exception as e:                          # a report beside the headline: never a reason to lose the line
+            log(f"[bench] configs[4] leg failed: {e!r}")
+            stress = dict(error=repr(e))
 
     return dict(
         metric="HTM timesteps/sec (SP + TM, learning on), 65536 cols x 32 cells", value=round(steps_per_s, 1),
@@ -237,10 +313,10 @@ def run_single(args):
         config=dict(workload="configs[2]: 65536 columns x 32 cells, SP + TM learning on, 1 MI355X",
                     input_dim=w["input_dim"], column_dim=w["column_dim"], cell_dim=w["cell_dim"], active_columns=k,
                     patterns=w["patterns"], input_density=w["density"], flip_noise=w["noise"],
-                    pretrain_steps=pretrain, segments=int(info.segments), segment_slots=w["segment_slots"],
+                    pretrain_steps=pretrain, segments=segments, segment_slots=w["segment_slots"],
                     hip_graph=use_graph, pipelined=pipeline, repetitions=reps),
         repetitions=[round(r, 1) for r in rates],
-        roofline=roofline, cpu_baseline=cpu,
+        roofline=roofline, cpu_baseline=cpu, stress=stress,
         role_us_one_per_launch={n: round(v, 2) for n, v in role_us.items()},
         role_bytes={n: int(v) for n, v in rb.items()})
 
@@ -255,6 +331,7 @@ def main():
     ap.add_argument("--reps", type=int, default=0, help="timed repetitions (default: enough for about 4000 timed steps, 3..15)")
     ap.add_argument("--cpu-steps", type=int, default=40)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-stress", action="store_true", help="skip the configs[4] leg (one rank's pre-populated shard)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="one role per launch (what the profiled replay always does)")
     args = ap.parse_args()

@@ -1,10 +1,12 @@
 """bench.py --gpus N (N > 1): the same workload column-sharded over N MI355X, one process per GPU
-(launched by torch.distributed.run), one RCCL all-gather per timestep.  Strong scaling: the model
-(65 536 columns x 32 cells) is fixed, each rank owns column_dim / N columns.
+(launched by torch.distributed.run), one RCCL all-gather per timestep -- each rank's top-k candidate columns with
+their cell words, 20 bytes each (27 KB per rank at 8-way) -- issued from inside the library on the engine's stream
+(`htm_shard_step`: one C call per timestep).  Strong scaling: the model (65 536 columns x 32 cells) is fixed, each
+rank owns column_dim / N columns, their cells and their cells' segments.
 
-BITHTM_DIST_BACKEND=gloo and BITHTM_SINGLE_DEVICE=1 rehearse the multi-process flow on a box with
-one GPU (records staged through host memory); the default is backend "nccl" (= RCCL) on
-cuda:LOCAL_RANK with the records exchanged device-to-device."""
+BITHTM_DIST_BACKEND=gloo and BITHTM_SINGLE_DEVICE=1 rehearse the multi-process flow on a box with one GPU (the
+step is then split around a host-staged gather); the default is backend "nccl" (= RCCL over xGMI) on
+cuda:LOCAL_RANK, torch.distributed being used only to hand the RCCL unique id to the ranks and for the barriers."""
 
 import os
 import sys
@@ -37,7 +39,7 @@ def run_sharded(args):
     C, I, K = w["column_dim"], w["input_dim"], w["cell_dim"]
 
     if backend == "nccl":
-        gather = None                                # torch.distributed.all_gather_into_tensor on device buffers
+        gather = None                                # ncclAllGather inside the library (htm_shard_step)
     else:
         def gather(recv, send):                      # rehearsal path: stage through host memory
             host = send.cpu()
@@ -77,26 +79,40 @@ def run_sharded(args):
     dist.all_reduce(lo, op=dist.ReduceOp.MIN)
     dist.all_reduce(hi, op=dist.ReduceOp.MAX)
     consistent = bool((lo == hi).all().item())
-    # per-kernel device time on this rank (HIP events on the engine's stream) over a short profiled replay;
-    # every rank takes part, the exchange is collective
+    # per-launch device time on this rank (HIP events on the engine's stream) over a short profiled replay; every
+    # rank takes part, the exchange is collective.  The dominant launch is the arg-max over ALL launches of the step.
     roofline = None
     try:
-        prof_steps = min(args.steps, 100)
+        prof_steps = max(min(args.steps, 100), 20)
         eng.profile(True)
         htm.run(bank, n_bank, prof_steps)
-        prof = eng.profile_read()
+        prof = {n: v for n, v in eng.profile_read().items() if v[1]}
         eng.profile(False)
-        if rank == 0 and "tm_scan" in prof:
+        if rank == 0 and prof:
             store = eng.read_store()
-            c0, c1 = htm.column_range
-            own = (store["seg_cell"] // K >= c0) & (store["seg_cell"] // K < c1)
-            nbytes = 4 * int(store["seg_nsyn"][own].sum()) + 8 * len(store["seg_nsyn"])
-            ms, n = prof["tm_scan"]
-            us = 1e3 * ms / max(n, 1)
-            roofline = dict(bound="hbm", kernel="tm_scan (rank 0's own segments)", achieved=round(nbytes / us / 1e3, 1), peak=bench.HBM_PEAK_GBS,
-                            unit="GB/s", frac=round(nbytes / us / 1e3 / bench.HBM_PEAK_GBS, 4), traffic=None, bytes_per_launch=nbytes,
-                            avg_launch_us=round(us, 2),
-                            kernel_us_per_step={k: round(1e3 * v[0] / prof_steps, 2) for k, v in prof.items()})
+            live = store["seg_gid"] >= 0
+            cl = C // world
+            k = htm.active_columns
+            kl = min(k, cl)
+            W = ((I + 127) // 128) * 4
+            S_own, syn_own = int(live.sum()), int(store["seg_nsyn"][live].sum())
+            info2 = eng.info()
+            launch_bytes = {      # algorithmic bytes of this rank's share
+                "shard_overlap": cl * W * 4 + W * 4 + cl * 4 + cl * 20 + 12 * C,
+                "sp_select": cl * 8 + 4 * 4096 * 4,
+                "shard_candidates": cl * 8 + 20 * kl + kl * (4 + 32 * 8),
+                "shard_select": 5 * 8 * world * kl + 20 * k,
+                "tm_mid": 13 * k + 8 * S_own + 12 * info2.matching_segments + (2 * 8 * I + W * 4) * k // world + 8 * cl,
+                "tm_learn": int(16 * syn_own / max(S_own, 1) * info2.work_items) + 4 * S_own,
+                "tm_scan": 4 * syn_own + 8 * S_own,
+            }
+            us = {n: 1e3 * ms / cnt for n, (ms, cnt) in prof.items()}
+            dominant = max((n for n in us if n in launch_bytes), key=lambda n: us[n])
+            ach = launch_bytes[dominant] / us[dominant] / 1e3
+            roofline = dict(bound="hbm", kernel=f"{dominant} (rank 0's share)", achieved=round(ach, 1), peak=bench.HBM_PEAK_GBS,
+                            unit="GB/s", frac=round(ach / bench.HBM_PEAK_GBS, 4), traffic=None,
+                            bytes_per_launch=int(launch_bytes[dominant]), avg_launch_us=round(us[dominant], 2),
+                            launches={n: dict(us=round(v, 2), bytes=int(launch_bytes.get(n, 0))) for n, v in us.items()})
     except Exception as e:                           # the roofline object is a report, never a reason to lose the line
         bench.log(f"[bench_sharded] roofline pass skipped: {e}")
     out = None
@@ -111,7 +127,8 @@ def run_sharded(args):
                         input_dim=I, column_dim=C, cell_dim=K, columns_per_gpu=C // world, active_columns=htm.active_columns,
                         patterns=w["patterns"], input_density=w["density"], flip_noise=w["noise"],
                         segments=int(info.segments), segment_slots=w["segment_slots"], backend=backend,
-                        exchange_bytes_per_rank=int(eng.shard_record_bytes()), ranks_consistent=consistent),
+                        exchange_bytes_per_rank=int(eng.shard_record_bytes()), exchange="in-library ncclAllGather" if backend == "nccl" else "host-staged gloo",
+                        ranks_consistent=consistent),
             roofline=roofline, cpu_baseline=None)
     dist.barrier()
     dist.destroy_process_group()

@@ -740,6 +740,8 @@ extern "C" int htm_prepare(htm_handle *h, const uint32_t *device_inputs, int32_t
 }
 
 static int read_counters(htm_handle *h, Counters *out);
+static int stage_input(htm_handle *h, const uint32_t *packed_input);
+static int ensure_shard_buffers(htm_handle *h);
 
 extern "C" int64_t htm_shard_record_bytes(htm_handle *h) {
     if (!h) return HTM_ERR_ARGUMENT;
@@ -845,6 +847,33 @@ extern "C" int htm_shard_unique_id(void *out128) {
     return HTM_OK;
 }
 
+// RCCL round trip at world size 1 on `device`: load the library, create a communicator, all-gather a buffer on a
+// stream, compare, destroy.  What a one-GPU box can verify of the in-library exchange (the symbols, the by-value
+// unique id, the call on a non-default stream); returns 0 or a negative status (htm_last_error(NULL)).
+extern "C" int htm_rccl_selftest(int32_t device) {
+    if (const char *err = load_rccl()) { g_create_error = err; return HTM_ERR_HIP; }
+    if (hipSetDevice(device) != hipSuccess) { g_create_error = "hipSetDevice failed"; return HTM_ERR_HIP; }
+    ncclUniqueIdBytes id;
+    if (g_rccl.get_unique_id(&id) != 0) { g_create_error = "ncclGetUniqueId failed"; return HTM_ERR_HIP; }
+    void *comm = nullptr;
+    if (g_rccl.comm_init_rank(&comm, 1, id, 0) != 0) { g_create_error = "ncclCommInitRank failed"; return HTM_ERR_HIP; }
+    hipStream_t stream;
+    unsigned char *a = nullptr, *b = nullptr;
+    const size_t n = 27264;                         // the record of 1311 candidates
+    std::vector<unsigned char> src(n), dst(n, 0);
+    for (size_t i = 0; i < n; ++i) src[i] = (unsigned char)(i * 131u + 7u);
+    bool ok = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) == hipSuccess && hipMalloc((void **)&a, n) == hipSuccess &&
+              hipMalloc((void **)&b, n) == hipSuccess && hipMemcpy(a, src.data(), n, hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && g_rccl.all_gather(a, b, n, 0, comm, stream) == 0 && hipStreamSynchronize(stream) == hipSuccess &&
+         hipMemcpy(dst.data(), b, n, hipMemcpyDeviceToHost) == hipSuccess && dst == src;
+    g_rccl.comm_destroy(comm);
+    if (a) hipFree(a);
+    if (b) hipFree(b);
+    hipStreamDestroy(stream);
+    if (!ok) { g_create_error = "RCCL all-gather self-test failed"; return HTM_ERR_HIP; }
+    return HTM_OK;
+}
+
 extern "C" int htm_shard_comm_init(htm_handle *h, const void *unique_id128) {
     if (!h || !unique_id128) return HTM_ERR_ARGUMENT;
     if (h->world < 2) { h->err = "htm_shard_comm_init: handle is not sharded"; return HTM_ERR_STATE; }
@@ -857,11 +886,57 @@ extern "C" int htm_shard_comm_init(htm_handle *h, const void *unique_id128) {
     const int rc = g_rccl.comm_init_rank(&comm, h->world, id, h->rank);
     if (rc != 0) { h->err = std::string("ncclCommInitRank: ") + (g_rccl.get_error_string ? g_rccl.get_error_string(rc) : "failed"); return HTM_ERR_HIP; }
     h->rccl_comm = comm;
-    const size_t rb = shard_record_bytes(h->d.n_cand);
-    int rc2 = dalloc(h, &h->shard_send, rb);
-    rc2 |= dalloc(h, &h->shard_recv, rb * (size_t)h->world);
+    int rc2 = ensure_shard_buffers(h);
     if (rc2) return rc2;
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    return HTM_OK;
+}
+
+static int ensure_shard_buffers(htm_handle *h) {
+    if (h->shard_send) return 0;
+    const size_t rb = shard_record_bytes(h->d.n_cand);
+    int rc = dalloc(h, &h->shard_send, rb);
+    rc |= dalloc(h, &h->shard_recv, rb * (size_t)h->world);
+    return rc;
+}
+
+// All the shards of a model inside ONE process on one device (tests, single-GPU rehearsals, bench.py's configs[4]
+// leg): handles[r] is rank r of n = shard_world, all of them on the same stream; the all-gather is n x n device copies.
+extern "C" int htm_shard_group_step(htm_handle *const *handles, int32_t n, const uint32_t *const *device_inputs, int32_t n_inputs,
+                                    const uint32_t *packed_input, int32_t learning) {
+    if (!handles || n < 2 || (!device_inputs == !packed_input)) return HTM_ERR_ARGUMENT;
+    for (int r = 0; r < n; ++r) {
+        htm_handle *h = handles[r];
+        if (!h || h->world != n || h->rank != r || h->stream != handles[0]->stream || h->device != handles[0]->device) {
+            if (h) h->err = "htm_shard_group_step: handles must be ranks 0..n-1 of one group on one stream";
+            return HTM_ERR_ARGUMENT;
+        }
+    }
+    for (int r = 0; r < n; ++r) {
+        htm_handle *h = handles[r];
+        HIPCHK(h, hipSetDevice(h->device));
+        refresh_exchange_mode(h);
+        int rc = ensure_shard_buffers(h);
+        if (rc) return rc;
+        const uint32_t *bank = device_inputs ? device_inputs[r] : nullptr;
+        if (packed_input) {
+            rc = stage_input(h, packed_input);
+            if (rc) return rc;
+            bank = h->d.input_stage;
+        }
+        h->shard_bank = bank;
+        h->shard_n_inputs = packed_input ? 1 : n_inputs;
+        rc = shard_enqueue_begin(h, h->shard_bank, h->shard_n_inputs, h->shard_send);
+        if (rc) return rc;
+    }
+    const size_t rb = shard_record_bytes(handles[0]->d.n_cand);
+    for (int r = 0; r < n; ++r)
+        for (int q = 0; q < n; ++q)
+            HIPCHK(handles[r], hipMemcpyAsync(handles[r]->shard_recv + (size_t)q * rb, handles[q]->shard_send, rb, hipMemcpyDeviceToDevice, handles[r]->stream));
+    for (int r = 0; r < n; ++r) {
+        int rc = shard_enqueue_finish(handles[r], handles[r]->shard_bank, handles[r]->shard_n_inputs, handles[r]->shard_recv, learning ? 1 : 0);
+        if (rc) return rc;
+    }
     return HTM_OK;
 }
 

@@ -799,15 +799,32 @@ __global__ __launch_bounds__(1024) void k_shard_select(Dev d, const unsigned cha
         const int r = i / KL, j = i - r * KL;
         return select_key(((const double *)(recv + (size_t)r * rb))[j]);
     };
-    u64 P = 0;
+    // the candidates are each rank's best: their keys share their leading bits (exponent, top of the mantissa).  The
+    // radix select starts below that common prefix -- its passes would each put every key into one bin
+    __shared__ u64 s_or, s_and;
+    if (tid == 0) { s_or = 0; s_and = ~0ull; }
+    __syncthreads();
+    {
+        u64 vo = 0, va = ~0ull;
+        for (int i = tid; i < n_tot; i += 1024) { const u64 kk = key_at(i); vo |= kk; va &= kk; }
+        for (int o = 32; o > 0; o >>= 1) {
+            vo |= ((u64)__shfl_xor((uint32_t)(vo >> 32), o) << 32) | __shfl_xor((uint32_t)vo, o);
+            va &= ((u64)__shfl_xor((uint32_t)(va >> 32), o) << 32) | __shfl_xor((uint32_t)va, o);
+        }
+        if (lane == 0) { atomicOr((unsigned long long *)&s_or, vo); atomicAnd((unsigned long long *)&s_and, va); }
+    }
+    __syncthreads();
+    const u64 differ = s_or ^ s_and;
+    const int top0 = differ ? 64 - __clzll((long long)differ) : 0;       // bits [top0, 64) are the same in every key
+    u64 P = top0 < 64 ? (s_and >> top0) << top0 : 0ull;
     uint32_t krem = (uint32_t)d.k;
-    for (int top = 64; top > d.low_zero;) {
-        const int bits = min(SEL_DIGIT, top - d.low_zero < SEL_DIGIT ? top - d.low_zero : SEL_DIGIT), shift = top - bits, nb = 1 << bits;
+    for (int top = top0; top > d.low_zero;) {
+        const int bits = min(SEL_DIGIT, top - d.low_zero), shift = top - bits, nb = 1 << bits;
         for (int i = tid; i < nb; i += 1024) h[i] = 0;
         __syncthreads();
         for (int i = tid; i < n_tot; i += 1024) {
             const u64 kk = key_at(i);
-            if (top == 64 || ((kk ^ P) >> top) == 0) atomicAdd(&h[(uint32_t)(kk >> shift) & (nb - 1)], 1u);
+            if (top >= 64 || ((kk ^ P) >> top) == 0) atomicAdd(&h[(uint32_t)(kk >> shift) & (nb - 1)], 1u);
         }
         __syncthreads();
         uint32_t bucket, above;

@@ -147,45 +147,75 @@ __device__ __forceinline__ void role_sp_row(const Dev &d, int p, const uint32_t 
 template <int BS>
 __device__ __forceinline__ void role_mid(const Dev &d, int p, int n_active, int want_winner, int learning, int blk, int n_cls) {
     Counters *c = d.ctr;
-    __shared__ int s_cnt, s_base;
     if (blk > 0) {
+        // Which of the previous matching segments learn, which are punished.  The scan left one bit per row; the
+        // items of a wave are appended with one reservation (same-address atomics are slow: ~88 per us).
         if (!learning || !c->has_distal) return;
         const int q = p ^ 1;
         const int n = d.world > 1 ? c->L : c->S;     // rows at or above the count of the last scan are not matching
-        const int stride = n_cls * BS;
-        for (int i0 = (blk - 1) * BS; i0 < n; i0 += stride) {
-            const int seg = i0 + threadIdx.x;
-            bool learn = false, punish = false;
-            // the scan leaves one bit per segment (matching or not) and an info word for the matching ones only
-            const bool was_matching = seg < n && ((d.match_bits[seg >> 5] >> (seg & 31)) & 1u);
-            const uint32_t info = was_matching ? d.seg_info[seg] : 0u;
-            const int cell = was_matching ? d.seg_cell[seg] : 0;     // fetched with the info word, not after it
-            if (was_matching) {
-                const int col = cell >> 5, bit = cell & 31;
-                const bool is_winner = (d.win[p][col] >> bit) & 1u;
-                const bool unpred = !((d.pred[q][col] >> bit) & 1u);                         // :266
-                const bool best = fabsf(d.seg_jit[seg] - __uint_as_float(d.cellmax[cell])) < EPS32;   // :267
-                learn = is_winner && ((info >> 31) || (unpred && best));                     // :268
-                punish = d.act[p][col] == 0;                                                 // :269
+        // classification of one matching row
+        auto classify = [&](int seg, bool &learn, bool &punish) {
+            const uint32_t info = d.seg_info[seg];
+            const int cell = d.seg_cell[seg];
+            const float jit = d.seg_jit[seg];
+            const int col = cell >> 5, cb = cell & 31;
+            const bool is_winner = (d.win[p][col] >> cb) & 1u;
+            const bool unpred = !((d.pred[q][col] >> cb) & 1u);                          // :266
+            const bool best = fabsf(jit - __uint_as_float(d.cellmax[cell])) < EPS32;     // :267
+            learn = is_winner && ((info >> 31) || (unpred && best));                     // :268
+            punish = d.act[p][col] == 0;                                                 // :269
+        };
+        if (n <= 8 * n_cls * BS) {
+            // small pools: one row per thread, so that the rows of a word -- segments created together match together --
+            // are classified side by side, not one after the other
+            for (int i0 = (blk - 1) * BS; i0 < n; i0 += n_cls * BS) {
+                const int seg = i0 + (int)threadIdx.x;
+                bool learn = false, punish = false;
+                if (seg < n && ((d.match_bits[seg >> 5] >> (seg & 31)) & 1u)) classify(seg, learn, punish);
+                const u64 ml = __ballot(learn), mp = __ballot(punish);
+                const int n_l = __popcll(ml), n_p = __popcll(mp);
+                if (n_l + n_p == 0) continue;
+                int base = 0;
+                if (lane_id() == 0) base = atomicAdd(&c->n_work, n_l + n_p);
+                base = __shfl(base, 0);
+                if (learn) {
+                    const int pos = base + __popcll(ml & lanemask_lt());
+                    if (pos < d.work_cap) d.work[pos] = (uint32_t)seg; else atomicOr(&c->error, 4);
+                }
+                if (punish) {
+                    const int pos = base + n_l + __popcll(mp & lanemask_lt());
+                    if (pos < d.work_cap) d.work[pos] = (uint32_t)seg | 0x80000000u; else atomicOr(&c->error, 4);
+                }
             }
-            if (threadIdx.x == 0) s_cnt = 0;
-            __syncthreads();
-            const u64 ml = __ballot(learn), mp = __ballot(punish);
-            const int n_l = __popcll(ml), n_p = __popcll(mp);
-            int woff = 0;
-            if (lane_id() == 0 && n_l + n_p) woff = atomicAdd(&s_cnt, n_l + n_p);
-            woff = __shfl(woff, 0);
-            __syncthreads();
-            if (threadIdx.x == 0 && s_cnt) s_base = atomicAdd(&c->n_work, s_cnt);     // one reservation per block
-            __syncthreads();
-            const int base = s_base + woff;
-            if (learn) {
-                const int pos = base + __popcll(ml & lanemask_lt());
-                if (pos < d.work_cap) d.work[pos] = (uint32_t)seg; else atomicOr(&c->error, 4);
+            return;
+        }
+        // large pools: a thread takes a 32-row word of match bits (coalesced; almost all are zero) and walks its set bits
+        const int nwords = (n + 31) >> 5;
+        for (int w0 = (blk - 1) * BS; w0 < nwords; w0 += n_cls * BS) {
+            const int w = w0 + (int)threadIdx.x;
+            const uint32_t word = w < nwords ? d.match_bits[w] : 0u;
+            uint32_t lmask = 0, pmask = 0;
+            for (uint32_t rest = word; rest; rest &= rest - 1) {
+                const int bit = __ffs(rest) - 1;
+                bool learn, punish;
+                classify(w * 32 + bit, learn, punish);
+                lmask |= (learn ? 1u : 0u) << bit;
+                pmask |= (punish ? 1u : 0u) << bit;
             }
-            if (punish) {
-                const int pos = base + n_l + __popcll(mp & lanemask_lt());
-                if (pos < d.work_cap) d.work[pos] = (uint32_t)seg | 0x80000000u; else atomicOr(&c->error, 4);
+            const uint32_t cnt = (uint32_t)(__popc(lmask) + __popc(pmask));
+            if (!__any(cnt != 0)) continue;
+            const uint32_t incl = wave_incl_scan(cnt);
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            int base = 0;
+            if (lane_id() == 63) base = atomicAdd(&c->n_work, (int)total);
+            int pos = __shfl(base, 63) + (int)(incl - cnt);
+            for (uint32_t rest = lmask; rest; rest &= rest - 1, ++pos) {
+                const uint32_t item = (uint32_t)(w * 32 + __ffs(rest) - 1);
+                if (pos < d.work_cap) d.work[pos] = item; else atomicOr(&c->error, 4);
+            }
+            for (uint32_t rest = pmask; rest; rest &= rest - 1, ++pos) {
+                const uint32_t item = (uint32_t)(w * 32 + __ffs(rest) - 1) | 0x80000000u;
+                if (pos < d.work_cap) d.work[pos] = item; else atomicOr(&c->error, 4);
             }
         }
         return;
@@ -355,8 +385,13 @@ __device__ __forceinline__ void role_learn(const Dev &d, int p, int blk, int nbl
     {   // forget the previous scan's per-cell maxima (sparse clear; every reader ran in an earlier
         // launch) and reset what the coming scan accumulates
         const int n = c->has_distal ? (d.world > 1 ? c->L : c->S) : 0;
-        for (int i = blk * BS + threadIdx.x; i < n; i += nblk * BS)
-            if ((d.match_bits[i >> 5] >> (i & 31)) & 1u) d.cellmax[d.seg_cell[i]] = 0u;
+        if (n <= 8 * nblk * BS) {                  // small pools: one row per thread (matching rows cluster in words)
+            for (int i = blk * BS + threadIdx.x; i < n; i += nblk * BS)
+                if ((d.match_bits[i >> 5] >> (i & 31)) & 1u) d.cellmax[d.seg_cell[i]] = 0u;
+        } else {                                   // large pools: one 32-row word per thread, almost all of them zero
+            for (int w = blk * BS + threadIdx.x; w < (n + 31) >> 5; w += nblk * BS)
+                for (uint32_t rest = d.match_bits[w]; rest; rest &= rest - 1) d.cellmax[d.seg_cell[w * 32 + __ffs(rest) - 1]] = 0u;
+        }
     }
     const int wv = threadIdx.x >> 6, lane = lane_id();
     const int n_front = min(c->n_work, d.work_cap), n_back = c->n_bind;

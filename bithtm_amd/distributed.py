@@ -96,18 +96,59 @@ class ShardedHTM:
 
 
 class LocalGroup:
-    """R shards inside ONE process on ONE GPU, with the all-gather replaced by device copies:
-    exercises every sharded kernel without multi-GPU hardware (tests/test_hip_sharded.py)."""
+    """R shards inside ONE process on ONE GPU (no torch): every rank's engine enqueues on the device's default stream
+    and the all-gather is R x R device copies inside the library (`htm_shard_group_step`).  Exercises every sharded
+    kernel without multi-GPU hardware (tests/test_hip_sharded.py, bench.py's configs[4] leg)."""
 
-    def __init__(self, world, *args, **kw):
-        self.members = [ShardedHTM(*args, rank=r, world=world, all_gather=lambda recv, send: None, **kw) for r in range(world)]
+    def __init__(self, world, input_dim, column_dim, cell_dim, active_columns=None, permanence=None, make_parts=None, seed=0,
+                 device=0):
+        import ctypes as C
+        if active_columns is None:
+            active_columns = round(column_dim * 0.02)
+        self.world, self.column_dim, self.cell_dim, self.active_columns = world, column_dim, cell_dim, active_columns
+        self.engines = []
+        for r in range(world):
+            parts = make_parts(r) if make_parts else {}
+            proximal = parts.get("proximal")
+            if proximal is None:
+                proximal = DenseProjection.__new__(DenseProjection)
+                proximal.input_dim, proximal.output_dim = input_dim, column_dim
+                proximal.permanence_threshold, proximal.permanence_increment, proximal.permanence_decrement = 0.0, 0.03, 0.015
+                proximal._engine, proximal._permanence = None, permanence
+            self.engines.append(Engine(input_dim, column_dim, cell_dim, active_columns, proximal=proximal,
+                                       boosting=parts.get("boosting") or ExponentialBoosting(column_dim, active_columns),
+                                       distal=parts.get("distal") or PredictiveProjection(column_dim * cell_dim),
+                                       seed=seed, device=device, stream="default", shard_rank=r, shard_world=world))
+        self._handles = (C.c_void_p * world)(*[e.h for e in self.engines])
+        self._banks = None
+        self.lib = self.engines[0].lib
+
+    @property
+    def members(self):                      # (objects with .engine / .rank / .column_range, as ShardedHTM has them)
+        from types import SimpleNamespace
+        return [SimpleNamespace(engine=e, rank=r, column_range=e.column_range) for r, e in enumerate(self.engines)]
+
+    def _check(self, rc):
+        if rc < 0:
+            errs = "; ".join(self.lib.htm_last_error(e.h).decode() for e in self.engines)
+            raise RuntimeError(f"htm_shard_group_step failed ({rc}): {errs}")
 
     def process(self, input_bits, learning=True):
-        for m in self.members:
-            m.engine.shard_begin(m.send.data_ptr(), input_bits=input_bits, learning=learning)
-        n = self.members[0].send.numel()
-        for m in self.members:
-            for r, src in enumerate(self.members):
-                m.recv[r * n:(r + 1) * n].copy_(src.send)
-        for m in self.members:
-            m.engine.shard_finish(m.recv.data_ptr(), learning=learning)
+        import ctypes as C
+        from .engine import pack_bits
+        packed = pack_bits(input_bits, self.engines[0].words)
+        self._check(self.lib.htm_shard_group_step(self._handles, self.world, None, 1, packed.ctypes.data_as(C.c_void_p), int(bool(learning))))
+        for e in self.engines:
+            e.steps += 1
+
+    def upload_bank(self, inputs):
+        import ctypes as C
+        self._banks = (C.c_void_p * self.world)(*[e.upload_bank(inputs) for e in self.engines])
+        self._n_inputs = len(inputs)
+
+    def run(self, steps, learning=True):
+        """`steps` timesteps over the bank of upload_bank (every rank holds its copy)."""
+        for _ in range(steps):
+            self._check(self.lib.htm_shard_group_step(self._handles, self.world, self._banks, self._n_inputs, None, int(bool(learning))))
+        for e in self.engines:
+            e.steps += steps

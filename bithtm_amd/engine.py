@@ -79,8 +79,9 @@ class Engine:
             cfg.segment_capacity_local = int(getattr(distal, "segment_capacity_local", None) or 0)
         cfg.seed = int(seed) & 0xFFFFFFFF
         cfg.shard_rank, cfg.shard_world = int(shard_rank), int(shard_world)
+        # stream: None = a private stream; "default" = the device's default stream; else a hipStream_t of the caller
         cfg.use_caller_stream = int(stream is not None)
-        cfg.stream = stream if stream else None
+        cfg.stream = stream if (stream and stream != "default") else None
         self.shard_rank, self.shard_world = int(shard_rank), max(int(shard_world), 1)
         per = self.column_dim // self.shard_world
         self.column_range = (self.shard_rank * per, (self.shard_rank + 1) * per)

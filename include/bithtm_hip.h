@@ -207,6 +207,15 @@ int htm_shard_unique_id(void *out128);
 int htm_shard_comm_init(htm_handle *h, const void *unique_id128);
 int htm_shard_step(htm_handle *h, const uint32_t *device_inputs, int32_t n_inputs, const uint32_t *packed_input,
                    int32_t learning);
+/* RCCL round trip at world size 1 on `device` (communicator, all-gather on a stream, compare): what a box with one
+ * GPU can verify of the path htm_shard_step takes. */
+int htm_rccl_selftest(int32_t device);
+
+/* All the shards of one model inside ONE process on one device: handles[r] = rank r of n = shard_world, created on
+ * the same stream; the all-gather becomes n x n device copies.  For tests and single-GPU rehearsals of the sharded
+ * path.  device_inputs[r] = rank r's copy of the input bank (or NULL and one host input, as for htm_step). */
+int htm_shard_group_step(htm_handle *const *handles, int32_t n, const uint32_t *const *device_inputs, int32_t n_inputs,
+                         const uint32_t *packed_input, int32_t learning);
 
 /* Pre-populated segment pool, generated on the device (BASELINE.json configs[4]: 255 segments per cell, a pure
  * scan stress): every cell with flat id in [cell_begin, cell_end) gets segments_per_cell segments of `synapses`

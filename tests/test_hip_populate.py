@@ -101,10 +101,9 @@ def _words(mat):
 def test_populated_pool_column_sharded(world):
     """The same generated pool on a column-sharded group (each rank generates the rows of its own cells), SP + TM with
     learning, against the unsharded oracle: the ranks hold exactly their own segments, under the global ids."""
-    import torch  # noqa: F401
     import bithtm_amd as B
     from bithtm_amd import _lib as L
-    from bithtm_amd.distributed import LocalGroup, ShardedHTM
+    from bithtm_amd.distributed import LocalGroup
     from bithtm_amd.engine import words_to_bool
     I, C, K, P, seed = 128, 1024, 8, 9, 21
     k = round(C * 0.02)
@@ -115,7 +114,7 @@ def test_populated_pool_column_sharded(world):
     ora = HTMOracle(I, C, K, active_columns=k, seed=seed, tm_params=tmp, permanence=perm)
     ora.temporal_memory.populate(12, synapses=16, seed=5)
 
-    def parts():
+    def parts(r):
         prox = B.DenseProjection.__new__(B.DenseProjection)
         prox.input_dim, prox.output_dim = I, C
         prox.permanence_threshold, prox.permanence_increment, prox.permanence_decrement = 0.0, 0.03, 0.015
@@ -123,9 +122,7 @@ def test_populated_pool_column_sharded(world):
         return dict(proximal=prox, boosting=B.ExponentialBoosting(C, k),
                     distal=B.PredictiveProjection(C * K, segment_capacity=1 << 18, segment_slots=64,
                                                   **{f: getattr(tmp, f) for f in tmp.__dataclass_fields__}))
-    group = LocalGroup.__new__(LocalGroup)
-    group.members = [ShardedHTM(I, C, K, rank=r, world=world, active_columns=k, seed=seed, all_gather=lambda a, b: None, **parts())
-                     for r in range(world)]
+    group = LocalGroup(world, I, C, K, active_columns=k, make_parts=parts, seed=seed)
     for m in group.members:
         m.engine.populate(12, synapses=16, seed=5)
     rng = np.random.RandomState(seed + 1)

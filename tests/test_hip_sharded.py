@@ -13,7 +13,6 @@ pytestmark = pytest.mark.gpu
 
 
 def _run(world, I, C, K, P, density, noise, steps, jump, seed, spp=None, tmp=None, slots=128):
-    import torch
     import bithtm_amd as B
     from bithtm_amd.distributed import LocalGroup
     from bithtm_amd.engine import words_to_bool
@@ -24,7 +23,7 @@ def _run(world, I, C, K, P, density, noise, steps, jump, seed, spp=None, tmp=Non
     k = round(C * 0.02)
     ora = HTMOracle(I, C, K, active_columns=k, seed=seed, sp_params=spp, tm_params=tmp, permanence=perm)
 
-    def parts():
+    def parts(r):
         prox = B.DenseProjection.__new__(B.DenseProjection)
         prox.input_dim, prox.output_dim = I, C
         prox.permanence_threshold, prox.permanence_increment, prox.permanence_decrement = \
@@ -33,10 +32,7 @@ def _run(world, I, C, K, P, density, noise, steps, jump, seed, spp=None, tmp=Non
         return dict(proximal=prox,
                     boosting=B.ExponentialBoosting(C, k, intensity=spp_.boost_intensity, momentum=spp_.boost_momentum),
                     distal=B.PredictiveProjection(C * K, segment_slots=slots, **{f: getattr(tmp_, f) for f in tmp_.__dataclass_fields__}))
-    from bithtm_amd.distributed import ShardedHTM
-    group = LocalGroup.__new__(LocalGroup)
-    group.members = [ShardedHTM(I, C, K, rank=r, world=world, active_columns=k, seed=seed, all_gather=lambda a, b: None, **parts())
-                     for r in range(world)]
+    group = LocalGroup(world, I, C, K, active_columns=k, make_parts=parts, seed=seed)
     rng = np.random.RandomState(seed + 1)
     bank = rng.rand(P, I) < density
     thr = tmp_.segment_matching_threshold
@@ -105,6 +101,16 @@ def _run(world, I, C, K, P, density, noise, steps, jump, seed, spp=None, tmp=Non
                 assert np.array_equal(eng.read_duty_cycle()[c0:c1].view(np.int32),
                                       ora.spatial_pooler.duty_cycle[c0:c1].view(np.int32)), f"{tag}: duty (own)"
     return dead_seen
+
+
+def test_rccl_all_gather_through_the_library_at_world_size_one():
+    """htm_shard_step's exchange is ncclAllGather, called from inside the library on the handle's stream (librccl is
+    loaded at run time).  One GPU can hold one rank: the self-test creates a communicator of size 1 and moves one
+    record through it."""
+    from bithtm_amd import _lib
+    lib = _lib.load()
+    rc = lib.htm_rccl_selftest(0)
+    assert rc == 0, lib.htm_last_error(None)
 
 
 def test_two_shards_default_parameters():
