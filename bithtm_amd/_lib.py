@@ -43,6 +43,7 @@ F_ACTIVE_COLUMN, F_OVERLAPS, F_BOOSTED, F_DUTY_CYCLE, F_CELL_ACTIVATION, F_CELL_
 F_WINNER_WORDS, F_BURSTING, F_WINNER_CELL, F_SEG_CELL, F_SEG_NSYN, F_SEG_PRESYN, F_SEG_PERM = 7, 8, 9, 10, 11, 12, 13
 F_SEGCOUNT, F_SEG_POTENTIAL, F_MATCH_SEGMENT, F_MATCH_INFO, F_MATCH_JITTER, F_CELL_MAX_JITTER = 14, 15, 16, 17, 18, 19
 F_SEG_GID = 20
+SP_OVERLAP, SP_BOOST, SP_SELECT, SP_ACTIVE, SP_LEARN, SP_DUTY, SP_COMMIT = 1, 2, 3, 4, 5, 6, 7
 
 EXPORTS = {
     "htm_abi_version": (C.c_int, []),
@@ -53,6 +54,7 @@ EXPORTS = {
     "htm_sp_get_permanence": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
     "htm_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     "htm_sp_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
+    "htm_sp_phase": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]),
     "htm_tm_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
     "htm_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "htm_prepare": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),

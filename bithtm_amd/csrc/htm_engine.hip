@@ -67,6 +67,9 @@ struct htm_handle {
     int seg_hint;                         // a lower bound of the segment count (see scan_spec_blocks)
     int *seg_pinned;                      // pinned word the end of each htm_run copies the count into
     int sp_blocks, sel_blocks, c256_blocks, s1024_blocks, scan_blocks, cus;
+    int phase_active;                     // htm_sp_phase: length of the current winner list
+    bool phase_open;                      // ... phases of the current (not yet closed) timestep have run: the Spatial Pooler
+                                          // fields htm_read returns are that step's
     // graphs keyed by (parity, learning, bank, n_inputs)
     std::map<std::tuple<int, int, const void *, int>, hipGraphExec_t> graphs;
     // state import staging (htm_write of the MATCH_* / SEG_POTENTIAL fields, applied at commit)
@@ -387,6 +390,8 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
     h->shard_open = false;
     h->rccl_comm = nullptr;
     h->shard_send = h->shard_recv = nullptr;
+    h->phase_active = 0;
+    h->phase_open = false;
     hipError_t e = hipSetDevice(cfg->device);
     if (e != hipSuccess) return fail_create(h, std::string("hipSetDevice: ") + hipGetErrorString(e), HTM_ERR_HIP);
     if (cfg->use_caller_stream) {
@@ -648,6 +653,88 @@ extern "C" int htm_sp_step(htm_handle *h, const uint32_t *packed_input, int32_t 
     return HTM_OK;
 }
 
+// SpatialPooler.process (networks.py:26-35) one phase per call, for plug-in objects that live on the host: the caller
+// (bithtm_amd/networks.py) interleaves these with the `process` / `update` methods of the user's objects.
+extern "C" int htm_sp_phase(htm_handle *h, int32_t phase, const void *data, int64_t count) {
+    if (!h) return HTM_ERR_ARGUMENT;
+    if (!h->cfg.enable_sp) { h->err = "handle has no Spatial Pooler"; return HTM_ERR_STATE; }
+    if (h->world > 1) { h->err = "htm_sp_phase: not available on a column-sharded handle"; return HTM_ERR_STATE; }
+    HIPCHK(h, hipSetDevice(h->device));
+    refresh_exchange_mode(h);
+    Dev &d = h->d;
+    const int p = (int)(h->step_host & 1);
+    const int c256 = (d.C + 255) / 256;
+    // the top-digit histogram of this step's keys is accumulated by the phase that makes the keys and consumed (and
+    // cleared) by the select: a phase that makes keys starts from a clean one, whatever ran before it in this step
+    if (phase == HTM_SP_OVERLAP || phase == HTM_SP_BOOST || (phase == HTM_SP_SELECT && data))
+        HIPCHK(h, hipMemsetAsync(d.hist0 + (size_t)p * HIST_REP * SEL_BINS, 0, (size_t)HIST_REP * SEL_BINS * 4, h->stream));
+    switch (phase) {
+        case HTM_SP_OVERLAP: {                     // DenseProjection.process + ExponentialBoosting.process; data = packed input
+            if (!data) return HTM_ERR_ARGUMENT;
+            int rc = stage_input(h, (const uint32_t *)data);
+            if (rc) return rc;
+            LAUNCH(h, "sp_overlap", k_sp_overlap, h->sp_blocks, RB, d, d.input_stage, 1, h->G, p, p, 0);
+            break;
+        }
+        case HTM_SP_BOOST: {                       // ExponentialBoosting.process on overlaps from the host; data = int32[C]
+            if (!data || count != d.C) { h->err = "htm_sp_phase(BOOST): need column_dim overlaps"; return HTM_ERR_ARGUMENT; }
+            HIPCHK(h, hipMemcpyAsync(d.overlap[p], data, (size_t)d.C * 4, hipMemcpyHostToDevice, h->stream));
+            HIPCHK(h, hipStreamSynchronize(h->stream));         // (the caller's buffer is borrowed for the call only)
+            LAUNCH(h, "sp_keys", k_sp_keys, std::min((d.C + RB - 1) / RB, 256), RB, d, p, 1);
+            break;
+        }
+        case HTM_SP_SELECT: {                      // GlobalInhibition.process; data = double[C] boosted overlaps, or NULL: the device's
+            if (data) {
+                if (count != d.C) { h->err = "htm_sp_phase(SELECT): need column_dim boosted overlaps"; return HTM_ERR_ARGUMENT; }
+                HIPCHK(h, hipMemcpyAsync(d.boosted[p], data, (size_t)d.C * 8, hipMemcpyHostToDevice, h->stream));
+                HIPCHK(h, hipStreamSynchronize(h->stream));
+                LAUNCH(h, "sp_keys", k_sp_keys, std::min((d.C + RB - 1) / RB, 256), RB, d, p, 0);
+            }
+            for (int pass = 1; pass < d.sel_passes; ++pass) LAUNCH(h, "sp_select", k_sel_pass, h->sel_blocks, RB, d, pass, p);
+            enqueue_sp_back(h, d.input_stage, 1, p, 0, 0, false);          // the list and its bitmap, nothing else
+            break;
+        }
+        case HTM_SP_ACTIVE: {                      // a winner list from the host; data = int32[count], distinct, any order
+            if ((!data && count) || count < 0 || count > d.k) { h->err = "htm_sp_phase(ACTIVE): at most active_columns columns"; return HTM_ERR_ARGUMENT; }
+            std::vector<int> cols((const int *)data, (const int *)data + count);
+            std::sort(cols.begin(), cols.end());
+            for (int64_t i = 0; i < count; ++i)
+                if (cols[i] < 0 || cols[i] >= d.C || (i && cols[i] == cols[i - 1])) { h->err = "htm_sp_phase(ACTIVE): bad column list"; return HTM_ERR_ARGUMENT; }
+            if (count) HIPCHK(h, hipMemcpyAsync(d.active_cols[p], cols.data(), (size_t)count * 4, hipMemcpyHostToDevice, h->stream));
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            h->phase_active = (int)count;
+            h->phase_open = true;
+            if (d.colbits[p]) {
+                LAUNCH(h, "sp_list_bits", k_sp_list_bits, std::max(1, (d.colwords + 255) / 256), 256, d, p, (int)count, 0);
+                if (count) LAUNCH(h, "sp_list_bits", k_sp_list_bits, (int)((count + 255) / 256), 256, d, p, (int)count, 1);
+            }
+            return HTM_OK;
+        }
+        case HTM_SP_LEARN:                         // DenseProjection.update on the current winner list, with the input of OVERLAP
+            if (data) {
+                int rc = stage_input(h, (const uint32_t *)data);
+                if (rc) return rc;
+            }
+            if (h->phase_active) LAUNCH(h, "sp_learn", k_sp_learn, h->phase_active, 256, d, d.input_stage, 1, p);
+            break;
+        case HTM_SP_DUTY:                          // ExponentialBoosting.update on the current winner list
+            LAUNCH(h, "sp_duty", k_sp_duty_list, c256, 256, d, p, h->phase_active, 0);
+            if (h->phase_active) LAUNCH(h, "sp_duty", k_sp_duty_list, (h->phase_active + 255) / 256, 256, d, p, h->phase_active, 1);
+            break;
+        case HTM_SP_COMMIT:                        // close the step of a handle without Temporal Memory
+            if (h->cfg.enable_tm) { h->err = "htm_sp_phase(COMMIT): the Temporal Memory's step closes the timestep (htm_tm_step)"; return HTM_ERR_STATE; }
+            hipLaunchKernelGGL(k_sp_commit, dim3(1), dim3(1), 0, h->stream, d, p);
+            h->step_host += 1;
+            break;
+        default: h->err = "htm_sp_phase: unknown phase"; return HTM_ERR_ARGUMENT;
+    }
+    if (phase == HTM_SP_SELECT) h->phase_active = d.k;
+    h->phase_open = phase != HTM_SP_COMMIT;
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { h->err = std::string("kernel launch: ") + hipGetErrorString(e); return HTM_ERR_HIP; }
+    return HTM_OK;
+}
+
 extern "C" int htm_tm_step(htm_handle *h, const int32_t *active_column, int32_t n, int32_t learning, int32_t return_winner_cell) {
     if (!h || (!active_column && n > 0)) return HTM_ERR_ARGUMENT;
     if (!h->cfg.enable_tm) { h->err = "handle has no Temporal Memory"; return HTM_ERR_STATE; }
@@ -666,6 +753,7 @@ extern "C" int htm_tm_step(htm_handle *h, const int32_t *active_column, int32_t 
     LAUNCH(h, "tm_activate", k_tm_activate, std::max(1, (n * 32 + 255) / 256), 256, d, p, n, want);
     enqueue_tm(h, n, learning ? 1 : 0, want, p, nullptr, 1, false);
     h->step_host += 1;
+    h->phase_open = false;
     return HTM_OK;
 }
 
@@ -1072,6 +1160,7 @@ extern "C" int64_t htm_read(htm_handle *h, int32_t field, void *dst, int64_t cou
     if (rc) return rc;
     Dev &d = h->d;
     const int q = (int)((h->step_host + 1) & 1);
+    const int qs = h->phase_open ? (int)(h->step_host & 1) : q;      // Spatial Pooler fields while a step is run phase by phase
     const bool sp = h->cfg.enable_sp, tm = h->cfg.enable_tm;
     const int64_t C = d.C, K = d.K, S = h->world > 1 ? c.L : c.S, E = d.E;      // S: rows of the per-segment fields
     auto need = [&](bool ok, int64_t n) -> int64_t {
@@ -1085,9 +1174,9 @@ extern "C" int64_t htm_read(htm_handle *h, int32_t field, void *dst, int64_t cou
     };
     int64_t n;
     switch (field) {
-        case HTM_F_ACTIVE_COLUMN: if ((n = need(true, d.k)) < 0) return n; return copy(d.active_cols[q], n, 4);
-        case HTM_F_OVERLAPS: if ((n = need(sp, C)) < 0) return n; return copy(d.overlap[q], n, 4);
-        case HTM_F_BOOSTED: if ((n = need(sp, C)) < 0) return n; return copy(d.boosted[q], n, 8);
+        case HTM_F_ACTIVE_COLUMN: if ((n = need(true, d.k)) < 0) return n; return copy(d.active_cols[qs], n, 4);
+        case HTM_F_OVERLAPS: if ((n = need(sp, C)) < 0) return n; return copy(d.overlap[qs], n, 4);
+        case HTM_F_BOOSTED: if ((n = need(sp, C)) < 0) return n; return copy(d.boosted[qs], n, 8);
         case HTM_F_DUTY_CYCLE: if ((n = need(sp, C)) < 0) return n; return copy(d.duty, n, 4);
         case HTM_F_CELL_ACTIVATION: if ((n = need(tm, C)) < 0) return n; return copy(d.act[q], n, 4);
         case HTM_F_CELL_PREDICTION: if ((n = need(tm, C)) < 0) return n; return copy(d.pred[q], n, 4);

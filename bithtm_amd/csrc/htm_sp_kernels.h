@@ -766,6 +766,59 @@ __global__ __launch_bounds__(256) void k_sp_learn(Dev d, const uint32_t *__restr
     }
 }
 
+// ---- SpatialPooler.process phase by phase (htm_sp_phase): kernels for values that come from the host ----------
+// keys + top-digit histogram from boosted overlaps that are already in d.boosted[p] (a foreign boosting object computed
+// them), or from overlaps in d.overlap[p] through the device's own boosting (a foreign proximal projection computed
+// those): what role_overlap does after its popcounts
+__global__ __launch_bounds__(RB) void k_sp_keys(Dev d, int p, int from_overlap) {
+    __shared__ uint32_t h[SEL_BINS];
+    const int gtid = blockIdx.x * RB + threadIdx.x, nthreads = gridDim.x * RB;
+    uint32_t *ghist = d.hist + p * SEL_MAX_PASSES * SEL_BINS;
+    if (gtid == 0) {
+        d.ctr->emit_epoch += 1;
+        d.ctr->sel_pass_prefix[p][0] = 0;
+        d.ctr->sel_pass_krem[p][0] = (uint32_t)d.sel_k;
+    }
+    for (int i = gtid; i < (d.sel_passes - 1) * SEL_BINS; i += nthreads) ghist[SEL_BINS + i] = 0;
+    for (int i = threadIdx.x; i < SEL_BINS; i += RB) h[i] = 0;
+    __syncthreads();
+    for (int c = d.sel_lo + gtid; c < d.sel_hi; c += nthreads) {
+        double bo;
+        if (from_overlap) {
+            const float f = htm_exp_f32(d.coef * d.duty[c]);                 // regularizations.py:16
+            bo = (double)f * (double)d.overlap[p][c];                        // :17
+            d.boosted[p][c] = bo;
+        } else {
+            bo = d.boosted[p][c];
+        }
+        const u64 key = select_key(bo);
+        d.key[p][c] = key;
+        atomicAdd(&h[(uint32_t)(key >> sel_shift(0))], 1u);
+    }
+    __syncthreads();
+    uint32_t *g0 = d.hist0 + (size_t)(p * HIST_REP + (blockIdx.x & (HIST_REP - 1))) * SEL_BINS;
+    for (int i = threadIdx.x; i < SEL_BINS; i += RB)
+        if (h[i]) atomicAdd(&g0[i], h[i]);
+}
+
+// a winner list that came from the host (already in d.active_cols[p], ascending): its column bitmap
+__global__ __launch_bounds__(256) void k_sp_list_bits(Dev d, int p, int n, int pass) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (pass == 0) { if (i < d.colwords) d.colbits[p][i] = 0; return; }
+    if (i < n) { const int c = d.active_cols[p][i]; atomicOr(&d.colbits[p][c >> 5], 1u << (c & 31)); }
+}
+
+// ExponentialBoosting.update (regularizations.py:19-21) as two launches: pass 0 `duty *= momentum` on every column,
+// pass 1 `duty[active] += 1 - momentum` on the n listed ones (float32, two separately rounded operations)
+__global__ __launch_bounds__(256) void k_sp_duty_list(Dev d, int p, int n, int pass) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (pass == 0) { if (i < d.C) d.duty[i] = d.duty[i] * d.mom; return; }
+    if (i < n) { const int c = d.active_cols[p][i]; d.duty[c] = d.duty[c] + d.dinc; }
+}
+
+// a Spatial Pooler without Temporal Memory stepped phase by phase: close the step
+__global__ void k_sp_commit(Dev d, int p) { d.ctr->step[p ^ 1] = d.ctr->step[p] + 1; }
+
 // ---- column sharding: the kernels on either side of the exchange -----------------------------
 // before the exchange, first launch: overlap + boost + top key digit of the OWN columns, and the zeroing of the
 // step's dense per-column words (the winners' words are written after the exchange)
@@ -792,6 +845,7 @@ __global__ __launch_bounds__(RB) void k_shard_overlap(Dev d, const uint32_t *__r
 __global__ __launch_bounds__(1024) void k_shard_select(Dev d, const unsigned char *__restrict__ recv, int p) {
     __shared__ uint32_t h[SEL_BINS];
     __shared__ uint32_t s_wave[16], s_out[2], s_cnt[2];
+    __shared__ u64 s_or, s_and;
     const int tid = threadIdx.x, lane = lane_id();
     const int KL = d.n_cand, n_tot = d.world * KL;
     const size_t rb = shard_record_bytes(KL);
@@ -799,14 +853,26 @@ __global__ __launch_bounds__(1024) void k_shard_select(Dev d, const unsigned cha
         const int r = i / KL, j = i - r * KL;
         return select_key(((const double *)(recv + (size_t)r * rb))[j]);
     };
+    // up to KPT keys per thread stay in registers over the passes (configs[3] 8-way: 10 488 candidates, 11 per thread);
+    // beyond that they are read again, from L2
+    constexpr int KPT = 12;
+    const bool in_regs = n_tot <= KPT * 1024;
+    u64 kreg[KPT];
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) kreg[j] = (in_regs && tid + j * 1024 < n_tot) ? key_at(tid + j * 1024) : 0ull;
     // the candidates are each rank's best: their keys share their leading bits (exponent, top of the mantissa).  The
     // radix select starts below that common prefix -- its passes would each put every key into one bin
-    __shared__ u64 s_or, s_and;
     if (tid == 0) { s_or = 0; s_and = ~0ull; }
     __syncthreads();
     {
         u64 vo = 0, va = ~0ull;
-        for (int i = tid; i < n_tot; i += 1024) { const u64 kk = key_at(i); vo |= kk; va &= kk; }
+        if (in_regs) {
+#pragma unroll
+            for (int j = 0; j < KPT; ++j)
+                if (tid + j * 1024 < n_tot) { vo |= kreg[j]; va &= kreg[j]; }
+        } else {
+            for (int i = tid; i < n_tot; i += 1024) { const u64 kk = key_at(i); vo |= kk; va &= kk; }
+        }
         for (int o = 32; o > 0; o >>= 1) {
             vo |= ((u64)__shfl_xor((uint32_t)(vo >> 32), o) << 32) | __shfl_xor((uint32_t)vo, o);
             va &= ((u64)__shfl_xor((uint32_t)(va >> 32), o) << 32) | __shfl_xor((uint32_t)va, o);
@@ -822,9 +888,17 @@ __global__ __launch_bounds__(1024) void k_shard_select(Dev d, const unsigned cha
         const int bits = min(SEL_DIGIT, top - d.low_zero), shift = top - bits, nb = 1 << bits;
         for (int i = tid; i < nb; i += 1024) h[i] = 0;
         __syncthreads();
-        for (int i = tid; i < n_tot; i += 1024) {
-            const u64 kk = key_at(i);
-            if (top >= 64 || ((kk ^ P) >> top) == 0) atomicAdd(&h[(uint32_t)(kk >> shift) & (nb - 1)], 1u);
+        if (in_regs) {
+#pragma unroll
+            for (int j = 0; j < KPT; ++j) {
+                const u64 kk = kreg[j];
+                if (tid + j * 1024 < n_tot && (top >= 64 || ((kk ^ P) >> top) == 0)) atomicAdd(&h[(uint32_t)(kk >> shift) & (nb - 1)], 1u);
+            }
+        } else {
+            for (int i = tid; i < n_tot; i += 1024) {
+                const u64 kk = key_at(i);
+                if (top >= 64 || ((kk ^ P) >> top) == 0) atomicAdd(&h[(uint32_t)(kk >> shift) & (nb - 1)], 1u);
+            }
         }
         __syncthreads();
         uint32_t bucket, above;
@@ -840,10 +914,19 @@ __global__ __launch_bounds__(1024) void k_shard_select(Dev d, const unsigned cha
     __syncthreads();
     {   // winners among the candidates of the ranks before this one
         uint32_t g = 0, e = 0;
-        for (int i = tid; i < lo; i += 1024) {
-            const u64 kk = key_at(i);
-            g += kk > T;
-            e += kk == T;
+        if (in_regs) {
+#pragma unroll
+            for (int j = 0; j < KPT; ++j) {
+                const bool before = tid + j * 1024 < lo;
+                g += before && kreg[j] > T;
+                e += before && kreg[j] == T;
+            }
+        } else {
+            for (int i = tid; i < lo; i += 1024) {
+                const u64 kk = key_at(i);
+                g += kk > T;
+                e += kk == T;
+            }
         }
         g = wave_sum(g);
         e = wave_sum(e);

@@ -96,7 +96,8 @@ class Engine:
         self._banks = []
         if self.has_sp:
             c0, c1 = self.column_range          # a sharded handle only ever reads its own rows
-            self.set_permanence(proximal._permanence[c0:c1], row_begin=c0)
+            self.set_permanence(proximal.permanence[c0:c1] if hasattr(type(proximal), "permanence") else proximal._permanence[c0:c1],
+                                row_begin=c0)
             self.words = self.info().words_per_row
 
     def __del__(self):
@@ -164,6 +165,20 @@ class Engine:
         packed = pack_bits(input_bits, self.words)
         self._check(self.lib.htm_sp_step(self.h, packed.ctypes.data_as(C.c_void_p), int(bool(learning))), "htm_sp_step")
         self.steps += 1
+
+    def sp_phase(self, phase, data=None, dtype=None):
+        """One phase of SpatialPooler.process on the current timestep (htm_sp_phase, include/bithtm_hip.h)."""
+        if data is None:
+            rc = self.lib.htm_sp_phase(self.h, int(phase), None, 0)
+        elif phase in (L.SP_OVERLAP, L.SP_LEARN):
+            packed = pack_bits(data, self.words)
+            rc = self.lib.htm_sp_phase(self.h, int(phase), packed.ctypes.data_as(C.c_void_p), packed.size)
+        else:
+            a = np.ascontiguousarray(data, dtype=dtype)
+            rc = self.lib.htm_sp_phase(self.h, int(phase), a.ctypes.data_as(C.c_void_p), a.size)
+        self._check(rc, "htm_sp_phase")
+        if phase == L.SP_COMMIT:
+            self.steps += 1
 
     def tm_step(self, active_column, learning=True, return_winner_cell=True):
         cols = np.ascontiguousarray(active_column, dtype=np.int32)

@@ -10,9 +10,12 @@ Differences from the reference, all documented in DESIGN.md:
   * `active_column` comes back in ascending order (reference: np.argpartition order) and ties at
     the k-th boosted overlap go to the lower column index;
   * random tie-breaks use keyed draws (`seed=`), not the global np.random stream;
-  * plug-in arguments accept the parameter objects of bithtm_amd.projections /
-    bithtm_amd.regularizations (same constructor signatures as the reference's); arbitrary
-    user objects are rejected with TypeError instead of being called on the host.
+  * plug-in arguments (`proximal_projection=`, `boosting=`, `inhibition=`: networks.py:16,22-24) accept the objects
+    of bithtm_amd.projections / bithtm_amd.regularizations (same constructor signatures as the reference's) -- the
+    timestep is then one fused device call -- and ANY other object with the reference's `process` / `update`
+    methods: SpatialPooler.process then runs phase by phase (htm_sp_phase), the device doing the parts that are
+    its own and the user's object being called on the host for the others, exactly in the order of networks.py:26-35.
+    `distal_projection=` takes a bithtm_amd PredictiveProjection only (its state is the device's segment store).
 """
 
 import weakref
@@ -22,7 +25,7 @@ import numpy as np
 from . import _lib as L
 from .engine import Engine, words_to_bool
 from .projections import DenseProjection, PredictiveProjection
-from .regularizations import ExponentialBoosting, GlobalInhibition
+from .regularizations import ExponentialBoosting, GlobalInhibition, _Placeholder
 
 
 class _Lazy:
@@ -83,31 +86,100 @@ class SpatialPooler:
         def _fetch(self):
             return self._engine.read_sp_fields()
 
+        @classmethod
+        def _eager(cls, active_column, overlaps, boosted_overlaps):
+            st = cls.__new__(cls)
+            object.__setattr__(st, "_engine", None)
+            object.__setattr__(st, "_step", -1)
+            object.__setattr__(st, "_cache", dict(active_column=active_column, overlaps=overlaps, boosted_overlaps=boosted_overlaps))
+            return st
+
     def __init__(self, input_dim, column_dim, active_columns, proximal_projection=None, boosting=None,
                  inhibition=None, device=0):
         self.input_dim = input_dim
         self.column_dim = column_dim
         self.active_columns = active_columns
         self.device = device
-        self.proximal_projection = _accept(proximal_projection, DenseProjection, "proximal_projection") \
-            or DenseProjection(input_dim, column_dim)                                   # networks.py:22
-        self.boosting = _accept(boosting, ExponentialBoosting, "boosting") \
-            or ExponentialBoosting(column_dim, active_columns)                          # :23
-        self.inhibition = _accept(inhibition, GlobalInhibition, "inhibition") or GlobalInhibition(active_columns)  # :24
+        self.proximal_projection = proximal_projection or DenseProjection(input_dim, column_dim)       # networks.py:22
+        self.boosting = boosting or ExponentialBoosting(column_dim, active_columns)                    # :23
+        self.inhibition = inhibition or GlobalInhibition(active_columns)                               # :24
+        for name, obj, methods in (("proximal_projection", self.proximal_projection, ("process", "update")),
+                                   ("boosting", self.boosting, ("process", "update")), ("inhibition", self.inhibition, ("process",))):
+            if not all(callable(getattr(obj, m, None)) for m in methods):
+                raise TypeError(f"{name} must have the reference's {' / '.join(methods)} methods; got {type(obj).__name__}")
+        # which parts are the device's own (exact types: a subclass may override the methods the device would skip)
+        self._own_proximal = type(self.proximal_projection) is DenseProjection
+        self._own_boosting = type(self.boosting) is ExponentialBoosting
+        self._own_inhibition = type(self.inhibition) is GlobalInhibition
         self._engine = None
         self._fused = False
 
+    @property
+    def _plain(self):
+        return self._own_proximal and self._own_boosting and self._own_inhibition
+
+    def _engine_parts(self):
+        """The parameter objects the engine is built from: the user's where they are the device's own kind."""
+        proximal = self.proximal_projection if self._own_proximal else _Placeholder(self.input_dim, self.column_dim)
+        boosting = self.boosting if self._own_boosting else ExponentialBoosting(self.column_dim, self.active_columns)
+        return proximal, boosting
+
     def _bind(self, engine, fused):
         self._engine, self._fused = engine, fused
-        self.proximal_projection._engine = engine
-        self.boosting._engine = engine
-        self.proximal_projection._permanence = None      # now lives in device memory
+        if self._own_proximal:
+            self.proximal_projection._engine = engine
+            self.proximal_projection._permanence = None      # now lives in device memory
+        if self._own_boosting:
+            self.boosting._engine = engine
 
     def _ensure_engine(self):
         if self._engine is None:
-            self._bind(Engine(self.input_dim, self.column_dim, 0, self.active_columns,
-                              proximal=self.proximal_projection, boosting=self.boosting, device=self.device), False)
+            proximal, boosting = self._engine_parts()
+            self._bind(Engine(self.input_dim, self.column_dim, 0, self.active_columns, proximal=proximal, boosting=boosting,
+                              device=self.device), False)
         return self._engine
+
+    def _process_phases(self, input, learning, commit):
+        """networks.py:26-35 with some of the three objects living on the host: the device runs the phases that are its
+        own (htm_sp_phase), the user's objects are called for the others, in the reference's order."""
+        eng = self._engine
+        C = self.column_dim
+        input = np.asarray(input, dtype=np.bool_)
+        overlaps = boosted = None
+        if self._own_proximal:
+            eng.sp_phase(L.SP_OVERLAP, input)                                         # :27 (and :28 with the device's boosting)
+        else:
+            overlaps = np.asarray(self.proximal_projection.process(input))
+            if self._own_boosting:
+                eng.sp_phase(L.SP_BOOST, overlaps, np.int32)                          # :28
+        if not self._own_boosting:
+            if overlaps is None:
+                overlaps = eng.read(L.F_OVERLAPS, np.int32, C).astype(np.int64)
+            boosted = np.asarray(self.boosting.process(overlaps))                     # :28
+        if self._own_inhibition:
+            eng.sp_phase(L.SP_SELECT, None if self._own_boosting else boosted, np.float64)     # :29
+            active_column = eng.read(L.F_ACTIVE_COLUMN, np.int32, self.active_columns).astype(np.int64)
+        else:
+            if boosted is None:
+                boosted = eng.read(L.F_BOOSTED, np.float64, C)
+            active_column = np.asarray(self.inhibition.process(boosted))              # :29
+            eng.sp_phase(L.SP_ACTIVE, active_column, np.int32)
+        if learning:                                                                  # :31-32
+            if self._own_proximal:
+                eng.sp_phase(L.SP_LEARN)
+            else:
+                self.proximal_projection.update(input, active_column)
+        if self._own_boosting:                                                        # :33
+            eng.sp_phase(L.SP_DUTY)
+        else:
+            self.boosting.update(active_column)
+        if overlaps is None:
+            overlaps = eng.read(L.F_OVERLAPS, np.int32, C).astype(np.int64)
+        if boosted is None:
+            boosted = eng.read(L.F_BOOSTED, np.float64, C)
+        if commit:
+            eng.sp_phase(L.SP_COMMIT)
+        return self.State._eager(active_column, overlaps, boosted)
 
     def process(self, input, learning=True):
         """networks.py:26-35."""
@@ -115,6 +187,8 @@ class SpatialPooler:
         if self._fused:
             raise RuntimeError("this SpatialPooler is fused into a HierarchicalTemporalMemory; call its process()")
         retire_states(eng)
+        if not self._plain:
+            return self._process_phases(input, learning, commit=True)
         eng.sp_step(input, learning=learning)
         return self.State(eng, eng.steps)
 
@@ -138,18 +212,21 @@ class TemporalMemory:
             cols = self._active_column
             if cols is None:
                 cols = eng.read(L.F_ACTIVE_COLUMN, np.int32, eng.active_columns).astype(np.int64)
-            cols = np.sort(np.asarray(cols, dtype=np.int64))
+            cols = np.asarray(cols, dtype=np.int64)             # in the CALLER's order, as the reference indexes with it
             act = words_to_bool(eng.read(L.F_CELL_ACTIVATION, np.uint32, C), K)
             rows, cells = np.where(act[cols])                                        # networks.py:116-117
+            bursting = np.empty(len(cols), dtype=np.bool_)      # (the device keeps it by ascending column)
+            bursting[np.argsort(cols, kind="stable")] = eng.read(L.F_BURSTING, np.uint8, eng.active_columns)[:len(cols)].astype(np.bool_)
             out = dict(
                 cell_activation=act,
                 cell_prediction=words_to_bool(eng.read(L.F_CELL_PREDICTION, np.uint32, C), K),
                 active_cell=(cols[rows], cells),
-                active_column_bursting=eng.read(L.F_BURSTING, np.uint8, eng.active_columns)[:len(cols)].astype(np.bool_)[:, None],
+                active_column_bursting=bursting[:, None],
                 winner_cell=None)
             if info.has_winner_cells:
-                flat = eng.read(L.F_WINNER_CELL, np.int32, info.winner_cells).astype(np.int64)
-                out["winner_cell"] = (flat // K, flat % K)                           # networks.py:103-104
+                winner = words_to_bool(eng.read(L.F_WINNER_WORDS, np.uint32, C), K)
+                rows, cells = np.where(winner[cols])                                 # networks.py:103-104
+                out["winner_cell"] = (cols[rows], cells)
             d = eng.read_distal()
             out["distal_state"] = None if d is None else _DistalState(d)
             return out
@@ -224,6 +301,13 @@ class TemporalMemory:
         active_column = np.asarray(sp_state.active_column, dtype=np.int64)
         eng = self._ensure_engine(max(len(active_column), 1))
         retire_states(eng)
+        if len(active_column) > eng.active_columns:          # the reference takes any number of columns: a larger engine,
+            bigger = Engine(0, self.column_dim, self.cell_dim, max(len(active_column), 2 * eng.active_columns),   # same state
+                            distal=self.distal_projection, seed=self.seed, device=self.device)
+            if eng.steps:
+                bigger.import_tm_state(eng.export_tm_state())
+            self._bind(bigger, False)
+            eng = bigger
         eng.tm_step(active_column, learning=learning, return_winner_cell=return_winner_cell)
         return self._new_state(active_column)
 
@@ -255,8 +339,9 @@ class HierarchicalTemporalMemory:
         sp, tm = self.spatial_pooler, self.temporal_memory
         if sp._engine is not None or tm._engine is not None:
             raise ValueError("spatial_pooler / temporal_memory must not have been stepped on their own before fusing")
+        proximal, boosting = sp._engine_parts()
         self._engine = Engine(sp.input_dim, column_dim, cell_dim, sp.active_columns,
-                              proximal=sp.proximal_projection, boosting=sp.boosting, distal=tm.distal_projection,
+                              proximal=proximal, boosting=boosting, distal=tm.distal_projection,
                               seed=tm.seed, device=device)
         sp._bind(self._engine, True)
         tm._bind(self._engine, True)
@@ -269,6 +354,10 @@ class HierarchicalTemporalMemory:
         """networks.py:146-149."""
         eng = self._engine
         retire_states(eng)
+        if not self.spatial_pooler._plain:          # plug-in objects on the host: SP phase by phase, then the TM with its winners
+            sp_state = self.spatial_pooler._process_phases(input, learning, commit=False)
+            eng.tm_step(sp_state.active_column, learning=learning)
+            return sp_state, self.temporal_memory._new_state(sp_state.active_column)
         eng.step(input, learning=learning)
         sp_state = SpatialPooler.State(eng, eng.steps)
         tm_state = self.temporal_memory._new_state(None)
@@ -306,6 +395,8 @@ class HierarchicalTemporalMemory:
         """`steps` timesteps over the rows of the boolean matrix `inputs`, cycled, with the input
         bank resident in device memory and no per-step host work (the loop of example.py:48-53).
         Returns nothing; read `temporal_memory.last_state` or call process() afterwards."""
+        if not self.spatial_pooler._plain:
+            raise RuntimeError("run() keeps the whole loop on the device: not available with plug-in objects that live on the host")
         eng = self._engine
         retire_states(eng)
         inputs = np.asarray(inputs, dtype=np.bool_)

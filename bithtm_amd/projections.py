@@ -38,10 +38,82 @@ class DenseProjection:
         else:
             self._permanence = value
 
-    def process(self, input_activation):
-        raise NotImplementedError("the overlap runs inside SpatialPooler.process on the GPU")
+    def _ensure_engine(self):
+        if self._engine is None:
+            from .engine import Engine
+            from .regularizations import ExponentialBoosting
+            # an engine of its own: a DenseProjection used outside a SpatialPooler (k is a formality here)
+            k = min(self.output_dim, 2048)
+            eng = Engine(self.input_dim, self.output_dim, 0, k, proximal=self, boosting=ExponentialBoosting(self.output_dim, k))
+            self._engine, self._permanence = eng, None
+        return self._engine
 
-    update = process
+    def process(self, input_activation):
+        """projections.py:18-21 on the device: popcount of (connected mask & input) per row."""
+        from . import _lib as L
+        eng = self._ensure_engine()
+        eng.sp_phase(L.SP_OVERLAP, np.asarray(input_activation, dtype=np.bool_))
+        return eng.read(L.F_OVERLAPS, np.int32, self.output_dim).astype(np.int64)
+
+    def update(self, input_activation, learning_output):
+        """projections.py:23-24 on the device (float64 rows, fused with the rebuild of their connected mask)."""
+        from . import _lib as L
+        eng = self._ensure_engine()
+        cols = np.unique(np.asarray(learning_output, dtype=np.int64).reshape(-1))      # (fancy-indexed += applies once per distinct row)
+        chunk = max(eng.active_columns, 1)
+        for lo in range(0, len(cols), chunk):
+            eng.sp_phase(L.SP_ACTIVE, cols[lo:lo + chunk], np.int32)
+            eng.sp_phase(L.SP_LEARN, np.asarray(input_activation, dtype=np.bool_))
+
+
+class SegmentProjectionView:
+    """The read surface of the reference's SparseProjection (projections.py:27-68) over a snapshot of the device's
+    segment store: what `reference_implementations.TemporalMemory.copy_custom` (:48-88) and other consumers of the
+    reference's layout touch.
+
+      output_edges[S, 1]       valid synapses per segment                       (projections.py:42)
+      output_edge[S, E]        slot_in_input_edge * (input_dim + 1) + target    (:43, :63-64); invalid = input_dim (:36)
+      output_permanence[S, E]  float32, -1.0 where invalid                      (:44, :58)
+      input_edge[N + 1, E_in]  per presynaptic cell the list of 1 + segment, 0 = free (:40, :35); row N is the pad row
+
+    The device keeps the pull form only (one packed row of presynaptic ids per segment); the mirrored push form is
+    rebuilt here, on the host, when somebody asks for it: slots of a cell's input_edge row are handed out in segment
+    order."""
+
+    def __init__(self, presyn, perm, input_dim):
+        presyn = np.asarray(presyn)
+        S, E = presyn.shape
+        N = int(input_dim)
+        self.input_dim, self.output_dim = N, S
+        self.invalid_input_edge, self.invalid_output_edge = 0, N
+        valid = presyn >= 0
+        seg, slot = np.nonzero(valid)                         # row-major: ascending segment, then slot
+        target = presyn[seg, slot].astype(np.int64)
+        order = np.argsort(target, kind="stable")             # groups by presynaptic cell, segments ascending inside
+        t_sorted = target[order]
+        first = np.flatnonzero(np.r_[True, t_sorted[1:] != t_sorted[:-1]]) if len(order) else np.zeros(0, np.int64)
+        sizes = np.diff(np.r_[first, len(order)])
+        in_slot = np.arange(len(order)) - np.repeat(first, sizes)
+        e_in = int(sizes.max(initial=0))
+        packed = np.empty(len(order), dtype=np.int64)
+        packed[order] = in_slot * (N + 1) + t_sorted
+        dtype = np.int32 if (e_in * (N + 1) + N) < 2 ** 31 else np.int64     # (the reference's int32 packing would overflow)
+        self.output_edge = np.full((S, E), N, dtype=dtype)
+        self.output_edge[seg, slot] = packed
+        self.output_permanence = np.where(valid, np.asarray(perm, dtype=np.float32), np.float32(-1.0))
+        self.output_edges = valid.sum(axis=1, dtype=np.int32)[:, None]
+        self.input_edge = np.zeros((N + 1, e_in), dtype=np.int32)
+        self.input_edge[t_sorted, in_slot] = 1 + seg[order]
+
+    def get_output_edge_target(self, output_edge):            # projections.py:60-61
+        return output_edge % (self.input_dim + 1)
+
+    def pack_output_edge(self, target_input, input_edge):     # :63-64
+        return input_edge * (self.input_dim + 1) + target_input
+
+    def unpack_output_edge(self, output_edge):                # :66-68
+        input_edge, target_input = np.divmod(output_edge, self.input_dim + 1)
+        return target_input, input_edge
 
 
 class PredictiveProjection:
@@ -80,7 +152,16 @@ class PredictiveProjection:
     def bundle_segments(self):
         return self._engine.read_store()["segcount"]
 
+    @property
+    def segment_projection(self):
+        """A snapshot of the synapse store in the reference's SparseProjection layout (see SegmentProjectionView):
+        `reference_implementations.TemporalMemory().copy_custom(tm)` accepts a bithtm_amd TemporalMemory through it."""
+        st = self._engine.read_store()
+        return SegmentProjectionView(st["presyn"], st["perm"], self.output_dim)
+
     def process(self, active_input, return_jittered_potential_info=True):
-        raise NotImplementedError("the segment scan runs inside TemporalMemory.process on the GPU")
+        raise NotImplementedError("PredictiveProjection.process / update work on the previous State objects of the "
+                                  "TemporalMemory that owns the projection; on the device they run inside "
+                                  "TemporalMemory.process (kernels k_tm_scan, k_mid_rows, k_tm_learn)")
 
     update = process

@@ -157,6 +157,26 @@ int htm_sp_step(htm_handle *h, const uint32_t *packed_input, int32_t learning);
 int htm_tm_step(htm_handle *h, const int32_t *active_column, int32_t n, int32_t learning,
                 int32_t return_winner_cell);
 
+/* SpatialPooler.process (networks.py:26-35) one phase per call, for handles whose plug-in objects (proximal_projection=,
+ * boosting=, inhibition=: networks.py:16,22-24) partly live on the host: the binding interleaves these calls with the
+ * user's `process` / `update` methods.  The phases work on the current timestep and do not close it: on a handle with
+ * a Temporal Memory htm_tm_step (with the winner list) does, on a Spatial Pooler alone HTM_SP_COMMIT.  Results are
+ * read with htm_read (HTM_F_OVERLAPS / _BOOSTED / _ACTIVE_COLUMN).  Each phase is also the stand-alone form of the
+ * reference method named beside it. */
+typedef enum htm_sp_phase_id {
+    HTM_SP_OVERLAP = 1, /* DenseProjection.process (projections.py:18-21) + ExponentialBoosting.process
+                           (regularizations.py:15-17); data = packed input as for htm_step */
+    HTM_SP_BOOST = 2,   /* ExponentialBoosting.process on overlaps computed elsewhere; data = int32[column_dim] */
+    HTM_SP_SELECT = 3,  /* GlobalInhibition.process (regularizations.py:28-29) on the device's boosted overlaps
+                           (data = NULL) or on boosted overlaps computed elsewhere (data = double[column_dim]) */
+    HTM_SP_ACTIVE = 4,  /* a winner list chosen elsewhere; data = int32[count] distinct columns, count <= active_columns */
+    HTM_SP_LEARN = 5,   /* DenseProjection.update (projections.py:23-24) on the current winner list; data = packed
+                           input, or NULL: the input of HTM_SP_OVERLAP */
+    HTM_SP_DUTY = 6,    /* ExponentialBoosting.update (regularizations.py:19-21) on the current winner list */
+    HTM_SP_COMMIT = 7   /* close the timestep of a handle without Temporal Memory */
+} htm_sp_phase_id;
+int htm_sp_phase(htm_handle *h, int32_t phase, const void *data, int64_t count);
+
 /* n_steps timesteps of htm_step over a bank of n_inputs packed inputs that is ALREADY IN
  * DEVICE MEMORY (words_per_row words each, see htm_info); step t reads input
  * (step_index % n_inputs).  Nothing is copied or synchronised: this is the loop

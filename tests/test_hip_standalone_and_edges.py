@@ -78,10 +78,16 @@ def test_standalone_temporal_memory_matches_oracle_with_unsorted_columns():
         want = ora.step(cols, learning=learning, return_winner_cell=rwc)
         assert np.array_equal(got.cell_activation, want.cell_activation), t
         assert np.array_equal(got.cell_prediction, want.cell_prediction), t
-        assert np.array_equal(got.active_column_bursting, want.active_column_bursting), t
-        assert np.array_equal(got.active_cell[0], want.active_cell[0]) and np.array_equal(got.active_cell[1], want.active_cell[1]), t
+        # per-column results come back in the CALLER's column order, as with the reference (networks.py:96-97,103-104,116-117)
+        back = np.searchsorted(cols, shuffled)
+        assert np.array_equal(got.active_column_bursting, want.active_column_bursting[back]), t
+        rows, cells = np.where(want.cell_activation[shuffled])
+        assert np.array_equal(got.active_cell[0], shuffled[rows]) and np.array_equal(got.active_cell[1], cells), t
         if learning or rwc:
-            assert np.array_equal(got.winner_cell[0], want.winner_cell[0]) and np.array_equal(got.winner_cell[1], want.winner_cell[1]), t
+            wm = np.zeros((C, K), dtype=bool)
+            wm[want.winner_cell] = True
+            rows, cells = np.where(wm[shuffled])
+            assert np.array_equal(got.winner_cell[0], shuffled[rows]) and np.array_equal(got.winner_cell[1], cells), t
         else:
             assert got.winner_cell is None and want.winner_cell is None
         d, od = got.distal_state, want.distal_state

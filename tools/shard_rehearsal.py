@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""All ranks of the column-sharded bench workload (configs[3]: 65 536 x 32) inside one process on one GPU
+(bithtm_amd.distributed.LocalGroup: every sharded kernel, the all-gather as device copies): per-launch device time of
+rank 0 -- what one rank's GPU would spend per timestep, the exchange itself excluded.
+
+    python tools/shard_rehearsal.py [--world 8] [--steps 600]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--world", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=600)
+    args = ap.parse_args()
+    import bithtm_amd as B
+    from bithtm_amd.distributed import LocalGroup
+    w = dict(bench.WORKLOAD)
+    noisy, perm = bench.make_inputs(w)
+    C, I, K = w["column_dim"], w["input_dim"], w["cell_dim"]
+    group = LocalGroup(args.world, I, C, K, permanence=perm,
+                       make_parts=lambda r: dict(distal=B.PredictiveProjection(C * K, segment_slots=w["segment_slots"])))
+    group.upload_bank(noisy)
+    group.run(args.steps)
+    eng = group.engines[0]
+    eng.sync()
+    t0 = time.perf_counter()
+    group.run(200)
+    eng.sync()
+    wall = (time.perf_counter() - t0) / 200
+    eng.profile(True)
+    group.run(200)
+    prof = {n: 1e3 * ms / cnt for n, (ms, cnt) in eng.profile_read().items() if cnt}
+    eng.profile(False)
+    info = eng.check_capacity()
+    print(json.dumps(dict(world=args.world, rank0_launch_us={n: round(v, 1) for n, v in prof.items()},
+                          rank0_kernels_us=round(sum(prof.values()), 1), all_ranks_wall_us_per_step=round(1e6 * wall, 1),
+                          segments=info.segments, rank0_rows=info.local_segments, record_bytes=eng.shard_record_bytes())))
+
+
+if __name__ == "__main__":
+    main()
