@@ -19,6 +19,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <algorithm>
+#include <chrono>
 #include <map>
 #include <mutex>
 #include <string>
@@ -67,6 +68,8 @@ struct htm_handle {
     int seg_hint;                         // a lower bound of the segment count (see scan_spec_blocks)
     int *seg_pinned;                      // pinned word the end of each htm_run copies the count into
     int sp_blocks, sel_blocks, c256_blocks, s1024_blocks, scan_blocks, cus;
+    const uint32_t *ahead_bank;           // htm_run ended with HTM_RUN_CONTINUE on this bank: the SP has done the next step
+    int ahead_n_inputs, ahead_learning;   //   and the front of the one after it
     int phase_active;                     // htm_sp_phase: length of the current winner list
     bool phase_open;                      // ... phases of the current (not yet closed) timestep have run: the Spatial Pooler
                                           // fields htm_read returns are that step's
@@ -113,6 +116,17 @@ static void refresh_exchange_mode(htm_handle *h) {
             (h)->err = std::string(#call) + ": " + hipGetErrorString(e_);                        \
             return HTM_ERR_HIP;                                                                  \
         }                                                                                        \
+    } while (0)
+
+// the Spatial Pooler is ahead of the Temporal Memory across a call boundary (htm_run with HTM_RUN_CONTINUE): only the
+// continuing htm_run may come next
+static bool sp_is_ahead(const htm_handle *h) { return h->ahead_bank != nullptr; }
+#define REJECT_WHEN_AHEAD(h)                                                                                      \
+    do {                                                                                                          \
+        if (sp_is_ahead(h)) {                                                                                     \
+            (h)->err = "the Spatial Pooler is ahead (htm_run ended with HTM_RUN_CONTINUE): continue with htm_run on the same bank"; \
+            return HTM_ERR_STATE;                                                                                 \
+        }                                                                                                         \
     } while (0)
 
 template <typename T>
@@ -392,6 +406,8 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
     h->shard_send = h->shard_recv = nullptr;
     h->phase_active = 0;
     h->phase_open = false;
+    h->ahead_bank = nullptr;
+    h->ahead_n_inputs = h->ahead_learning = 0;
     hipError_t e = hipSetDevice(cfg->device);
     if (e != hipSuccess) return fail_create(h, std::string("hipSetDevice: ") + hipGetErrorString(e), HTM_ERR_HIP);
     if (cfg->use_caller_stream) {
@@ -577,6 +593,15 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
 extern "C" int htm_sync(htm_handle *h) {
     if (!h) return HTM_ERR_ARGUMENT;
     HIPCHK(h, hipSetDevice(h->device));
+    // a short run ends within a millisecond: poll for that long (a blocking wait is woken tens of microseconds late),
+    // then block
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t e = hipStreamQuery(h->stream);
+        if (e == hipSuccess) return HTM_OK;
+        if (e != hipErrorNotReady) { h->err = std::string("hipStreamQuery: ") + hipGetErrorString(e); return HTM_ERR_HIP; }
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+    }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return HTM_OK;
 }
@@ -594,6 +619,7 @@ static int check_rows(htm_handle *h, const void *rows, int row_begin, int row_co
 extern "C" int htm_sp_set_permanence(htm_handle *h, const double *rows, int32_t row_begin, int32_t row_count) {
     int rc = check_rows(h, rows, row_begin, row_count);
     if (rc) return rc;
+    REJECT_WHEN_AHEAD(h);
     if (row_count == 0) return HTM_OK;
     Dev &d = h->d;
     HIPCHK(h, hipSetDevice(h->device));
@@ -609,6 +635,7 @@ extern "C" int htm_sp_set_permanence(htm_handle *h, const double *rows, int32_t 
 extern "C" int htm_sp_get_permanence(htm_handle *h, double *rows, int32_t row_begin, int32_t row_count) {
     int rc = check_rows(h, rows, row_begin, row_count);
     if (rc) return rc;
+    REJECT_WHEN_AHEAD(h);
     if (row_count == 0) return HTM_OK;
     Dev &d = h->d;
     HIPCHK(h, hipSetDevice(h->device));
@@ -627,6 +654,7 @@ static int stage_input(htm_handle *h, const uint32_t *packed_input) {
 
 extern "C" int htm_step(htm_handle *h, const uint32_t *packed_input, int32_t learning) {
     if (!h || !packed_input) return HTM_ERR_ARGUMENT;
+    REJECT_WHEN_AHEAD(h);
     if (!h->cfg.enable_sp || !h->cfg.enable_tm) { h->err = "htm_step needs a handle with SP and TM"; return HTM_ERR_STATE; }
     if (h->world > 1) { h->err = "sharded handle: use htm_shard_begin / htm_shard_finish"; return HTM_ERR_STATE; }
     HIPCHK(h, hipSetDevice(h->device));
@@ -638,6 +666,7 @@ extern "C" int htm_step(htm_handle *h, const uint32_t *packed_input, int32_t lea
 
 extern "C" int htm_sp_step(htm_handle *h, const uint32_t *packed_input, int32_t learning) {
     if (!h || !packed_input) return HTM_ERR_ARGUMENT;
+    REJECT_WHEN_AHEAD(h);
     if (!h->cfg.enable_sp) { h->err = "handle has no Spatial Pooler"; return HTM_ERR_STATE; }
     // a handle that also owns a Temporal Memory steps both layers together: an SP-only step would skip the SP
     // learning that rides in the TM's middle launch and leave the TM's parity buffers one step behind
@@ -657,6 +686,7 @@ extern "C" int htm_sp_step(htm_handle *h, const uint32_t *packed_input, int32_t 
 // (bithtm_amd/networks.py) interleaves these with the `process` / `update` methods of the user's objects.
 extern "C" int htm_sp_phase(htm_handle *h, int32_t phase, const void *data, int64_t count) {
     if (!h) return HTM_ERR_ARGUMENT;
+    REJECT_WHEN_AHEAD(h);
     if (!h->cfg.enable_sp) { h->err = "handle has no Spatial Pooler"; return HTM_ERR_STATE; }
     if (h->world > 1) { h->err = "htm_sp_phase: not available on a column-sharded handle"; return HTM_ERR_STATE; }
     HIPCHK(h, hipSetDevice(h->device));
@@ -737,6 +767,7 @@ extern "C" int htm_sp_phase(htm_handle *h, int32_t phase, const void *data, int6
 
 extern "C" int htm_tm_step(htm_handle *h, const int32_t *active_column, int32_t n, int32_t learning, int32_t return_winner_cell) {
     if (!h || (!active_column && n > 0)) return HTM_ERR_ARGUMENT;
+    REJECT_WHEN_AHEAD(h);
     if (!h->cfg.enable_tm) { h->err = "handle has no Temporal Memory"; return HTM_ERR_STATE; }
     Dev &d = h->d;
     if (n < 0 || n > d.k) { h->err = "htm_tm_step: more active columns than active_columns"; return HTM_ERR_ARGUMENT; }
@@ -768,17 +799,24 @@ static int run_or_prepare(htm_handle *h, const uint32_t *device_inputs, int32_t 
     learning = learning ? 1 : 0;
     const bool graph = (use_graph & 1) && !h->profile;
     const bool pipeline = !(use_graph & 2) && can_pipeline(h);
+    const bool resume = sp_is_ahead(h);            // the previous call left the SP one step (and a front) ahead
+    if (resume && (h->ahead_bank != device_inputs || h->ahead_n_inputs != n_inputs || h->ahead_learning != learning || !pipeline)) {
+        h->err = "htm_run: the previous call ended with HTM_RUN_CONTINUE; this one must use the same bank, n_inputs, learning and schedule";
+        return HTM_ERR_STATE;
+    }
+    const bool cont = (use_graph & 4) && pipeline && n_steps > 0;      // keep looking ahead past the end of this call
+    if ((use_graph & 4) && !pipeline) { h->err = "htm_run: HTM_RUN_CONTINUE needs the pipelined schedule"; return HTM_ERR_STATE; }
     if (dry && !graph) return HTM_OK;
-    // Graphs hold the launches of one step, or of kGraphSteps consecutive steady-state steps (a graph
+    // Graphs hold the launches of one step, or of up to kGraphSteps consecutive steady-state steps (a graph
     // launch boundary costs about 5 us more than a kernel boundary inside a graph: tools/step_timeline.py).
     // Nothing in a graph depends on the step index: kernels read it, and with it the bank row, from
     // the device counter.
     const int kGraphSteps = h->graph_steps;
     if (h->seg_pinned) { const int seen = *(volatile int *)h->seg_pinned; h->seg_hint = std::max(h->seg_hint, seen); }      // what the last run left
-    bool sp_done = false;                           // the SP has already done the coming step
+    bool sp_done = resume;                          // the SP has already done the coming step
     long long step = h->step_host;
     for (int t = 0; t < n_steps;) {
-        const StepPlan plan{sp_done, pipeline && t + 1 < n_steps, pipeline && t + 2 < n_steps};
+        const StepPlan plan{sp_done, pipeline && (t + 1 < n_steps || cont), pipeline && (t + 2 < n_steps || cont)};
         sp_done = plan.next_sp;
         if (!graph) {
             int rc = enqueue_step(h, device_inputs, n_inputs, learning, plan);
@@ -787,13 +825,18 @@ static int run_or_prepare(htm_handle *h, const uint32_t *device_inputs, int32_t 
             continue;
         }
         const int p = (int)(step & 1);
-        // steady state: this and the next kGraphSteps - 1 steps all look ahead fully
-        const int span = (plan.sp_done && plan.next_front && t + kGraphSteps + 1 < n_steps) ? kGraphSteps : 1;
+        // steady state: this and the next span - 1 steps all look ahead fully
+        int span = 1;
+        if (plan.sp_done && plan.next_front) {
+            const int steady = cont ? n_steps - t : n_steps - t - 2;       // steps from here on that look ahead fully
+            if (cont && steady > 1 && steady < 2 * kGraphSteps) span = steady;      // a continuing call's (last) stretch: one graph
+            else if (steady >= kGraphSteps) span = kGraphSteps;
+        }
         if (!dry) {
             if (!plan.sp_done && !plan.next_sp) enqueue_sp_front(h, device_inputs, n_inputs, p);    // eager
             enqueue_cold_start(h, device_inputs, n_inputs, learning, plan);                         // eager: first step of a pipelined run
         }
-        auto key = std::make_tuple(p, learning * 16 + (span > 1 ? 8 : 0) + (plan.sp_done ? 4 : 0) + (plan.next_sp ? 2 : 0) + (plan.next_front ? 1 : 0) + 32 * scan_spec_blocks(h) + (scan_pool_is_large(h) ? (1 << 20) : 0) + (h->emit_fused ? (1 << 21) : 0),
+        auto key = std::make_tuple(p, learning * 16 + (plan.sp_done ? 4 : 0) + (plan.next_sp ? 2 : 0) + (plan.next_front ? 1 : 0) + 32 * scan_spec_blocks(h) + (scan_pool_is_large(h) ? (1 << 20) : 0) + (h->emit_fused ? (1 << 21) : 0) + (span << 22),
                                    (const void *)device_inputs, n_inputs);
         auto it = h->graphs.find(key);
         if (it == h->graphs.end()) {
@@ -814,8 +857,16 @@ static int run_or_prepare(htm_handle *h, const uint32_t *device_inputs, int32_t 
         step += span;
         t += span;
     }
-    // leave the segment count where the next call finds it (no wait: it may see the one before)
-    if (!dry && h->seg_pinned && n_steps > 0) HIPCHK(h, hipMemcpyAsync(h->seg_pinned, &h->d.ctr->S, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    if (dry) return HTM_OK;
+    if (n_steps > 0) {
+        if (resume && !cont && n_steps == 1)        // the front computed for the step after this one is never consumed:
+            HIPCHK(h, hipMemsetAsync(h->d.hist0 + (size_t)(h->step_host & 1) * HIST_REP * SEL_BINS, 0, (size_t)HIST_REP * SEL_BINS * 4, h->stream));    // its digit histogram
+        h->ahead_bank = cont ? device_inputs : nullptr;
+        h->ahead_n_inputs = n_inputs;
+        h->ahead_learning = learning;
+        // leave the segment count where the next call finds it (no wait: it may see the one before)
+        if (h->seg_pinned) HIPCHK(h, hipMemcpyAsync(h->seg_pinned, &h->d.ctr->S, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    }
     return HTM_OK;
 }
 
@@ -1175,9 +1226,9 @@ extern "C" int64_t htm_read(htm_handle *h, int32_t field, void *dst, int64_t cou
     int64_t n;
     switch (field) {
         case HTM_F_ACTIVE_COLUMN: if ((n = need(true, d.k)) < 0) return n; return copy(d.active_cols[qs], n, 4);
-        case HTM_F_OVERLAPS: if ((n = need(sp, C)) < 0) return n; return copy(d.overlap[qs], n, 4);
-        case HTM_F_BOOSTED: if ((n = need(sp, C)) < 0) return n; return copy(d.boosted[qs], n, 8);
-        case HTM_F_DUTY_CYCLE: if ((n = need(sp, C)) < 0) return n; return copy(d.duty, n, 4);
+        case HTM_F_OVERLAPS: REJECT_WHEN_AHEAD(h); if ((n = need(sp, C)) < 0) return n; return copy(d.overlap[qs], n, 4);
+        case HTM_F_BOOSTED: REJECT_WHEN_AHEAD(h); if ((n = need(sp, C)) < 0) return n; return copy(d.boosted[qs], n, 8);
+        case HTM_F_DUTY_CYCLE: REJECT_WHEN_AHEAD(h); if ((n = need(sp, C)) < 0) return n; return copy(d.duty, n, 4);
         case HTM_F_CELL_ACTIVATION: if ((n = need(tm, C)) < 0) return n; return copy(d.act[q], n, 4);
         case HTM_F_CELL_PREDICTION: if ((n = need(tm, C)) < 0) return n; return copy(d.pred[q], n, 4);
         case HTM_F_WINNER_WORDS: if ((n = need(tm, C)) < 0) return n; return copy(d.win[q], n, 4);
@@ -1273,6 +1324,7 @@ extern "C" int64_t htm_read(htm_handle *h, int32_t field, void *dst, int64_t cou
 
 extern "C" int htm_write(htm_handle *h, int32_t field, const void *src, int64_t count) {
     if (!h || (!src && count > 0) || count < 0) return HTM_ERR_ARGUMENT;
+    REJECT_WHEN_AHEAD(h);
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     Dev &d = h->d;
@@ -1322,6 +1374,7 @@ extern "C" int htm_write(htm_handle *h, int32_t field, const void *src, int64_t 
 
 extern "C" int htm_import_begin(htm_handle *h, int64_t step_index) {
     if (!h || step_index < 0) return HTM_ERR_ARGUMENT;
+    REJECT_WHEN_AHEAD(h);
     if (h->world > 1) { h->err = "state import is not available on a column-sharded handle"; return HTM_ERR_STATE; }
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream));

@@ -198,15 +198,16 @@ class Engine:
         self._check(self.lib.htm_bank_upload(self.h, packed.ctypes.data_as(C.c_void_p), n, C.byref(ptr)), "htm_bank_upload")
         return ptr.value
 
-    def run(self, device_bank, n_inputs, n_steps, learning=True, use_graph=True, pipeline=True):
-        flags = (1 if use_graph else 0) | (0 if pipeline else 2)
+    def run(self, device_bank, n_inputs, n_steps, learning=True, use_graph=True, pipeline=True, continuing=False):
+        """`continuing`: the next call is another run() on the same bank (HTM_RUN_CONTINUE, include/bithtm_hip.h)."""
+        flags = (1 if use_graph else 0) | (0 if pipeline else 2) | (4 if continuing else 0)
         self._check(self.lib.htm_run(self.h, C.c_void_p(device_bank), int(n_inputs), int(n_steps), int(bool(learning)),
                                      flags), "htm_run")
         self.steps += n_steps
 
-    def prepare(self, device_bank, n_inputs, n_steps, learning=True, use_graph=True, pipeline=True):
+    def prepare(self, device_bank, n_inputs, n_steps, learning=True, use_graph=True, pipeline=True, continuing=False):
         """Build (capture + instantiate) the hipGraphs the run() call with these arguments will replay."""
-        flags = (1 if use_graph else 0) | (0 if pipeline else 2)
+        flags = (1 if use_graph else 0) | (0 if pipeline else 2) | (4 if continuing else 0)
         self._check(self.lib.htm_prepare(self.h, C.c_void_p(device_bank), int(n_inputs), int(n_steps), int(bool(learning)),
                                          flags), "htm_prepare")
 

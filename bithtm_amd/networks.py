@@ -391,10 +391,12 @@ class HierarchicalTemporalMemory:
         with np.load(path) as z:
             self.load_state_dict({k: z[k] for k in z.files})
 
-    def run(self, inputs, steps, learning=True, use_graph=True, pipeline=True):
+    def run(self, inputs, steps, learning=True, use_graph=True, pipeline=True, continuing=False):
         """`steps` timesteps over the rows of the boolean matrix `inputs`, cycled, with the input
         bank resident in device memory and no per-step host work (the loop of example.py:48-53).
-        Returns nothing; read `temporal_memory.last_state` or call process() afterwards."""
+        Returns nothing; read `temporal_memory.last_state` or call process() afterwards.  `continuing=True`: the
+        caller streams its input in chunks and the next call is another run() on the same inputs (HTM_RUN_CONTINUE:
+        the Spatial Pooler keeps working ahead across the calls; finish with a run() without it)."""
         if not self.spatial_pooler._plain:
             raise RuntimeError("run() keeps the whole loop on the device: not available with plug-in objects that live on the host")
         eng = self._engine
@@ -404,7 +406,7 @@ class HierarchicalTemporalMemory:
         bank = getattr(self, "_bank", None)
         if bank is None or bank[0] != key:
             self._bank = bank = (key, eng.upload_bank(inputs))
-        eng.run(bank[1], inputs.shape[0], steps, learning=learning, use_graph=use_graph, pipeline=pipeline)
+        eng.run(bank[1], inputs.shape[0], steps, learning=learning, use_graph=use_graph, pipeline=pipeline, continuing=continuing)
         self.temporal_memory._new_state(None)
         eng.check_capacity()
 

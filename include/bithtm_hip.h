@@ -188,6 +188,16 @@ int htm_sp_phase(htm_handle *h, int32_t phase, const void *data, int64_t count);
  * is exactly that of n_steps htm_step calls. */
 int htm_run(htm_handle *h, const uint32_t *device_inputs, int32_t n_inputs, int32_t n_steps,
             int32_t learning, int32_t use_graph);
+/* use_graph bit 2 (HTM_RUN_CONTINUE): a caller that streams its input in chunks promises that the next call is another
+ * htm_run on the same bank, n_inputs and learning flag.  The Spatial Pooler then keeps working ahead across the end
+ * of this call (the next step's winner list, permanence rows and duty cycle, and the overlaps of the one after it,
+ * are computed beside this call's last Temporal Memory steps) and the next call starts in the steady state instead
+ * of with a cold start of six launches.  Until a later htm_run ends without the bit, every other call that needs the
+ * Spatial Pooler's state (htm_step, htm_sp_*, htm_tm_step, state import, the Spatial Pooler fields of htm_read)
+ * returns HTM_ERR_STATE; the Temporal Memory's state is that of exactly the steps run so far. */
+#define HTM_RUN_GRAPH 1
+#define HTM_RUN_NO_PIPELINE 2
+#define HTM_RUN_CONTINUE 4
 
 /* Capture and instantiate, without running anything, every hipGraph the htm_run call with the same
  * arguments will replay when it comes next (graphs are otherwise built lazily inside htm_run, the first

@@ -183,7 +183,7 @@ def test_batched_run_equals_step_by_step():
     rng = np.random.RandomState(11)
     bank = rng.rand(30, 200) < 0.08
     outs = []
-    for mode in ("graph", "eager", "graph-nopipe", "mixed", "chunks", "chunks-eager", "process"):
+    for mode in ("graph", "eager", "graph-nopipe", "mixed", "chunks", "chunks-eager", "continuing", "continuing-eager", "process"):
         np.random.seed(12)
         htm = B.HierarchicalTemporalMemory(200, 2048, 16)
         if mode == "process":
@@ -200,6 +200,18 @@ def test_batched_run_equals_step_by_step():
         elif mode.startswith("chunks"):
             for n in (1, 2, 3, 1, 17, 18, 19, 34):
                 htm.run(bank, n, use_graph=(mode == "chunks"))
+        elif mode.startswith("continuing"):        # a caller streaming in chunks: the SP stays ahead across the calls
+            g = mode == "continuing"
+            for n in (1, 2, 3, 20, 1, 16, 33):
+                htm.run(bank, n, use_graph=g, continuing=True)
+            assert htm.temporal_memory.last_state.cell_prediction.shape == (2048, 16)     # TM fields can be read meanwhile
+            with pytest.raises(B.HtmError, match="ahead"):
+                htm.process(bank[0])                                                     # ... SP-dependent calls cannot
+            with pytest.raises(B.HtmError, match="ahead"):
+                htm.engine.read_duty_cycle()
+            htm.run(bank, 1, use_graph=g)          # a one-step drain (leaves a computed front unused)
+            htm.run(bank, 5, use_graph=g, continuing=True)
+            htm.run(bank, 13, use_graph=g)         # 1+2+3+20+1+16+33 + 1 + 5 + 13 = 95
         else:
             htm.run(bank, 95, use_graph=mode.startswith("graph"), pipeline=(mode != "graph-nopipe"))
         st = htm.engine.read_store()
