@@ -9,11 +9,16 @@ patterns, cycled, with flip noise: BASELINE.md section 4) is resident in HBM bef
 region.  Prints ONE JSON line (rank 0).
 
 Besides the contract fields the line carries
-  roofline      the dominant kernel's achieved HBM GB/s: algorithmic bytes per launch (formulas in
-                DESIGN.md) / its average launch time, measured here with HIP events on the
-                engine's stream over a profiled replay of the same workload;
+  roofline      the dominant launch of the TIMED schedule: algorithmic bytes of its roles (formulas in DESIGN.md
+                section 4 and in role_bytes below) / its average duration, measured here with HIP events on the
+                engine's stream over an eager replay of the same schedule; every launch is listed;
   cpu_baseline  the NumPy oracle (a port of the reference's CPU path) timed on this box's host
-                cores from the same learned state, on a bounded sample of steps.
+                cores from the same learned state, on a bounded sample of steps;
+  stress        BASELINE.json configs[4] as far as one GPU holds it: one rank's pre-populated shard (133.7 M
+                segments) inside an 8-rank group, its segment scan against the HBM roofline.
+
+The model is brought to the learned state (10 passes over the pattern bank) in untimed setup, whatever --warmup
+says; `value` is the median of several repetitions of [W warm-up steps, exactly K timed steps].
 """
 
 import argparse
@@ -197,6 +202,7 @@ def stress_leg(steps=8, warmup=3):
                avg_launch_us=round(scan_us, 1), achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4),
                rank0_launch_us={n: round(v, 1) for n, v in prof.items()}, rank0_step_us=round(sum(prof.values()), 1),
                exchange_bytes_per_rank=int(eng.shard_record_bytes()), setup_s=round(setup_s, 1))
+    out.update(recorded_traffic("k_tm_scan_wide"))
     log(f"[bench] configs[4] leg: rank 0 scans {rows} segments in {scan_us:.0f} us = {ach:.0f} GB/s ({ach / HBM_PEAK_GBS:.1%} of peak); "
         f"its step {out['rank0_step_us']:.0f} us; setup {setup_s:.1f} s")
     del group
@@ -338,9 +344,13 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=40)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stress", action="store_true", help="skip the configs[4] leg (one rank's pre-populated shard)")
+    ap.add_argument("--stress-only", action="store_true", help="run only the configs[4] leg and print its object (profiling)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="one role per launch (what the profiled replay always does)")
     args = ap.parse_args()
+    if args.stress_only:
+        print(json.dumps(stress_leg()), flush=True)
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # started by hand without the launcher: start one process per GPU as a CHILD (this process has
         # not touched the GPU) and pass its exit code on

@@ -627,16 +627,6 @@ __global__ __launch_bounds__(RB) void k_tm_learn(Dev d, int p) {
 // prefix counts + active words) costs three bank-conflicted LDS reads per synapse and was 1.6x slower; one
 // guarded cell-word gather per slot (sixteen per wave and iteration, most of them for a single lane) left the
 // kernel issue-bound at ~400 vector instructions per wave and iteration.
-struct ScanLds { const uint32_t *colbits; };
-__device__ __forceinline__ uint32_t scan_cell_active(const uint32_t *act, const ScanLds &L, int enc, bool valid, bool use_lds) {
-    const int col = enc >> 5;
-    uint32_t maybe = valid ? 1u : 0u;
-    if (use_lds) maybe &= (L.colbits[col >> 5] >> (col & 31));
-    uint32_t aw = 0;
-    if (maybe) aw = act[col];          // exec-masked: only lanes of active columns issue a request
-    return maybe & (aw >> (enc & 31));
-}
-
 // One 128-byte chunk of two rows, 8 slots per lane: e[u * 4 + qq] = slot `first + l * 4 + qq` of row u, of which
 // row u has n[u] valid ones.  chunk_issue builds the lane's hit mask and issues the cell-word reads of its first
 // two hits (lanes without a hit read act[0], one shared line: no branch, so the reads of several chunks and the
@@ -680,6 +670,7 @@ __device__ __forceinline__ ChunkHits chunk_issue(const uint32_t *__restrict__ ac
     return h;
 }
 
+template <bool BATCH>
 __device__ __forceinline__ void chunk_finish(const uint32_t *__restrict__ act, const uint32_t (&e)[8], const ChunkHits &h, uint32_t (&acc)[2]) {
     {
         const uint32_t a = h.j1 >= 0 ? (h.aw1 >> (h.e1 & 31)) & 1u : 0u;
@@ -693,17 +684,60 @@ __device__ __forceinline__ void chunk_finish(const uint32_t *__restrict__ act, c
         acc[0] += (h.j2 & 4) ? 0u : add;
         acc[1] += (h.j2 & 4) ? add : 0u;
     }
-    uint32_t m = h.m_rest;
-    while (__any(m != 0)) {                          // a third hit among a lane's eight slots: one per pass
-        const int j = __ffs(m) - 1;
+    // Third and later hits of a lane.  Rare among random synapses (4 lanes in 10 000) -- but the synapses of a MATCHING
+    // segment are mostly active, and segments created together match together: whole blocks of them.  Their reads
+    // are therefore all issued before any is used (one pass per hit, with a dependent read each, made those blocks
+    // the tail of the launch); the passes beyond the lanes' largest hit count are skipped by wave-uniform branches.
+    // (BATCH = false, the large-pool kernels: one hit per pass -- the six extra registers cost them a wave per SIMD)
+    if (!BATCH) {
+        uint32_t m = h.m_rest;
+        while (__any(m != 0)) {
+            const int j = __ffs(m) - 1;
+            const uint32_t ej = select8(e, j);
+            uint32_t aw = 0;
+            if (m) aw = act[(ej & SYN_CELL) >> 5];
+            const uint32_t a = (aw >> (ej & 31)) & 1u;   // (aw = 0 without a hit)
+            const uint32_t add = a + ((a & (ej >> 31)) << 16);
+            acc[0] += (j & 4) ? 0u : add;
+            acc[1] += (j & 4) ? add : 0u;
+            m &= m - 1;
+        }
+        return;
+    }
+    uint32_t rest = h.m_rest;
+    if (__any(rest != 0)) {                          // hits three to six of a lane: all reads first
+        uint32_t aw[4];
+        uint32_t m = rest;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            aw[t] = 0;
+            if (t > 0 && !__any(m != 0)) break;
+            const uint32_t ej = m ? select8(e, __ffs(m) - 1) : 0u;
+            aw[t] = act[(ej & SYN_CELL) >> 5];
+            m &= m - 1;
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (t > 0 && !__any(rest != 0)) break;
+            const int j = __ffs(rest) - 1;
+            const uint32_t ej = rest ? select8(e, j) : 0u;
+            const uint32_t a = rest ? (aw[t] >> (ej & 31)) & 1u : 0u;
+            const uint32_t add = a + ((a & (ej >> 31)) << 16);
+            acc[0] += (j & 4) ? 0u : add;
+            acc[1] += (j & 4) ? add : 0u;
+            rest &= rest - 1;
+        }
+    }
+    while (__any(rest != 0)) {                       // hits seven and eight: one per pass
+        const int j = __ffs(rest) - 1;
         const uint32_t ej = select8(e, j);
         uint32_t aw = 0;
-        if (m) aw = act[(ej & SYN_CELL) >> 5];
-        const uint32_t a = (aw >> (ej & 31)) & 1u;   // (aw = 0 without a hit)
+        if (rest) aw = act[(ej & SYN_CELL) >> 5];
+        const uint32_t a = (aw >> (ej & 31)) & 1u;
         const uint32_t add = a + ((a & (ej >> 31)) << 16);
         acc[0] += (j & 4) ? 0u : add;
         acc[1] += (j & 4) ? add : 0u;
-        m &= m - 1;
+        rest &= rest - 1;
     }
 }
 
@@ -715,7 +749,6 @@ __device__ __forceinline__ void role_scan(const Dev &d, int p, int blk, int nblk
     constexpr int U = 2;                           // segments in flight per lane group
     uint32_t *s_colbits = lds + 4;
     constexpr bool need_cell = !LARGE;
-    const ScanLds L{s_colbits};
     Counters *c = d.ctr;
     const int S = d.world > 1 ? c->L : c->S;         // rows to scan (a shard scans its local rows; a free row is empty)
     if (blk == 0 && threadIdx.x == 0) {
@@ -777,28 +810,51 @@ __device__ __forceinline__ void role_scan(const Dev &d, int p, int blk, int nblk
         // would make the compiler wait for them with everything else)
         Batch nxt = cur;
         if (LARGE) nxt = fetch(b_next);
-        chunk_finish(act, e1, h1, acc);
-        if (__any(n[0] > 32 || n[1] > 32)) {         // (skipped by waves in which no row is that long)
-            const uint32_t e2[8] = {(uint32_t)ps2[0].x, (uint32_t)ps2[0].y, (uint32_t)ps2[0].z, (uint32_t)ps2[0].w,
-                                    (uint32_t)ps2[1].x, (uint32_t)ps2[1].y, (uint32_t)ps2[1].z, (uint32_t)ps2[1].w};
-            const ChunkHits h2 = chunk_issue<use_lds>(act, s_colbits, e2, 32, l, n);
-            chunk_finish(act, e2, h2, acc);
+        const bool any_long = __any(n[0] > 32 || n[1] > 32);         // (most waves have a row that long: 35 % of the rows are)
+        const uint32_t e2[8] = {(uint32_t)ps2[0].x, (uint32_t)ps2[0].y, (uint32_t)ps2[0].z, (uint32_t)ps2[0].w,
+                                (uint32_t)ps2[1].x, (uint32_t)ps2[1].y, (uint32_t)ps2[1].z, (uint32_t)ps2[1].w};
+        if (!LARGE) {
+            // small pools: the second chunk's first cell-word reads go out before the first chunk's are waited for
+            // (its rows were requested before the first chunk's lookups): one round trip less on the blocks' chain
+            ChunkHits h2 = h1;
+            if (any_long) h2 = chunk_issue<use_lds>(act, s_colbits, e2, 32, l, n);
+            chunk_finish<true>(act, e1, h1, acc);
+            if (any_long) chunk_finish<true>(act, e2, h2, acc);
+        } else {
+            chunk_finish<false>(act, e1, h1, acc);
+            if (any_long) {                          // (skipped by waves in which no row is that long)
+                const ChunkHits h2 = chunk_issue<use_lds>(act, s_colbits, e2, 32, l, n);
+                chunk_finish<false>(act, e2, h2, acc);
+            }
+        }
+        // rows longer than two chunks (a few per thousand at cfg 3, and what set the kernel's tail: five dependent round
+        // trips per further chunk when they were read and looked up one after the other): two chunks per pass, their
+        // four row loads in flight together, then their cell-word reads
+        // (the large-pool kernels take one chunk per pass: the second pair of rows in registers costs them a wave per SIMD)
+        for (int c = 2; __any(n[0] > c * 32 || n[1] > c * 32); c += LARGE ? 1 : 2) {
+            int4 pa[U], pb[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int *prow = d.presyn + (size_t)seg[u] * d.E + l * 4;
+                pa[u] = n[u] > c * 32 ? *(const int4 *)(prow + c * 32) : make_int4(0, 0, 0, 0);
+                if (!LARGE) pb[u] = n[u] > (c + 1) * 32 ? *(const int4 *)(prow + (c + 1) * 32) : make_int4(0, 0, 0, 0);
+            }
+            const uint32_t ea[8] = {(uint32_t)pa[0].x, (uint32_t)pa[0].y, (uint32_t)pa[0].z, (uint32_t)pa[0].w,
+                                    (uint32_t)pa[1].x, (uint32_t)pa[1].y, (uint32_t)pa[1].z, (uint32_t)pa[1].w};
+            const ChunkHits ha = chunk_issue<use_lds>(act, s_colbits, ea, c * 32, l, n);
+            if (!LARGE) {
+                const uint32_t eb[8] = {(uint32_t)pb[0].x, (uint32_t)pb[0].y, (uint32_t)pb[0].z, (uint32_t)pb[0].w,
+                                        (uint32_t)pb[1].x, (uint32_t)pb[1].y, (uint32_t)pb[1].z, (uint32_t)pb[1].w};
+                const ChunkHits hb = chunk_issue<use_lds>(act, s_colbits, eb, (c + 1) * 32, l, n);
+                chunk_finish<true>(act, ea, ha, acc);
+                chunk_finish<true>(act, eb, hb, acc);
+            } else {
+                chunk_finish<false>(act, ea, ha, acc);
+            }
         }
         bool matching[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            if (n[u] > 64) {                         // rare: rows longer than two chunks
-                const int *prow = d.presyn + (size_t)seg[u] * d.E;
-                for (int i = 64 + l * 4; i < n[u]; i += 32) {
-                    const int4 pv = *(const int4 *)(prow + i);
-                    const uint32_t e[4] = {(uint32_t)pv.x, (uint32_t)pv.y, (uint32_t)pv.z, (uint32_t)pv.w};
-#pragma unroll
-                    for (int qq = 0; qq < 4; ++qq) {
-                        const uint32_t a = scan_cell_active(act, L, (int)(e[qq] & SYN_CELL), i + qq < n[u], use_lds);
-                        acc[u] += a + ((a & (e[qq] >> 31)) << 16);
-                    }
-                }
-            }
             const uint32_t sum = (uint32_t)group8_sum_first((int)acc[u]);     // (valid in the segment's first lane only)
             const int pot = (int)(sum & 0xFFFFu), conn = (int)(sum >> 16);
             matching[u] = l == 0 && seg[u] < S && pot >= d.match_thr;                 // :247

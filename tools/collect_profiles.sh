@@ -19,10 +19,13 @@ timeout -k 10 300 python tools/scan_stress.py --columns 262144 --cells 16 --segm
 cd /tmp && export TMPDIR=/tmp
 # (a) one role per launch: every role its own kernel
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $GRAFT_REPO_ROOT/bench.py --steps 500 --warmup 100 --reps 1 --no-cpu-baseline --no-stress --no-graph --no-pipeline > $OUT/stats.log 2>&1; echo "stats exit=$?"
-# (b) the pipelined schedule bench.py times by default (eager instead of hipGraph: rocprofv3 crashes on graph replay here), with the configs[4] leg
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_pipelined -- python3 $GRAFT_REPO_ROOT/bench.py --steps 500 --warmup 100 --reps 1 --no-cpu-baseline --no-graph > $OUT/stats_pipelined.log 2>&1; echo "stats_pipelined exit=$?"
+# (b) the pipelined schedule bench.py times by default (eager instead of hipGraph: rocprofv3 crashes on graph replay here)
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_pipelined -- python3 $GRAFT_REPO_ROOT/bench.py --steps 500 --warmup 100 --reps 1 --no-cpu-baseline --no-stress --no-graph > $OUT/stats_pipelined.log 2>&1; echo "stats_pipelined exit=$?"
+# (c) the configs[4] leg alone
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_stress -- python3 $GRAFT_REPO_ROOT/bench.py --stress-only > $OUT/stats_stress.log 2>&1; echo "stats_stress exit=$?"
 for ctr in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 400 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $OUT/pmc_$ctr -- python3 $GRAFT_REPO_ROOT/bench.py --steps 200 --warmup 100 --reps 1 --no-cpu-baseline --no-graph > $OUT/pmc_$ctr.log 2>&1; echo "$ctr exit=$?"
+  timeout -k 10 400 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $OUT/pmc_$ctr -- python3 $GRAFT_REPO_ROOT/bench.py --steps 200 --warmup 100 --reps 1 --no-cpu-baseline --no-stress --no-graph > $OUT/pmc_$ctr.log 2>&1; echo "$ctr exit=$?"
+  timeout -k 10 400 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $OUT/pmc_stress_$ctr -- python3 $GRAFT_REPO_ROOT/bench.py --stress-only > $OUT/pmc_stress_$ctr.log 2>&1; echo "$ctr (stress) exit=$?"
 done
 # keep the merged-back payload small: summarise the per-dispatch traces, then drop them
 python3 - <<'PY'
@@ -30,12 +33,13 @@ import csv, glob, os, collections, json
 out = os.environ["OUT"]
 summary = {}
 for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
-    for f in glob.glob(os.path.join(out, f"pmc_{ctr}", "*", "*counter_collection.csv")):
-        d = collections.defaultdict(list)
+    d = collections.defaultdict(list)
+    for f in glob.glob(os.path.join(out, f"pmc_{ctr}", "*", "*counter_collection.csv")) + glob.glob(os.path.join(out, f"pmc_stress_{ctr}", "*", "*counter_collection.csv")):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] == ctr:
-                d[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
-        summary[ctr] = {k: {"launches": len(v), "mean_last150_KB": sum(v[-150:]) / len(v[-150:])} for k, v in d.items()}
+                name = r["Kernel_Name"].split("(")[0] + (" [configs[4] leg]" if "pmc_stress_" in f else "")
+                d[name].append(float(r["Counter_Value"]))
+    summary[ctr] = {k: {"launches": len(v), "mean_last150_KB": sum(v[-150:]) / len(v[-150:])} for k, v in d.items()}
 json.dump(summary, open(os.path.join(out, "pmc_summary.json"), "w"), indent=1)
 # per-kernel duration of the LAST 300 launches of the pipelined trace (steady state; the --stats file averages the whole run)
 for f in glob.glob(os.path.join(out, "stats_pipelined", "*", "*kernel_trace.csv")):
