@@ -510,6 +510,9 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
             rc |= dalloc(h, &d.lfree, S);
             rc |= dalloc(h, &d.asg_gid, k * 32);
             rc |= dalloc(h, &d.cand_cols, (size_t)d.n_cand + 8);
+            rc |= dalloc(h, &d.spec_win, (size_t)(d.c1 - d.c0));
+            rc |= dalloc(h, &d.spec_unacc, (size_t)(d.c1 - d.c0));
+            rc |= dalloc(h, &d.spec_burst, (size_t)(d.c1 - d.c0));
             if (!rc && (hipMemsetAsync(d.seg_gid, 0xFF, S * 4, h->stream) != hipSuccess ||
                         hipMemsetAsync(d.g2l, 0xFF, G * 4, h->stream) != hipSuccess)) { h->err = "hipMemsetAsync failed"; rc = HTM_ERR_HIP; }
         }
@@ -894,7 +897,9 @@ static int shard_enqueue_begin(htm_handle *h, const uint32_t *bank, int n_inputs
     d.send = (unsigned char *)send_device;
     // own columns: overlap + boost + top digit, and the zeroing of the step's dense words; digit 1; local select finish
     // + speculative cell words of the candidates, packed into the record
-    LAUNCH(h, "shard_overlap", k_shard_overlap, h->sp_blocks + std::min((d.C + RB - 1) / RB, 64), RB, d, bank, n_inputs, h->G, p, h->sp_blocks);
+    const int n_word_blocks = ((d.c1 - d.c0) * 32 + RB - 1) / RB;        // one own column per half-wave
+    LAUNCH(h, "shard_overlap", k_shard_overlap, h->sp_blocks + n_word_blocks + std::min((d.C + RB - 1) / RB, 64), RB, d, bank, n_inputs, h->G, p,
+           h->sp_blocks, n_word_blocks);
     for (int pass = 1; pass < d.sel_passes; ++pass) LAUNCH(h, "sp_select", k_sel_pass, h->sel_blocks, RB, d, pass, p);
     LAUNCH(h, "shard_candidates", k_sp_emit, h->c256_blocks, 256, d, p, 1, 1, EMIT_LOCAL);
     return 0;

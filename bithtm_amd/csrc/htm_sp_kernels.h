@@ -403,7 +403,7 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
     const bool own_col = c < d.sel_hi && c >= d.c0 && c < d.c1;
     const float my_duty = (own_col && (mode & EMIT_DUTY)) ? d.duty[c] : 0.f;
     const bool tm_here = d.act[0] && (mode & EMIT_ACTIVATE);
-    s_predw[tid] = (c < d.sel_hi && (tm_here || local)) ? d.pred[p ^ 1][c] : 0u;
+    s_predw[tid] = (c < d.sel_hi && tm_here) ? d.pred[p ^ 1][c] : 0u;
     u64 T;
     uint32_t r;                                     // how many of the keys == T are selected
     bool second_round = false;                      // per-block counts still to be exchanged
@@ -711,18 +711,12 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
     if (local) {                                   // this block's candidates into the exchange record
         double *r_boost = (double *)d.send;
         uint32_t *r_col = (uint32_t *)(d.send + (size_t)d.n_cand * 8), *r_win = r_col + d.n_cand, *r_unacc = r_win + d.n_cand;
-        for (int i0 = 0; i0 < n_sel; i0 += 8) {    // 8 half-waves
-            const int i = i0 + (tid >> 5);
-            const bool ok = i < n_sel;
-            const int a = ok ? s_col[i] : d.sel_lo;
-            const ColumnWords w = tm_column_words(d, p, 1, ok, a, ok ? s_predw[a - cbase] : 0u);
-            if (ok && (lane_id() & 31) == 0) {
-                const int pos = first_pos + i;
-                r_boost[pos] = d.boosted[p][a];
-                r_col[pos] = (uint32_t)a | (w.burst ? 0x80000000u : 0u);
-                r_win[pos] = w.winner;
-                r_unacc[pos] = w.unacc;
-            }
+        for (int i = tid; i < n_sel; i += 256) {   // (the words of every own column were computed beside the overlap)
+            const int a = s_col[i], pos = first_pos + i;
+            r_boost[pos] = d.boosted[p][a];
+            r_col[pos] = (uint32_t)a | (d.spec_burst[a - d.c0] ? 0x80000000u : 0u);
+            r_win[pos] = d.spec_win[a - d.c0];
+            r_unacc[pos] = d.spec_unacc[a - d.c0];
         }
         if (b == 0) {                              // and the segments that died while the previous step learned
             uint32_t *r_dead = r_unacc + d.n_cand;
@@ -820,15 +814,33 @@ __global__ __launch_bounds__(256) void k_sp_duty_list(Dev d, int p, int n, int p
 __global__ void k_sp_commit(Dev d, int p) { d.ctr->step[p ^ 1] = d.ctr->step[p] + 1; }
 
 // ---- column sharding: the kernels on either side of the exchange -----------------------------
-// before the exchange, first launch: overlap + boost + top key digit of the OWN columns, and the zeroing of the
-// step's dense per-column words (the winners' words are written after the exchange)
-__global__ __launch_bounds__(RB) void k_shard_overlap(Dev d, const uint32_t *__restrict__ bank, int n_inputs, int G, int p, int n_overlap_blocks) {
+// before the exchange, first launch: overlap + boost + top key digit of the OWN columns, the speculative cell words of
+// the own columns, and the zeroing of the step's dense per-column words (the winners' words are written after the exchange)
+__global__ __launch_bounds__(RB) void k_shard_overlap(Dev d, const uint32_t *__restrict__ bank, int n_inputs, int G, int p, int n_overlap_blocks, int n_word_blocks) {
     __shared__ uint32_t h[SEL_BINS];
-    if ((int)blockIdx.x < n_overlap_blocks) {
-        role_overlap<RB>(d, bank, n_inputs, G, p, p, 0, blockIdx.x, n_overlap_blocks, h);
+    int b = blockIdx.x;
+    if (b < n_overlap_blocks) {
+        role_overlap<RB>(d, bank, n_inputs, G, p, p, 0, b, n_overlap_blocks, h);
         return;
     }
-    const int nb = (int)gridDim.x - n_overlap_blocks, b = (int)blockIdx.x - n_overlap_blocks;
+    b -= n_overlap_blocks;
+    if (b < n_word_blocks) {
+        // the cell words every OWN column would have if it became active (networks.py:95-104; they only depend on the
+        // previous step's predictions, segment maxima and segment counts): one column per half-wave.  The local select
+        // that follows copies the words of its candidates into the exchange record.
+        const int i = (b * RB + (int)threadIdx.x) >> 5, cl = d.c1 - d.c0;
+        const bool ok = i < cl;
+        const int a = d.c0 + (ok ? i : 0);
+        const ColumnWords w = tm_column_words(d, p, 1, ok, a, ok ? d.pred[p ^ 1][a] : 0u);
+        if (ok && (lane_id() & 31) == 0) {
+            d.spec_win[i] = w.winner;
+            d.spec_unacc[i] = w.unacc;
+            d.spec_burst[i] = w.burst ? 1 : 0;
+        }
+        return;
+    }
+    b -= n_word_blocks;
+    const int nb = (int)gridDim.x - n_overlap_blocks - n_word_blocks;
     for (int c = b * RB + (int)threadIdx.x; c < d.C; c += nb * RB) {
         d.act[p][c] = 0;
         d.win[p][c] = 0;

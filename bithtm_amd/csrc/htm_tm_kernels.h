@@ -37,10 +37,9 @@ __device__ __forceinline__ int seg_gid_of(const Dev &d, int row) { return d.seg_
 // work-list slot `pos`; rows are packed, so clearing a recycled row (projections.py:82-85) is nsyn = 0.
 // Unsharded handles (row == id).
 __device__ __forceinline__ void tm_bind_segment(const Dev &d, int seg, int cell, bool recycled, int pos) {
+    // (the recyclable counts per 1024 ids are settled by the caller for all the ids it binds, once per 1024-block:
+    // what becomes of an empty row is known before the learning role has grown it, and same-address atomics are slow)
     if (recycled) atomicSub(&d.segcount[d.seg_cell[seg]], 1);
-    // recyclable count of the id's 1024-block: a recycled id was counted and still is (its row is empty until the
-    // learning role has grown it, which then takes it off the count); a fresh id enters as an empty row
-    else atomicAdd(&d.recyc_cnt[seg >> 10], 1);
     d.seg_cell[seg] = cell;
     d.seg_nsyn[seg] = 0;
     atomicAdd(&d.segcount[cell], 1);
@@ -339,9 +338,15 @@ __device__ __forceinline__ void role_mid(const Dev &d, int p, int n_active, int 
             }
             rank += (int)fl[j];
         }
+        // the ids recycled out of this 1024-block leave its recyclable count if the learning role is going to grow
+        // them past the matching threshold (known now: an empty row grows `grown` synapses) -- one update per block
+        if (whole && threadIdx.x == 0 && grown >= d.match_thr) atomicSub(&d.recyc_cnt[b], max(0, min((int)total, n_r - off)));
     }
     if (whole) {
         for (int i = threadIdx.x; i < n_new; i += BS) tm_bind_segment(d, S + i, d.unacc_list[n_r + i], false, wbase + n_r + i);
+        if (n_new > 0 && grown < d.match_thr)      // fresh ids [S, S + n_new) that will stay below the matching threshold
+            for (int b = (S >> 10) + (int)threadIdx.x; b <= (S + n_new - 1) >> 10; b += BS)
+                atomicAdd(&d.recyc_cnt[b], min(S + n_new, (b + 1) << 10) - max(S, b << 10));
     } else {                                    // sharded: ids first, then rows given up, then rows taken
         __syncthreads();
         for (int pass = 0; pass < 2; ++pass) {
@@ -578,7 +583,7 @@ __device__ __forceinline__ void role_learn(const Dev &d, int p, int blk, int nbl
             // then; what becomes of a row bound this step every rank knew when it was bound (shard_bind).
             const bool was_dead = n < d.match_thr, is_dead = n_total < d.match_thr;
             if (d.world == 1) {
-                if (was_dead != is_dead) atomicAdd(&d.recyc_cnt[seg >> 10], is_dead ? 1 : -1);
+                if (item < n_front && was_dead != is_dead) atomicAdd(&d.recyc_cnt[seg >> 10], is_dead ? 1 : -1);   // (bound this step: settled at binding)
             } else if (!was_dead && is_dead) {
                 const int slot = atomicAdd(&d.dead_list[0], 1);
                 if (slot < DEAD_CAP) d.dead_list[1 + slot] = (int)gid; else atomicOr(&c->error, 8);
