@@ -123,7 +123,7 @@ def run_sharded(args):
             unit="timesteps/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
             ms_per_step=round(1e3 * dt / args.steps, 5), higher_is_better=True, scaling="strong", vs_baseline=None,
             dtype="u32 bit-packed / f64 + f32 permanences", data="synthetic",
-            config=dict(workload=f"configs[3]: 65536 columns x 32 cells sharded {world}-way, winner all-gather per step",
+            config=dict(workload=f"configs[3]: 65536 columns x 32 cells sharded {world}-way, winner-candidate all-gather per step",
                         input_dim=I, column_dim=C, cell_dim=K, columns_per_gpu=C // world, active_columns=htm.active_columns,
                         patterns=w["patterns"], input_density=w["density"], flip_noise=w["noise"],
                         segments=int(info.segments), segment_slots=w["segment_slots"], backend=backend,

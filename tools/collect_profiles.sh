@@ -14,6 +14,9 @@ timeout -k 10 200 python tools/step_timeline.py > $OUT/step_timeline.txt 2>&1
 timeout -k 10 200 python tools/cold_phase.py > $OUT/cold_phase.txt 2>&1
 timeout -k 10 200 python tools/pcie_rate.py > $OUT/pcie_rate.txt 2>&1
 for w in 2 8; do timeout -k 10 200 python tools/shard_rehearsal.py --world $w; done > $OUT/shard_rehearsal.jsonl 2>&1
+# bench.py --gpus 2 as two processes on this one GPU, records staged through the host over gloo (the multi-process flow of
+# bench_sharded.py; the RCCL path needs one GPU per rank)
+BITHTM_DIST_BACKEND=gloo BITHTM_SINGLE_DEVICE=1 timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 2 --steps 300 --warmup 100 > $OUT/bench_2ranks_one_gpu_gloo.json 2> $OUT/bench_2ranks_one_gpu_gloo.log; echo "2-rank rehearsal exit=$?"
 timeout -k 10 600 python tools/scan_stress.py --segments 250000 1000000 4000000 16000000 --slots 64 > $OUT/scan_stress.jsonl 2> $OUT/scan_stress.log
 timeout -k 10 300 python tools/scan_stress.py --columns 262144 --cells 16 --segments 4000000 16000000 --slots 64 >> $OUT/scan_stress.jsonl 2>> $OUT/scan_stress.log
 cd /tmp && export TMPDIR=/tmp
