@@ -538,6 +538,7 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
     h->c256_blocks = (d.sel_hi - d.sel_lo + 255) / 256;        // blocks of the emit role: 256 columns of the select's range each
     h->s1024_blocks = std::max(1, (d.Scap + 1023) / 1024);
     h->scan_blocks = std::max(1, std::min((d.Lcap + SCAN_SEGS - 1) / SCAN_SEGS, 2048));
+    if (h->scan_blocks > 256) h->scan_blocks = (h->scan_blocks + 255) & ~255;     // (role_scan: whole groups of 256 blocks)
     {
         hipDeviceProp_t prop;
         h->cus = hipGetDeviceProperties(&prop, h->device) == hipSuccess ? prop.multiProcessorCount : 256;

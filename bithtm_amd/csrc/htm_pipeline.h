@@ -26,8 +26,8 @@
 struct TraceScope {                                 // BITHTM_TRACE=1: first / last device clock of every block
     unsigned long long *t;
     __device__ TraceScope(const Dev &d, int slot) {
-#ifdef BITHTM_LEARN_STAMPS
-        t = nullptr;                                // the diagnostic build of the learning role uses the buffer
+#if defined(BITHTM_LEARN_STAMPS) || defined(BITHTM_SCAN_STAMPS)
+        t = nullptr;                                // the diagnostic builds of the learning role and of the scan use the buffer
         return;
 #endif
         t = (d.trace && blockIdx.x < 4096 && d.ctr->step[slot >> 2] < d.trace_until) ? d.trace + ((size_t)slot * 4096 + blockIdx.x) * 2 : nullptr;

@@ -693,7 +693,7 @@ __device__ __forceinline__ void chunk_finish(const uint32_t *__restrict__ act, c
     // segment are mostly active, and segments created together match together: whole blocks of them.  Their reads
     // are therefore all issued before any is used (one pass per hit, with a dependent read each, made those blocks
     // the tail of the launch); the passes beyond the lanes' largest hit count are skipped by wave-uniform branches.
-    // (BATCH = false, the large-pool kernels: one hit per pass -- the six extra registers cost them a wave per SIMD)
+    // (BATCH = false, the large-pool kernels: one hit per pass -- the extra registers cost them a wave per SIMD)
     if (!BATCH) {
         uint32_t m = h.m_rest;
         while (__any(m != 0)) {
@@ -710,11 +710,14 @@ __device__ __forceinline__ void chunk_finish(const uint32_t *__restrict__ act, c
         return;
     }
     uint32_t rest = h.m_rest;
-    if (__any(rest != 0)) {                          // hits three to six of a lane: all reads first
-        uint32_t aw[4];
+    if (__any(rest != 0)) {                          // hits three to eight of a lane: all reads first
+        // (a lane holds four slots of each of two rows, and nearly every synapse of a matching segment is active: the
+        // lanes of two matching neighbours have eight hits each -- with the last two read one dependent pass after the
+        // other, those blocks took 9 us against the others' 5)
+        uint32_t aw[6];
         uint32_t m = rest;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int t = 0; t < 6; ++t) {
             aw[t] = 0;
             if (t > 0 && !__any(m != 0)) break;
             const uint32_t ej = m ? select8(e, __ffs(m) - 1) : 0u;
@@ -722,7 +725,7 @@ __device__ __forceinline__ void chunk_finish(const uint32_t *__restrict__ act, c
             m &= m - 1;
         }
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int t = 0; t < 6; ++t) {
             if (t > 0 && !__any(rest != 0)) break;
             const int j = __ffs(rest) - 1;
             const uint32_t ej = rest ? select8(e, j) : 0u;
@@ -733,24 +736,90 @@ __device__ __forceinline__ void chunk_finish(const uint32_t *__restrict__ act, c
             rest &= rest - 1;
         }
     }
-    while (__any(rest != 0)) {                       // hits seven and eight: one per pass
-        const int j = __ffs(rest) - 1;
-        const uint32_t ej = select8(e, j);
-        uint32_t aw = 0;
-        if (rest) aw = act[(ej & SYN_CELL) >> 5];
-        const uint32_t a = (aw >> (ej & 31)) & 1u;
+}
+
+// The same for small pools (latency-bound: every block is resident at once and the launch is as long as its slowest
+// block): ALL of a lane's cell-word reads are issued here, the first two unconditionally and the others while any lane
+// of the wave still has a hit -- a lane holds four slots of each of two rows and nearly every synapse of a matching
+// segment is active, so the lanes of two matching neighbours have eight hits each; read in dependent passes (two, then
+// four, then one by one) those blocks took 9 us against the others' 5.
+struct ChunkHitsAll { uint32_t m; uint32_t aw[2]; };
+
+template <bool use_lds, int NOW>
+__device__ __forceinline__ ChunkHitsAll chunk_issue_all(const uint32_t *__restrict__ act, const uint32_t *s_colbits, const uint32_t (&e)[8],
+                                                        int first, int l, const int (&n)[2]) {
+    uint32_t m = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        uint32_t on = 1u;
+        if (use_lds) {
+            const uint32_t w = s_colbits[(e[i] & SYN_CELL) >> 10];
+            on = (w >> ((e[i] >> 5) & 31)) & 1u;
+        }
+        m |= on << i;
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int nv = min(max(n[u] - first - l * 4, 0), 4);
+        m &= ~(((0xFu << nv) & 0xFu) << (4 * u));
+    }
+    ChunkHitsAll h;
+    h.m = m;
+    uint32_t mm = m;
+#pragma unroll
+    for (int t = 0; t < NOW; ++t) {
+        const uint32_t ej = mm ? select8(e, __ffs(mm) - 1) : 0u;     // (lanes without a hit read entry 0: no branch)
+        h.aw[t] = act[(ej & SYN_CELL) >> 5];
+        mm &= mm - 1;
+    }
+    return h;
+}
+
+// NOW = what chunk_issue_all has read; the rest is read here, three hits per pass (all three reads before any is used)
+template <int NOW>
+__device__ __forceinline__ void chunk_finish_all(const uint32_t *__restrict__ act, const uint32_t (&e)[8], const ChunkHitsAll &h, uint32_t (&acc)[2]) {
+    auto count = [&](uint32_t mm, uint32_t aw) {     // the lane's lowest remaining hit, if it has one
+        const int j = __ffs(mm) - 1;
+        const uint32_t ej = mm ? select8(e, j) : 0u;
+        const uint32_t a = mm ? (aw >> (ej & 31)) & 1u : 0u;
         const uint32_t add = a + ((a & (ej >> 31)) << 16);
         acc[0] += (j & 4) ? 0u : add;
         acc[1] += (j & 4) ? add : 0u;
-        rest &= rest - 1;
+    };
+    uint32_t mm = h.m;
+#pragma unroll
+    for (int t = 0; t < NOW; ++t) {
+        count(mm, h.aw[t]);
+        mm &= mm - 1;
+    }
+    while (__any(mm != 0)) {
+        uint32_t aw[3], m2 = mm;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const uint32_t ej = m2 ? select8(e, __ffs(m2) - 1) : 0u;
+            aw[t] = act[(ej & SYN_CELL) >> 5];
+            m2 &= m2 - 1;
+        }
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            count(mm, aw[t]);
+            mm &= mm - 1;
+        }
     }
 }
+
+// diagnostic build (-DBITHTM_SCAN_STAMPS, handle created under BITHTM_TRACE=1): device clock at the phases of the first
+// iteration of every wave of the first 2048 scan blocks, d.trace[(block * 4 + wave) * 8 + phase] (tools/scan_phases.py)
+#ifdef BITHTM_SCAN_STAMPS
+#define SCAN_STAMP(i) do { if (d.trace && blk < 2048 && BS == 256 && (threadIdx.x & 63) == 0 && first_iter) d.trace[(size_t)(blk * 4 + wave) * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define SCAN_STAMP(i) do { } while (0)
+#endif
 
 // LDS: from word 4: column bitmap [colwords] (words 0..3 unused)
 template <int BS, bool use_lds, bool LARGE>
 __device__ __forceinline__ void role_scan(const Dev &d, int p, int blk, int nblk, int n_spec, uint32_t *lds) {
     static_assert(BS % 64 == 0, "whole waves of 16 segments");
-    constexpr int SEGS = BS / 4;                   // segments per block iteration: 16 per wave
     constexpr int U = 2;                           // segments in flight per lane group
     uint32_t *s_colbits = lds + 4;
     constexpr bool need_cell = !LARGE;
@@ -766,6 +835,16 @@ __device__ __forceinline__ void role_scan(const Dev &d, int p, int blk, int nblk
     const uint32_t *act = d.act[p];
     const uint32_t base3 = htm_stream_base(d.seed, HTM_STREAM_SEGMENT_JITTER, c->step[p]);
     const int wave = threadIdx.x >> 6, gi = (threadIdx.x & 63) >> 3, l = threadIdx.x & 7;
+    // Which 16 segments a wave takes.  Large pools stream: block after block, wave after wave.  Small pools are
+    // latency-bound and every block is resident at once: there the waves of a block take groups 256 blocks apart --
+    // segments created together are used together (a pattern's ~1 300 segments are 80 consecutive groups, nearly all of
+    // their synapses active at once), and four such waves on one CU, each gathering a thousand cell words, were the tail
+    // of the launch (8.2 us against 4.6 for the others); one per CU is not.
+    constexpr int WPB = BS / 64;
+    const int sg = LARGE ? 1 : (nblk % 256 == 0 ? 256 : nblk);
+    const int gw = LARGE ? wave : wave * sg;                                          // this wave's group within the block's
+    const int g_first = LARGE ? blk * WPB : (blk / sg) * (sg * WPB) + blk % sg;      // the block's first group
+    const int gstride = nblk * WPB;
     // round trip 1 of an iteration: synapse count, owner cell and the first chunk of each row, all unconditional
     // (rows are clamped to the pool and masked once the row count is known)
     struct Batch { int seg[U], n[U], cell[U]; int4 ps[U]; };
@@ -773,7 +852,7 @@ __device__ __forceinline__ void role_scan(const Dev &d, int p, int blk, int nblk
         Batch t;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            t.seg[u] = min(b * SEGS + wave * 16 + u * 8 + gi, d.Lcap - 1);
+            t.seg[u] = min((b + gw) * 16 + u * 8 + gi, d.Lcap - 1);
             t.n[u] = d.seg_nsyn[t.seg[u]];
             t.cell[u] = need_cell ? d.seg_cell[t.seg[u]] : 0;
             t.ps[u] = *(const int4 *)(d.presyn + (size_t)t.seg[u] * d.E + l * 4);
@@ -782,17 +861,21 @@ __device__ __forceinline__ void role_scan(const Dev &d, int p, int blk, int nblk
     };
     // In the first n_spec blocks (the ones that had segments when the host last saw the segment count)
     // the loads of the first batch do not wait for the count: one dependent round trip less.
-    const bool speculative = blk < n_spec;
-    if (!speculative && blk * SEGS >= S) return;
-    Batch cur = fetch(blk);
+    const bool speculative = g_first * 16 < n_spec * SCAN_SEGS;
+    if (!speculative && g_first * 16 >= S) return;
+    bool first_iter = true;
+    (void)first_iter;
+    SCAN_STAMP(0);
+    Batch cur = fetch(g_first);
     if (use_lds)                                     // the bitmap staging overlaps with those loads
         for (int i = threadIdx.x; i < d.colwords; i += BS) s_colbits[i] = d.colbits[p][i];
     __syncthreads();                                 // the only barrier: from here on the waves share nothing
-    for (int b = blk; b * SEGS < S; b += nblk) {
+    SCAN_STAMP(1);
+    for (int b = g_first; b * 16 < S; b += gstride) {    // b = the block's first group of this iteration
         int seg[U], n[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const bool ok = b * SEGS + wave * 16 + u * 8 + gi < S;
+            const bool ok = (b + gw) * 16 + u * 8 + gi < S;
             n[u] = ok ? cur.n[u] : 0;
             seg[u] = ok ? cur.seg[u] : S;
         }
@@ -803,13 +886,17 @@ __device__ __forceinline__ void role_scan(const Dev &d, int p, int blk, int nblk
             ps2[u] = make_int4(0, 0, 0, 0);
             if (n[u] > 32) ps2[u] = *(const int4 *)(d.presyn + (size_t)seg[u] * d.E + 32 + l * 4);
         }
+        SCAN_STAMP(2);                               // (synapse counts are here)
         uint32_t acc[U] = {0u, 0u};                  // this lane's share of potential (:247) | connected-active count << 16 (:171-172)
         const uint32_t e1[8] = {(uint32_t)cur.ps[0].x, (uint32_t)cur.ps[0].y, (uint32_t)cur.ps[0].z, (uint32_t)cur.ps[0].w,
                                 (uint32_t)cur.ps[1].x, (uint32_t)cur.ps[1].y, (uint32_t)cur.ps[1].z, (uint32_t)cur.ps[1].w};
-        const ChunkHits h1 = chunk_issue<use_lds>(act, s_colbits, e1, 0, l, n);
+        ChunkHits h1;
+        ChunkHitsAll g1;
+        if (LARGE) h1 = chunk_issue<use_lds>(act, s_colbits, e1, 0, l, n);
+        else g1 = chunk_issue_all<use_lds, 2>(act, s_colbits, e1, 0, l, n);
         // large pools: the next iteration's rows are requested now, behind this iteration's cell-word reads (loads
         // return in issue order: requested earlier they would be waited for with those reads)
-        const int b_next = b + nblk;
+        const int b_next = b + gstride;
         const int cell_cur[U] = {cur.cell[0], cur.cell[1]};
         // (unconditional -- past the last batch the clamped ids fetch a row nobody uses: a branch around the loads
         // would make the compiler wait for them with everything else)
@@ -821,10 +908,10 @@ __device__ __forceinline__ void role_scan(const Dev &d, int p, int blk, int nblk
         if (!LARGE) {
             // small pools: the second chunk's first cell-word reads go out before the first chunk's are waited for
             // (its rows were requested before the first chunk's lookups): one round trip less on the blocks' chain
-            ChunkHits h2 = h1;
-            if (any_long) h2 = chunk_issue<use_lds>(act, s_colbits, e2, 32, l, n);
-            chunk_finish<true>(act, e1, h1, acc);
-            if (any_long) chunk_finish<true>(act, e2, h2, acc);
+            ChunkHitsAll g2 = g1;
+            if (any_long) g2 = chunk_issue_all<use_lds, 2>(act, s_colbits, e2, 32, l, n);
+            chunk_finish_all<2>(act, e1, g1, acc);
+            if (any_long) chunk_finish_all<2>(act, e2, g2, acc);
         } else {
             chunk_finish<false>(act, e1, h1, acc);
             if (any_long) {                          // (skipped by waves in which no row is that long)
@@ -846,17 +933,21 @@ __device__ __forceinline__ void role_scan(const Dev &d, int p, int blk, int nblk
             }
             const uint32_t ea[8] = {(uint32_t)pa[0].x, (uint32_t)pa[0].y, (uint32_t)pa[0].z, (uint32_t)pa[0].w,
                                     (uint32_t)pa[1].x, (uint32_t)pa[1].y, (uint32_t)pa[1].z, (uint32_t)pa[1].w};
-            const ChunkHits ha = chunk_issue<use_lds>(act, s_colbits, ea, c * 32, l, n);
+            ChunkHits ha;
+            ChunkHitsAll ga;
+            if (LARGE) ha = chunk_issue<use_lds>(act, s_colbits, ea, c * 32, l, n);
+            else ga = chunk_issue_all<use_lds, 2>(act, s_colbits, ea, c * 32, l, n);
             if (!LARGE) {
                 const uint32_t eb[8] = {(uint32_t)pb[0].x, (uint32_t)pb[0].y, (uint32_t)pb[0].z, (uint32_t)pb[0].w,
                                         (uint32_t)pb[1].x, (uint32_t)pb[1].y, (uint32_t)pb[1].z, (uint32_t)pb[1].w};
-                const ChunkHits hb = chunk_issue<use_lds>(act, s_colbits, eb, (c + 1) * 32, l, n);
-                chunk_finish<true>(act, ea, ha, acc);
-                chunk_finish<true>(act, eb, hb, acc);
+                const ChunkHitsAll gb = chunk_issue_all<use_lds, 2>(act, s_colbits, eb, (c + 1) * 32, l, n);
+                chunk_finish_all<2>(act, ea, ga, acc);
+                chunk_finish_all<2>(act, eb, gb, acc);
             } else {
                 chunk_finish<false>(act, ea, ha, acc);
             }
         }
+        SCAN_STAMP(3);                               // (every synapse counted)
         bool matching[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -873,14 +964,17 @@ __device__ __forceinline__ void role_scan(const Dev &d, int p, int blk, int nblk
                 d.seg_jit[seg[u]] = jit;
             }
         }
+        SCAN_STAMP(4);                               // (matching segments published)
         {   // the wave's 16 match bits: the ballots hold one bit per lane group at lane 8 * gi; a multiplication
             // gathers those eight bits into the top byte (all partial products fall on different bit positions)
             const u64 m0 = __ballot(matching[0]), m1 = __ballot(matching[1]);
             const uint32_t b0 = (uint32_t)(((m0 & 0x0101010101010101ull) * 0x0102040810204080ull) >> 56);
             const uint32_t b1 = (uint32_t)(((m1 & 0x0101010101010101ull) * 0x0102040810204080ull) >> 56);
-            if ((threadIdx.x & 63) == 0) ((uint16_t *)d.match_bits)[b * (SEGS / 16) + wave] = (uint16_t)(b0 | (b1 << 8));
+            if ((threadIdx.x & 63) == 0) ((uint16_t *)d.match_bits)[b + gw] = (uint16_t)(b0 | (b1 << 8));
         }
-        if (b_next * SEGS >= S) break;
+        SCAN_STAMP(5);
+        first_iter = false;
+        if (b_next * 16 >= S) break;
         cur = LARGE ? nxt : fetch(b_next);
     }
 }

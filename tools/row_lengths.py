@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Row lengths of the segment store in bench.py's learned state: synapses per segment by 32-slot chunk, and how the
+long rows sit together (per 64-segment scan block).  Diagnostic for the scan's tail."""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+
+
+def main():
+    w = dict(bench.WORKLOAD)
+    noisy, perm = bench.make_inputs(w)
+    htm = bench.build_htm(w, perm, 0)
+    eng = htm.engine
+    bank = eng.upload_bank(noisy)
+    eng.run(bank, noisy.shape[0], 10 * w["patterns"] + 1500, learning=True)
+    eng.sync()
+    st = eng.read_store()
+    n = np.asarray(st["seg_nsyn"])
+    S = len(n)
+    chunks = (n + 31) // 32
+    print(f"S={S} mean synapses {n.mean():.1f}")
+    for c in range(0, 6):
+        print(f"  rows with {c} chunks: {int((chunks == c).sum())} ({100.0 * (chunks == c).mean():.2f} %)")
+    blocks = chunks[: S // 64 * 64].reshape(-1, 64).max(axis=1)
+    for c in range(1, 6):
+        print(f"  64-segment blocks whose longest row has {c} chunks: {int((blocks == c).sum())}")
+    waves = chunks[: S // 16 * 16].reshape(-1, 16).max(axis=1)
+    for c in range(1, 6):
+        print(f"  16-segment waves whose longest row has {c} chunks: {int((waves == c).sum())}")
+
+
+if __name__ == "__main__":
+    main()

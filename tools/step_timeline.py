@@ -44,7 +44,8 @@ def main():
     eng = htm.engine
     bank = eng.upload_bank(noisy)
     eng.run(bank, noisy.shape[0], args.warmup, learning=True)
-    eng.run(bank, noisy.shape[0], args.steps, learning=True, use_graph=True, pipeline=True)
+    # (TIMELINE_LEARNING=0: the traced steps run with learning off -- what the learning role's writes cost the others)
+    eng.run(bank, noisy.shape[0], args.steps, learning=os.environ.get("TIMELINE_LEARNING", "1") != "0", use_graph=True, pipeline=True)
     eng.sync()
     t = eng.trace_read()
     k, C = htm.active_columns, w["column_dim"]
