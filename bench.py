@@ -145,6 +145,8 @@ def cpu_baseline(w, htm, noisy, start_step, sample_steps):
 
 STRESS = dict(input_dim=1024, column_dim=262144, cell_dim=16, world=8, segments_per_cell=255, synapses=32,
               perm_lo=0.3, perm_hi=0.7, seed=0, segment_slots=64, patterns=8, density=0.02)
+if os.environ.get("BITHTM_STRESS_SPC"):           # experiments: a smaller pool (segments per cell)
+    STRESS["segments_per_cell"] = int(os.environ["BITHTM_STRESS_SPC"])
 
 
 class LazyPermanence:

@@ -18,6 +18,8 @@ typedef unsigned long long u64;
 #define MAX_SLOTS 512
 #define SYN_CONNECTED 0x80000000u   // a presynaptic id carries `permanence >= threshold` in its top bit ...
 #define SYN_CELL 0x7FFFFFFF         // ... and the cell (column * 32 + cell) below it
+#define SEG_BUSY 0x40000000         // in seg_nsyn: the segment is on this step's work list -- the learning role is about to
+                                    // rewrite its row (and clears the flag with the new count); the scan leaves it alone
 #define EPS32 1e-8f           // `epsilon=1e-8` against float32 arrays (weak Python scalar)
 
 // Select key of a boosted overlap: an order-preserving image of the double's bits that spends 8 bits on the
@@ -45,8 +47,10 @@ struct Counters {
     int32_t has_winner[2];    // winner list of parity p is valid (winner_cell is not None)
     int32_t has_distal;       // a scan has run (distal_state is not None)
     int32_t n_active_cells;
-    int32_t n_work;           // learning / punish work items of this step (front of the work array)
-    int32_t n_bind;           // newly bound segments of this step (back of the work array, growing down)
+    // (by step parity: the scan of step t, which resets the counts for step t + 1, may share its launch with the
+    // learning role of step t, which reads them)
+    int32_t n_work[2];        // learning / punish work items of the step (front of the work array)
+    int32_t n_bind[2];        // newly bound segments of the step (back of the work array, growing down)
     int32_t n_work_last;      // ... of the last completed step (telemetry)
     int32_t sel_fallbacks;    // steps whose top-k select took the in-kernel fallback (telemetry)
     uint32_t emit_epoch;      // bumped by every overlap launch: tags the records k_sp_emit's blocks exchange
@@ -106,8 +110,12 @@ struct Dev {
     int *presyn;              // [Scap][E] presynaptic cell (enc)
     float *sperm;             // [Scap][E] float32 permanence
     int *segcount;            // [C*32] segments per cell
-    uint32_t *cellmax;        // [C*32] float bits of max jittered potential per cell (0 = none)
-    uint32_t *match_bits;     // [ceil(Scap/32)] last scan: segment is matching (projections.py:247); whole words are written
+    // results of the scan of step t live in buffer t & 1: step t + 1 reads them (activation, classification) while its
+    // own scan, which may share a launch with its learning role, accumulates into the other one
+    uint32_t *cellmax[2];     // [C*32] float bits of max jittered potential per cell (0 = none); entries are cleared by the
+                              // learning role of the step after the scan that set them
+    uint32_t *match_bits[2];  // [ceil(Scap/32)] segment is matching (projections.py:247); zeroed by the middle launch of the
+                              // step whose scan (and learning role) then set bits with atomicOr
     uint32_t *seg_info;       // [Scap] last scan, MATCHING segments only: potential | activation << 12 | 1 << 30 | active << 31
     float *seg_jit;           // [Scap] jittered potential of the matching segments
     uint32_t *work;           // [work_cap] segment | mode << 31 (0 = learn + grow, 1 = punish)

@@ -67,7 +67,7 @@ struct htm_handle {
     int sel_passes_fused, sel_passes_full; // launched select digits with / without the in-kernel finish
     int seg_hint;                         // a lower bound of the segment count (see scan_spec_blocks)
     int *seg_pinned;                      // pinned word the end of each htm_run copies the count into
-    int sp_blocks, sel_blocks, c256_blocks, s1024_blocks, scan_blocks, cus;
+    int sp_blocks, sel_blocks, c256_blocks, s1024_blocks, scan_blocks, zero_blocks, cus;
     const uint32_t *ahead_bank;           // htm_run ended with HTM_RUN_CONTINUE on this bank: the SP has done the next step
     int ahead_n_inputs, ahead_learning;   //   and the front of the one after it
     int phase_active;                     // htm_sp_phase: length of the current winner list
@@ -250,7 +250,7 @@ static void enqueue_tm(htm_handle *h, int n_active, int learning, int want_winne
     const int n_cls = learning ? kClassifyBlocks : 0;
     const int n_sp_rows = (sp_rows && learning && h->cfg.enable_sp) ? d.k : 0;
     const int n_duty = h->world > 1 ? (d.c1 - d.c0 + 255) / 256 : 0;      // (unsharded: the emit role updates the duty cycle)
-    LAUNCH(h, "tm_mid", k_mid_rows, 1 + n_cls + n_sp_rows + n_duty, 256, d, p, n_active, want_winner, learning, n_cls, bank, n_inputs, n_sp_rows, 0, n_duty);
+    LAUNCH(h, "tm_mid", k_mid_rows, 1 + n_cls + n_sp_rows + n_duty + h->zero_blocks, 256, d, p, n_active, want_winner, learning, n_cls, bank, n_inputs, n_sp_rows, 0, n_duty);
     launch_learn(h, p);
     launch_scan(h, p, scan_lds(d, 1) <= 64 * 1024);
 }
@@ -279,7 +279,7 @@ static void enqueue_pipelined(htm_handle *h, int p, int learning, const uint32_t
     const int n_emit = plan.next_sp ? h->c256_blocks : 0;
     LAUNCH_ON(h, h->stream, sizeof(EmitShared), "tm_activate+sp_emit", k_open_emit, n_emit + (d.k * 32 + 255) / 256, 256, d, p, n_emit, d.k);
     const int n_rows = (plan.next_sp && learning) ? d.k : 0, n_duty = plan.next_sp ? h->c256_blocks : 0;
-    LAUNCH(h, "tm_mid+sp_learn", k_mid_rows, 1 + n_cls + n_rows + n_duty, 256, d, p, d.k, 1, learning, n_cls, bank, n_inputs, n_rows, 1, n_duty);
+    LAUNCH(h, "tm_mid+sp_learn", k_mid_rows, 1 + n_cls + n_rows + n_duty + h->zero_blocks, 256, d, p, d.k, 1, learning, n_cls, bank, n_inputs, n_rows, 1, n_duty);
     {
         const int epl = learn_epl(d);
         const size_t lds = std::max(learn_lds(epl), (size_t)SEL_BINS * 4);
@@ -495,8 +495,10 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
         rc |= dalloc(h, &d.presyn, S * E);
         rc |= dalloc(h, &d.sperm, S * E);
         rc |= dalloc(h, &d.segcount, C * 32);
-        rc |= dalloc(h, &d.cellmax, C * 32);
-        rc |= dalloc(h, &d.match_bits, (S + 255) / 256 * 8);
+        for (int q = 0; q < 2; ++q) {
+            rc |= dalloc(h, &d.cellmax[q], C * 32);
+            rc |= dalloc(h, &d.match_bits[q], (S + 255) / 256 * 8);
+        }
         rc |= dalloc(h, &d.seg_info, S);
         rc |= dalloc(h, &d.seg_jit, S);
         rc |= dalloc(h, &d.work, (size_t)d.work_cap);
@@ -539,6 +541,7 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
     h->s1024_blocks = std::max(1, (d.Scap + 1023) / 1024);
     h->scan_blocks = std::max(1, std::min((d.Lcap + SCAN_SEGS - 1) / SCAN_SEGS, 2048));
     if (h->scan_blocks > 256) h->scan_blocks = (h->scan_blocks + 255) & ~255;     // (role_scan: whole groups of 256 blocks)
+    h->zero_blocks = std::max(1, std::min((d.Lcap / 128 + 4095) / 4096, 1024));     // k_mid_rows: 16 stores of 16 bytes per thread at most
     {
         hipDeviceProp_t prop;
         h->cus = hipGetDeviceProperties(&prop, h->device) == hipSuccess ? prop.multiProcessorCount : 256;
@@ -1182,7 +1185,7 @@ extern "C" int htm_get_info(htm_handle *h, htm_info *out) {
     out->matching_segments = 0;
     if (c.has_distal && rows > 0) {
         std::vector<uint32_t> bits(((size_t)rows + 31) / 32);
-        HIPCHK(h, hipMemcpy(bits.data(), h->d.match_bits, bits.size() * 4, hipMemcpyDeviceToHost));
+        HIPCHK(h, hipMemcpy(bits.data(), h->d.match_bits[q], bits.size() * 4, hipMemcpyDeviceToHost));
         for (int i = 0; i < rows; ++i) out->matching_segments += (bits[(size_t)i >> 5] >> (i & 31)) & 1u;
     }
     out->winner_cells = c.n_win[q];
@@ -1266,7 +1269,7 @@ extern "C" int64_t htm_read(htm_handle *h, int32_t field, void *dst, int64_t cou
             std::vector<uint32_t> bits(((size_t)S + 31) / 32, 0u);
             std::vector<uint32_t> info((size_t)S);
             std::vector<float> jit((size_t)S);
-            if (S && c.has_distal && (hipMemcpy(bits.data(), d.match_bits, bits.size() * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+            if (S && c.has_distal && (hipMemcpy(bits.data(), d.match_bits[q], bits.size() * 4, hipMemcpyDeviceToHost) != hipSuccess ||
                                       hipMemcpy(info.data(), d.seg_info, (size_t)S * 4, hipMemcpyDeviceToHost) != hipSuccess ||
                                       hipMemcpy(jit.data(), d.seg_jit, (size_t)S * 4, hipMemcpyDeviceToHost) != hipSuccess)) { h->err = "htm_read: hipMemcpy failed"; return HTM_ERR_HIP; }
             auto is_matching = [&](int64_t i) { return (bits[(size_t)i >> 5] >> (i & 31)) & 1u; };
@@ -1311,7 +1314,7 @@ extern "C" int64_t htm_read(htm_handle *h, int32_t field, void *dst, int64_t cou
         case HTM_F_CELL_MAX_JITTER: {
             if ((n = need(tm, C * K)) < 0) return n;
             std::vector<uint32_t> tmp((size_t)C * 32);
-            const void *src = field == HTM_F_SEGCOUNT ? (const void *)d.segcount : (const void *)d.cellmax;
+            const void *src = field == HTM_F_SEGCOUNT ? (const void *)d.segcount : (const void *)d.cellmax[q];
             if (hipMemcpy(tmp.data(), src, tmp.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) { h->err = "htm_read: hipMemcpy failed"; return HTM_ERR_HIP; }
             uint32_t *v = (uint32_t *)dst;
             for (int64_t col = 0; col < C; ++col)
@@ -1372,7 +1375,7 @@ extern "C" int htm_write(htm_handle *h, int32_t field, const void *src, int64_t 
             const uint32_t *v = (const uint32_t *)src;
             for (int64_t col = 0; col < C; ++col)
                 for (int64_t j = 0; j < K; ++j) tmp[(size_t)col * 32 + j] = v[col * K + j];
-            return put(field == HTM_F_SEGCOUNT ? (void *)d.segcount : (void *)d.cellmax, tmp.data(), (int64_t)tmp.size(), 4, (int64_t)tmp.size());
+            return put(field == HTM_F_SEGCOUNT ? (void *)d.segcount : (void *)d.cellmax[q], tmp.data(), (int64_t)tmp.size(), 4, (int64_t)tmp.size());
         }
         default: h->err = "htm_write: field is not writable"; return HTM_ERR_ARGUMENT;
     }
@@ -1399,8 +1402,8 @@ extern "C" int htm_import_commit(htm_handle *h, int32_t segments, int32_t matchi
     if (rc) return rc;
     const int q = (int)((h->step_host + 1) & 1);
     c.step[h->step_host & 1] = (uint32_t)h->step_host;
-    c.n_work = 0;
-    c.n_bind = 0;
+    c.n_work[0] = c.n_work[1] = 0;
+    c.n_bind[0] = c.n_bind[1] = 0;
     c.S = segments;
     h->seg_hint = segments;                         // (the one place where the count can go down)
     if (h->seg_pinned) *h->seg_pinned = segments;
@@ -1428,7 +1431,10 @@ extern "C" int htm_import_commit(htm_handle *h, int32_t segments, int32_t matchi
         }
         // all of the bitmap: the import is the one place where the segment count can shrink (rollback to an
         // earlier checkpoint), and ids at or above it must read "not matching", as the classification assumes
-        HIPCHK(h, hipMemcpy(d.match_bits, bits.data(), bits.size() * 4, hipMemcpyHostToDevice));
+        HIPCHK(h, hipMemcpy(d.match_bits[q], bits.data(), bits.size() * 4, hipMemcpyHostToDevice));
+        // the other buffers (what the coming step's scan accumulates into) start clean
+        HIPCHK(h, hipMemset(d.match_bits[q ^ 1], 0, bits.size() * 4));
+        HIPCHK(h, hipMemset(d.cellmax[q ^ 1], 0, (size_t)d.C * 32 * 4));
         h->imp_pot.clear(); h->imp_match_seg.clear(); h->imp_match_info.clear(); h->imp_match_jit.clear();
     }
     c.n_win[q] = winner_cells;

@@ -71,11 +71,21 @@ __global__ __launch_bounds__(256, 8) void k_mid_rows(Dev d, int p, int n_active,
     }
     b -= n_rows;
     const int c = d.c0 + b * 256 + (int)threadIdx.x;              // (own columns)
-    if (b < n_duty_blocks && c < d.c1) {
-        float dc = d.duty[c] * d.mom;
-        if ((d.colbits[rows_ahead ? q : p][c >> 5] >> (c & 31)) & 1u) dc = dc + d.dinc;
-        d.duty[c] = dc;
+    if (b < n_duty_blocks) {
+        if (c < d.c1) {
+            float dc = d.duty[c] * d.mom;
+            if ((d.colbits[rows_ahead ? q : p][c >> 5] >> (c & 31)) & 1u) dc = dc + d.dinc;
+            d.duty[c] = dc;
+        }
+        return;
     }
+    // the remaining blocks: zero the match bits this step's scan (and learning role) will set with atomicOr -- the buffer
+    // holds the bits of the scan two steps back, whose readers are done.  (Rows at or above the segment count never had one.)
+    b -= n_duty_blocks;
+    const int nz = (int)gridDim.x - 1 - n_cls - n_rows - n_duty_blocks;
+    const int words4 = ((d.world > 1 ? d.ctr->L : d.ctr->S) + 127) >> 7;
+    uint4 *mb = (uint4 *)d.match_bits[p];
+    for (int i = b * 256 + (int)threadIdx.x; i < words4; i += nz * 256) mb[i] = make_uint4(0u, 0u, 0u, 0u);
 }
 
 template <int EPL>

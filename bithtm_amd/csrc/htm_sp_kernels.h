@@ -246,7 +246,7 @@ __device__ __forceinline__ ColumnWords tm_column_words(const Dev &d, int p, int 
     const uint32_t act = burst ? cell_mask(d.K) : pw;        // networks.py:115
     const int has_distal = d.ctr->has_distal;
     float cm = -1.0f;
-    if (valid && has_distal) cm = __uint_as_float(d.cellmax[a * 32 + j]);
+    if (valid && has_distal) cm = __uint_as_float(d.cellmax[p ^ 1][a * 32 + j]);
     uint32_t winner = pw, unacc = 0;
     if (want_winner) {
         float colmax = cm;

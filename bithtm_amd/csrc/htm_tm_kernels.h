@@ -41,7 +41,7 @@ __device__ __forceinline__ void tm_bind_segment(const Dev &d, int seg, int cell,
     // what becomes of an empty row is known before the learning role has grown it, and same-address atomics are slow)
     if (recycled) atomicSub(&d.segcount[d.seg_cell[seg]], 1);
     d.seg_cell[seg] = cell;
-    d.seg_nsyn[seg] = 0;
+    d.seg_nsyn[seg] = (int)SEG_BUSY;
     atomicAdd(&d.segcount[cell], 1);
     if (pos < d.work_cap) d.work[pos] = (uint32_t)seg; else atomicOr(&d.ctr->error, 4);
 }
@@ -52,7 +52,7 @@ __device__ __forceinline__ void tm_bind_segment(const Dev &d, int seg, int cell,
 // learning role.  `grown`: the synapses the row will have once that role has run (projections.py:114-127 on an
 // empty row: min(sampling, previous winners)) -- known everywhere, so the bits can be set now.
 // pass 0: give up rows (pushes on the free stack); pass 1: take rows (pops) -- the two are separated by a barrier.
-__device__ __forceinline__ void shard_bind(const Dev &d, int gid, int cell, bool recycled, int grown, int pass) {
+__device__ __forceinline__ void shard_bind(const Dev &d, int p, int gid, int cell, bool recycled, int grown, int pass) {
     Counters *c = d.ctr;
     const bool to_me = col_is_local(d, cell);
     const int old_row = recycled ? d.g2l[gid] : -1;                 // >= 0: the id was mine
@@ -86,9 +86,9 @@ __device__ __forceinline__ void shard_bind(const Dev &d, int gid, int cell, bool
         d.g2l[gid] = row;
     }
     d.seg_cell[row] = cell;
-    d.seg_nsyn[row] = 0;
+    d.seg_nsyn[row] = (int)SEG_BUSY;
     atomicAdd(&d.segcount[cell], 1);
-    const int pos = atomicAdd(&c->n_work, 1);
+    const int pos = atomicAdd(&c->n_work[p], 1);
     if (pos < d.work_cap) d.work[pos] = (uint32_t)row; else atomicOr(&c->error, 4);
 }
 
@@ -160,7 +160,7 @@ __device__ __forceinline__ void role_mid(const Dev &d, int p, int n_active, int 
             const int col = cell >> 5, cb = cell & 31;
             const bool is_winner = (d.win[p][col] >> cb) & 1u;
             const bool unpred = !((d.pred[q][col] >> cb) & 1u);                          // :266
-            const bool best = fabsf(jit - __uint_as_float(d.cellmax[cell])) < EPS32;     // :267
+            const bool best = fabsf(jit - __uint_as_float(d.cellmax[q][cell])) < EPS32;  // :267
             learn = is_winner && ((info >> 31) || (unpred && best));                     // :268
             punish = d.act[p][col] == 0;                                                 // :269
         };
@@ -170,12 +170,13 @@ __device__ __forceinline__ void role_mid(const Dev &d, int p, int n_active, int 
             for (int i0 = (blk - 1) * BS; i0 < n; i0 += n_cls * BS) {
                 const int seg = i0 + (int)threadIdx.x;
                 bool learn = false, punish = false;
-                if (seg < n && ((d.match_bits[seg >> 5] >> (seg & 31)) & 1u)) classify(seg, learn, punish);
+                if (seg < n && ((d.match_bits[q][seg >> 5] >> (seg & 31)) & 1u)) classify(seg, learn, punish);
+                if (learn || punish) d.seg_nsyn[seg] |= (int)SEG_BUSY;
                 const u64 ml = __ballot(learn), mp = __ballot(punish);
                 const int n_l = __popcll(ml), n_p = __popcll(mp);
                 if (n_l + n_p == 0) continue;
                 int base = 0;
-                if (lane_id() == 0) base = atomicAdd(&c->n_work, n_l + n_p);
+                if (lane_id() == 0) base = atomicAdd(&c->n_work[p], n_l + n_p);
                 base = __shfl(base, 0);
                 if (learn) {
                     const int pos = base + __popcll(ml & lanemask_lt());
@@ -192,7 +193,7 @@ __device__ __forceinline__ void role_mid(const Dev &d, int p, int n_active, int 
         const int nwords = (n + 31) >> 5;
         for (int w0 = (blk - 1) * BS; w0 < nwords; w0 += n_cls * BS) {
             const int w = w0 + (int)threadIdx.x;
-            const uint32_t word = w < nwords ? d.match_bits[w] : 0u;
+            const uint32_t word = w < nwords ? d.match_bits[q][w] : 0u;
             uint32_t lmask = 0, pmask = 0;
             for (uint32_t rest = word; rest; rest &= rest - 1) {
                 const int bit = __ffs(rest) - 1;
@@ -200,13 +201,14 @@ __device__ __forceinline__ void role_mid(const Dev &d, int p, int n_active, int 
                 classify(w * 32 + bit, learn, punish);
                 lmask |= (learn ? 1u : 0u) << bit;
                 pmask |= (punish ? 1u : 0u) << bit;
+                if (learn || punish) d.seg_nsyn[w * 32 + bit] |= (int)SEG_BUSY;
             }
             const uint32_t cnt = (uint32_t)(__popc(lmask) + __popc(pmask));
             if (!__any(cnt != 0)) continue;
             const uint32_t incl = wave_incl_scan(cnt);
             const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
             int base = 0;
-            if (lane_id() == 63) base = atomicAdd(&c->n_work, (int)total);
+            if (lane_id() == 63) base = atomicAdd(&c->n_work[p], (int)total);
             int pos = __shfl(base, 63) + (int)(incl - cnt);
             for (uint32_t rest = lmask; rest; rest &= rest - 1, ++pos) {
                 const uint32_t item = (uint32_t)(w * 32 + __ffs(rest) - 1);
@@ -284,7 +286,7 @@ __device__ __forceinline__ void role_mid(const Dev &d, int p, int n_active, int 
         c->has_winner[p] = want_winner;
         c->n_un = n_un;
         c->n_active_cells = (int)s_cells;
-        if (n_un == 0) c->n_bind = 0;
+        if (n_un == 0) c->n_bind[p] = 0;
     }
     if (n_un == 0) return;
     uint32_t carry = 0;                       // recyclable segments seen so far
@@ -351,14 +353,14 @@ __device__ __forceinline__ void role_mid(const Dev &d, int p, int n_active, int 
         __syncthreads();
         for (int pass = 0; pass < 2; ++pass) {
             for (int i = threadIdx.x; i < n_r + n_new; i += BS)
-                shard_bind(d, i < n_r ? d.asg_gid[i] : S + (i - n_r), d.unacc_list[i], i < n_r, grown, pass);
+                shard_bind(d, p, i < n_r ? d.asg_gid[i] : S + (i - n_r), d.unacc_list[i], i < n_r, grown, pass);
             __syncthreads();
         }
     }
     if (threadIdx.x == 0) {
         c->n_recycled = n_r;
         c->n_new = n_new;
-        c->n_bind = whole ? n_r + n_new : 0;
+        c->n_bind[p] = whole ? n_r + n_new : 0;
         c->S_old = S;
         c->S = S + n_new;
     }
@@ -392,14 +394,15 @@ __device__ __forceinline__ void role_learn(const Dev &d, int p, int blk, int nbl
         const int n = c->has_distal ? (d.world > 1 ? c->L : c->S) : 0;
         if (n <= 8 * nblk * BS) {                  // small pools: one row per thread (matching rows cluster in words)
             for (int i = blk * BS + threadIdx.x; i < n; i += nblk * BS)
-                if ((d.match_bits[i >> 5] >> (i & 31)) & 1u) d.cellmax[d.seg_cell[i]] = 0u;
+                if ((d.match_bits[p ^ 1][i >> 5] >> (i & 31)) & 1u) d.cellmax[p ^ 1][d.seg_cell[i]] = 0u;
         } else {                                   // large pools: one 32-row word per thread, almost all of them zero
             for (int w = blk * BS + threadIdx.x; w < (n + 31) >> 5; w += nblk * BS)
-                for (uint32_t rest = d.match_bits[w]; rest; rest &= rest - 1) d.cellmax[d.seg_cell[w * 32 + __ffs(rest) - 1]] = 0u;
+                for (uint32_t rest = d.match_bits[p ^ 1][w]; rest; rest &= rest - 1) d.cellmax[p ^ 1][d.seg_cell[w * 32 + __ffs(rest) - 1]] = 0u;
         }
     }
     const int wv = threadIdx.x >> 6, lane = lane_id();
-    const int n_front = min(c->n_work, d.work_cap), n_back = c->n_bind;
+    const int n_front = min(c->n_work[p], d.work_cap), n_back = c->n_bind[p];
+    if (blk == 0 && threadIdx.x == 0) c->n_work_last = n_front + n_back;
     if (n_front + n_back > d.work_cap && blk == 0 && threadIdx.x == 0) atomicOr(&c->error, 4);
     const int n_work = min(n_front + n_back, d.work_cap);
     const uint32_t *act_prev = d.act[p ^ 1];
@@ -423,7 +426,7 @@ __device__ __forceinline__ void role_learn(const Dev &d, int p, int blk, int nbl
         const uint32_t gid = (uint32_t)seg_gid_of(d, seg);                    // the random draws are keyed by the global id
         const double dA = mode ? d.pun_act : d.lrn_act, dI = mode ? d.pun_inact : d.lrn_inact;
         const bool prune = mode ? d.pun_prune : d.lrn_prune;
-        const int n = d.seg_nsyn[seg];
+        const int n = d.seg_nsyn[seg] & ~(int)SEG_BUSY;
         int *prow = d.presyn + (size_t)seg * d.E;
         float *mrow = d.sperm + (size_t)seg * d.E;
         int n_keep = 0, n_active = 0;
@@ -828,9 +831,8 @@ __device__ __forceinline__ void role_scan(const Dev &d, int p, int blk, int nblk
     if (blk == 0 && threadIdx.x == 0) {
         c->step[p ^ 1] = c->step[p] + 1;
         c->has_distal = 1;
-        c->n_work_last = c->n_work + c->n_bind;
-        c->n_work = 0;
-        c->n_bind = 0;
+        c->n_work[p ^ 1] = 0;                       // (the coming step's; this step's learning role may still be reading its own)
+        c->n_bind[p ^ 1] = 0;
     }
     const uint32_t *act = d.act[p];
     const uint32_t base3 = htm_stream_base(d.seed, HTM_STREAM_SEGMENT_JITTER, c->step[p]);
@@ -876,7 +878,7 @@ __device__ __forceinline__ void role_scan(const Dev &d, int p, int blk, int nblk
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const bool ok = (b + gw) * 16 + u * 8 + gi < S;
-            n[u] = ok ? cur.n[u] : 0;
+            n[u] = (ok && !(cur.n[u] & (int)SEG_BUSY)) ? cur.n[u] : 0;       // (a row the learning role is rewriting is its to scan)
             seg[u] = ok ? cur.seg[u] : S;
         }
         // round trip 2 (only rows longer than one chunk): second chunk, in flight during the lookups of the first
@@ -958,7 +960,7 @@ __device__ __forceinline__ void role_scan(const Dev &d, int p, int blk, int nblk
                 const bool active = conn >= d.act_thr;                                // :250
                 const int cell = need_cell ? cell_cur[u] : d.seg_cell[seg[u]];
                 const float jit = htm_jitter((float)pot, htm_draw24(base3, (uint32_t)seg_gid_of(d, seg[u]), 0u));   // :234-235
-                atomicMax(&d.cellmax[cell], __float_as_uint(jit));                   // :237
+                atomicMax(&d.cellmax[p][cell], __float_as_uint(jit));                // :237
                 if (active) atomicOr(&d.pred[p][cell >> 5], 1u << (cell & 31));       // :251, networks.py:122
                 d.seg_info[seg[u]] = (uint32_t)pot | ((uint32_t)conn << 12) | 0x40000000u | (active ? 0x80000000u : 0u);
                 d.seg_jit[seg[u]] = jit;
@@ -970,7 +972,8 @@ __device__ __forceinline__ void role_scan(const Dev &d, int p, int blk, int nblk
             const u64 m0 = __ballot(matching[0]), m1 = __ballot(matching[1]);
             const uint32_t b0 = (uint32_t)(((m0 & 0x0101010101010101ull) * 0x0102040810204080ull) >> 56);
             const uint32_t b1 = (uint32_t)(((m1 & 0x0101010101010101ull) * 0x0102040810204080ull) >> 56);
-            if ((threadIdx.x & 63) == 0) ((uint16_t *)d.match_bits)[b + gw] = (uint16_t)(b0 | (b1 << 8));
+            const uint32_t bits = b0 | (b1 << 8);      // (the words were zeroed by this step's middle launch)
+            if ((threadIdx.x & 63) == 0 && bits) atomicOr(&d.match_bits[p][(b + gw) >> 1], bits << (16 * ((b + gw) & 1)));
         }
         SCAN_STAMP(5);
         first_iter = false;
