@@ -33,6 +33,29 @@ __device__ __forceinline__ u64 select_key(double boosted) {
     return bits ? (bits - ((u64)(1023 - 150) << 52)) << KEY_SHIFT : 0ull;
 }
 
+// The windowed select of the three-launch schedule: ONE histogram pass.  The bins are not the key's top 12 bits but a
+// monotone function of the key that spends them where the k-th key is expected -- WIN_COARSE values of the top digit
+// starting at `base` (the previous step's k-th key minus half the window), each split 128 ways by the next 7 bits
+// (19 key bits resolved inside the window), one bin for everything below and one for everything above.  The k-th
+// boosted overlap of a learned pattern is up to 1.5 times that of a new one (measured: a window of a factor 1.44 either
+// way missed 7 % of the bench workload's steps); this window spans a factor of 2.6 either way.  If the key falls outside,
+// the select finishes by the exact fallback of role_emit (slow, rare, same result).
+#define WIN_COARSE 31
+#define WIN_FINE 7
+#define WIN_BINS (2 + (WIN_COARSE << WIN_FINE))
+#define WIN_LOWBITS (52 - WIN_FINE)        // key bits left unresolved inside the window
+static_assert(WIN_BINS <= SEL_BINS, "the window's bins fit the select histogram");
+__host__ __device__ __forceinline__ uint32_t win_bin(u64 key, uint32_t base) {
+    const uint32_t c = (uint32_t)(key >> 52);
+    if (c < base) return 0u;
+    const uint32_t o = c - base;
+    return o >= WIN_COARSE ? 1u + (WIN_COARSE << WIN_FINE) : 1u + ((o << WIN_FINE) | ((uint32_t)(key >> WIN_LOWBITS) & ((1u << WIN_FINE) - 1u)));
+}
+__host__ __device__ __forceinline__ uint32_t win_base_for(u64 kth_key) {
+    const uint32_t c = (uint32_t)(kth_key >> 52);
+    return c > WIN_COARSE / 2 ? min(c - WIN_COARSE / 2, 4096u - WIN_COARSE) : 0u;
+}
+
 // radix-select digit p covers key bits [shift, shift + bits): 12 bits from the top, the last one 4
 __host__ __device__ __forceinline__ int sel_shift(int pass) { return pass < 5 ? 52 - SEL_DIGIT * pass : 0; }
 __host__ __device__ __forceinline__ int sel_bits(int pass) { return pass < 5 ? SEL_DIGIT : 4; }
@@ -63,6 +86,8 @@ struct Counters {
     // pipelined schedule computes step t+1's overlap / select digits while step t's TM runs)
     u64 sel_prefix[2];        // k-th largest key and how many of the keys equal to it are winners
     uint32_t sel_krem[2];
+    uint32_t sel_win[2];      // windowed select (win_bin): lowest top-digit value of the window for the SP step of parity p,
+                              // set from the k-th key of the step before
     u64 sel_pass_prefix[2][SEL_MAX_PASSES + 1];    // radix-select state entering pass p
     uint32_t sel_pass_krem[2][SEL_MAX_PASSES + 1];
 };

@@ -67,7 +67,7 @@ struct htm_handle {
     int sel_passes_fused, sel_passes_full; // launched select digits with / without the in-kernel finish
     int seg_hint;                         // a lower bound of the segment count (see scan_spec_blocks)
     int *seg_pinned;                      // pinned word the end of each htm_run copies the count into
-    int sp_blocks, sel_blocks, c256_blocks, s1024_blocks, scan_blocks, zero_blocks, cus;
+    int sp_blocks, sel_blocks, c256_blocks, s1024_blocks, scan_blocks, zero_blocks, lean_learn_blocks, lean_scan_blocks, cus;
     const uint32_t *ahead_bank;           // htm_run ended with HTM_RUN_CONTINUE on this bank: the SP has done the next step
     int ahead_n_inputs, ahead_learning;   //   and the front of the one after it
     int phase_active;                     // htm_sp_phase: length of the current winner list
@@ -271,6 +271,35 @@ static bool can_pipeline(const htm_handle *h) {
     return h->cfg.enable_sp && h->cfg.enable_tm && h->world == 1 && h->emit_fused_open && h->d.sel_passes == 2;
 }
 
+// the three-launch schedule (htm_pipeline.h): the scan's LDS bitmap, one select histogram, the learning role and the
+// scan in one launch.  BITHTM_LEAN=0: the four-launch schedule below.
+static bool can_lean(const htm_handle *h) {
+    static const int env = getenv("BITHTM_LEAN") ? atoi(getenv("BITHTM_LEAN")) : 1;
+    return env != 0 && can_pipeline(h) && scan_lds(h->d, 1) <= 64 * 1024 && h->c256_blocks <= 2 * h->cus;
+}
+
+// sp_done: the winner list of this step exists (the previous step's last launch, or the cold start).  next_sp: select
+// the next step's winners beside this step's Temporal Memory.
+static void enqueue_lean(htm_handle *h, int p, int learning, const uint32_t *bank, int n_inputs, StepPlan plan) {
+    Dev &d = h->d;
+    const int n_act = (d.k * 32 + 255) / 256, n_rows = learning ? d.k : 0;
+    LAUNCH(h, "tm_activate+sp_learn", k_act_rows, n_act + n_rows + 2 * h->c256_blocks, 256, d, p, d.k, n_act, bank, n_inputs, n_rows, h->c256_blocks);
+    const int n_cls = learning ? kClassifyBlocks : 0, n_ov = plan.next_sp ? h->sp_blocks * (RB / 256) : 0;
+    LAUNCH_ON(h, h->stream, (size_t)SEL_BINS * 4, "tm_mid+sp_overlap", k_mid_overlap, 1 + n_cls + n_ov + h->zero_blocks, 256, d, p, d.k, 1, learning, n_cls,
+              bank, n_inputs, h->G, n_ov);
+    const int epl = learn_epl(d), n_emit = plan.next_sp ? h->c256_blocks : 0, spec = scan_spec_blocks(h);
+    const size_t lds = std::max(std::max(learn_lds(epl, 256), scan_lds(d, 1)), sizeof(EmitShared));
+    const int n_learn = h->lean_learn_blocks, n_scan = h->lean_scan_blocks;
+    const int grid = n_emit + n_learn + n_scan;
+#define LAUNCH_LSE(EPL_, MINW_) LAUNCH_ON(h, h->stream, lds, "tm_learn+tm_scan+sp_emit", (k_learn_scan_emit<EPL_, MINW_>), grid, 256, d, p, n_emit, n_learn, n_scan, spec)
+    if (scan_pool_is_large(h)) {
+        switch (epl) { case 1: LAUNCH_LSE(1, 1); break; case 2: LAUNCH_LSE(2, 1); break; case 4: LAUNCH_LSE(4, 1); break; default: LAUNCH_LSE(8, 1); break; }
+    } else {
+        switch (epl) { case 1: LAUNCH_LSE(1, 6); break; case 2: LAUNCH_LSE(2, 6); break; case 4: LAUNCH_LSE(4, 6); break; default: LAUNCH_LSE(8, 6); break; }
+    }
+#undef LAUNCH_LSE
+}
+
 // the four launches of a pipelined step (see the kernels): step p's Temporal Memory beside SP work of
 // the following steps
 static void enqueue_pipelined(htm_handle *h, int p, int learning, const uint32_t *bank, int n_inputs, StepPlan plan) {
@@ -279,7 +308,28 @@ static void enqueue_pipelined(htm_handle *h, int p, int learning, const uint32_t
     const int n_emit = plan.next_sp ? h->c256_blocks : 0;
     LAUNCH_ON(h, h->stream, sizeof(EmitShared), "tm_activate+sp_emit", k_open_emit, n_emit + (d.k * 32 + 255) / 256, 256, d, p, n_emit, d.k);
     const int n_rows = (plan.next_sp && learning) ? d.k : 0, n_duty = plan.next_sp ? h->c256_blocks : 0;
+    static const int fuse_env = getenv("BITHTM_FUSE") ? atoi(getenv("BITHTM_FUSE")) : 1;
+    const bool fuse = fuse_env != 0 && scan_lds(d, 1) <= 64 * 1024;
     LAUNCH(h, "tm_mid+sp_learn", k_mid_rows, 1 + n_cls + n_rows + n_duty + h->zero_blocks, 256, d, p, d.k, 1, learning, n_cls, bank, n_inputs, n_rows, 1, n_duty);
+    if (fuse) {
+        // the learning role (with the scan of its own rows), the scan and the overlap of step + 2 in one launch
+        const int epl = learn_epl(d);
+        const size_t lds = std::max(std::max(learn_lds(epl, 256), scan_lds(d, 1)), (size_t)SEL_BINS * 4);
+        const int n_ov = plan.next_front ? h->sp_blocks * (RB / 256) : 0, spec = scan_spec_blocks(h);
+        const int grid = kLearnBlocks + h->scan_blocks + n_ov;
+#define LAUNCH_LS(EPL_, MINW_) LAUNCH_ON(h, h->stream, lds, "tm_learn+tm_scan+sp_overlap", (k_learn_scan<EPL_, MINW_>), grid, 256, d, p, kLearnBlocks, h->scan_blocks, n_ov, bank, n_inputs, h->G, spec)
+        if (scan_pool_is_large(h)) {
+            switch (epl) { case 1: LAUNCH_LS(1, 1); break; case 2: LAUNCH_LS(2, 1); break; case 4: LAUNCH_LS(4, 1); break; default: LAUNCH_LS(8, 1); break; }
+        } else {
+            switch (epl) { case 1: LAUNCH_LS(1, 6); break; case 2: LAUNCH_LS(2, 6); break; case 4: LAUNCH_LS(4, 6); break; default: LAUNCH_LS(8, 6); break; }
+        }
+#undef LAUNCH_LS
+        // what is left of the fourth launch: select digit 1 of step + 2, the clears for step + 1
+        const int n_sel = plan.next_front ? 64 : 0, n_clear = plan.next_sp ? h->c256_blocks : 0;
+        if (n_sel + n_clear > 0)
+            LAUNCH_ON(h, h->stream, sizeof(SelShared), "sp_select+clear", (k_scan_sel<true, 6>), n_sel + n_clear, 256, d, p, n_sel, n_clear, p, 0);
+        return;
+    }
     {
         const int epl = learn_epl(d);
         const size_t lds = std::max(learn_lds(epl), (size_t)SEL_BINS * 4);
@@ -311,6 +361,11 @@ static void enqueue_cold_start(htm_handle *h, const uint32_t *bank, int n_inputs
     Dev &d = h->d;
     const int p = (int)(h->step_host & 1);
     if (plan.sp_done || !plan.next_sp) return;
+    if (can_lean(h)) {                              // the winner list of this step, nothing else
+        enqueue_sp_front(h, bank, n_inputs, p);
+        enqueue_sp_back(h, bank, n_inputs, p, 1, 0, false);
+        return;
+    }
     enqueue_sp_front(h, bank, n_inputs, p);
     enqueue_sp_back(h, bank, n_inputs, p, 1, EMIT_DUTY | EMIT_CLEAR, learning != 0);
     LAUNCH(h, "sp_overlap", k_sp_overlap, h->sp_blocks, RB, d, bank, n_inputs, h->G, p, p ^ 1, 1);
@@ -318,7 +373,9 @@ static void enqueue_cold_start(htm_handle *h, const uint32_t *bank, int n_inputs
 }
 
 static void enqueue_rest(htm_handle *h, int p, const uint32_t *bank, int n_inputs, int learning, StepPlan plan) {
-    if (plan.sp_done || plan.next_sp) {
+    if ((plan.sp_done || plan.next_sp) && can_lean(h)) {
+        enqueue_lean(h, p, learning, bank, n_inputs, plan);
+    } else if (plan.sp_done || plan.next_sp) {
         enqueue_pipelined(h, p, learning, bank, n_inputs, plan);
     } else {                                        // one role per launch
         enqueue_sp_back(h, bank, n_inputs, p, 1, EMIT_ALL, false);
@@ -542,6 +599,10 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
     h->scan_blocks = std::max(1, std::min((d.Lcap + SCAN_SEGS - 1) / SCAN_SEGS, 2048));
     if (h->scan_blocks > 256) h->scan_blocks = (h->scan_blocks + 255) & ~255;     // (role_scan: whole groups of 256 blocks)
     h->zero_blocks = std::max(1, std::min((d.Lcap / 128 + 4095) / 4096, 1024));     // k_mid_rows: 16 stores of 16 bytes per thread at most
+    // the three-launch schedule: waves of one 256-thread block per work item in the steady state; the scan's waves take
+    // two groups of segments each, so that emit + learn + scan are all resident at once (tuning knobs)
+    h->lean_learn_blocks = getenv("BITHTM_LEAN_LEARN") ? std::max(1, atoi(getenv("BITHTM_LEAN_LEARN"))) : 512;
+    h->lean_scan_blocks = getenv("BITHTM_LEAN_SCAN") ? std::max(1, atoi(getenv("BITHTM_LEAN_SCAN"))) : (h->scan_blocks > 512 ? std::max(256, (h->scan_blocks * 3 / 8 + 255) & ~255) : h->scan_blocks);
     {
         hipDeviceProp_t prop;
         h->cus = hipGetDeviceProperties(&prop, h->device) == hipSuccess ? prop.multiProcessorCount : 256;
@@ -823,7 +884,8 @@ static int run_or_prepare(htm_handle *h, const uint32_t *device_inputs, int32_t 
     bool sp_done = resume;                          // the SP has already done the coming step
     long long step = h->step_host;
     for (int t = 0; t < n_steps;) {
-        const StepPlan plan{sp_done, pipeline && (t + 1 < n_steps || cont), pipeline && (t + 2 < n_steps || cont)};
+        const bool lean = pipeline && can_lean(h);      // (looks one step ahead, not two)
+        const StepPlan plan{sp_done, pipeline && (t + 1 < n_steps || cont), pipeline && !lean && (t + 2 < n_steps || cont)};
         sp_done = plan.next_sp;
         if (!graph) {
             int rc = enqueue_step(h, device_inputs, n_inputs, learning, plan);
@@ -834,8 +896,8 @@ static int run_or_prepare(htm_handle *h, const uint32_t *device_inputs, int32_t 
         const int p = (int)(step & 1);
         // steady state: this and the next span - 1 steps all look ahead fully
         int span = 1;
-        if (plan.sp_done && plan.next_front) {
-            const int steady = cont ? n_steps - t : n_steps - t - 2;       // steps from here on that look ahead fully
+        if (plan.sp_done && (lean ? plan.next_sp : plan.next_front)) {
+            const int steady = cont ? n_steps - t : n_steps - t - (lean ? 1 : 2);       // steps from here on that look ahead fully
             if (cont && steady > 1 && steady < 2 * kGraphSteps) span = steady;      // a continuing call's (last) stretch: one graph
             else if (steady >= kGraphSteps) span = kGraphSteps;
         }
@@ -843,7 +905,7 @@ static int run_or_prepare(htm_handle *h, const uint32_t *device_inputs, int32_t 
             if (!plan.sp_done && !plan.next_sp) enqueue_sp_front(h, device_inputs, n_inputs, p);    // eager
             enqueue_cold_start(h, device_inputs, n_inputs, learning, plan);                         // eager: first step of a pipelined run
         }
-        auto key = std::make_tuple(p, learning * 16 + (plan.sp_done ? 4 : 0) + (plan.next_sp ? 2 : 0) + (plan.next_front ? 1 : 0) + 32 * scan_spec_blocks(h) + (scan_pool_is_large(h) ? (1 << 20) : 0) + (h->emit_fused ? (1 << 21) : 0) + (span << 22),
+        auto key = std::make_tuple(p, learning * 16 + (plan.sp_done ? 4 : 0) + (plan.next_sp ? 2 : 0) + (plan.next_front ? 1 : 0) + 32 * scan_spec_blocks(h) + (scan_pool_is_large(h) ? (1 << 20) : 0) + (h->emit_fused ? (1 << 21) : 0) + (span << 22) + (lean ? 8 : 0),
                                    (const void *)device_inputs, n_inputs);
         auto it = h->graphs.find(key);
         if (it == h->graphs.end()) {

@@ -101,6 +101,7 @@ __global__ __launch_bounds__(RB) void k_learn_overlap(Dev d, int p, int n_learn_
 // blocks [0, n_sel): select digit 1 for the SP step with parity sp; then n_clear blocks that zero the
 // dense per-column words of the coming step (what EMIT_CLEAR does when the winner list is emitted in a
 // launch of its own: here the learning role still needed them after the emit); the rest: the scan.
+// (with the learning role and the scan in one launch, k_learn_scan below, this one is left with the SP roles)
 // The few short SP blocks come first: behind the scan blocks they would wait for a free CU slot.
 template <bool use_lds, int MINW>
 __global__ __launch_bounds__(256, MINW) void k_scan_sel(Dev d, int p, int n_sel_blocks, int n_clear_blocks, int sp, int n_spec) {
@@ -122,6 +123,114 @@ __global__ __launch_bounds__(256, MINW) void k_scan_sel(Dev d, int p, int n_sel_
     }
     b -= n_clear_blocks;
     role_scan<256, use_lds, MINW == 1>(d, p, b, gridDim.x - n_sel_blocks - n_clear_blocks, n_spec, (uint32_t *)dyn_lds);
+}
+
+// ---- the three-launch schedule -------------------------------------------------------------------------------
+// The Temporal Memory's chain is activate -> mid -> learn -> scan, the Spatial Pooler's emit -> rows -> overlap -> select
+// digit -> emit; a dependent launch costs about 2 us whatever is in it.  Two changes make both chains three long:
+// the learning role and the scan share a launch (role_learn SELF, SEG_BUSY), and the select needs one histogram pass
+// (win_bin).  The SP is then one stage ahead of the TM (t = the TM's step):
+//
+//   k_act_rows(t)      activate(t), dense-word clears of the step   | rows(t) + duty(t)       SP learning of this step
+//   k_mid_overlap(t)   mid(t), match-bit zeroing                     | overlap(t+1)            + windowed histogram
+//   k_learn_scan_emit(t)  learn(t) + scan(t)                         | emit(t+1)               select finish + winner list
+//
+// (emit(t+1) only reads: the SP's persistent state -- permanences, duty cycle -- is never ahead of the TM's step.)
+__global__ __launch_bounds__(256, 8) void k_act_rows(Dev d, int p, int n_active, int n_act_blocks, const uint32_t *__restrict__ bank, int n_inputs,
+                                                     int n_rows, int n_duty_blocks) {
+    TraceScope ts(d, 0 + 4 * p);
+    int b = blockIdx.x;
+    if (b < n_act_blocks) {                         // one active column per half-wave
+        const int idx = (b * 256 + (int)threadIdx.x) >> 5;
+        const bool ok = idx < n_active;
+        const int a = ok ? d.active_cols[p][idx] : 0;
+        tm_activate_column(d, p, 1, ok, a, idx, ok ? d.pred[p ^ 1][a] : 0u);
+        return;
+    }
+    b -= n_act_blocks;
+    if (b < n_rows) {
+        role_sp_row<256>(d, p, bank, n_inputs, 0, b, threadIdx.x);
+        return;
+    }
+    b -= n_rows;
+    const int c = b * 256 + (int)threadIdx.x;
+    if (b < n_duty_blocks) {
+        if (c < d.C) {
+            float dc = d.duty[c] * d.mom;
+            if ((d.colbits[p][c >> 5] >> (c & 31)) & 1u) dc = dc + d.dinc;
+            d.duty[c] = dc;
+        }
+        return;
+    }
+    // the step's dense per-column words: predictions (the scan sets bits), and the active / winner words of the columns
+    // that are NOT active (the activation blocks of this launch write the others)
+    const int cc = (b - n_duty_blocks) * 256 + (int)threadIdx.x;
+    if (cc < d.C) {
+        d.pred[p][cc] = 0;
+        if (!((d.colbits[p][cc >> 5] >> (cc & 31)) & 1u)) { d.act[p][cc] = 0; d.win[p][cc] = 0; }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_mid_overlap(Dev d, int p, int n_active, int want_winner, int learning, int n_cls,
+                                                     const uint32_t *__restrict__ bank, int n_inputs, int G, int n_overlap_blocks) {
+    TraceScope ts(d, 1 + 4 * p);
+    int b = blockIdx.x;
+    if (b <= n_cls) {
+        role_mid<256>(d, p, n_active, want_winner, learning, b, n_cls);
+        return;
+    }
+    b -= 1 + n_cls;
+    if (b < n_overlap_blocks) {
+        role_overlap<256>(d, bank, n_inputs, G, p, p ^ 1, 1, b, n_overlap_blocks, (uint32_t *)dyn_lds, 1);
+        return;
+    }
+    b -= n_overlap_blocks;
+    const int nz = (int)gridDim.x - 1 - n_cls - n_overlap_blocks;      // (see k_mid_rows)
+    const int words4 = ((d.world > 1 ? d.ctr->L : d.ctr->S) + 127) >> 7;
+    uint4 *mb = (uint4 *)d.match_bits[p];
+    for (int i = b * 256 + (int)threadIdx.x; i < words4; i += nz * 256) mb[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+
+// the emit blocks wait for each other's records: they come first in the grid (all resident whatever the others do);
+// then the learning role, whose items are the longest chains; then the scan
+template <int EPL, int MINW>
+__global__ __launch_bounds__(256, MINW) void k_learn_scan_emit(Dev d, int p, int n_emit_blocks, int n_learn_blocks, int n_scan_blocks, int n_spec) {
+    TraceScope ts(d, 2 + 4 * p);
+    int b = blockIdx.x;
+    if (b < n_emit_blocks) {
+        role_emit(d, p ^ 1, 1, 1, 0, b, n_emit_blocks, (EmitShared *)dyn_lds, 1);
+        return;
+    }
+    b -= n_emit_blocks;
+    if (b < n_learn_blocks) {
+        role_learn<EPL, 256, true>(d, p, b, n_learn_blocks, (LearnShared<EPL, 256> *)dyn_lds);
+        return;
+    }
+    b -= n_learn_blocks;
+    role_scan<256, true, MINW == 1>(d, p, b, n_scan_blocks, n_spec, (uint32_t *)dyn_lds);
+}
+
+// (an intermediate form, kept for measurements: BITHTM_LEAN=0 BITHTM_FUSE=1)
+// Step t's learning role, its scan and the overlap + boost + select digit 0 of step t + 2 in one launch.  The learning
+// waves do the scan's work for the rows they rewrite (role_learn SELF; the scan passes over rows flagged SEG_BUSY), both
+// publish with atomics into the buffers of the step's parity.  Blocks in the order they should start: the learning
+// role's items are the longest chains, the scan wants to be resident all at once, the overlap streams.
+template <int EPL, int MINW>
+__global__ __launch_bounds__(256, MINW) void k_learn_scan(Dev d, int p, int n_learn_blocks, int n_scan_blocks, int n_overlap_blocks,
+                                                           const uint32_t *__restrict__ bank, int n_inputs, int G, int n_spec) {
+    TraceScope ts(d, 2 + 4 * p);
+    int b = blockIdx.x;
+    if (b < n_learn_blocks) {
+        role_learn<EPL, 256, true>(d, p, b, n_learn_blocks, (LearnShared<EPL, 256> *)dyn_lds);
+        return;
+    }
+    b -= n_learn_blocks;
+    if (b < n_scan_blocks) {
+        role_scan<256, true, MINW == 1>(d, p, b, n_scan_blocks, n_spec, (uint32_t *)dyn_lds);
+        return;
+    }
+    b -= n_scan_blocks;
+    if (b < n_overlap_blocks) role_overlap<256>(d, bank, n_inputs, G, p, p, 2, b, n_overlap_blocks, (uint32_t *)dyn_lds);
 }
 
 #endif

@@ -30,8 +30,9 @@ __global__ __launch_bounds__(256) void k_sp_build_mask(Dev d, int row_begin, int
 // roles can share one launch (pipelined schedule: step t's TM work beside step t+1's SP work).
 // sp = parity buffer of the SP step being computed; step_offset = that step minus the current one.
 template <int BS>
+// wmode: the histogram of the windowed select (win_bin) instead of the top key digit
 __device__ __forceinline__ void role_overlap(const Dev &d, const uint32_t *__restrict__ bank, int n_inputs, int G,
-                                             int p, int sp, int step_offset, int blk, int nblk, uint32_t *h) {
+                                             int p, int sp, int step_offset, int blk, int nblk, uint32_t *h, int wmode = 0) {
     const int gtid = blk * BS + threadIdx.x;
     const int nthreads = nblk * BS;
     const bool do_hist = true;
@@ -46,6 +47,7 @@ __device__ __forceinline__ void role_overlap(const Dev &d, const uint32_t *__res
         }
         __syncthreads();
     }
+    const uint32_t wbase = wmode ? d.ctr->sel_win[sp] : 0u;
     const uint4 *in4 = (const uint4 *)(bank + (size_t)((d.ctr->step[p] + (uint32_t)step_offset) % (uint32_t)n_inputs) * d.W);
     const uint4 *mask4 = (const uint4 *)d.mask;
     const int lane = lane_id();
@@ -91,7 +93,7 @@ __device__ __forceinline__ void role_overlap(const Dev &d, const uint32_t *__res
             }
             // (plain LDS atomics: only the 64 / G row owners of the wave take part, and hist_add's loop over the
             // distinct digits, a dependent shuffle + ballot + atomic each, cost 0.3 us per call here)
-            if (do_hist && owner) atomicAdd(&h[(uint32_t)(key >> sel_shift(0))], 1u);
+            if (do_hist && owner) atomicAdd(&h[wmode ? win_bin(key, wbase) : (uint32_t)(key >> sel_shift(0))], 1u);
         }
     }
     if (!do_hist) return;
@@ -219,6 +221,7 @@ __global__ __launch_bounds__(256) void k_sp_count(Dev d, int sp) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         d.ctr->sel_prefix[sp] = T;              // skipped low digits are zero in every key
         d.ctr->sel_krem[sp] = r;
+        d.ctr->sel_win[sp ^ 1] = win_base_for(T);
     }
     if (d.sel_passes > 1)                       // pass-0 histogram is consumed: clear it for its next use
         for (int i = blockIdx.x * 256 + threadIdx.x; i < HIST_REP * SEL_BINS; i += gridDim.x * 256) d.hist0[(size_t)sp * HIST_REP * SEL_BINS + i] = 0;
@@ -314,7 +317,7 @@ __host__ __device__ __forceinline__ size_t shard_record_bytes(int n_cand) {
 // per-block counts are exchanged in a second tagged round.
 #define CAND_D 15             // distinct bucket keys one block can publish (head + 15 granules = its 128-byte record)
 #define CAND_RAW 64           // ... and collect from its waves before merging duplicates
-#define CAND_MAX 2048         // bucket entries a block can merge
+#define CAND_MAX 1024         // bucket entries a block can merge
 #define CAND_OTHERS 160         // ... after folding the copies of one key, if at most this many others remain
 #define CAND_PAIRWISE 160      // ... by comparing all pairs; above that, by radix refinement in LDS
 
@@ -381,7 +384,8 @@ struct EmitShared {
     int n, nraw, ne;
 };
 
-__device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, int fused, int mode, int b, int nblk, EmitShared *sh) {
+// wmode (with fused): the launched part of the select was the windowed histogram (win_bin) of role_overlap
+__device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, int fused, int mode, int b, int nblk, EmitShared *sh, int wmode = 0) {
     uint32_t *h = sh->h;
     uint32_t *s_wave = sh->wave, *s_out = sh->out, *s_predw = sh->predw, *s_bc = sh->bc;
     u64 *s_bk = sh->bk;
@@ -411,9 +415,41 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
     if (fused) {
         u64 P;
         uint32_t krem;
-        sel_resolve<256>(d, p, d.sel_passes - 1, h, s_wave, &P, &krem, &s_prefix, &s_krem);    // (ends behind a barrier)
-        const int lowbits = sel_shift(d.sel_passes - 1);        // key bits not resolved by launches
-        const u64 hiP = P >> lowbits, hi = my_key >> lowbits;
+        int lowbits = sel_shift(d.sel_passes - 1);              // key bits not resolved by launches
+        if (wmode) {
+            {   // the histogram: sum of the copies (16-byte loads, all in flight)
+                constexpr int PER4 = SEL_BINS / 256 / 4;
+                const uint32_t *g0 = d.hist0 + (size_t)p * HIST_REP * SEL_BINS;
+                uint4 v[PER4];
+#pragma unroll
+                for (int j = 0; j < PER4; ++j) v[j] = make_uint4(0, 0, 0, 0);
+                for (int r = 0; r < HIST_REP; ++r)
+#pragma unroll
+                    for (int j = 0; j < PER4; ++j) {
+                        const uint4 a = *(const uint4 *)(g0 + (size_t)r * SEL_BINS + 4 * (j * 256 + tid));
+                        v[j].x += a.x; v[j].y += a.y; v[j].z += a.z; v[j].w += a.w;
+                    }
+#pragma unroll
+                for (int j = 0; j < PER4; ++j) *(uint4 *)(h + 4 * (j * 256 + tid)) = v[j];
+            }
+            __syncthreads();
+            uint32_t bucket, above;
+            sel_pick<256>(h, WIN_BINS, (uint32_t)d.sel_k, s_wave, s_out, &bucket, &above);
+            __syncthreads();
+            if (bucket >= 1u && bucket <= (WIN_COARSE << WIN_FINE)) {
+                const uint32_t fine = bucket - 1u;
+                P = ((u64)(d.ctr->sel_win[p] + (fine >> WIN_FINE)) << 52) | ((u64)(fine & ((1u << WIN_FINE) - 1u)) << WIN_LOWBITS);
+                krem = (uint32_t)d.sel_k - above;
+                lowbits = WIN_LOWBITS;
+            } else {                                 // the k-th key is outside the window: nothing resolved, the fallback does it all
+                P = 0;
+                krem = (uint32_t)d.sel_k;
+                lowbits = 64;
+            }
+        } else {
+            sel_resolve<256>(d, p, d.sel_passes - 1, h, s_wave, &P, &krem, &s_prefix, &s_krem);    // (ends behind a barrier)
+        }
+        const u64 hiP = lowbits < 64 ? P >> lowbits : 0ull, hi = lowbits < 64 ? my_key >> lowbits : 0ull;
         const bool c_gt = c < d.sel_hi && hi > hiP, c_cand = c < d.sel_hi && hi == hiP;
         // ---- this block's record
         {
@@ -450,23 +486,23 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
         // record = up to 16 self-validating 64-bit granules (form R2: every granule carries the epoch, one
         // aligned 8-byte write-through store each, so no separate tag and no drain):
         //   [0]      epoch:12 | overflow:1 | pairs:4 | keys above the bucket:9 | multiplicity:9 | key bits:29
-        //   [j >= 1] epoch:12 | multiplicity:12 | low 40 key bits   (the high bits are the bucket's)
+        //   [j >= 1] epoch:12 | multiplicity:12 | the unresolved key bits above low_zero, at most 40   (the high bits are the bucket's)
         // The first pair rides in the head granule -- the low_zero bottom bits of every key are zero, so
         // 29 bits hold the rest for input_dim up to 2^17 -- and a block with at most one bucket key, the
         // usual case and the one of a many-way tie, is read with a single load.
         u64 *rec = (u64 *)(d.sel_rec + (size_t)b * 32);
         const u64 etag = (u64)epoch << 52;
-        const u64 lowmask = (1ull << lowbits) - 1ull;
+        const u64 lowmask = lowbits < 64 ? (1ull << lowbits) - 1ull : ~0ull;
         const bool inline_ok = lowbits - d.low_zero <= 29;
         if (tid < 64) {                              // wave 0 compacts the survivors into the record
             const bool alive = tid < nraw && first == tid;
             const u64 ma = __ballot(alive);
             const int n_pairs = __popcll(ma), pos = __popcll(ma & lanemask_lt());
-            const bool overflow = s_nraw > CAND_RAW || n_pairs > d.cand_d || (n_pairs > 0 && !inline_ok);
+            const bool overflow = s_nraw > CAND_RAW || n_pairs > d.cand_d || (n_pairs > 0 && !inline_ok) || lowbits - d.low_zero > 40;
             const u64 mine = alive ? (s_bk[tid] & lowmask) : 0ull;
             const uint32_t cnt = alive ? s_bc[tid] : 0u;
             if (alive && pos >= 1 && pos < CAND_D)
-                __hip_atomic_store(rec + pos, etag | ((u64)cnt << 40) | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(rec + pos, etag | ((u64)cnt << 40) | (mine >> d.low_zero), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int l0 = ma ? __ffsll((long long)ma) - 1 : 0;      // the lane of pair 0
             const u64 k0 = ((u64)__shfl((uint32_t)(mine >> 32), l0) << 32) | __shfl((uint32_t)mine, l0);
             const uint32_t c0 = __shfl(cnt, l0);
@@ -507,8 +543,8 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
                 if (j < np) {
                     const int slot = atomicAdd(&s_ne, 1);
                     if (slot < CAND_MAX) {
-                        const u64 low = j == 0 ? (g[0] & 0x1FFFFFFFull) << d.low_zero : g[j] & lowmask;
-                        s_ek[slot] = (hiP << lowbits) | low;
+                        const u64 low = (j == 0 ? g[0] & 0x1FFFFFFFull : g[j] & 0xFFFFFFFFFFull) << d.low_zero;
+                        s_ek[slot] = (lowbits < 64 ? hiP << lowbits : 0ull) | low;
                         s_ec[slot] = (uint16_t)(j == 0 ? (g[0] >> 29) & 0x1FFu : (g[j] >> 40) & 0xFFFu);
                         s_eb[slot] = (uint16_t)rb;
                     }
@@ -594,7 +630,7 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
                     rem -= s_out[1];
                     top = shift;
                 }
-                T = (hiP << lowbits) | pref;
+                T = (lowbits < 64 ? hiP << lowbits : 0ull) | pref;
                 r = rem;
             }
             uint32_t g = gthi_before, e2 = 0;         // winners of the blocks before this one
@@ -618,7 +654,7 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
                 for (int c0 = d.sel_lo + (tid & ~63); c0 < d.sel_hi; c0 += 256) {
                     const int cc = c0 + lane;
                     const u64 kk = cc < d.sel_hi ? keys[cc] : 0;
-                    hist_add(h, (uint32_t)(kk >> shift) & (nb - 1), cc < d.sel_hi && ((kk ^ P2) >> top) == 0);
+                    hist_add(h, (uint32_t)(kk >> shift) & (nb - 1), cc < d.sel_hi && (top >= 64 || ((kk ^ P2) >> top) == 0));
                 }
                 __syncthreads();
                 uint32_t bucket, above;
@@ -633,7 +669,7 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
             second_round = true;
             if (b == 0 && tid == 0) d.ctr->sel_fallbacks += 1;
         }
-        if (b == 0 && tid == 0) { d.ctr->sel_prefix[p] = T; d.ctr->sel_krem[p] = r; }
+        if (b == 0 && tid == 0) { d.ctr->sel_prefix[p] = T; d.ctr->sel_krem[p] = r; d.ctr->sel_win[p ^ 1] = win_base_for(T); }
         // the pass-0 histogram is consumed: clear it for its next use (here, not earlier: a barrier
         // waits for outstanding stores, and the record exchange above is the critical chain)
         if (d.sel_passes > 1)

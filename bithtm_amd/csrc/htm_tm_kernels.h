@@ -384,7 +384,10 @@ static_assert(CAND_CAP == 4 * 64, "the growth path holds the staged winners four
 #define LCOUNT(i, v) do { } while (0)
 #endif
 
-template <int EPL, int BS>
+// SELF: the wave also does the segment scan's work for its segment (potential and connected-active count against this
+// step's active cells, from the synapses it holds in registers; publication as in role_scan) -- the schedule in which the
+// learning role and the scan share a launch: the scan leaves the rows on the work list alone (SEG_BUSY).
+template <int EPL, int BS, bool SELF = false>
 __device__ __forceinline__ void role_learn(const Dev &d, int p, int blk, int nblk, LearnShared<EPL, BS> *sh) {
     int (*s_keep)[EPL * 64] = sh->keep;
     u64 (*s_cand)[CAND_CAP] = sh->cand;
@@ -405,7 +408,8 @@ __device__ __forceinline__ void role_learn(const Dev &d, int p, int blk, int nbl
     if (blk == 0 && threadIdx.x == 0) c->n_work_last = n_front + n_back;
     if (n_front + n_back > d.work_cap && blk == 0 && threadIdx.x == 0) atomicOr(&c->error, 4);
     const int n_work = min(n_front + n_back, d.work_cap);
-    const uint32_t *act_prev = d.act[p ^ 1];
+    const uint32_t *act_prev = d.act[p ^ 1], *act_cur = d.act[p];
+    const uint32_t base3 = htm_stream_base(d.seed, HTM_STREAM_SEGMENT_JITTER, c->step[p]);
     const int *winners = d.winners[p ^ 1];
     const int n_w = c->has_winner[p ^ 1] ? c->n_win[p ^ 1] : -1;       // -1: winner_input is None
     const uint32_t base2 = htm_stream_base(d.seed, HTM_STREAM_GROWTH, c->step[p]);
@@ -430,6 +434,7 @@ __device__ __forceinline__ void role_learn(const Dev &d, int p, int blk, int nbl
         int *prow = d.presyn + (size_t)seg * d.E;
         float *mrow = d.sperm + (size_t)seg * d.E;
         int n_keep = 0, n_active = 0;
+        int pot = 0, conn = 0;                       // SELF: active presynaptic cells of THIS step (projections.py:247), connected ones (:171-172)
 #pragma unroll
         for (int jj = 0; jj < EPL; ++jj) {
             const int idx = jj * 64 + lane;
@@ -438,18 +443,24 @@ __device__ __forceinline__ void role_learn(const Dev &d, int p, int blk, int nbl
             float pm = 0.f;
             if (valid) { ps = prow[idx] & SYN_CELL; pm = mrow[idx]; }
             const bool a = valid && ((act_prev[ps >> 5] >> (ps & 31)) & 1u);
+            const bool a_now = SELF && valid && ((act_cur[ps >> 5] >> (ps & 31)) & 1u);
             const double p64 = (double)pm + (a ? dA : dI);               // :102-103
             const bool keep = valid && !(prune && p64 < 0.0);            // :105-108
+            const float p32 = (float)p64;                                  // :104
+            const bool connected = p32 >= d.perm_thr;
             const u64 mk = __ballot(keep);
             if (keep) {
                 const int pos = n_keep + __popcll(mk & lanemask_lt());
-                const float p32 = (float)p64;                              // :104
-                prow[pos] = ps | (p32 >= d.perm_thr ? (int)SYN_CONNECTED : 0);   // the scan's `permanence >= threshold`, kept with the id
+                prow[pos] = ps | (connected ? (int)SYN_CONNECTED : 0);     // the scan's `permanence >= threshold`, kept with the id
                 mrow[pos] = p32;
                 s_keep[wv][pos] = ps;
             }
             n_keep += __popcll(mk);
             n_active += __popcll(__ballot(keep && a));                    // :114
+            if (SELF) {
+                pot += __popcll(__ballot(keep && a_now));
+                conn += __popcll(__ballot(keep && a_now && connected));
+            }
         }
         __builtin_amdgcn_wave_barrier();
         LSTAMP(1);
@@ -561,14 +572,22 @@ __device__ __forceinline__ void role_learn(const Dev &d, int p, int blk, int nbl
                     }
 #pragma unroll
                     for (int j = 0; j < SL; ++j) {
+                        bool a_now = false;
                         if (j * 64 + lane < n_c && rank[j] < take_n) {
                             const int slot = n_keep + rank[j];
                             if (slot < d.E) {
-                                prow[slot] = winner_at((int)(uint32_t)key[j]) | (d.perm_init >= d.perm_thr ? (int)SYN_CONNECTED : 0);
+                                const int wc = winner_at((int)(uint32_t)key[j]);
+                                prow[slot] = wc | (d.perm_init >= d.perm_thr ? (int)SYN_CONNECTED : 0);
                                 mrow[slot] = d.perm_init;                               // :149,158
+                                a_now = SELF && ((act_cur[wc >> 5] >> (wc & 31)) & 1u);
                             } else {
                                 atomicOr(&c->error, 2);
                             }
+                        }
+                        if (SELF) {
+                            const int na = __popcll(__ballot(a_now));
+                            pot += na;
+                            conn += d.perm_init >= d.perm_thr ? na : 0;
                         }
                     }
                 };
@@ -578,6 +597,16 @@ __device__ __forceinline__ void role_learn(const Dev &d, int p, int blk, int nbl
                 n_total = min(n_keep + take_n, d.E);                                    // :161
                 LSTAMP(5);
             }
+        }
+        if (SELF && lane == 0 && pot >= d.match_thr) {                          // role_scan's publication (:247-251, :229-239)
+            const bool active = conn >= d.act_thr;
+            const int cell = d.seg_cell[seg];
+            const float jit = htm_jitter((float)pot, htm_draw24(base3, gid, 0u));
+            atomicMax(&d.cellmax[p][cell], __float_as_uint(jit));
+            if (active) atomicOr(&d.pred[p][cell >> 5], 1u << (cell & 31));
+            d.seg_info[seg] = (uint32_t)pot | ((uint32_t)conn << 12) | 0x40000000u | (active ? 0x80000000u : 0u);
+            d.seg_jit[seg] = jit;
+            atomicOr(&d.match_bits[p][seg >> 5], 1u << (seg & 31));
         }
         if (lane == 0) {
             d.seg_nsyn[seg] = n_total;
