@@ -69,6 +69,11 @@ def build_htm(w, perm, device, column_range=None):
     return B.HierarchicalTemporalMemory(I, C, K, active_columns=k, spatial_pooler=sp, temporal_memory=tm, device=device)
 
 
+# the launches of the pipelined schedules (htm_pipeline.h) and the roles each holds: three per timestep (the default) ...
+LEAN_KERNEL = {"tm_activate+sp_learn": "k_act_rows", "tm_mid+sp_overlap": "k_mid_overlap", "tm_learn+tm_scan+sp_emit": "k_learn_scan_emit"}
+LEAN_ROLES = {"tm_activate+sp_learn": ("tm_activate", "sp_rows", "tm_clear"), "tm_mid+sp_overlap": ("tm_mid", "sp_overlap"),
+              "tm_learn+tm_scan+sp_emit": ("tm_learn", "tm_scan", "sp_emit")}
+# ... or four (BITHTM_LEAN=0)
 LAUNCH_KERNEL = {"tm_activate+sp_emit": "k_open_emit", "tm_mid+sp_learn": "k_mid_rows",
                  "tm_learn+sp_overlap": "k_learn_overlap", "tm_scan+sp_select": "k_scan_sel"}
 LAUNCH_ROLES = {"tm_activate+sp_emit": ("tm_activate", "sp_emit"), "tm_mid+sp_learn": ("tm_mid", "sp_rows"),
@@ -84,12 +89,12 @@ def role_bytes(w, k, seg_nsyn, n_work, n_match):
     S, syn = len(nsyn), int(nsyn.sum())
     mean_syn = syn / max(S, 1)
     return {
-        # mask rows + input + duty read + overlap / boosted / key writes
+        # mask rows + input + duty read + overlap / boosted / key writes (+ the select histogram: LDS, then a few KB of atomics)
         "sp_overlap": C * W * 4 + W * 4 + C * 4 + C * (4 + 8 + 8),
         # digit 1: the keys once + the digit-0 histogram copies
         "sp_select": C * 8 + 4 * 4096 * 4,
-        # select finish + winner list: keys, per-block records (write + read), column bitmap, list
-        "sp_emit": C * 8 + 2 * 128 * ((C + 255) // 256) + C // 8 + 4 * k,
+        # select finish + winner list: histogram copies, keys, per-block records (write + read), column bitmap, list
+        "sp_emit": 4 * 4096 * 4 + C * 8 + 2 * 128 * ((C + 255) // 256) + C // 8 + 4 * k,
         # k winner rows: float64 read + write, mask row rewrite; duty cycle read + write, column bitmap
         "sp_rows": 2 * 8 * k * I + k * W * 4 + 2 * 4 * C + C // 8,
         # per winner column: previous prediction word, 32 x (cell maximum + segment count), six result words
@@ -278,7 +283,11 @@ def run_single(args):
     role_us = {n: 1e3 * ms / cnt for n, (ms, cnt) in prof_roles.items() if cnt}
     log("[bench] one role per launch, average launch (us): " +
         ", ".join(f"{n}={v:.1f}" for n, v in sorted(role_us.items(), key=lambda kv: -kv[1])))
-    if pipeline and all(prof_timed.get(n, (0, 0))[1] for n in LAUNCH_ROLES):
+    if pipeline and all(prof_timed.get(n, (0, 0))[1] for n in LEAN_ROLES):
+        launch_us = {n: 1e3 * prof_timed[n][0] / max(prof_timed[n][1], 1) for n in LEAN_ROLES}
+        launch_bytes = {n: sum(rb[r] for r in roles) for n, roles in LEAN_ROLES.items()}
+        kernel_of = LEAN_KERNEL
+    elif pipeline and all(prof_timed.get(n, (0, 0))[1] for n in LAUNCH_ROLES):
         launch_us = {n: 1e3 * prof_timed[n][0] / max(prof_timed[n][1], 1) for n in LAUNCH_ROLES}
         launch_bytes = {n: sum(rb[r] for r in roles) for n, roles in LAUNCH_ROLES.items()}
         kernel_of = LAUNCH_KERNEL
@@ -293,7 +302,7 @@ def run_single(args):
         f"; sum {sum(launch_us.values()):.1f} of {1e6 / steps_per_s:.1f} us per step")
     dominant = max(launch_us, key=lambda n: launch_us[n])
     achieved = launch_bytes[dominant] / (launch_us[dominant] * 1e-6) / 1e9
-    whole = int(sum(rb.values()))
+    whole = int(sum(launch_bytes.values()))
     roofline = dict(bound="hbm", kernel=f"{kernel_of[dominant]} ({dominant})", achieved=round(achieved, 1), peak=HBM_PEAK_GBS,
                     unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
                     bytes_per_launch=int(launch_bytes[dominant]), avg_launch_us=round(launch_us[dominant], 2),
@@ -328,7 +337,7 @@ def run_single(args):
                     input_dim=w["input_dim"], column_dim=w["column_dim"], cell_dim=w["cell_dim"], active_columns=k,
                     patterns=w["patterns"], input_density=w["density"], flip_noise=w["noise"],
                     pretrain_steps=pretrain, segments=segments, segment_slots=w["segment_slots"],
-                    hip_graph=use_graph, pipelined=pipeline, repetitions=reps, streamed_calls=bool(stream["continuing"])),
+                    hip_graph=use_graph, pipelined=pipeline, launches_per_step=len(launch_us), repetitions=reps, streamed_calls=bool(stream["continuing"])),
         repetitions=[round(r, 1) for r in rates],
         roofline=roofline, cpu_baseline=cpu, stress=stress,
         role_us_one_per_launch={n: round(v, 2) for n, v in role_us.items()},

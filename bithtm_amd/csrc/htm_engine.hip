@@ -67,7 +67,7 @@ struct htm_handle {
     int sel_passes_fused, sel_passes_full; // launched select digits with / without the in-kernel finish
     int seg_hint;                         // a lower bound of the segment count (see scan_spec_blocks)
     int *seg_pinned;                      // pinned word the end of each htm_run copies the count into
-    int sp_blocks, sel_blocks, c256_blocks, s1024_blocks, scan_blocks, zero_blocks, lean_learn_blocks, lean_scan_blocks, cus;
+    int sp_blocks, sel_blocks, c256_blocks, s1024_blocks, scan_blocks, zero_blocks, lean_learn_blocks, lean_scan_blocks, lean_overlap_blocks, cus;
     const uint32_t *ahead_bank;           // htm_run ended with HTM_RUN_CONTINUE on this bank: the SP has done the next step
     int ahead_n_inputs, ahead_learning;   //   and the front of the one after it
     int phase_active;                     // htm_sp_phase: length of the current winner list
@@ -284,7 +284,7 @@ static void enqueue_lean(htm_handle *h, int p, int learning, const uint32_t *ban
     Dev &d = h->d;
     const int n_act = (d.k * 32 + 255) / 256, n_rows = learning ? d.k : 0;
     LAUNCH(h, "tm_activate+sp_learn", k_act_rows, n_act + n_rows + 2 * h->c256_blocks, 256, d, p, d.k, n_act, bank, n_inputs, n_rows, h->c256_blocks);
-    const int n_cls = learning ? kClassifyBlocks : 0, n_ov = plan.next_sp ? h->sp_blocks * (RB / 256) : 0;
+    const int n_cls = learning ? kClassifyBlocks : 0, n_ov = plan.next_sp ? h->lean_overlap_blocks : 0;
     LAUNCH_ON(h, h->stream, (size_t)SEL_BINS * 4, "tm_mid+sp_overlap", k_mid_overlap, 1 + n_cls + n_ov + h->zero_blocks, 256, d, p, d.k, 1, learning, n_cls,
               bank, n_inputs, h->G, n_ov);
     const int epl = learn_epl(d), n_emit = plan.next_sp ? h->c256_blocks : 0, spec = scan_spec_blocks(h);
@@ -308,28 +308,7 @@ static void enqueue_pipelined(htm_handle *h, int p, int learning, const uint32_t
     const int n_emit = plan.next_sp ? h->c256_blocks : 0;
     LAUNCH_ON(h, h->stream, sizeof(EmitShared), "tm_activate+sp_emit", k_open_emit, n_emit + (d.k * 32 + 255) / 256, 256, d, p, n_emit, d.k);
     const int n_rows = (plan.next_sp && learning) ? d.k : 0, n_duty = plan.next_sp ? h->c256_blocks : 0;
-    static const int fuse_env = getenv("BITHTM_FUSE") ? atoi(getenv("BITHTM_FUSE")) : 1;
-    const bool fuse = fuse_env != 0 && scan_lds(d, 1) <= 64 * 1024;
     LAUNCH(h, "tm_mid+sp_learn", k_mid_rows, 1 + n_cls + n_rows + n_duty + h->zero_blocks, 256, d, p, d.k, 1, learning, n_cls, bank, n_inputs, n_rows, 1, n_duty);
-    if (fuse) {
-        // the learning role (with the scan of its own rows), the scan and the overlap of step + 2 in one launch
-        const int epl = learn_epl(d);
-        const size_t lds = std::max(std::max(learn_lds(epl, 256), scan_lds(d, 1)), (size_t)SEL_BINS * 4);
-        const int n_ov = plan.next_front ? h->sp_blocks * (RB / 256) : 0, spec = scan_spec_blocks(h);
-        const int grid = kLearnBlocks + h->scan_blocks + n_ov;
-#define LAUNCH_LS(EPL_, MINW_) LAUNCH_ON(h, h->stream, lds, "tm_learn+tm_scan+sp_overlap", (k_learn_scan<EPL_, MINW_>), grid, 256, d, p, kLearnBlocks, h->scan_blocks, n_ov, bank, n_inputs, h->G, spec)
-        if (scan_pool_is_large(h)) {
-            switch (epl) { case 1: LAUNCH_LS(1, 1); break; case 2: LAUNCH_LS(2, 1); break; case 4: LAUNCH_LS(4, 1); break; default: LAUNCH_LS(8, 1); break; }
-        } else {
-            switch (epl) { case 1: LAUNCH_LS(1, 6); break; case 2: LAUNCH_LS(2, 6); break; case 4: LAUNCH_LS(4, 6); break; default: LAUNCH_LS(8, 6); break; }
-        }
-#undef LAUNCH_LS
-        // what is left of the fourth launch: select digit 1 of step + 2, the clears for step + 1
-        const int n_sel = plan.next_front ? 64 : 0, n_clear = plan.next_sp ? h->c256_blocks : 0;
-        if (n_sel + n_clear > 0)
-            LAUNCH_ON(h, h->stream, sizeof(SelShared), "sp_select+clear", (k_scan_sel<true, 6>), n_sel + n_clear, 256, d, p, n_sel, n_clear, p, 0);
-        return;
-    }
     {
         const int epl = learn_epl(d);
         const size_t lds = std::max(learn_lds(epl), (size_t)SEL_BINS * 4);
@@ -601,6 +580,7 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
     h->zero_blocks = std::max(1, std::min((d.Lcap / 128 + 4095) / 4096, 1024));     // k_mid_rows: 16 stores of 16 bytes per thread at most
     // the three-launch schedule: waves of one 256-thread block per work item in the steady state; the scan's waves take
     // two groups of segments each, so that emit + learn + scan are all resident at once (tuning knobs)
+    h->lean_overlap_blocks = getenv("BITHTM_LEAN_OVERLAP") ? std::max(1, atoi(getenv("BITHTM_LEAN_OVERLAP"))) : h->sp_blocks * (RB / 256);
     h->lean_learn_blocks = getenv("BITHTM_LEAN_LEARN") ? std::max(1, atoi(getenv("BITHTM_LEAN_LEARN"))) : 512;
     h->lean_scan_blocks = getenv("BITHTM_LEAN_SCAN") ? std::max(1, atoi(getenv("BITHTM_LEAN_SCAN"))) : (h->scan_blocks > 512 ? std::max(256, (h->scan_blocks * 3 / 8 + 255) & ~255) : h->scan_blocks);
     {
@@ -644,6 +624,7 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
         if (const char *e = getenv("BITHTM_CAND_D")) d.cand_d = std::max(0, std::min(CAND_D, atoi(e)));
         d.cand_pairwise = CAND_PAIRWISE;
         if (const char *e = getenv("BITHTM_CAND_PAIRWISE")) d.cand_pairwise = std::max(0, atoi(e));     // test knobs
+        d.win_offset = getenv("BITHTM_SEL_WINDOW_OFFSET") ? std::max(0, atoi(getenv("BITHTM_SEL_WINDOW_OFFSET"))) : 0;
         d.cand_others = CAND_OTHERS;
         if (const char *e = getenv("BITHTM_CAND_OTHERS")) d.cand_others = std::max(0, std::min(CAND_OTHERS, atoi(e)));
     }

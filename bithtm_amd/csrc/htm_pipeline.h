@@ -210,27 +210,4 @@ __global__ __launch_bounds__(256, MINW) void k_learn_scan_emit(Dev d, int p, int
     role_scan<256, true, MINW == 1>(d, p, b, n_scan_blocks, n_spec, (uint32_t *)dyn_lds);
 }
 
-// (an intermediate form, kept for measurements: BITHTM_LEAN=0 BITHTM_FUSE=1)
-// Step t's learning role, its scan and the overlap + boost + select digit 0 of step t + 2 in one launch.  The learning
-// waves do the scan's work for the rows they rewrite (role_learn SELF; the scan passes over rows flagged SEG_BUSY), both
-// publish with atomics into the buffers of the step's parity.  Blocks in the order they should start: the learning
-// role's items are the longest chains, the scan wants to be resident all at once, the overlap streams.
-template <int EPL, int MINW>
-__global__ __launch_bounds__(256, MINW) void k_learn_scan(Dev d, int p, int n_learn_blocks, int n_scan_blocks, int n_overlap_blocks,
-                                                           const uint32_t *__restrict__ bank, int n_inputs, int G, int n_spec) {
-    TraceScope ts(d, 2 + 4 * p);
-    int b = blockIdx.x;
-    if (b < n_learn_blocks) {
-        role_learn<EPL, 256, true>(d, p, b, n_learn_blocks, (LearnShared<EPL, 256> *)dyn_lds);
-        return;
-    }
-    b -= n_learn_blocks;
-    if (b < n_scan_blocks) {
-        role_scan<256, true, MINW == 1>(d, p, b, n_scan_blocks, n_spec, (uint32_t *)dyn_lds);
-        return;
-    }
-    b -= n_scan_blocks;
-    if (b < n_overlap_blocks) role_overlap<256>(d, bank, n_inputs, G, p, p, 2, b, n_overlap_blocks, (uint32_t *)dyn_lds);
-}
-
 #endif

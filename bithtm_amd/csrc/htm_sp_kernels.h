@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256) void k_sp_count(Dev d, int sp) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         d.ctr->sel_prefix[sp] = T;              // skipped low digits are zero in every key
         d.ctr->sel_krem[sp] = r;
-        d.ctr->sel_win[sp ^ 1] = win_base_for(T);
+        d.ctr->sel_win[sp ^ 1] = min(win_base_for(T) + (uint32_t)d.win_offset, 4096u - WIN_COARSE);
     }
     if (d.sel_passes > 1)                       // pass-0 histogram is consumed: clear it for its next use
         for (int i = blockIdx.x * 256 + threadIdx.x; i < HIST_REP * SEL_BINS; i += gridDim.x * 256) d.hist0[(size_t)sp * HIST_REP * SEL_BINS + i] = 0;
@@ -669,7 +669,7 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
             second_round = true;
             if (b == 0 && tid == 0) d.ctr->sel_fallbacks += 1;
         }
-        if (b == 0 && tid == 0) { d.ctr->sel_prefix[p] = T; d.ctr->sel_krem[p] = r; d.ctr->sel_win[p ^ 1] = win_base_for(T); }
+        if (b == 0 && tid == 0) { d.ctr->sel_prefix[p] = T; d.ctr->sel_krem[p] = r; d.ctr->sel_win[p ^ 1] = min(win_base_for(T) + (uint32_t)d.win_offset, 4096u - WIN_COARSE); }
         // the pass-0 histogram is consumed: clear it for its next use (here, not earlier: a barrier
         // waits for outstanding stores, and the record exchange above is the critical chain)
         if (d.sel_passes > 1)

@@ -223,6 +223,45 @@ def test_batched_run_equals_step_by_step():
             assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("env", [{}, {"BITHTM_LEAN": "0"}, {"BITHTM_SEL_WINDOW_OFFSET": "4000"}, {"BITHTM_CAND_D": "0"}, {"BITHTM_CAND_D": "1"},
+                                 {"BITHTM_CAND_PAIRWISE": "0", "BITHTM_CAND_OTHERS": "0"}, {"BITHTM_CAND_PAIRWISE": "0", "BITHTM_CAND_OTHERS": "4"},
+                                 {"BITHTM_LEAN_SCAN": "1", "BITHTM_LEAN_LEARN": "1"}, {"BITHTM_LEAN_SCAN": "3", "BITHTM_LEAN_LEARN": "2", "BITHTM_LEAN_OVERLAP": "3"}],
+                         ids=lambda e: ",".join(f"{k[7:]}={v}" for k, v in e.items()) or "default")
+def test_pipelined_schedules_and_select_paths_equal_step_by_step(env, monkeypatch):
+    """htm.run in its pipelined schedules -- three launches per step (the learning role scanning its own rows beside the
+    scan, the one-pass windowed select) and the four-launch one -- against process(), with the select forced down every
+    path: a window that always misses (exact fallback each step), records that overflow (slots 0 / 1), the tie merge
+    (pairwise 0; others 0 = radix refinement only), and grids of a few blocks (every wave loops)."""
+    import bithtm_amd as B
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    rng = np.random.RandomState(21)
+    bank = rng.rand(30, 300) < 0.06
+    outs = []
+    for mode in ("graph", "eager", "continuing", "process"):
+        np.random.seed(22)
+        htm = B.HierarchicalTemporalMemory(300, 4096, 8)
+        if mode == "process":
+            for t in range(120):
+                htm.process(bank[t % 30])
+        elif mode == "continuing":
+            for n in (1, 2, 40, 17, 60):
+                htm.run(bank, n, continuing=n != 60)
+        else:
+            htm.run(bank, 120, use_graph=mode == "graph")
+        info = htm.engine.check_capacity()
+        if mode == "graph" and "BITHTM_SEL_WINDOW_OFFSET" in env:
+            assert info.select_fallbacks >= 100          # (the knob did what it is for)
+        st = htm.engine.read_store()
+        d = htm.engine.read_distal()
+        outs.append((htm.engine.read_sp_fields()["active_column"], st["seg_cell"], st["seg_nsyn"], st["presyn"], st["perm"],
+                     htm.temporal_memory.last_state.cell_prediction, htm.engine.read_duty_cycle(), d["matching_segment"],
+                     d["max_jittered_potential"], d["segment_potential"]))
+    for o in outs[:-1]:
+        for a, b in zip(outs[-1], o):
+            assert np.array_equal(a, b)
+
+
 def test_batched_run_with_learning_switched_off_and_on():
     """The pipelined schedule with learning=False (no SP rows, no classification, no learning launches
     doing work) between learning runs == the same schedule of flags through process()."""

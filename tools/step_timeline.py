@@ -21,11 +21,23 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 
 LAUNCHES = ("tm_activate+sp_emit", "tm_mid+sp_learn", "tm_learn+sp_overlap", "tm_scan+sp_select")
+LEAN = ("tm_activate+sp_learn", "tm_mid+sp_overlap", "tm_learn+tm_scan+sp_emit", "-")
+LEAN_ON = os.environ.get("BITHTM_LEAN", "1") != "0"
 
 
 def roles(launch, k, C):
     """(first block, last block + 1, name) of the roles of each launch, as bench's handle lays them out."""
     c256, cls = (C + 255) // 256, 96
+    if LEAN_ON:                                      # the three-launch schedule (htm_pipeline.h); block counts as htm_create sets them
+        n_act, n_learn = (k * 32 + 255) // 256, int(os.environ.get("BITHTM_LEAN_LEARN", 512))
+        n_ov = int(os.environ.get("BITHTM_LEAN_OVERLAP", 512))
+        if launch == 0:
+            return ((0, n_act, "tm_activate"), (n_act, n_act + k, "sp rows"), (n_act + k, n_act + k + c256, "sp duty"), (n_act + k + c256, 4096, "clear"))
+        if launch == 1:
+            return ((0, 1, "tm_mid block 0"), (1, 1 + 4 * cls, "tm_mid classify"), (1 + 4 * cls, 1 + 4 * cls + n_ov, "sp_overlap"), (1 + 4 * cls + n_ov, 4096, "zero match bits"))
+        if launch == 2:
+            return ((0, c256, "sp_emit"), (c256, c256 + n_learn, "tm_learn"), (c256 + n_learn, 4096, "tm_scan"))
+        return ()
     if launch == 0:
         return ((0, c256, "sp_emit"), (c256, 4096, "tm_activate"))
     if launch == 1:
@@ -58,7 +70,7 @@ def main():
     t0, prev = events[0][0], None
     for first, last, slot, blocks in events:
         gap = "" if prev is None or first - prev > 3000 else f"  gap {(first - prev) / 100:5.2f}"
-        print(f"parity {slot // 4} {LAUNCHES[slot % 4]:20s} {(first - t0) / 100:7.2f} .. {(last - t0) / 100:7.2f} us  span {(last - first) / 100:6.2f}{gap}")
+        print(f"parity {slot // 4} {(LEAN if LEAN_ON else LAUNCHES)[slot % 4]:24s} {(first - t0) / 100:7.2f} .. {(last - t0) / 100:7.2f} us  span {(last - first) / 100:6.2f}{gap}")
         prev = last
         for lo, hi, name in roles(slot % 4, k, C):
             sel = blocks[(blocks >= lo) & (blocks < hi)]
