@@ -251,6 +251,20 @@ static void enqueue_tm(htm_handle *h, int n_active, int learning, int want_winne
     const int n_sp_rows = (sp_rows && learning && h->cfg.enable_sp) ? d.k : 0;
     const int n_duty = h->world > 1 ? (d.c1 - d.c0 + 255) / 256 : 0;      // (unsharded: the emit role updates the duty cycle)
     LAUNCH(h, "tm_mid", k_mid_rows, 1 + n_cls + n_sp_rows + n_duty + h->zero_blocks, 256, d, p, n_active, want_winner, learning, n_cls, bank, n_inputs, n_sp_rows, 0, n_duty);
+    // the learning role and the scan: one launch (k_learn_scan_emit without emit blocks: the learning waves scan their own
+    // rows), unless the pool is large (the streaming scan kernels) or somebody is timing the roles one by one
+    static const int fuse_env = getenv("BITHTM_FUSE_TM") ? atoi(getenv("BITHTM_FUSE_TM")) : 1;
+    if (fuse_env && !h->profile && !scan_pool_is_large(h) && scan_lds(d, 1) <= 64 * 1024) {
+        const int epl = learn_epl(d), n_learn = h->lean_learn_blocks, n_scan = h->lean_scan_blocks, spec = scan_spec_blocks(h);
+        const size_t lds = std::max(learn_lds(epl, 256), scan_lds(d, 1));
+        switch (epl) {
+            case 1: LAUNCH_ON(h, h->stream, lds, "tm_learn+tm_scan", (k_learn_scan_emit<1, 6>), n_learn + n_scan, 256, d, p, 0, n_learn, n_scan, spec); break;
+            case 2: LAUNCH_ON(h, h->stream, lds, "tm_learn+tm_scan", (k_learn_scan_emit<2, 6>), n_learn + n_scan, 256, d, p, 0, n_learn, n_scan, spec); break;
+            case 4: LAUNCH_ON(h, h->stream, lds, "tm_learn+tm_scan", (k_learn_scan_emit<4, 6>), n_learn + n_scan, 256, d, p, 0, n_learn, n_scan, spec); break;
+            default: LAUNCH_ON(h, h->stream, lds, "tm_learn+tm_scan", (k_learn_scan_emit<8, 6>), n_learn + n_scan, 256, d, p, 0, n_learn, n_scan, spec); break;
+        }
+        return;
+    }
     launch_learn(h, p);
     launch_scan(h, p, scan_lds(d, 1) <= 64 * 1024);
 }

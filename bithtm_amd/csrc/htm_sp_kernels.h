@@ -385,6 +385,13 @@ struct EmitShared {
 };
 
 // wmode (with fused): the launched part of the select was the windowed histogram (win_bin) of role_overlap
+// diagnostic build (-DBITHTM_EMIT_STAMPS, handle created under BITHTM_TRACE=1): device clock at the phases of every emit
+// block of the three-launch schedule, d.trace[block * 8 + phase], + the merged bucket entries (tools/emit_phases.py)
+#ifdef BITHTM_EMIT_STAMPS
+#define EMIT_STAMP(i) do { if (d.trace && wmode && tid == 0 && b < 1024) d.trace[(size_t)b * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define EMIT_STAMP(i) do { } while (0)
+#endif
 __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, int fused, int mode, int b, int nblk, EmitShared *sh, int wmode = 0) {
     uint32_t *h = sh->h;
     uint32_t *s_wave = sh->wave, *s_out = sh->out, *s_predw = sh->predw, *s_bc = sh->bc;
@@ -399,6 +406,7 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
     uint32_t *s_mh = sh->mh;
     static_assert(2 * CAND_MAX <= SEL_BINS, "bucket keys must fit the histogram");
     const int tid = threadIdx.x, lane = lane_id();
+    EMIT_STAMP(0);
     if (tid == 0) { s_gt = 0; s_eq = 0; s_n = 0; s_nraw = 0; s_ne = 0; s_flags = 0; }
     const int cbase = d.sel_lo + b * 256, c = cbase + tid;      // the select covers columns [sel_lo, sel_hi)
     const bool local = mode & EMIT_LOCAL;
@@ -449,6 +457,7 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
         } else {
             sel_resolve<256>(d, p, d.sel_passes - 1, h, s_wave, &P, &krem, &s_prefix, &s_krem);    // (ends behind a barrier)
         }
+        EMIT_STAMP(1);                               // (the launched part of the select is resolved)
         const u64 hiP = lowbits < 64 ? P >> lowbits : 0ull, hi = lowbits < 64 ? my_key >> lowbits : 0ull;
         const bool c_gt = c < d.sel_hi && hi > hiP, c_cand = c < d.sel_hi && hi == hiP;
         // ---- this block's record
@@ -513,6 +522,7 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
             }
         }
         if (tid == 0) s_gt = 0;
+        EMIT_STAMP(2);                               // (own record published)
         // ---- everybody's records: the head granule is polled alone (one lane-load per spin keeps the
         // polling traffic low); further pairs, if any, are fetched in one batch; each granule validates itself
         uint32_t gthi_before = 0;
@@ -552,6 +562,10 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
         }
         __syncthreads();
         const int ne = s_ne;
+        EMIT_STAMP(3);                               // (everybody's records read)
+#ifdef BITHTM_EMIT_STAMPS
+        if (d.trace && wmode && tid == 0 && b < 1024) d.trace[(size_t)b * 8 + 7] = (unsigned long long)ne | ((unsigned long long)s_nraw << 32);
+#endif
         if (!(s_flags & 1u) && ne <= CAND_MAX) {
             bool folded = false;
             if (ne <= d.cand_pairwise) {                // the krem-th largest of the merged bucket: all pairs
@@ -679,6 +693,7 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
         r = d.ctr->sel_krem[p];
     }
     __syncthreads();
+    EMIT_STAMP(4);                                   // (the k-th key is known)
     uint32_t flag = 0;
     if (c < d.sel_hi) flag = (my_key > T) ? 1u : ((my_key == T) ? 0x10000u : 0u);
     uint32_t total;
@@ -741,6 +756,7 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
         }
     }
     if (b == 0 && tid == 0 && !d.act[0]) d.ctr->step[p ^ 1] = d.ctr->step[p] + 1;   // SP-only handle
+    EMIT_STAMP(5);                                   // (winner list and bitmap written)
     if (!tm_here && !local) return;
     __syncthreads();
     const int n_sel = s_n;
