@@ -88,6 +88,7 @@ struct Counters {
     uint32_t sel_krem[2];
     uint32_t sel_win[2];      // windowed select (win_bin): lowest top-digit value of the window for the SP step of parity p,
                               // set from the k-th key of the step before
+    uint32_t sel_win_global;  // column-sharded handles: the same for the global select over the ranks' candidates (k_shard_select)
     u64 sel_pass_prefix[2][SEL_MAX_PASSES + 1];    // radix-select state entering pass p
     uint32_t sel_pass_krem[2][SEL_MAX_PASSES + 1];
 };
@@ -240,6 +241,19 @@ __device__ __forceinline__ void hist_add(uint32_t *h, uint32_t digit, bool activ
         if (lane_id() == leader) atomicAdd(&h[dl], (uint32_t)__popcll(same));
         todo &= ~same;
     }
+}
+
+// The same for keys that are mostly different but may hold one value many times (a many-way tie): the copies of the
+// first active lane's digit are counted with one atomic (same-address LDS atomics run one after the other), the other
+// lanes add theirs as they are.  All lanes of the wave must call.
+__device__ __forceinline__ void hist_add_tie(uint32_t *h, uint32_t digit, bool active) {
+    const u64 act = __ballot(active);
+    if (!act) return;
+    const int leader = __ffsll((long long)act) - 1;
+    const uint32_t dl = __shfl(digit, leader);
+    const u64 same = __ballot(active && digit == dl);
+    if (lane_id() == leader) atomicAdd(&h[dl], (uint32_t)__popcll(same));
+    if (active && digit != dl) atomicAdd(&h[digit], 1u);
 }
 
 // bits of v moved to the even bit positions of a 64-bit word

@@ -236,7 +236,7 @@ static void enqueue_sp_back(htm_handle *h, const uint32_t *bank, int n_inputs, i
     Dev &d = h->d;
     const int fused = h->emit_fused;               // all blocks co-resident: count inside emit
     if (!fused) LAUNCH(h, "sp_count", k_sp_count, h->c256_blocks, 256, d, p);
-    LAUNCH(h, "sp_emit", k_sp_emit, h->c256_blocks, 256, d, p, want_winner, fused, mode);
+    LAUNCH(h, "sp_emit", k_sp_emit, h->c256_blocks, 256, d, p, want_winner, fused, mode, 0);
     // (a forked graph branch for this independent update was measured at +17..29 us per step on
     // this runtime, against 2.3 us for one more kernel in the chain: tools/launch_overhead.hip)
     if (sp_learn) LAUNCH(h, "sp_learn", k_sp_learn, d.k, 256, d, bank, n_inputs, p);
@@ -436,6 +436,7 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
     const int world = cfg->shard_world > 1 ? cfg->shard_world : 1;
     if (world > 1) {
         if (!cfg->enable_sp || !cfg->enable_tm) return fail_create(nullptr, "htm_create: a sharded handle needs SP and TM", HTM_ERR_ARGUMENT);
+        if (world > 64) return fail_create(nullptr, "htm_create: at most 64 shards", HTM_ERR_ARGUMENT);
         if (cfg->shard_rank < 0 || cfg->shard_rank >= world) return fail_create(nullptr, "htm_create: shard_rank out of range", HTM_ERR_ARGUMENT);
         if (cfg->column_dim % (world * 64)) return fail_create(nullptr, "htm_create: column_dim must be a multiple of 64 * shard_world", HTM_ERR_ARGUMENT);
     }
@@ -959,10 +960,14 @@ static int shard_enqueue_begin(htm_handle *h, const uint32_t *bank, int n_inputs
     // own columns: overlap + boost + top digit, and the zeroing of the step's dense words; digit 1; local select finish
     // + speculative cell words of the candidates, packed into the record
     const int n_word_blocks = ((d.c1 - d.c0) * 32 + RB - 1) / RB;        // one own column per half-wave
+    // (the local select: one windowed histogram pass beside the overlap, finished inside the candidates kernel;
+    // BITHTM_SHARD_WINDOW=0: two launched digits)
+    static const int wmode = getenv("BITHTM_SHARD_WINDOW") ? (atoi(getenv("BITHTM_SHARD_WINDOW")) != 0) : 1;
     LAUNCH(h, "shard_overlap", k_shard_overlap, h->sp_blocks + n_word_blocks + std::min((d.C + RB - 1) / RB, 64), RB, d, bank, n_inputs, h->G, p,
-           h->sp_blocks, n_word_blocks);
-    for (int pass = 1; pass < d.sel_passes; ++pass) LAUNCH(h, "sp_select", k_sel_pass, h->sel_blocks, RB, d, pass, p);
-    LAUNCH(h, "shard_candidates", k_sp_emit, h->c256_blocks, 256, d, p, 1, 1, EMIT_LOCAL);
+           h->sp_blocks, n_word_blocks, wmode);
+    if (!wmode)
+        for (int pass = 1; pass < d.sel_passes; ++pass) LAUNCH(h, "sp_select", k_sel_pass, h->sel_blocks, RB, d, pass, p);
+    LAUNCH(h, "shard_candidates", k_sp_emit, h->c256_blocks, 256, d, p, 1, 1, EMIT_LOCAL, wmode);
     return 0;
 }
 

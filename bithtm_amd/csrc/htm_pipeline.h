@@ -26,7 +26,7 @@
 struct TraceScope {                                 // BITHTM_TRACE=1: first / last device clock of every block
     unsigned long long *t;
     __device__ TraceScope(const Dev &d, int slot) {
-#if defined(BITHTM_LEARN_STAMPS) || defined(BITHTM_SCAN_STAMPS) || defined(BITHTM_EMIT_STAMPS)
+#if defined(BITHTM_LEARN_STAMPS) || defined(BITHTM_SCAN_STAMPS) || defined(BITHTM_EMIT_STAMPS) || defined(BITHTM_SHARD_STAMPS)
         t = nullptr;                                // the diagnostic builds of the learning role and of the scan use the buffer
         return;
 #endif

@@ -786,9 +786,9 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
     }
 }
 
-__global__ __launch_bounds__(256) void k_sp_emit(Dev d, int p, int want_winner, int fused, int mode) {
+__global__ __launch_bounds__(256) void k_sp_emit(Dev d, int p, int want_winner, int fused, int mode, int wmode) {
     __shared__ EmitShared sh;
-    role_emit(d, p, want_winner, fused, mode, blockIdx.x, gridDim.x, &sh);
+    role_emit(d, p, want_winner, fused, mode, blockIdx.x, gridDim.x, &sh, wmode);
 }
 
 // DenseProjection.update (projections.py:23-24) on the k winner rows, fused with the rebuild
@@ -868,11 +868,11 @@ __global__ void k_sp_commit(Dev d, int p) { d.ctr->step[p ^ 1] = d.ctr->step[p] 
 // ---- column sharding: the kernels on either side of the exchange -----------------------------
 // before the exchange, first launch: overlap + boost + top key digit of the OWN columns, the speculative cell words of
 // the own columns, and the zeroing of the step's dense per-column words (the winners' words are written after the exchange)
-__global__ __launch_bounds__(RB) void k_shard_overlap(Dev d, const uint32_t *__restrict__ bank, int n_inputs, int G, int p, int n_overlap_blocks, int n_word_blocks) {
+__global__ __launch_bounds__(RB) void k_shard_overlap(Dev d, const uint32_t *__restrict__ bank, int n_inputs, int G, int p, int n_overlap_blocks, int n_word_blocks, int wmode) {
     __shared__ uint32_t h[SEL_BINS];
     int b = blockIdx.x;
     if (b < n_overlap_blocks) {
-        role_overlap<RB>(d, bank, n_inputs, G, p, p, 0, b, n_overlap_blocks, h);
+        role_overlap<RB>(d, bank, n_inputs, G, p, p, 0, b, n_overlap_blocks, h, wmode);
         return;
     }
     b -= n_overlap_blocks;
@@ -906,6 +906,11 @@ __global__ __launch_bounds__(RB) void k_shard_overlap(Dev d, const uint32_t *__r
 // ascending winner list -- the records are in rank order and each is in ascending column order, so the candidates
 // ARE in ascending column order and the tie rule (lower column first) is their order -- together with the cell
 // words the owner computed.  Block 0 also applies every rank's death reports to the replicated dead bits.
+#ifdef BITHTM_SHARD_STAMPS                       // diagnostic build: device clock at the phases of block 0, d.trace[phase]
+#define SHARD_STAMP(i) do { if (d.trace && blockIdx.x == 0 && threadIdx.x == 0) d.trace[i] = wall_clock64(); } while (0)
+#else
+#define SHARD_STAMP(i) do { } while (0)
+#endif
 __global__ __launch_bounds__(1024) void k_shard_select(Dev d, const unsigned char *__restrict__ recv, int p) {
     __shared__ uint32_t h[SEL_BINS];
     __shared__ uint32_t s_wave[16], s_out[2], s_cnt[2];
@@ -913,17 +918,24 @@ __global__ __launch_bounds__(1024) void k_shard_select(Dev d, const unsigned cha
     const int tid = threadIdx.x, lane = lane_id();
     const int KL = d.n_cand, n_tot = d.world * KL;
     const size_t rb = shard_record_bytes(KL);
+    const uint32_t inv_kl = (uint32_t)(((1ull << 32) + (uint32_t)KL - 1) / (uint32_t)KL);      // i / KL for i < 2^16-ish: one multiplication
     auto key_at = [&](int i) -> u64 {
-        const int r = i / KL, j = i - r * KL;
+        int r = (int)(((u64)(uint32_t)i * inv_kl) >> 32);
+        if (r * KL > i) --r;
+        const int j = i - r * KL;
         return select_key(((const double *)(recv + (size_t)r * rb))[j]);
     };
     // up to KPT keys per thread stay in registers over the passes (configs[3] 8-way: 10 488 candidates, 11 per thread);
     // beyond that they are read again, from L2
+    SHARD_STAMP(0);
     constexpr int KPT = 12;
     const bool in_regs = n_tot <= KPT * 1024;
     u64 kreg[KPT];
 #pragma unroll
-    for (int j = 0; j < KPT; ++j) kreg[j] = (in_regs && tid + j * 1024 < n_tot) ? key_at(tid + j * 1024) : 0ull;
+    for (int j = 0; j < KPT; ++j) {                // (clamped and unconditional: a branch around a load makes the compiler wait for it)
+        const u64 kk = key_at(min(tid + j * 1024, n_tot - 1));
+        kreg[j] = (in_regs && tid + j * 1024 < n_tot) ? kk : 0ull;
+    }
     // the candidates are each rank's best: their keys share their leading bits (exponent, top of the mantissa).  The
     // radix select starts below that common prefix -- its passes would each put every key into one bin
     if (tid == 0) { s_or = 0; s_and = ~0ull; }
@@ -944,11 +956,62 @@ __global__ __launch_bounds__(1024) void k_shard_select(Dev d, const unsigned cha
         if (lane == 0) { atomicOr((unsigned long long *)&s_or, vo); atomicAnd((unsigned long long *)&s_and, va); }
     }
     __syncthreads();
+    SHARD_STAMP(1);                                // (keys loaded, common prefix known)
     const u64 differ = s_or ^ s_and;
     const int top0 = differ ? 64 - __clzll((long long)differ) : 0;       // bits [top0, 64) are the same in every key
     u64 P = top0 < 64 ? (s_and >> top0) << top0 : 0ull;
     uint32_t krem = (uint32_t)d.k;
-    for (int top = top0; top > d.low_zero;) {
+    // First the windowed pass of the three-launch schedule (win_bin): one histogram around the previous step's k-th key
+    // -- the 12-bit digits below put thousands of candidates into a handful of bins, and same-address LDS atomics run
+    // one after the other -- then the few keys of the chosen bin are ranked against each other.  A k-th key outside
+    // the window, or a crowded bin, leaves it to the digit passes (same result).
+    bool done = false;
+    u64 T = 0;
+    int top_start = top0;
+    if (in_regs) {
+        const uint32_t base = d.ctr->sel_win_global;
+        for (int i = tid; i < SEL_BINS; i += 1024) h[i] = 0;
+        if (tid == 0) { s_cnt[0] = 0; s_out[0] = 0; }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) hist_add_tie(h, win_bin(kreg[j], base), tid + j * 1024 < n_tot);
+        __syncthreads();
+        uint32_t bucket, above;
+        sel_pick<1024>(h, WIN_BINS, krem, s_wave, s_out, &bucket, &above);
+        __syncthreads();
+        const bool inside = bucket >= 1u && bucket <= (WIN_COARSE << WIN_FINE);
+        const uint32_t in_bin = inside ? h[bucket] : 0u;
+        __syncthreads();
+        if (inside && in_bin > 256u) {                 // a crowded bin (ties): the digit passes below, from the window's resolution on
+            const uint32_t fine = bucket - 1u;
+            P = ((u64)(base + (fine >> WIN_FINE)) << 52) | ((u64)(fine & ((1u << WIN_FINE) - 1u)) << WIN_LOWBITS);
+            krem -= above;
+            top_start = WIN_LOWBITS;
+        } else if (inside) {
+            const uint32_t kb = krem - above;          // the kb-th largest of the bin's keys is the k-th overall
+            u64 *list = (u64 *)h;                                      // (the histogram is done with)
+#pragma unroll
+            for (int j = 0; j < KPT; ++j)
+                if (tid + j * 1024 < n_tot && win_bin(kreg[j], base) == bucket) list[atomicAdd(&s_cnt[0], 1u)] = kreg[j];
+            __syncthreads();
+            for (uint32_t e = tid; e < in_bin; e += 1024) {
+                const u64 ke = list[e];
+                uint32_t ng = 0, nq = 0;
+                for (uint32_t f = 0; f < in_bin; ++f) {
+                    const u64 kf = list[f];
+                    ng += kf > ke;
+                    nq += kf == ke;
+                }
+                if (ng < kb && kb <= ng + nq) { s_or = ke; s_out[1] = kb - ng; }      // (equal keys write the same pair)
+            }
+            __syncthreads();
+            T = s_or;
+            krem = s_out[1];
+            done = true;
+            __syncthreads();
+        }
+    }
+    for (int top = top_start; !done && top > d.low_zero;) {
         const int bits = min(SEL_DIGIT, top - d.low_zero), shift = top - bits, nb = 1 << bits;
         for (int i = tid; i < nb; i += 1024) h[i] = 0;
         __syncthreads();
@@ -956,7 +1019,7 @@ __global__ __launch_bounds__(1024) void k_shard_select(Dev d, const unsigned cha
 #pragma unroll
             for (int j = 0; j < KPT; ++j) {
                 const u64 kk = kreg[j];
-                if (tid + j * 1024 < n_tot && (top >= 64 || ((kk ^ P) >> top) == 0)) atomicAdd(&h[(uint32_t)(kk >> shift) & (nb - 1)], 1u);
+                hist_add_tie(h, (uint32_t)(kk >> shift) & (nb - 1), tid + j * 1024 < n_tot && (top >= 64 || ((kk ^ P) >> top) == 0));
             }
         } else {
             for (int i = tid; i < n_tot; i += 1024) {
@@ -972,8 +1035,13 @@ __global__ __launch_bounds__(1024) void k_shard_select(Dev d, const unsigned cha
         top = shift;
         __syncthreads();
     }
-    const u64 T = P;                               // the k-th largest key; krem of the keys equal to it win
+    SHARD_STAMP(2);                                // (k-th key known)
+    if (!done) T = P;                              // the k-th largest key; krem of the keys equal to it win
     const int b = blockIdx.x, lo = b * KL;
+    if (b == 0 && tid == 0) {
+        d.ctr->sel_win_global = min(win_base_for(T) + (uint32_t)d.win_offset, 4096u - WIN_COARSE);
+        if (!done && top_start == top0) d.ctr->sel_fallbacks += 1;       // (telemetry: the window missed)
+    }
     if (tid < 2) s_cnt[tid] = 0;
     __syncthreads();
     {   // winners among the candidates of the ranks before this one
@@ -997,19 +1065,21 @@ __global__ __launch_bounds__(1024) void k_shard_select(Dev d, const unsigned cha
         if (lane == 0) { atomicAdd(&s_cnt[0], g); atomicAdd(&s_cnt[1], e); }
     }
     __syncthreads();
+    SHARD_STAMP(3);
     uint32_t gt_run = s_cnt[0], eq_run = s_cnt[1];
     const unsigned char *rec = recv + (size_t)b * rb;
     const uint32_t *r_col = (const uint32_t *)(rec + (size_t)KL * 8), *r_win = r_col + KL, *r_unacc = r_win + KL;
     for (int j0 = 0; j0 < KL; j0 += 1024) {
         const int j = j0 + tid;
         const u64 kk = j < KL ? key_at(lo + j) : 0;
+        // (the candidate's words with its key, not after the scan: one round trip per pass instead of two)
+        const uint32_t cw = j < KL ? r_col[j] : 0u, wn = j < KL ? r_win[j] : 0u, un = j < KL ? r_unacc[j] : 0u;
         const uint32_t flag = j < KL ? ((kk > T) ? 1u : ((kk == T) ? 0x10000u : 0u)) : 0u;
         uint32_t total;
         const uint32_t ex = block_excl_scan<1024>(flag, s_wave, total);
         const uint32_t g = gt_run + (ex & 0xFFFFu), e = eq_run + (ex >> 16);
         if ((flag & 1u) || ((flag >> 16) && e < krem)) {
             const int pos = (int)(g + min(e, krem));
-            const uint32_t cw = r_col[j], wn = r_win[j];
             const int col = (int)(cw & 0x7FFFFFFFu);
             const bool burst = cw >> 31;
             const uint32_t act = burst ? cell_mask(d.K) : wn;                   // networks.py:115
@@ -1018,25 +1088,37 @@ __global__ __launch_bounds__(1024) void k_shard_select(Dev d, const unsigned cha
             d.act[p][col] = act;
             d.win[p][col] = wn;
             d.bursting[pos] = burst ? 1 : 0;
-            d.unacc_word[pos] = r_unacc[j];
+            d.unacc_word[pos] = un;
             d.winw_idx[pos] = wn;
             d.actcnt[pos] = (uint8_t)__popc(act);
         }
         gt_run += total & 0xFFFFu;
         eq_run += total >> 16;
     }
+    SHARD_STAMP(4);                                // (own winners emitted)
     if (b == 0) {
-        for (int r = 0; r < d.world; ++r) {
+        // every rank's death reports, all at once (rank after rank, each with its dependent loads and atomics, this was
+        // 8 x 2 round trips at the end of the step's longest kernel): thread -> (rank, entry) through the counts
+        __shared__ int s_dead[64 + 1];
+        if (tid <= 64) s_dead[tid] = 0;
+        __syncthreads();
+        const int nr = min(d.world, 64);
+        if (tid < nr) s_dead[tid + 1] = min((int)((const uint32_t *)(recv + (size_t)tid * rb + (size_t)KL * 20))[0], DEAD_CAP);
+        __syncthreads();
+        if (tid == 0) for (int r = 0; r < nr; ++r) s_dead[r + 1] += s_dead[r];
+        __syncthreads();
+        const int total_dead = s_dead[nr];
+        for (int e = tid; e < total_dead; e += 1024) {
+            int r = 0;
+            while (s_dead[r + 1] <= e) ++r;
             const uint32_t *r_dead = (const uint32_t *)(recv + (size_t)r * rb + (size_t)KL * 20);
-            const int n = min((int)r_dead[0], DEAD_CAP);
-            for (int j = tid; j < n; j += 1024) {
-                const int gid = (int)r_dead[1 + j];
-                const uint32_t old = atomicOr(&d.dead_bits[gid >> 5], 1u << (gid & 31));
-                if (!((old >> (gid & 31)) & 1u)) atomicAdd(&d.recyc_cnt[gid >> 10], 1);
-            }
+            const int gid = (int)r_dead[1 + e - s_dead[r]];
+            const uint32_t old = atomicOr(&d.dead_bits[gid >> 5], 1u << (gid & 31));
+            if (!((old >> (gid & 31)) & 1u)) atomicAdd(&d.recyc_cnt[gid >> 10], 1);
         }
         if (tid == 0) d.dead_list[0] = 0;          // reported; the coming learning role collects this step's
     }
+    SHARD_STAMP(5);
 }
 
 #endif
