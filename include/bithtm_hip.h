@@ -183,16 +183,16 @@ int htm_sp_phase(htm_handle *h, int32_t phase, const void *data, int64_t count);
  * example.py:48-53 runs, with the input bank resident in HBM.  use_graph bit 0: replay captured
  * hipGraphs (one per step, or per 16 steady-state steps) instead of issuing the launches one by one;
  * bit 1: do NOT pipeline.  By default the Spatial Pooler works ahead of the Temporal Memory inside the
- * call -- its next steps share the four launches of the current TM step -- which includes its
- * permanence and duty-cycle updates; it never looks past n_steps, so the state a call leaves behind
- * is exactly that of n_steps htm_step calls. */
+ * call -- the next step's overlaps and winner list are computed in the three launches of the current TM step
+ * (its permanence and duty-cycle updates are not ahead; in the four-launch schedule a handle falls back to when the
+ * scan's column bitmap does not fit the LDS they are) --; it never looks past n_steps, so the state a call leaves
+ * behind is exactly that of n_steps htm_step calls. */
 int htm_run(htm_handle *h, const uint32_t *device_inputs, int32_t n_inputs, int32_t n_steps,
             int32_t learning, int32_t use_graph);
 /* use_graph bit 2 (HTM_RUN_CONTINUE): a caller that streams its input in chunks promises that the next call is another
  * htm_run on the same bank, n_inputs and learning flag.  The Spatial Pooler then keeps working ahead across the end
- * of this call (the next step's winner list, permanence rows and duty cycle, and the overlaps of the one after it,
- * are computed beside this call's last Temporal Memory steps) and the next call starts in the steady state instead
- * of with a cold start of six launches.  Until a later htm_run ends without the bit, every other call that needs the
+ * of this call (the next step's overlaps and winner list are computed beside this call's last Temporal Memory
+ * step) and the next call starts in the steady state instead of with a cold start of three more launches.  Until a later htm_run ends without the bit, every other call that needs the
  * Spatial Pooler's state (htm_step, htm_sp_*, htm_tm_step, state import, the Spatial Pooler fields of htm_read)
  * returns HTM_ERR_STATE; the Temporal Memory's state is that of exactly the steps run so far. */
 #define HTM_RUN_GRAPH 1
@@ -284,10 +284,10 @@ int htm_profile_read(htm_handle *h, int32_t max_kernels, const char **names, dou
 
 /* Device-clock timeline of the pipelined launches (diagnostic; handle created with the environment
  * variable BITHTM_TRACE=1, otherwise HTM_ERR_STATE).  dst receives 8 x 4096 x 2 values: for slot =
- * launch (0..3) + 4 * step parity and block b, the 100 MHz device wall clock when the block
+ * launch (0..2; 0..3 in the four-launch schedule) + 4 * step parity and block b, the 100 MHz device wall clock when the block
  * started and when it ended, 0 where that block did not run.  Each launch overwrites its slot,
  * so after a run the buffer holds the last two steps -- of those with an index below BITHTM_TRACE_UNTIL,
- * if that is set (the last two steps of a run look ahead less than the steady state).  Returns the
+ * if that is set (the last step of a run looks ahead less than the steady state).  Returns the
  * number of values. */
 #define HTM_TRACE_VALUES (8 * 4096 * 2)
 int64_t htm_trace_read(htm_handle *h, uint64_t *dst, int64_t count);

@@ -11,6 +11,11 @@ cd $GRAFT_REPO_ROOT
 timeout -k 10 400 python bench.py > $OUT/bench.json 2> $OUT/bench.log; echo "bench exit=$?"
 timeout -k 10 300 python bench.py --steps 20 --warmup 5 --no-stress > $OUT/bench_driver_args.json 2> $OUT/bench_driver_args.log; echo "bench (driver args) exit=$?"
 timeout -k 10 200 python tools/step_timeline.py > $OUT/step_timeline.txt 2>&1
+# the four-launch schedule, for comparison
+BITHTM_LEAN=0 timeout -k 10 300 python bench.py --no-cpu-baseline --no-stress > $OUT/bench_four_launches.json 2> $OUT/bench_four_launches.log; echo "bench (four launches) exit=$?"
+BITHTM_LEAN=0 timeout -k 10 200 python tools/step_timeline.py > $OUT/step_timeline_four_launches.txt 2>&1
+# from scratch: the first 250 steps (every column bursting at first, ~1 300 new segments per step)
+timeout -k 10 200 python bench.py --no-cpu-baseline --no-stress --pretrain 0 --steps 250 --warmup 0 --reps 1 > $OUT/bench_cold_250.json 2> $OUT/bench_cold_250.log; echo "bench (cold) exit=$?"
 timeout -k 10 200 python tools/cold_phase.py > $OUT/cold_phase.txt 2>&1
 timeout -k 10 200 python tools/pcie_rate.py > $OUT/pcie_rate.txt 2>&1
 for w in 2 8; do timeout -k 10 200 python tools/shard_rehearsal.py --world $w; done > $OUT/shard_rehearsal.jsonl 2>&1
@@ -53,4 +58,9 @@ for f in glob.glob(os.path.join(out, "stats_pipelined", "*", "*kernel_trace.csv"
               open(os.path.join(out, "pipelined_kernel_us.json"), "w"), indent=1)
 PY
 find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*counter_collection.csv" -delete
+# diagnostic builds (device-clock stamps inside the scan and the emit role of the three-launch schedule), then the normal one again
+cd $GRAFT_REPO_ROOT
+BITHTM_EXTRA_FLAGS=-DBITHTM_SCAN_STAMPS python -m bithtm_amd.build --force > /dev/null 2>&1 && timeout -k 10 200 python tools/scan_phases.py > $OUT/scan_phases.txt 2>&1
+BITHTM_EXTRA_FLAGS=-DBITHTM_EMIT_STAMPS python -m bithtm_amd.build --force > /dev/null 2>&1 && timeout -k 10 200 python tools/emit_phases.py > $OUT/emit_phases.txt 2>&1
+python -m bithtm_amd.build --force > /dev/null 2>&1
 ls -R $OUT | head -60

@@ -3,7 +3,8 @@
 
     BITHTM_EXTRA_FLAGS=-DBITHTM_SCAN_STAMPS python -m bithtm_amd.build --force && python tools/scan_phases.py
 
-Every wave of the pipelined k_scan_sel launch stamps the device clock (100 MHz) at: 0 start, 1 bitmap staged,
+Every scan wave of the three-launch schedule's k_learn_scan_emit stamps, in its first iteration, the device clock
+(100 MHz) at: 0 start, 1 bitmap staged,
 2 synapse counts + first chunks here, 3 every synapse counted (cell words read), 4 matching segments published
 (atomics, info words), 5 match bits stored.  Printed for the last step of bench.py's learned state: median wave and the
 slowest waves, with what their segments were (matching segments, synapses on active columns)."""
@@ -30,12 +31,16 @@ def main():
     t = eng.trace_read().reshape(-1)[: 2048 * 4 * 8].reshape(2048 * 4, 8).astype(np.float64) / 100.0
     S = eng.info().segments
     nw = (S + 15) // 16
-    # trace row = block * 4 + wave; the wave's group of 16 segments (role_scan, small pools): waves of a block are 256 blocks apart
-    blk, wave = np.arange(2048 * 4) // 4, np.arange(2048 * 4) % 4
+    # trace row = block * 4 + wave; the wave's group of 16 segments (role_scan, small pools): waves of a block are 256 blocks
+    # apart.  The schedule's scan grid is smaller than the pool (every wave loops): the first iteration covers the first groups.
+    n_scan = int(os.environ.get("BITHTM_LEAN_SCAN", 768))
+    blk, wave = np.arange(n_scan * 4) // 4, np.arange(n_scan * 4) % 4
     grp = (blk // 256) * 1024 + wave * 256 + blk % 256
+    nw = min(nw, n_scan * 4)
     rows = np.argsort(grp)[:nw]                                  # trace row of group 0, 1, ...
     t = t[rows]
-    pot = np.pad(eng.read(L.F_SEG_POTENTIAL, np.int32, S), (0, nw * 16 - S)).reshape(nw, 16)
+    pot = eng.read(L.F_SEG_POTENTIAL, np.int32, S)
+    pot = np.pad(pot, (0, max(0, nw * 16 - S)))[: nw * 16].reshape(nw, 16)
     matching = (pot >= 10).sum(1)
     t0 = t[:, 0].min()
     ph = np.diff(t[:, :6], axis=1)
