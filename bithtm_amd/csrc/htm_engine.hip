@@ -307,7 +307,7 @@ static void enqueue_lean(htm_handle *h, int p, int learning, const uint32_t *ban
     const int grid = n_emit + n_learn + n_scan;
 #define LAUNCH_LSE(EPL_, MINW_) LAUNCH_ON(h, h->stream, lds, "tm_learn+tm_scan+sp_emit", (k_learn_scan_emit<EPL_, MINW_>), grid, 256, d, p, n_emit, n_learn, n_scan, spec)
     if (scan_pool_is_large(h)) {
-        switch (epl) { case 1: LAUNCH_LSE(1, 1); break; case 2: LAUNCH_LSE(2, 1); break; case 4: LAUNCH_LSE(4, 1); break; default: LAUNCH_LSE(8, 1); break; }
+        switch (epl) { case 1: LAUNCH_LSE(1, 4); break; case 2: LAUNCH_LSE(2, 4); break; case 4: LAUNCH_LSE(4, 4); break; default: LAUNCH_LSE(8, 4); break; }
     } else {
         switch (epl) { case 1: LAUNCH_LSE(1, 6); break; case 2: LAUNCH_LSE(2, 6); break; case 4: LAUNCH_LSE(4, 6); break; default: LAUNCH_LSE(8, 6); break; }
     }

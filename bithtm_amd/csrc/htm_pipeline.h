@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256, MINW) void k_learn_scan_emit(Dev d, int p, int
         return;
     }
     b -= n_learn_blocks;
-    role_scan<256, true, MINW == 1>(d, p, b, n_scan_blocks, n_spec, (uint32_t *)dyn_lds);
+    role_scan<256, true, MINW < 6>(d, p, b, n_scan_blocks, n_spec, (uint32_t *)dyn_lds);      // (MINW < 6: the large-pool form)
 }
 
 #endif
