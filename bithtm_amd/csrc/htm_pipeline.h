@@ -1,14 +1,15 @@
-// The four fused launches of the pipelined schedule and the device-clock trace.
+// The fused launches of htm_run's pipelined schedules -- three per timestep (below: k_act_rows, k_mid_overlap,
+// k_learn_scan_emit), or four where the scan's column bitmap does not fit the LDS -- and the device-clock trace.
 // Part of the single translation unit htm_engine.hip (included there, in this order:
 // htm_dev.h, htm_sp_kernels.h, htm_tm_kernels.h, htm_pipeline.h).
 #ifndef BITHTM_HTM_PIPELINE_H
 #define BITHTM_HTM_PIPELINE_H
 
-// ---- pipelined schedule: roles of different steps share every launch ---------------------------
+// ---- pipelined schedules: roles of different steps share every launch --------------------------
 // A forked stream / graph branch costs 17-29 us on this runtime and every dependent launch 1.2-3 us
 // plus its own chain of memory round trips; heterogeneous blocks in one launch cost nothing.  The
 // Spatial Pooler never reads Temporal Memory state, so inside a batched run it works ahead of the
-// Temporal Memory, role by role, in the same four launches (t = the TM's step):
+// Temporal Memory.  The four-launch schedule (BITHTM_LEAN=0; t = the TM's step):
 //
 //   k_open_emit(t)      activation of step t's winner columns     | rest of the select + winner list (t+1)
 //   k_mid_rows(t)       segment allocation, learn/punish list     | SP permanence rows + duty cycle (t+1)
@@ -19,7 +20,7 @@
 // gathers fill the memory pipeline and stretch every dependent access of a co-resident wave, and its
 // blocks take every CU slot, so it shares its launch only with the lightest SP role; the
 // latency-bound select finish runs beside the cheap activation; the two streaming roles (rows,
-// overlap) sit beside the latency-bound mid and learn roles.  The look-ahead includes the SP's
+// overlap) sit beside the latency-bound mid and learn roles.  Here the look-ahead includes the SP's
 // persistent updates (rows, duty cycle), so it only happens between two steps of one htm_run
 // call: the last two steps of a run look ahead less (StepPlan) and no call returns with SP work
 // outstanding.
