@@ -63,6 +63,7 @@ struct htm_handle {
     int G;                                // lanes per SP row
     int graph_steps;                      // steady-state steps per captured graph (BITHTM_GRAPH_STEPS)
     bool emit_fused, emit_fused_open;     // the emit grid is resident at once in k_sp_emit / in k_open_emit (refreshed per call)
+    bool emit_fits_lean;                  // ... and in k_learn_scan_emit
     bool emit_fits, emit_fits_open;       // ... as far as this handle's own grids go (fixed at creation)
     int sel_passes_fused, sel_passes_full; // launched select digits with / without the in-kernel finish
     int seg_hint;                         // a lower bound of the segment count (see scan_spec_blocks)
@@ -289,7 +290,7 @@ static bool can_pipeline(const htm_handle *h) {
 // scan in one launch.  BITHTM_LEAN=0: the four-launch schedule below.
 static bool can_lean(const htm_handle *h) {
     static const int env = getenv("BITHTM_LEAN") ? atoi(getenv("BITHTM_LEAN")) : 1;
-    return env != 0 && can_pipeline(h) && scan_lds(h->d, 1) <= 64 * 1024 && h->c256_blocks <= 2 * h->cus;
+    return env != 0 && can_pipeline(h) && scan_lds(h->d, 1) <= 64 * 1024 && h->emit_fits_lean;
 }
 
 // sp_done: the winner list of this step exists (the previous step's last launch, or the cold start).  next_sp: select
@@ -626,9 +627,17 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
                 h->emit_fits = c256 <= std::min(1024, per_cu_emit * cus);
                 // the pipelined launch puts the activation blocks of the current step behind the emit blocks
                 h->emit_fits_open = h->emit_fits && c256 + (d.k * 32 + 255) / 256 <= std::min(1024, per_cu_open * cus);
+                // the three-launch schedule: the emit blocks come first in the grid of the learn + scan + emit kernel
+                int per_cu_lean = 0;
+                const size_t lean_lds = std::max(std::max(learn_lds(learn_epl(d), 256), scan_lds(d, 1)), sizeof(EmitShared));
+                const void *kern = learn_epl(d) == 1 ? (const void *)k_learn_scan_emit<1, 6> : learn_epl(d) == 2 ? (const void *)k_learn_scan_emit<2, 6>
+                                 : learn_epl(d) == 4 ? (const void *)k_learn_scan_emit<4, 6> : (const void *)k_learn_scan_emit<8, 6>;
+                h->emit_fits_lean = cfg->enable_tm && h->emit_fits && lean_lds <= 64 * 1024 &&
+                                    hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_lean, kern, 256, lean_lds) == hipSuccess &&
+                                    c256 <= std::min(1024, per_cu_lean * cus);
             } else {
                 (void)hipGetLastError();
-                h->emit_fits = h->emit_fits_open = false;
+                h->emit_fits = h->emit_fits_open = h->emit_fits_lean = false;
             }
         }
         h->sel_passes_full = d.sel_passes;
