@@ -72,9 +72,10 @@ struct Counters {
     int32_t n_active_cells;
     // (by step parity: the scan of step t, which resets the counts for step t + 1, may share its launch with the
     // learning role of step t, which reads them)
-    int32_t n_work[2];        // learning / punish work items of the step (front of the work array)
+    alignas(128) int32_t n_work[2];   // learning / punish work items of the step (front of the work array): the one field of this
+                              // block that takes atomics from many blocks -- on a line of its own, away from the scalars everybody reads
     int32_t n_bind[2];        // newly bound segments of the step (back of the work array, growing down)
-    int32_t n_work_last;      // ... of the last completed step (telemetry)
+    alignas(128) int32_t n_work_last;      // ... of the last completed step (telemetry)
     int32_t sel_fallbacks;    // steps whose top-k select took the in-kernel fallback (telemetry)
     uint32_t emit_epoch;      // bumped by every overlap launch: tags the records k_sp_emit's blocks exchange
     int32_t n_un;             // winners needing a new segment
