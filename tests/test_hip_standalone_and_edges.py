@@ -262,6 +262,32 @@ def test_pipelined_schedules_and_select_paths_equal_step_by_step(env, monkeypatc
             assert np.array_equal(a, b)
 
 
+def test_prepare_builds_the_graphs_and_runs_nothing():
+    """htm_prepare (include/bithtm_hip.h): the graphs of a coming htm_run call are captured and instantiated ahead of
+    time; the state does not move, and the run that follows gives what a run without it gives -- for one-shot calls and
+    for a stream of continuing calls (every launch plan: cold start, steady-state graphs, the last step)."""
+    import bithtm_amd as B
+    rng = np.random.RandomState(41)
+    bank = rng.rand(20, 200) < 0.08
+    outs = []
+    for prepared in (False, True):
+        np.random.seed(42)
+        htm = B.HierarchicalTemporalMemory(200, 2048, 16)
+        eng = htm.engine
+        dev = eng.upload_bank(bank)
+        for n, cont in ((37, False), (3, True), (18, True), (1, True), (40, False)):
+            if prepared:
+                before = eng.info().step_index
+                eng.prepare(dev, bank.shape[0], n, continuing=cont)
+                assert eng.info().step_index == before
+            eng.run(dev, bank.shape[0], n, continuing=cont)
+        eng.check_capacity()
+        st = eng.read_store()
+        outs.append((eng.read_sp_fields()["active_column"], st["seg_cell"], st["seg_nsyn"], st["presyn"], st["perm"], eng.read_duty_cycle()))
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
+
+
 def test_batched_run_with_learning_switched_off_and_on():
     """The pipelined schedule with learning=False (no SP rows, no classification, no learning launches
     doing work) between learning runs == the same schedule of flags through process()."""
