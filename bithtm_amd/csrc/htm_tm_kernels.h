@@ -345,7 +345,19 @@ __device__ __forceinline__ void role_mid(const Dev &d, int p, int n_active, int 
         if (whole && threadIdx.x == 0 && grown >= d.match_thr) atomicSub(&d.recyc_cnt[b], max(0, min((int)total, n_r - off)));
     }
     if (whole) {
-        for (int i = threadIdx.x; i < n_new; i += BS) tm_bind_segment(d, S + i, d.unacc_list[n_r + i], false, wbase + n_r + i);
+        // (the cells of eight bindings per thread first, clamped and unconditional, then their stores: with one load per
+        // iteration the compiler waits for everything outstanding, the previous iteration's stores and atomics included --
+        // six round trips while every column bursts)
+        for (int i0 = 0; i0 < n_new; i0 += 8 * BS) {
+            int cl[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) cl[j] = d.unacc_list[n_r + min(i0 + j * BS + (int)threadIdx.x, n_new - 1)];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int i = i0 + j * BS + (int)threadIdx.x;
+                if (i < n_new) tm_bind_segment(d, S + i, cl[j], false, wbase + n_r + i);
+            }
+        }
         if (n_new > 0 && grown < d.match_thr)      // fresh ids [S, S + n_new) that will stay below the matching threshold
             for (int b = (S >> 10) + (int)threadIdx.x; b <= (S + n_new - 1) >> 10; b += BS)
                 atomicAdd(&d.recyc_cnt[b], min(S + n_new, (b + 1) << 10) - max(S, b << 10));
