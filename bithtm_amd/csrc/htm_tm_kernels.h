@@ -443,17 +443,27 @@ __device__ __forceinline__ void role_learn(const Dev &d, int p, int blk, int nbl
         const double dA = mode ? d.pun_act : d.lrn_act, dI = mode ? d.pun_inact : d.lrn_inact;
         const bool prune = mode ? d.pun_prune : d.lrn_prune;
         const int n = d.seg_nsyn[seg] & ~(int)SEG_BUSY;
+        const int owner = SELF ? d.seg_cell[seg] : 0;                     // (with the count: behind the row's stores it would wait for them)
         int *prow = d.presyn + (size_t)seg * d.E;
         float *mrow = d.sperm + (size_t)seg * d.E;
         int n_keep = 0, n_active = 0;
         int pot = 0, conn = 0;                       // SELF: active presynaptic cells of THIS step (projections.py:247), connected ones (:171-172)
+        // (the whole row first: a chunk's loads behind the previous chunk's stores would wait for those to complete)
+        int ps_all[EPL];
+        float pm_all[EPL];
+#pragma unroll
+        for (int jj = 0; jj < EPL; ++jj) {
+            const int idx = jj * 64 + lane;
+            ps_all[jj] = 0;
+            pm_all[jj] = 0.f;
+            if (idx < n) { ps_all[jj] = prow[idx] & SYN_CELL; pm_all[jj] = mrow[idx]; }
+        }
 #pragma unroll
         for (int jj = 0; jj < EPL; ++jj) {
             const int idx = jj * 64 + lane;
             const bool valid = idx < n;
-            int ps = 0;
-            float pm = 0.f;
-            if (valid) { ps = prow[idx] & SYN_CELL; pm = mrow[idx]; }
+            const int ps = ps_all[jj];
+            const float pm = pm_all[jj];
             const bool a = valid && ((act_prev[ps >> 5] >> (ps & 31)) & 1u);
             const bool a_now = SELF && valid && ((act_cur[ps >> 5] >> (ps & 31)) & 1u);
             const double p64 = (double)pm + (a ? dA : dI);               // :102-103
@@ -612,7 +622,7 @@ __device__ __forceinline__ void role_learn(const Dev &d, int p, int blk, int nbl
         }
         if (SELF && lane == 0 && pot >= d.match_thr) {                          // role_scan's publication (:247-251, :229-239)
             const bool active = conn >= d.act_thr;
-            const int cell = d.seg_cell[seg];
+            const int cell = owner;
             const float jit = htm_jitter((float)pot, htm_draw24(base3, gid, 0u));
             atomicMax(&d.cellmax[p][cell], __float_as_uint(jit));
             if (active) atomicOr(&d.pred[p][cell >> 5], 1u << (cell & 31));
