@@ -906,6 +906,106 @@ __global__ __launch_bounds__(RB) void k_shard_overlap(Dev d, const uint32_t *__r
 // ascending winner list -- the records are in rank order and each is in ascending column order, so the candidates
 // ARE in ascending column order and the tie rule (lower column first) is their order -- together with the cell
 // words the owner computed.  Block 0 also applies every rank's death reports to the replicated dead bits.
+// The k-th largest of the keys a 1024-thread block holds in registers (bit j of vmask: kreg[j] is a key), and how many
+// of the keys equal to it are among the k largest.  First the windowed pass of the three-launch schedule (win_bin): one
+// histogram around `base` (the previous step's k-th key) -- 12-bit digits put thousands of similar keys into a handful
+// of bins, and same-address LDS atomics run one after the other --, counted tie-aware; a chosen bin of up to 256 keys
+// is ranked directly, a crowded one (ties) finished by 12-bit digit passes from the window's resolution on.  A k-th key
+// outside the window leaves it all to the digit passes, which start below the keys' common prefix (same result;
+// *missed says so).  All threads call; h = SEL_BINS words of LDS.
+struct BlockSelLds { uint32_t *h, *s_wave, *s_out, *s_cnt; u64 *s_or, *s_and; };
+
+template <int KPT>
+__device__ __forceinline__ void block_select_regs(const u64 (&kreg)[KPT], uint32_t vmask, uint32_t k, uint32_t base, int low_zero,
+                                                  const BlockSelLds &L, u64 *T_out, uint32_t *r_out, bool *missed) {
+    const int tid = threadIdx.x, lane = lane_id();
+    uint32_t *h = L.h;
+    if (tid == 0) { *L.s_or = 0; *L.s_and = ~0ull; }
+    __syncthreads();
+    {
+        u64 vo = 0, va = ~0ull;
+#pragma unroll
+        for (int j = 0; j < KPT; ++j)
+            if ((vmask >> j) & 1u) { vo |= kreg[j]; va &= kreg[j]; }
+        for (int o = 32; o > 0; o >>= 1) {
+            vo |= ((u64)__shfl_xor((uint32_t)(vo >> 32), o) << 32) | __shfl_xor((uint32_t)vo, o);
+            va &= ((u64)__shfl_xor((uint32_t)(va >> 32), o) << 32) | __shfl_xor((uint32_t)va, o);
+        }
+        if (lane == 0) { atomicOr((unsigned long long *)L.s_or, vo); atomicAnd((unsigned long long *)L.s_and, va); }
+    }
+    __syncthreads();
+    const u64 differ = *L.s_or ^ *L.s_and;
+    const int top0 = differ ? 64 - __clzll((long long)differ) : 0;       // bits [top0, 64) are the same in every key
+    u64 P = top0 < 64 ? (*L.s_and >> top0) << top0 : 0ull;
+    uint32_t krem = k;
+    bool done = false;
+    u64 T = 0;
+    int top_start = top0;
+    {
+        __syncthreads();
+        for (int i = tid; i < SEL_BINS; i += 1024) h[i] = 0;
+        if (tid == 0) { L.s_cnt[0] = 0; L.s_out[0] = 0; }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) hist_add_tie(h, win_bin(kreg[j], base), (vmask >> j) & 1u);
+        __syncthreads();
+        uint32_t bucket, above;
+        sel_pick<1024>(h, WIN_BINS, krem, L.s_wave, L.s_out, &bucket, &above);
+        __syncthreads();
+        const bool inside = bucket >= 1u && bucket <= (WIN_COARSE << WIN_FINE);
+        const uint32_t in_bin = inside ? h[bucket] : 0u;
+        __syncthreads();
+        if (inside && in_bin > 256u) {                 // a crowded bin: the digit passes below, from the window's resolution on
+            const uint32_t fine = bucket - 1u;
+            P = ((u64)(base + (fine >> WIN_FINE)) << 52) | ((u64)(fine & ((1u << WIN_FINE) - 1u)) << WIN_LOWBITS);
+            krem -= above;
+            top_start = WIN_LOWBITS;
+        } else if (inside) {
+            const uint32_t kb = krem - above;          // the kb-th largest of the bin's keys is the k-th overall
+            u64 *list = (u64 *)h;                      // (the histogram is done with)
+#pragma unroll
+            for (int j = 0; j < KPT; ++j)
+                if (((vmask >> j) & 1u) && win_bin(kreg[j], base) == bucket) list[atomicAdd(&L.s_cnt[0], 1u)] = kreg[j];
+            __syncthreads();
+            for (uint32_t e = tid; e < in_bin; e += 1024) {
+                const u64 ke = list[e];
+                uint32_t ng = 0, nq = 0;
+                for (uint32_t f = 0; f < in_bin; ++f) {
+                    const u64 kf = list[f];
+                    ng += kf > ke;
+                    nq += kf == ke;
+                }
+                if (ng < kb && kb <= ng + nq) { *L.s_or = ke; L.s_out[1] = kb - ng; }      // (equal keys write the same pair)
+            }
+            __syncthreads();
+            T = *L.s_or;
+            krem = L.s_out[1];
+            done = true;
+            __syncthreads();
+        }
+    }
+    for (int top = top_start; !done && top > low_zero;) {
+        const int bits = min(SEL_DIGIT, top - low_zero), shift = top - bits, nb = 1 << bits;
+        for (int i = tid; i < nb; i += 1024) h[i] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) {
+            const u64 kk = kreg[j];
+            hist_add_tie(h, (uint32_t)(kk >> shift) & (nb - 1), ((vmask >> j) & 1u) && (top >= 64 || ((kk ^ P) >> top) == 0));
+        }
+        __syncthreads();
+        uint32_t bucket, above;
+        sel_pick<1024>(h, nb, krem, L.s_wave, L.s_out, &bucket, &above);
+        P |= (u64)bucket << shift;
+        krem -= above;
+        top = shift;
+        __syncthreads();
+    }
+    *T_out = done ? T : P;
+    *r_out = krem;
+    *missed = !done && top_start == top0;
+}
+
 #ifdef BITHTM_SHARD_STAMPS                       // diagnostic build: device clock at the phases of block 0, d.trace[phase]
 #define SHARD_STAMP(i) do { if (d.trace && blockIdx.x == 0 && threadIdx.x == 0) d.trace[i] = wall_clock64(); } while (0)
 #else
@@ -936,111 +1036,59 @@ __global__ __launch_bounds__(1024) void k_shard_select(Dev d, const unsigned cha
         const u64 kk = key_at(min(tid + j * 1024, n_tot - 1));
         kreg[j] = (in_regs && tid + j * 1024 < n_tot) ? kk : 0ull;
     }
-    // the candidates are each rank's best: their keys share their leading bits (exponent, top of the mantissa).  The
-    // radix select starts below that common prefix -- its passes would each put every key into one bin
-    if (tid == 0) { s_or = 0; s_and = ~0ull; }
-    __syncthreads();
-    {
-        u64 vo = 0, va = ~0ull;
-        if (in_regs) {
-#pragma unroll
-            for (int j = 0; j < KPT; ++j)
-                if (tid + j * 1024 < n_tot) { vo |= kreg[j]; va &= kreg[j]; }
-        } else {
-            for (int i = tid; i < n_tot; i += 1024) { const u64 kk = key_at(i); vo |= kk; va &= kk; }
-        }
-        for (int o = 32; o > 0; o >>= 1) {
-            vo |= ((u64)__shfl_xor((uint32_t)(vo >> 32), o) << 32) | __shfl_xor((uint32_t)vo, o);
-            va &= ((u64)__shfl_xor((uint32_t)(va >> 32), o) << 32) | __shfl_xor((uint32_t)va, o);
-        }
-        if (lane == 0) { atomicOr((unsigned long long *)&s_or, vo); atomicAnd((unsigned long long *)&s_and, va); }
-    }
-    __syncthreads();
-    SHARD_STAMP(1);                                // (keys loaded, common prefix known)
-    const u64 differ = s_or ^ s_and;
-    const int top0 = differ ? 64 - __clzll((long long)differ) : 0;       // bits [top0, 64) are the same in every key
-    u64 P = top0 < 64 ? (s_and >> top0) << top0 : 0ull;
-    uint32_t krem = (uint32_t)d.k;
-    // First the windowed pass of the three-launch schedule (win_bin): one histogram around the previous step's k-th key
-    // -- the 12-bit digits below put thousands of candidates into a handful of bins, and same-address LDS atomics run
-    // one after the other -- then the few keys of the chosen bin are ranked against each other.  A k-th key outside
-    // the window, or a crowded bin, leaves it to the digit passes (same result).
-    bool done = false;
-    u64 T = 0;
-    int top_start = top0;
+    u64 T;                                         // the k-th largest key; krem of the keys equal to it win
+    uint32_t krem;
+    bool missed = false;
     if (in_regs) {
-        const uint32_t base = d.ctr->sel_win_global;
-        for (int i = tid; i < SEL_BINS; i += 1024) h[i] = 0;
-        if (tid == 0) { s_cnt[0] = 0; s_out[0] = 0; }
-        __syncthreads();
+        uint32_t vmask = 0;
 #pragma unroll
-        for (int j = 0; j < KPT; ++j) hist_add_tie(h, win_bin(kreg[j], base), tid + j * 1024 < n_tot);
+        for (int j = 0; j < KPT; ++j) vmask |= (tid + j * 1024 < n_tot ? 1u : 0u) << j;
+        const BlockSelLds L{h, s_wave, s_out, s_cnt, &s_or, &s_and};
+        SHARD_STAMP(1);                            // (keys loaded)
+        block_select_regs<KPT>(kreg, vmask, (uint32_t)d.k, d.ctr->sel_win_global, d.low_zero, L, &T, &krem, &missed);
+    } else {
+        // more candidates than the registers hold (configs[4]: 42 k): 12-bit digit passes over the records, from below the
+        // keys' common prefix
+        if (tid == 0) { s_or = 0; s_and = ~0ull; }
         __syncthreads();
-        uint32_t bucket, above;
-        sel_pick<1024>(h, WIN_BINS, krem, s_wave, s_out, &bucket, &above);
-        __syncthreads();
-        const bool inside = bucket >= 1u && bucket <= (WIN_COARSE << WIN_FINE);
-        const uint32_t in_bin = inside ? h[bucket] : 0u;
-        __syncthreads();
-        if (inside && in_bin > 256u) {                 // a crowded bin (ties): the digit passes below, from the window's resolution on
-            const uint32_t fine = bucket - 1u;
-            P = ((u64)(base + (fine >> WIN_FINE)) << 52) | ((u64)(fine & ((1u << WIN_FINE) - 1u)) << WIN_LOWBITS);
-            krem -= above;
-            top_start = WIN_LOWBITS;
-        } else if (inside) {
-            const uint32_t kb = krem - above;          // the kb-th largest of the bin's keys is the k-th overall
-            u64 *list = (u64 *)h;                                      // (the histogram is done with)
-#pragma unroll
-            for (int j = 0; j < KPT; ++j)
-                if (tid + j * 1024 < n_tot && win_bin(kreg[j], base) == bucket) list[atomicAdd(&s_cnt[0], 1u)] = kreg[j];
-            __syncthreads();
-            for (uint32_t e = tid; e < in_bin; e += 1024) {
-                const u64 ke = list[e];
-                uint32_t ng = 0, nq = 0;
-                for (uint32_t f = 0; f < in_bin; ++f) {
-                    const u64 kf = list[f];
-                    ng += kf > ke;
-                    nq += kf == ke;
-                }
-                if (ng < kb && kb <= ng + nq) { s_or = ke; s_out[1] = kb - ng; }      // (equal keys write the same pair)
+        {
+            u64 vo = 0, va = ~0ull;
+            for (int i = tid; i < n_tot; i += 1024) { const u64 kk = key_at(i); vo |= kk; va &= kk; }
+            for (int o = 32; o > 0; o >>= 1) {
+                vo |= ((u64)__shfl_xor((uint32_t)(vo >> 32), o) << 32) | __shfl_xor((uint32_t)vo, o);
+                va &= ((u64)__shfl_xor((uint32_t)(va >> 32), o) << 32) | __shfl_xor((uint32_t)va, o);
             }
-            __syncthreads();
-            T = s_or;
-            krem = s_out[1];
-            done = true;
-            __syncthreads();
+            if (lane == 0) { atomicOr((unsigned long long *)&s_or, vo); atomicAnd((unsigned long long *)&s_and, va); }
         }
-    }
-    for (int top = top_start; !done && top > d.low_zero;) {
-        const int bits = min(SEL_DIGIT, top - d.low_zero), shift = top - bits, nb = 1 << bits;
-        for (int i = tid; i < nb; i += 1024) h[i] = 0;
         __syncthreads();
-        if (in_regs) {
-#pragma unroll
-            for (int j = 0; j < KPT; ++j) {
-                const u64 kk = kreg[j];
-                hist_add_tie(h, (uint32_t)(kk >> shift) & (nb - 1), tid + j * 1024 < n_tot && (top >= 64 || ((kk ^ P) >> top) == 0));
-            }
-        } else {
+        SHARD_STAMP(1);
+        const u64 differ = s_or ^ s_and;
+        const int top0 = differ ? 64 - __clzll((long long)differ) : 0;
+        u64 P = top0 < 64 ? (s_and >> top0) << top0 : 0ull;
+        krem = (uint32_t)d.k;
+        for (int top = top0; top > d.low_zero;) {
+            const int bits = min(SEL_DIGIT, top - d.low_zero), shift = top - bits, nb = 1 << bits;
+            for (int i = tid; i < nb; i += 1024) h[i] = 0;
+            __syncthreads();
             for (int i = tid; i < n_tot; i += 1024) {
                 const u64 kk = key_at(i);
-                if (top >= 64 || ((kk ^ P) >> top) == 0) atomicAdd(&h[(uint32_t)(kk >> shift) & (nb - 1)], 1u);
+                hist_add_tie(h, (uint32_t)(kk >> shift) & (nb - 1), top >= 64 || ((kk ^ P) >> top) == 0);
             }
+            __syncthreads();
+            uint32_t bucket, above;
+            sel_pick<1024>(h, nb, krem, s_wave, s_out, &bucket, &above);
+            P |= (u64)bucket << shift;
+            krem -= above;
+            top = shift;
+            __syncthreads();
         }
-        __syncthreads();
-        uint32_t bucket, above;
-        sel_pick<1024>(h, nb, krem, s_wave, s_out, &bucket, &above);
-        P |= (u64)bucket << shift;
-        krem -= above;
-        top = shift;
-        __syncthreads();
+        T = P;
     }
     SHARD_STAMP(2);                                // (k-th key known)
-    if (!done) T = P;                              // the k-th largest key; krem of the keys equal to it win
     const int b = blockIdx.x, lo = b * KL;
     if (b == 0 && tid == 0) {
         d.ctr->sel_win_global = min(win_base_for(T) + (uint32_t)d.win_offset, 4096u - WIN_COARSE);
-        if (!done && top_start == top0) d.ctr->sel_fallbacks += 1;       // (telemetry: the window missed)
+        if (missed) d.ctr->sel_fallbacks += 1;     // (telemetry: the window missed)
     }
     if (tid < 2) s_cnt[tid] = 0;
     __syncthreads();
