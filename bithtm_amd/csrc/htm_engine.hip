@@ -64,6 +64,7 @@ struct htm_handle {
     int graph_steps;                      // steady-state steps per captured graph (BITHTM_GRAPH_STEPS)
     bool emit_fused, emit_fused_open;     // the emit grid is resident at once in k_sp_emit / in k_open_emit (refreshed per call)
     bool emit_fits_lean;                  // ... and in k_learn_scan_emit
+    int knob_lean, knob_fuse_tm, knob_shard_window, knob_scan_large;      // environment knobs, read when the handle is created
     bool emit_fits, emit_fits_open;       // ... as far as this handle's own grids go (fixed at creation)
     int sel_passes_fused, sel_passes_full; // launched select digits with / without the in-kernel finish
     int seg_hint;                         // a lower bound of the segment count (see scan_spec_blocks)
@@ -199,8 +200,7 @@ static int scan_spec_blocks(const htm_handle *h) { return std::min(h->seg_hint /
 
 // more segments than three rounds of resident blocks: the scan is bandwidth-bound (see k_tm_scan)
 static bool scan_pool_is_large(const htm_handle *h) {
-    static const int force = getenv("BITHTM_SCAN_LARGE") ? atoi(getenv("BITHTM_SCAN_LARGE")) : -1;      // tuning knob
-    if (force >= 0) return force != 0;
+    if (h->knob_scan_large >= 0) return h->knob_scan_large != 0;      // (BITHTM_SCAN_LARGE: tuning knob)
     return h->seg_hint > 3 * 1536 * SCAN_SEGS;
 }
 
@@ -254,8 +254,7 @@ static void enqueue_tm(htm_handle *h, int n_active, int learning, int want_winne
     LAUNCH(h, "tm_mid", k_mid_rows, 1 + n_cls + n_sp_rows + n_duty + h->zero_blocks, 256, d, p, n_active, want_winner, learning, n_cls, bank, n_inputs, n_sp_rows, 0, n_duty);
     // the learning role and the scan: one launch (k_learn_scan_emit without emit blocks: the learning waves scan their own
     // rows), unless the pool is large (the streaming scan kernels) or somebody is timing the roles one by one
-    static const int fuse_env = getenv("BITHTM_FUSE_TM") ? atoi(getenv("BITHTM_FUSE_TM")) : 1;
-    if (fuse_env && !h->profile && !scan_pool_is_large(h) && scan_lds(d, 1) <= 64 * 1024) {
+    if (h->knob_fuse_tm && !h->profile && !scan_pool_is_large(h) && scan_lds(d, 1) <= 64 * 1024) {
         const int epl = learn_epl(d), n_learn = h->lean_learn_blocks, n_scan = h->lean_scan_blocks, spec = scan_spec_blocks(h);
         const size_t lds = std::max(learn_lds(epl, 256), scan_lds(d, 1));
         switch (epl) {
@@ -289,8 +288,7 @@ static bool can_pipeline(const htm_handle *h) {
 // the three-launch schedule (htm_pipeline.h): the scan's LDS bitmap, one select histogram, the learning role and the
 // scan in one launch.  BITHTM_LEAN=0: the four-launch schedule below.
 static bool can_lean(const htm_handle *h) {
-    static const int env = getenv("BITHTM_LEAN") ? atoi(getenv("BITHTM_LEAN")) : 1;
-    return env != 0 && can_pipeline(h) && scan_lds(h->d, 1) <= 64 * 1024 && h->emit_fits_lean;
+    return h->knob_lean && can_pipeline(h) && scan_lds(h->d, 1) <= 64 * 1024 && h->emit_fits_lean;
 }
 
 // sp_done: the winner list of this step exists (the previous step's last launch, or the cold start).  next_sp: select
@@ -596,6 +594,10 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
     h->zero_blocks = std::max(1, std::min((d.Lcap / 128 + 4095) / 4096, 1024));     // k_mid_rows: 16 stores of 16 bytes per thread at most
     // the three-launch schedule: waves of one 256-thread block per work item in the steady state; the scan's waves take
     // two groups of segments each, so that emit + learn + scan are all resident at once (tuning knobs)
+    h->knob_lean = getenv("BITHTM_LEAN") ? atoi(getenv("BITHTM_LEAN")) != 0 : 1;
+    h->knob_fuse_tm = getenv("BITHTM_FUSE_TM") ? atoi(getenv("BITHTM_FUSE_TM")) != 0 : 1;
+    h->knob_shard_window = getenv("BITHTM_SHARD_WINDOW") ? atoi(getenv("BITHTM_SHARD_WINDOW")) != 0 : 1;
+    h->knob_scan_large = getenv("BITHTM_SCAN_LARGE") ? atoi(getenv("BITHTM_SCAN_LARGE")) : -1;
     h->lean_overlap_blocks = getenv("BITHTM_LEAN_OVERLAP") ? std::max(1, atoi(getenv("BITHTM_LEAN_OVERLAP"))) : h->sp_blocks * (RB / 256);
     h->lean_learn_blocks = getenv("BITHTM_LEAN_LEARN") ? std::max(1, atoi(getenv("BITHTM_LEAN_LEARN"))) : 512;
     h->lean_scan_blocks = getenv("BITHTM_LEAN_SCAN") ? std::max(1, atoi(getenv("BITHTM_LEAN_SCAN"))) : (h->scan_blocks > 512 ? std::max(256, (h->scan_blocks * 3 / 8 + 255) & ~255) : h->scan_blocks);
@@ -971,7 +973,7 @@ static int shard_enqueue_begin(htm_handle *h, const uint32_t *bank, int n_inputs
     const int n_word_blocks = ((d.c1 - d.c0) * 32 + RB - 1) / RB;        // one own column per half-wave
     // (the local select: one windowed histogram pass beside the overlap, finished inside the candidates kernel;
     // BITHTM_SHARD_WINDOW=0: two launched digits)
-    static const int wmode = getenv("BITHTM_SHARD_WINDOW") ? (atoi(getenv("BITHTM_SHARD_WINDOW")) != 0) : 1;
+    const int wmode = h->knob_shard_window;
     LAUNCH(h, "shard_overlap", k_shard_overlap, h->sp_blocks + n_word_blocks + std::min((d.C + RB - 1) / RB, 64), RB, d, bank, n_inputs, h->G, p,
            h->sp_blocks, n_word_blocks, wmode);
     if (!wmode)

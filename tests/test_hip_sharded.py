@@ -117,6 +117,16 @@ def test_two_shards_default_parameters():
     _run(2, I=256, C=2048, K=32, P=50, density=0.06, noise=0.01, steps=300, jump=0.0, seed=51)
 
 
+@pytest.mark.parametrize("env", [{"BITHTM_SHARD_WINDOW": "0"}, {"BITHTM_FUSE_TM": "0"}, {"BITHTM_SEL_WINDOW_OFFSET": "4000"}],
+                         ids=lambda e: ",".join(f"{k[7:]}={v}" for k, v in e.items()))
+def test_four_shards_with_the_other_select_and_launch_forms(env, monkeypatch):
+    """The sharded step with two launched digits instead of the windowed histogram in the local select, with the
+    learning role and the scan as two launches, and with both windows (local and global) forced to miss every step."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    _run(4, I=200, C=1024, K=16, P=20, density=0.08, noise=0.01, steps=120, jump=0.02, seed=57)
+
+
 def test_four_shards_stress_parameters_with_recycling():
     spp = SPParams(permanence_mean=0.01, permanence_std=0.08, permanence_threshold=0.02, permanence_increment=0.05,
                    permanence_decrement=0.02, boost_intensity=0.5, boost_momentum=0.95)

@@ -225,7 +225,8 @@ def test_batched_run_equals_step_by_step():
 
 @pytest.mark.parametrize("env", [{}, {"BITHTM_LEAN": "0"}, {"BITHTM_SEL_WINDOW_OFFSET": "4000"}, {"BITHTM_CAND_D": "0"}, {"BITHTM_CAND_D": "1"},
                                  {"BITHTM_CAND_PAIRWISE": "0", "BITHTM_CAND_OTHERS": "0"}, {"BITHTM_CAND_PAIRWISE": "0", "BITHTM_CAND_OTHERS": "4"},
-                                 {"BITHTM_LEAN_SCAN": "1", "BITHTM_LEAN_LEARN": "1"}, {"BITHTM_LEAN_SCAN": "3", "BITHTM_LEAN_LEARN": "2", "BITHTM_LEAN_OVERLAP": "3"}],
+                                 {"BITHTM_LEAN_SCAN": "1", "BITHTM_LEAN_LEARN": "1"}, {"BITHTM_LEAN_SCAN": "3", "BITHTM_LEAN_LEARN": "2", "BITHTM_LEAN_OVERLAP": "3"},
+                                 {"BITHTM_FUSE_TM": "0"}],
                          ids=lambda e: ",".join(f"{k[7:]}={v}" for k, v in e.items()) or "default")
 def test_pipelined_schedules_and_select_paths_equal_step_by_step(env, monkeypatch):
     """htm.run in its pipelined schedules -- three launches per step (the learning role scanning its own rows beside the
