@@ -1,6 +1,8 @@
 """GPU: the stand-alone SpatialPooler / TemporalMemory classes (htm_sp_step / htm_tm_step), the
 learning / return_winner_cell switches, edge-case inputs and the loud failure modes."""
 
+import os
+
 import numpy as np
 import pytest
 
@@ -261,6 +263,52 @@ def test_pipelined_schedules_and_select_paths_equal_step_by_step(env, monkeypatc
     for o in outs[:-1]:
         for a, b in zip(outs[-1], o):
             assert np.array_equal(a, b)
+
+
+def test_random_call_patterns_equal_step_by_step():
+    """Seeded random sequences of htm.run (graph / eager, continuing or not, learning on or off, run lengths on either
+    side of the 16-step graphs), host-fed process() steps in between, on random small shapes -- against a twin that only
+    ever calls process().  (A longer sweep: BITHTM_CALL_FUZZ_SEQUENCES.)"""
+    import bithtm_amd as B
+
+    def digest(htm):
+        st, d = htm.engine.read_store(), htm.engine.read_distal()
+        return (htm.engine.read_sp_fields()["active_column"], st["seg_cell"], st["seg_nsyn"], st["presyn"], st["perm"],
+                htm.temporal_memory.last_state.cell_prediction, htm.engine.read_duty_cycle(), d["matching_segment"], d["max_jittered_potential"])
+
+    for seed in range(int(os.environ.get("BITHTM_CALL_FUZZ_SEQUENCES", "12"))):
+        rng = np.random.RandomState(1000 + seed)
+        I, C, K = int(rng.choice([64, 200, 300])), int(rng.choice([1024, 2048, 4096])), int(rng.choice([4, 8, 16, 32]))
+        bank = rng.rand(int(rng.choice([5, 17, 30])), I) < rng.choice([0.05, 0.1])
+        np.random.seed(seed)
+        a = B.HierarchicalTemporalMemory(I, C, K)
+        np.random.seed(seed)
+        b = B.HierarchicalTemporalMemory(I, C, K)
+        t, ahead = 0, False
+        for _ in range(int(rng.randint(4, 12))):
+            kind = "run" if ahead else str(rng.choice(["run", "run", "run", "process", "nolearn"]))
+            if kind == "process":
+                n = int(rng.randint(1, 6))
+                for i in range(n):
+                    a.process(bank[(t + i) % len(bank)])
+            else:
+                n = int(rng.choice([1, 2, 3, 5, 16, 17, 18, 33, 40]))
+                cont, g = bool(rng.rand() < 0.5) and kind == "run", bool(rng.rand() < 0.7)
+                try:
+                    a.run(bank, n, learning=kind != "nolearn", use_graph=g, continuing=cont)
+                except B.HtmError as e:            # (a shape the pipelined schedule does not take: no streaming either)
+                    assert "needs the pipelined schedule" in str(e)
+                    cont = False
+                    a.run(bank, n, learning=kind != "nolearn", use_graph=g)
+                ahead = cont
+            for i in range(n):
+                b.process(bank[(t + i) % len(bank)], learning=kind != "nolearn")
+            t += n
+        if ahead:
+            a.run(bank, 1)
+            b.process(bank[t % len(bank)])
+        for x, y in zip(digest(a), digest(b)):
+            assert np.array_equal(x, y), (seed, I, C, K, t)
 
 
 def test_prepare_builds_the_graphs_and_runs_nothing():
