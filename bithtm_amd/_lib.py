@@ -51,6 +51,7 @@ EXPORTS = {
     "htm_destroy": (None, [C.c_void_p]),
     "htm_last_error": (C.c_char_p, [C.c_void_p]),
     "htm_sp_set_permanence": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
+    "htm_set_epsilon": (C.c_int, [C.c_void_p, C.c_float]),
     "htm_sp_get_permanence": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
     "htm_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     "htm_sp_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),

@@ -20,7 +20,7 @@ typedef unsigned long long u64;
 #define SYN_CELL 0x7FFFFFFF         // ... and the cell (column * 32 + cell) below it
 #define SEG_BUSY 0x40000000         // in seg_nsyn: the segment is on this step's work list -- the learning role is about to
                                     // rewrite its row (and clears the flag with the new count); the scan leaves it alone
-#define EPS32 1e-8f           // `epsilon=1e-8` against float32 arrays (weak Python scalar)
+#define EPS32 1e-8f           // `epsilon=1e-8` against float32 arrays (weak Python scalar): the default of Dev::eps
 
 // Select key of a boosted overlap: an order-preserving image of the double's bits that spends 8 bits on the
 // exponent instead of 12 on sign + exponent.  boosted = (float32 factor) x (overlap <= input_dim <= 2^17) is 0 or
@@ -106,6 +106,7 @@ struct Dev {
     double lrn_act, lrn_inact, pun_act, pun_inact;
     int lrn_prune, pun_prune;
     float perm_init, perm_thr;
+    float eps;                // TemporalMemory.process(epsilon=...) (networks.py:91), as float32: 1e-8 unless htm_set_epsilon says otherwise
     int act_thr, match_thr, sample;
     uint32_t seed;
     // Spatial Pooler

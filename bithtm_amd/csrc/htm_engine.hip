@@ -497,6 +497,7 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
     d.pun_act = cfg->tm_punish_active; d.pun_inact = cfg->tm_punish_inactive;
     d.lrn_prune = cfg->tm_learn_prune; d.pun_prune = cfg->tm_punish_prune;
     d.perm_init = cfg->tm_permanence_initial; d.perm_thr = cfg->tm_permanence_threshold;
+    d.eps = EPS32;
     d.act_thr = cfg->segment_activation_threshold; d.match_thr = cfg->segment_matching_threshold;
     d.sample = cfg->segment_sampling_synapses;
     d.seed = cfg->seed;
@@ -662,6 +663,22 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
     }
     refresh_exchange_mode(h);
     *out = h;
+    return HTM_OK;
+}
+
+// TemporalMemory.process(..., epsilon=) (networks.py:91): the tolerance of the "best matching" / "least used" ties
+// (networks.py:81,88; projections.py:267), compared as float32.  0 < epsilon <= 1: the other uses (prediction > epsilon,
+// potential < epsilon) then mean what they mean at 1e-8.  Kernels get it with their arguments: cached graphs are dropped.
+extern "C" int htm_set_epsilon(htm_handle *h, float epsilon) {
+    if (!h) return HTM_ERR_ARGUMENT;
+    if (!(epsilon > 0.f) || epsilon > 1.f) { h->err = "htm_set_epsilon: need 0 < epsilon <= 1"; return HTM_ERR_ARGUMENT; }
+    REJECT_WHEN_AHEAD(h);
+    if (epsilon == h->d.eps) return HTM_OK;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (auto &kv : h->graphs) hipGraphExecDestroy(kv.second);
+    h->graphs.clear();
+    h->d.eps = epsilon;
     return HTM_OK;
 }
 

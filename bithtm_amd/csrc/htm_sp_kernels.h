@@ -255,7 +255,7 @@ __device__ __forceinline__ ColumnWords tm_column_words(const Dev &d, int p, int 
         float colmax = cm;
         for (int o = 16; o > 0; o >>= 1) colmax = fmaxf(colmax, __shfl_xor(colmax, o));
         const bool col_matching = has_distal && colmax >= (float)d.match_thr;      // networks.py:80
-        const bool best = valid && has_distal && fabsf(cm - colmax) < EPS32;       // :81
+        const bool best = valid && has_distal && fabsf(cm - colmax) < d.eps;       // :81
         float jit = 3.0e38f;
         if (valid) {
             uint32_t base = htm_stream_base(d.seed, HTM_STREAM_LEAST_USED, d.ctr->step[p]);
@@ -263,12 +263,12 @@ __device__ __forceinline__ ColumnWords tm_column_words(const Dev &d, int p, int 
         }
         float mn = jit;
         for (int o = 16; o > 0; o >>= 1) mn = fminf(mn, __shfl_xor(mn, o));
-        const bool least = valid && fabsf(jit - mn) < EPS32;                       // :88
+        const bool least = valid && fabsf(jit - mn) < d.eps;                       // :88
         const bool wbit = col_matching ? best : least;
         const u64 bw = __ballot(wbit);
         const uint32_t pick = (uint32_t)(bw >> (half * 32));
         if (burst) winner = pick;                                                  // :102
-        const u64 bm = __ballot(valid && has_distal && !(cm < EPS32));             // cell has a matching segment
+        const u64 bm = __ballot(valid && has_distal && !(cm < d.eps));             // cell has a matching segment
         unacc = has_distal ? (winner & ~(uint32_t)(bm >> (half * 32))) : 0u;       // projections.py:271
     }
     return ColumnWords{act, want_winner ? winner : 0u, unacc, burst};

@@ -160,7 +160,7 @@ __device__ __forceinline__ void role_mid(const Dev &d, int p, int n_active, int 
             const int col = cell >> 5, cb = cell & 31;
             const bool is_winner = (d.win[p][col] >> cb) & 1u;
             const bool unpred = !((d.pred[q][col] >> cb) & 1u);                          // :266
-            const bool best = fabsf(jit - __uint_as_float(d.cellmax[q][cell])) < EPS32;  // :267
+            const bool best = fabsf(jit - __uint_as_float(d.cellmax[q][cell])) < d.eps;  // :267
             learn = is_winner && ((info >> 31) || (unpred && best));                     // :268
             punish = d.act[p][col] == 0;                                                 // :269
         };

@@ -129,6 +129,10 @@ class Engine:
     def sync(self):
         self._check(self.lib.htm_sync(self.h), "htm_sync")
 
+    def set_epsilon(self, epsilon):
+        """TemporalMemory.process(epsilon=) (networks.py:91): 0 < epsilon <= 1, compared as float32; stays until set again."""
+        self._check(self.lib.htm_set_epsilon(self.h, C.c_float(float(epsilon))), "htm_set_epsilon")
+
     def read(self, field, dtype, count):
         out = np.empty(int(count), dtype=dtype)
         n = self._check(self.lib.htm_read(self.h, field, out.ctypes.data_as(C.c_void_p), out.size), "htm_read")

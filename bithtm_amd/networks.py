@@ -291,11 +291,12 @@ class TemporalMemory:
 
     def process(self, sp_state, prev_state=None, learning=True, return_winner_cell=True, epsilon=1e-8):
         """networks.py:91-128.  `prev_state` may only be None or this object's `last_state`: the
-        previous step's state lives in device memory."""
+        previous step's state lives in device memory.  `epsilon` (the tolerance of the best-matching / least-used ties,
+        as float32): any value in (0, 1]."""
         if prev_state is not None and prev_state is not self.last_state:
             raise NotImplementedError("prev_state other than last_state is not supported")
-        if epsilon != 1e-8:
-            raise NotImplementedError("epsilon is fixed at 1e-8")
+        if not 0.0 < epsilon <= 1.0:
+            raise NotImplementedError("epsilon must lie in (0, 1]")
         if self._fused:
             raise RuntimeError("this TemporalMemory is fused into a HierarchicalTemporalMemory; call its process()")
         active_column = np.asarray(sp_state.active_column, dtype=np.int64)
@@ -308,6 +309,9 @@ class TemporalMemory:
                 bigger.import_tm_state(eng.export_tm_state())
             self._bind(bigger, False)
             eng = bigger
+        if getattr(eng, "_epsilon", 1e-8) != epsilon:
+            eng.set_epsilon(epsilon)
+            eng._epsilon = epsilon
         eng.tm_step(active_column, learning=learning, return_winner_cell=return_winner_cell)
         return self._new_state(active_column)
 

@@ -143,6 +143,12 @@ int htm_abi_version(void);
 /* DenseProjection.permanence (projections.py:16): rows [row_begin, row_begin+row_count) of the
  * float64 [column_dim, input_dim] matrix, row-major, no padding. set rebuilds the connected mask. */
 int htm_sp_set_permanence(htm_handle *h, const double *rows, int32_t row_begin, int32_t row_count);
+
+/* TemporalMemory.process(..., epsilon=1e-8) (networks.py:91): the tolerance, compared as float32 the way NumPy compares
+ * a Python scalar with float32 arrays, of the "best matching" and "least used" ties (networks.py:81,88) and of the
+ * "best matching segment" test of learning (projections.py:267).  0 < epsilon <= 1 (the reference's other uses --
+ * prediction > epsilon, max potential < epsilon -- then mean what they mean at 1e-8); stays until set again. */
+int htm_set_epsilon(htm_handle *h, float epsilon);
 int htm_sp_get_permanence(htm_handle *h, double *rows, int32_t row_begin, int32_t row_count);
 
 /* One timestep, enqueued asynchronously.  packed_input: input bit i is bit (i & 31) of word

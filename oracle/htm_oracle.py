@@ -170,6 +170,7 @@ class TemporalMemoryOracle:
         self.perm = np.full((0, slots), -1.0, dtype=np.float32)
         self.segcount = np.zeros(self.N, dtype=np.int32)
         self.step_index = 0
+        self.eps = EPS32                       # TemporalMemory.process(epsilon=) (networks.py:91), as float32; 0 < eps <= 1
         # previous-step state (networks.py:57-65)
         self.prev_prediction = np.zeros((column_dim, cell_dim), dtype=np.bool_)
         self.prev_activation = np.zeros((column_dim, cell_dim), dtype=np.bool_)
@@ -313,13 +314,13 @@ class TemporalMemoryOracle:
         is_winner = np.zeros(self.N, dtype=np.bool_)
         is_winner[winner_flat] = True
         unpredicted = d.prediction[mcell] < 1e-8                              # :266
-        best = np.abs(d.matching_segment_jittered_potential - d.max_jittered_potential[mcell]) < EPS32  # :267
+        best = np.abs(d.matching_segment_jittered_potential - d.max_jittered_potential[mcell]) < self.eps  # :267
         learning = m[is_winner[mcell] & (d.matching_segment_active | (unpredicted & best))]     # :268
         column_active = np.zeros(self.column_dim, dtype=np.bool_)
         column_active[active_column] = True
         punished = m[~column_active[mcell // K]]                              # :269, networks.py:107-111
 
-        unaccounted = winner_flat[d.max_jittered_potential[winner_flat] < EPS32]   # :271
+        unaccounted = winner_flat[d.max_jittered_potential[winner_flat] < self.eps]   # :271
         if len(unaccounted):
             recycled = np.flatnonzero(self.seg_nsyn[:self.S] < p.segment_matching_threshold)[:len(unaccounted)]  # :80-81
             n_r = len(recycled)
@@ -388,11 +389,11 @@ class TemporalMemoryOracle:
                 cell_max = self.prev_distal.max_jittered_potential.reshape(C, K)[active_column]
                 column_max = cell_max.max(axis=1, keepdims=True) if len(active_column) else cell_max[:, :1]
                 column_matching = (column_max >= self.params.segment_matching_threshold)[:, 0]
-                best = np.abs(cell_max - column_max) < EPS32
+                best = np.abs(cell_max - column_max) < self.eps
             count = self.segcount.reshape(C, K)[active_column].astype(np.float32)     # :85-86
             u = draw_unit(self.seed, STREAM_LEAST_USED, t, flat)
             jittered = (count.astype(np.float64) + u).astype(np.float32)              # :87
-            least = (np.abs(jittered - jittered.min(axis=1, keepdims=True)) < EPS32
+            least = (np.abs(jittered - jittered.min(axis=1, keepdims=True)) < self.eps
                      if len(active_column) else jittered.astype(np.bool_))            # :88
             winner = predicted | (bursting[:, None] & np.where(column_matching[:, None], best, least))  # :102
             winner_flat = flat[winner]                                        # :103-104 (row-major)

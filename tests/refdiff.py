@@ -117,13 +117,15 @@ def pattern_index(t, patterns, jump, rng):
 
 def run_lockstep(ref, seed, input_dim, column_dim, cell_dim, patterns, density, noise, steps,
                  store_every=10, learning_schedule=None, record=None, sp_params=None, tm_params=None,
-                 jump=0.0):
+                 jump=0.0, epsilon=None):
     """Run both for `steps` timesteps; assert equality of every output each step.
 
     `record(t, x, ref_sp, ref_tm, ref_htm)` is called after every step if given.
     Returns statistics used to assert that the run contains no implementation-defined choice.
     """
     ref_htm, ora = build_pair(ref, seed, input_dim, column_dim, cell_dim, sp_params=sp_params, tm_params=tm_params)
+    if epsilon is not None:                          # TemporalMemory.process(epsilon=) (networks.py:91): a Python float there
+        ora.temporal_memory.eps = np.float32(epsilon)
     bank, rng = make_inputs(seed + 1, patterns, input_dim, density)
     stats = dict(ambiguous_topk=0, steps=steps)
     with keyed_rand(seed, cell_dim) as patch:
@@ -131,7 +133,11 @@ def run_lockstep(ref, seed, input_dim, column_dim, cell_dim, patterns, density, 
             x = bank[pattern_index(t, patterns, jump, rng)] ^ (rng.rand(input_dim) < noise)
             learning = True if learning_schedule is None else bool(learning_schedule(t))
             patch.step = t
-            ref_sp, ref_tm = ref_htm.process(x, learning=learning)
+            if epsilon is None:
+                ref_sp, ref_tm = ref_htm.process(x, learning=learning)
+            else:                                    # (HierarchicalTemporalMemory.process does not pass it on: the two layers by hand, networks.py:146-149)
+                ref_sp = ref_htm.spatial_pooler.process(x, learning=learning)
+                ref_tm = ref_htm.temporal_memory.process(ref_sp, learning=learning, epsilon=epsilon)
             ora_sp, ora_tm = ora.step(x, learning=learning)
             compare_step(t, ref_sp, ref_tm, ora_sp, ora_tm, cell_dim)
             if t % store_every == 0 or t == steps - 1:

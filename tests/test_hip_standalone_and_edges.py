@@ -105,6 +105,43 @@ def test_standalone_temporal_memory_matches_oracle_with_unsorted_columns():
     assert tm.flatten_cell((np.array([2, 3]), np.array([1, 5]))).tolist() == [2 * K + 1, 3 * K + 5]
 
 
+def test_temporal_memory_epsilon_matches_oracle():
+    """TemporalMemory.process(..., epsilon=) (networks.py:91): ties a third of a count wide -- several winner cells per
+    bursting column, several "best" segments per cell -- then back to the default, against the oracle (which the CPU
+    suite pins against the reference run with the same epsilon)."""
+    import bithtm_amd as B
+    from types import SimpleNamespace
+    C, K, k = 1024, 8, 24
+    tm = B.TemporalMemory(C, K, seed=9)
+    ora = TemporalMemoryOracle(C, K, seed=9)
+    rng = np.random.RandomState(10)
+    seqs = [np.sort(rng.choice(C, k, replace=False)) for _ in range(10)]
+    multi = 0
+    for t in range(160):
+        eps = 1e-8 if 100 <= t < 130 else 0.3
+        cols = seqs[t % 10] if rng.rand() > 0.1 else seqs[rng.randint(10)]
+        ora.eps = np.float32(eps)
+        got = tm.process(SimpleNamespace(active_column=cols), epsilon=eps)
+        want = ora.step(cols)
+        assert np.array_equal(got.cell_activation, want.cell_activation), t
+        assert np.array_equal(got.cell_prediction, want.cell_prediction), t
+        wm = np.zeros((C, K), dtype=bool)
+        wm[want.winner_cell] = True
+        rows, cells = np.where(wm[cols])
+        assert np.array_equal(got.winner_cell[0], cols[rows]) and np.array_equal(got.winner_cell[1], cells), t
+        multi += int((wm[cols].sum(axis=1) > 1).sum())
+        d, od = got.distal_state, want.distal_state
+        assert np.array_equal(d.matching_segment, od.matching_segment), t
+        assert np.array_equal(d.max_jittered_potential.view(np.int32), od.max_jittered_potential.view(np.int32)), t
+    assert multi > 50                                  # (the wide ties happened)
+    st = tm._engine.read_store()
+    a = canonical_synapses(st["seg_cell"], st["presyn"], st["perm"])
+    b = canonical_synapses(ora.seg_cell[:ora.S], ora.presyn[:ora.S], ora.perm[:ora.S])
+    assert len(a) == len(b) and all(x[0] == y[0] and np.array_equal(x[1], y[1]) and np.array_equal(x[2].view(np.int32), y[2].view(np.int32)) for x, y in zip(a, b))
+    with pytest.raises(NotImplementedError):
+        tm.process(SimpleNamespace(active_column=cols), epsilon=2.0)
+
+
 def test_sp_and_tm_objects_fuse_into_one_engine_and_compute_alias():
     import bithtm_amd as B
     np.random.seed(4)

@@ -23,6 +23,15 @@ def test_lockstep_small(ref):
     assert stats["segments"] > 1000
 
 
+def test_lockstep_with_a_wide_epsilon(ref):
+    """TemporalMemory.process(epsilon=0.3): best-matching and least-used ties a third of a count wide (several winner
+    cells per bursting column, several best segments per cell)."""
+    import refdiff
+    stats, _, _ = refdiff.run_lockstep(ref, seed=33, input_dim=160, column_dim=1024, cell_dim=8, patterns=20,
+                                       density=0.1, noise=0.02, steps=160, store_every=20, jump=0.1, epsilon=0.3)
+    assert stats["segments"] > 500
+
+
 def test_lockstep_learning_off_and_jumps(ref):
     import refdiff
     stats, _, _ = refdiff.run_lockstep(ref, seed=32, input_dim=160, column_dim=1024, cell_dim=16, patterns=30,
