@@ -69,6 +69,9 @@ struct Counters {
     int32_t n_win[2];         // winner cells of step parity p
     int32_t has_winner[2];    // winner list of parity p is valid (winner_cell is not None)
     int32_t has_distal;       // a scan has run (distal_state is not None)
+    uint32_t cm_dense_step;   // 1 + the step whose learning role clears ALL of the previous per-cell maxima, not just those of
+                              // the matching segments: set by a state import (the imported maxima need not belong to the
+                              // cells the imported matching segments belong to now)
     int32_t n_active_cells;
     // (by step parity: the scan of step t, which resets the counts for step t + 1, may share its launch with the
     // learning role of step t, which reads them)

@@ -1530,6 +1530,7 @@ extern "C" int htm_import_commit(htm_handle *h, int32_t segments, int32_t matchi
     c.n_win[q] = winner_cells;
     c.has_winner[q] = has_winner_cells ? 1 : 0;
     c.has_distal = has_distal_state ? 1 : 0;
+    c.cm_dense_step = (uint32_t)h->step_host + 1u;
     c.error = 0;
     HIPCHK(h, hipMemcpy(d.ctr, &c, sizeof(c), hipMemcpyHostToDevice));
     if (h->cfg.enable_tm) {

@@ -407,7 +407,9 @@ __device__ __forceinline__ void role_learn(const Dev &d, int p, int blk, int nbl
     {   // forget the previous scan's per-cell maxima (sparse clear; every reader ran in an earlier
         // launch) and reset what the coming scan accumulates
         const int n = c->has_distal ? (d.world > 1 ? c->L : c->S) : 0;
-        if (n <= 8 * nblk * BS) {                  // small pools: one row per thread (matching rows cluster in words)
+        if (c->cm_dense_step == c->step[p] + 1u) {  // the step after a state import: everything
+            for (int i = blk * BS + threadIdx.x; i < d.C * 32; i += nblk * BS) d.cellmax[p ^ 1][i] = 0u;
+        } else if (n <= 8 * nblk * BS) {           // small pools: one row per thread (matching rows cluster in words)
             for (int i = blk * BS + threadIdx.x; i < n; i += nblk * BS)
                 if ((d.match_bits[p ^ 1][i >> 5] >> (i & 31)) & 1u) d.cellmax[p ^ 1][d.seg_cell[i]] = 0u;
         } else {                                   // large pools: one 32-row word per thread, almost all of them zero

@@ -129,6 +129,34 @@ class Engine:
     def sync(self):
         self._check(self.lib.htm_sync(self.h), "htm_sync")
 
+    def import_prev_state(self, prediction, activation, winner_flat, distal):
+        """TemporalMemory.process(prev_state=X) (networks.py:92-93): X's fields become the handle's "previous step" --
+        cell predictions and activations (bool [C, K]), winner cells (flat ids, or None), the PredictiveProjection.State
+        (or None) -- while the segment store and the step index stay what they are."""
+        K = self.cell_dim
+        S = self.info().segments
+        self._check(self.lib.htm_import_begin(self.h, int(self.steps)), "htm_import_begin")
+        self.write(L.F_CELL_PREDICTION, bool_to_words(np.asarray(prediction).reshape(self.column_dim, K)), np.uint32)
+        self.write(L.F_CELL_ACTIVATION, bool_to_words(np.asarray(activation).reshape(self.column_dim, K)), np.uint32)
+        winners = np.zeros(0, np.int32) if winner_flat is None else np.asarray(winner_flat, dtype=np.int32)
+        self.write(L.F_WINNER_CELL, winners, np.int32)
+        M = 0
+        if distal is not None:
+            seg = np.asarray(distal.matching_segment, dtype=np.int32)
+            M = len(seg)
+            pot = np.zeros(S, dtype=np.int64)              # (the store may have grown since X: potentials of newer segments are not used)
+            old = np.asarray(distal.segment_potential, dtype=np.int64)[:S]
+            pot[:len(old)] = old
+            minfo = (pot[seg].astype(np.uint32) | (np.asarray(distal.matching_segment_activation).astype(np.uint32) << 12)
+                     | (np.asarray(distal.matching_segment_active).astype(np.uint32) << 31))
+            self.write(L.F_SEG_POTENTIAL, pot, np.int32)
+            self.write(L.F_MATCH_SEGMENT, seg, np.int32)
+            self.write(L.F_MATCH_INFO, minfo, np.uint32)
+            self.write(L.F_MATCH_JITTER, np.asarray(distal.matching_segment_jittered_potential, dtype=np.float32), np.float32)
+            self.write(L.F_CELL_MAX_JITTER, np.asarray(distal.max_jittered_potential, dtype=np.float32).view(np.uint32), np.uint32)
+        self._check(self.lib.htm_import_commit(self.h, int(S), int(M), len(winners), int(distal is not None), int(winner_flat is not None)),
+                    "htm_import_commit")
+
     def set_epsilon(self, epsilon):
         """TemporalMemory.process(epsilon=) (networks.py:91): 0 < epsilon <= 1, compared as float32; stays until set again."""
         self._check(self.lib.htm_set_epsilon(self.h, C.c_float(float(epsilon))), "htm_set_epsilon")

@@ -290,11 +290,15 @@ class TemporalMemory:
         return st
 
     def process(self, sp_state, prev_state=None, learning=True, return_winner_cell=True, epsilon=1e-8):
-        """networks.py:91-128.  `prev_state` may only be None or this object's `last_state`: the
-        previous step's state lives in device memory.  `epsilon` (the tolerance of the best-matching / least-used ties,
-        as float32): any value in (0, 1]."""
+        """networks.py:91-128.  `prev_state`: None / this object's `last_state` (the previous step's state lives in
+        device memory), or any State this object returned earlier -- its fields are then written back as the device's
+        previous step (a host round trip).  `epsilon` (the tolerance of the best-matching / least-used ties, as
+        float32): any value in (0, 1]."""
+        adopt = None
         if prev_state is not None and prev_state is not self.last_state:
-            raise NotImplementedError("prev_state other than last_state is not supported")
+            d = prev_state.distal_state                                     # (reading the fields materialises a lazy State)
+            adopt = (prev_state.cell_prediction, prev_state.cell_activation,
+                     None if prev_state.winner_cell is None else self.flatten_cell(prev_state.winner_cell), d)
         if not 0.0 < epsilon <= 1.0:
             raise NotImplementedError("epsilon must lie in (0, 1]")
         if self._fused:
@@ -312,6 +316,8 @@ class TemporalMemory:
         if getattr(eng, "_epsilon", 1e-8) != epsilon:
             eng.set_epsilon(epsilon)
             eng._epsilon = epsilon
+        if adopt is not None:
+            eng.import_prev_state(*adopt)
         eng.tm_step(active_column, learning=learning, return_winner_cell=return_winner_cell)
         return self._new_state(active_column)
 

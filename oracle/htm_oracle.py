@@ -372,9 +372,14 @@ class TemporalMemoryOracle:
             max_jittered_potential=cell_max, matching_segment_jittered_potential=jittered)
 
     # ---- one timestep
-    def step(self, active_column, learning=True, return_winner_cell=True):
-        """networks.py:91-128.  `active_column` must be sorted ascending (stable top-k)."""
+    def step(self, active_column, learning=True, return_winner_cell=True, prev_state=None):
+        """networks.py:91-128.  `active_column` must be sorted ascending (stable top-k).  `prev_state`: a state this
+        method returned earlier, to be used instead of the last one (networks.py:92-93)."""
         C, K = self.column_dim, self.cell_dim
+        if prev_state is not None:
+            self.prev_prediction, self.prev_activation = prev_state.cell_prediction, prev_state.cell_activation
+            self.prev_winner = None if prev_state.winner_cell is None else prev_state.winner_cell[0].astype(np.int64) * K + prev_state.winner_cell[1]
+            self.prev_distal = prev_state.distal_state
         active_column = np.asarray(active_column, dtype=np.int64)
         t = self.step_index
         predicted = self.prev_prediction[active_column]                       # :96

@@ -117,7 +117,7 @@ def pattern_index(t, patterns, jump, rng):
 
 def run_lockstep(ref, seed, input_dim, column_dim, cell_dim, patterns, density, noise, steps,
                  store_every=10, learning_schedule=None, record=None, sp_params=None, tm_params=None,
-                 jump=0.0, epsilon=None):
+                 jump=0.0, epsilon=None, prev_schedule=None):
     """Run both for `steps` timesteps; assert equality of every output each step.
 
     `record(t, x, ref_sp, ref_tm, ref_htm)` is called after every step if given.
@@ -128,17 +128,28 @@ def run_lockstep(ref, seed, input_dim, column_dim, cell_dim, patterns, density, 
         ora.temporal_memory.eps = np.float32(epsilon)
     bank, rng = make_inputs(seed + 1, patterns, input_dim, density)
     stats = dict(ambiguous_topk=0, steps=steps)
+    ref_hist, ora_hist = [ref_htm.temporal_memory.get_empty_state()], [None]      # states after step t - 1 (index t); [0] = the empty state
     with keyed_rand(seed, cell_dim) as patch:
         for t in range(steps):
             x = bank[pattern_index(t, patterns, jump, rng)] ^ (rng.rand(input_dim) < noise)
             learning = True if learning_schedule is None else bool(learning_schedule(t))
             patch.step = t
-            if epsilon is None:
+            back = None if prev_schedule is None else prev_schedule(t)     # TemporalMemory.process(prev_state=): the state of `back` steps ago
+            if epsilon is None and back is None:
                 ref_sp, ref_tm = ref_htm.process(x, learning=learning)
-            else:                                    # (HierarchicalTemporalMemory.process does not pass it on: the two layers by hand, networks.py:146-149)
+            else:                                    # (HierarchicalTemporalMemory.process passes neither on: the two layers by hand, networks.py:146-149)
                 ref_sp = ref_htm.spatial_pooler.process(x, learning=learning)
-                ref_tm = ref_htm.temporal_memory.process(ref_sp, learning=learning, epsilon=epsilon)
-            ora_sp, ora_tm = ora.step(x, learning=learning)
+                kw = {} if epsilon is None else dict(epsilon=epsilon)
+                if back is not None:
+                    kw["prev_state"] = ref_hist[max(len(ref_hist) - back, 1)]
+                ref_tm = ref_htm.temporal_memory.process(ref_sp, learning=learning, **kw)
+            if back is None:
+                ora_sp, ora_tm = ora.step(x, learning=learning)
+            else:
+                ora_sp = ora.spatial_pooler.step(x, learning=learning)
+                ora_tm = ora.temporal_memory.step(ora_sp.active_column, learning=learning, prev_state=ora_hist[max(len(ora_hist) - back, 1)])
+            ref_hist.append(ref_tm)
+            ora_hist.append(ora_tm)
             compare_step(t, ref_sp, ref_tm, ora_sp, ora_tm, cell_dim)
             if t % store_every == 0 or t == steps - 1:
                 compare_store(t, ref_htm, ora)

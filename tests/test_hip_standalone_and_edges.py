@@ -142,6 +142,45 @@ def test_temporal_memory_epsilon_matches_oracle():
         tm.process(SimpleNamespace(active_column=cols), epsilon=2.0)
 
 
+def test_temporal_memory_prev_state_matches_oracle():
+    """TemporalMemory.process(sp_state, prev_state=X) (networks.py:91-93) with X an earlier State of the same object,
+    or the empty state (a sequence reset): X's fields become the device's previous step.  Against the oracle, which the
+    CPU suite pins against the reference run with the same prev_state schedule."""
+    import bithtm_amd as B
+    from types import SimpleNamespace
+    C, K, k = 1024, 8, 24
+    tm = B.TemporalMemory(C, K, seed=11)
+    ora = TemporalMemoryOracle(C, K, seed=11)
+    rng = np.random.RandomState(12)
+    seqs = [np.sort(rng.choice(C, k, replace=False)) for _ in range(10)]
+    got_hist, want_hist = [], []
+    empty = SimpleNamespace(cell_prediction=np.zeros((C, K), bool), cell_activation=np.zeros((C, K), bool), winner_cell=None, distal_state=None)
+    for t in range(130):
+        cols = seqs[t % 10]
+        learning = t % 13 != 5
+        if t in (50, 90):
+            got = tm.process(SimpleNamespace(active_column=cols), prev_state=tm.get_empty_state(), learning=learning)
+            want = ora.step(cols, learning=learning, prev_state=empty)
+        elif t > 10 and t % 9 == 0:
+            got = tm.process(SimpleNamespace(active_column=cols), prev_state=got_hist[-3], learning=learning)
+            want = ora.step(cols, learning=learning, prev_state=want_hist[-3])
+        else:
+            got = tm.process(SimpleNamespace(active_column=cols), learning=learning)
+            want = ora.step(cols, learning=learning)
+        got_hist.append(got)
+        want_hist.append(want)
+        assert np.array_equal(got.cell_activation, want.cell_activation), t
+        assert np.array_equal(got.cell_prediction, want.cell_prediction), t
+        assert np.array_equal(got.active_column_bursting, want.active_column_bursting), t
+        d, od = got.distal_state, want.distal_state
+        assert np.array_equal(d.matching_segment, od.matching_segment), t
+        assert np.array_equal(d.max_jittered_potential.view(np.int32), od.max_jittered_potential.view(np.int32)), t
+    st = tm._engine.read_store()
+    a = canonical_synapses(st["seg_cell"], st["presyn"], st["perm"])
+    b = canonical_synapses(ora.seg_cell[:ora.S], ora.presyn[:ora.S], ora.perm[:ora.S])
+    assert len(a) == len(b) and all(x[0] == y[0] and np.array_equal(x[1], y[1]) and np.array_equal(x[2].view(np.int32), y[2].view(np.int32)) for x, y in zip(a, b))
+
+
 def test_sp_and_tm_objects_fuse_into_one_engine_and_compute_alias():
     import bithtm_amd as B
     np.random.seed(4)
@@ -210,7 +249,7 @@ def test_bad_arguments_fail_loudly():
     with pytest.raises(B.HtmError):
         tm.process(SimpleNamespace(active_column=np.array([1, 1, 2])))   # duplicate column
     with pytest.raises(NotImplementedError):
-        tm.process(SimpleNamespace(active_column=np.array([1, 2])), prev_state=tm.get_empty_state())
+        tm.process(SimpleNamespace(active_column=np.array([1, 2])), epsilon=0.0)     # (0, 1] only
 
 
 def test_batched_run_equals_step_by_step():

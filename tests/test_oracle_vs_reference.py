@@ -32,6 +32,15 @@ def test_lockstep_with_a_wide_epsilon(ref):
     assert stats["segments"] > 500
 
 
+def test_lockstep_with_earlier_states_as_prev_state(ref):
+    """TemporalMemory.process(prev_state=): every seventh step runs from the state of three steps earlier."""
+    import refdiff
+    stats, _, _ = refdiff.run_lockstep(ref, seed=34, input_dim=160, column_dim=1024, cell_dim=8, patterns=20,
+                                       density=0.1, noise=0.02, steps=150, store_every=15,
+                                       prev_schedule=lambda t: 3 if t > 10 and t % 7 == 0 else None)
+    assert stats["segments"] > 500
+
+
 def test_lockstep_learning_off_and_jumps(ref):
     import refdiff
     stats, _, _ = refdiff.run_lockstep(ref, seed=32, input_dim=160, column_dim=1024, cell_dim=16, patterns=30,
