@@ -152,6 +152,8 @@ struct Dev {
     float *seg_jit;           // [Scap] jittered potential of the matching segments
     uint32_t *work;           // [work_cap] segment | mode << 31 (0 = learn + grow, 1 = punish)
     int *recyc_cnt;           // [ceil(Scap/1024)] recyclable segments per 1024-segment block
+    int *recyc_cnt2;          // [ceil(Scap/2^20)] ... and per 1024 of those blocks: the allocation looks at these first (a pool of
+                              // 134 M segments has 130 k block counts, nearly all of them zero)
     int *recyc_need;          // [2*k*32] (block, first rank) pairs of the blocks add_output draws from
     // Column sharding (world > 1).  Segment ids are global (they key the random draws and order the recycling, and
     // must be what an unsharded run would assign), rows are local: a rank stores only the segments of its own
@@ -232,6 +234,12 @@ __device__ __forceinline__ int wave_append(int *counter, bool pred) {
     if (lane_id() == leader) base = atomicAdd(counter, __popcll(m));
     base = __shfl(base, leader);
     return pred ? base + __popcll(m & lanemask_lt()) : -1;
+}
+
+// recyclable-segment counts, both levels (blk1024 = id >> 10)
+__device__ __forceinline__ void recyc_add(const Dev &d, int blk1024, int delta) {
+    atomicAdd(&d.recyc_cnt[blk1024], delta);
+    atomicAdd(&d.recyc_cnt2[blk1024 >> 10], delta);
 }
 
 // h[digit] += 1 for every lane with `active`, one LDS atomic per distinct digit in the wave (keys

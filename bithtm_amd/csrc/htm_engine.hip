@@ -554,6 +554,7 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
         rc |= dalloc(h, &d.seg_jit, S);
         rc |= dalloc(h, &d.work, (size_t)d.work_cap);
         rc |= dalloc(h, &d.recyc_cnt, (G + 1023) / 1024);
+        rc |= dalloc(h, &d.recyc_cnt2, ((G + 1023) / 1024 + 1023) / 1024 + 1);
         rc |= dalloc(h, &d.recyc_need, 2 * k * 32);
         rc |= dalloc(h, &d.dead_list, (size_t)1 + DEAD_CAP);
         if (world > 1) {
@@ -1534,6 +1535,7 @@ extern "C" int htm_import_commit(htm_handle *h, int32_t segments, int32_t matchi
     c.error = 0;
     HIPCHK(h, hipMemcpy(d.ctr, &c, sizeof(c), hipMemcpyHostToDevice));
     if (h->cfg.enable_tm) {
+        HIPCHK(h, hipMemsetAsync(d.recyc_cnt2, 0, ((size_t)(h->s1024_blocks + 1023) / 1024 + 1) * sizeof(int), h->stream));
         hipLaunchKernelGGL(k_tm_recount, dim3(h->s1024_blocks), dim3(256), 0, h->stream, d);
         hipLaunchKernelGGL(k_tm_flag_connected, dim3(std::min(4096, std::max(1, (int)(((long long)segments * d.E + 255) / 256)))), dim3(256), 0, h->stream, d);
         HIPCHK(h, hipStreamSynchronize(h->stream));

@@ -1162,7 +1162,7 @@ __global__ __launch_bounds__(1024) void k_shard_select(Dev d, const unsigned cha
             const uint32_t *r_dead = (const uint32_t *)(recv + (size_t)r * rb + (size_t)KL * 20);
             const int gid = (int)r_dead[1 + e - s_dead[r]];
             const uint32_t old = atomicOr(&d.dead_bits[gid >> 5], 1u << (gid & 31));
-            if (!((old >> (gid & 31)) & 1u)) atomicAdd(&d.recyc_cnt[gid >> 10], 1);
+            if (!((old >> (gid & 31)) & 1u)) recyc_add(d, gid >> 10, 1);
         }
         if (tid == 0) d.dead_list[0] = 0;          // reported; the coming learning role collects this step's
     }

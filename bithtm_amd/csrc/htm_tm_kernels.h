@@ -58,8 +58,8 @@ __device__ __forceinline__ void shard_bind(const Dev &d, int p, int gid, int cel
     const int old_row = recycled ? d.g2l[gid] : -1;                 // >= 0: the id was mine
     if (pass == 0) {
         const bool alive = grown >= d.match_thr;
-        if (recycled && alive) { atomicAnd(&d.dead_bits[gid >> 5], ~(1u << (gid & 31))); atomicSub(&d.recyc_cnt[gid >> 10], 1); }
-        if (!recycled && !alive) { atomicOr(&d.dead_bits[gid >> 5], 1u << (gid & 31)); atomicAdd(&d.recyc_cnt[gid >> 10], 1); }
+        if (recycled && alive) { atomicAnd(&d.dead_bits[gid >> 5], ~(1u << (gid & 31))); recyc_add(d, gid >> 10, -1); }
+        if (!recycled && !alive) { atomicOr(&d.dead_bits[gid >> 5], 1u << (gid & 31)); recyc_add(d, gid >> 10, 1); }
         if (old_row >= 0) {
             atomicSub(&d.segcount[d.seg_cell[old_row]], 1);
             if (!to_me) {                                           // the id moves to another rank: free the row
@@ -290,18 +290,30 @@ __device__ __forceinline__ void role_mid(const Dev &d, int p, int n_active, int 
     }
     if (n_un == 0) return;
     uint32_t carry = 0;                       // recyclable segments seen so far
-    for (int base = 0; base < nb; base += BS) {
-        const int b = base + threadIdx.x;
-        const uint32_t v = base == 0 ? recyc_first : (b < nb ? (uint32_t)d.recyc_cnt[b] : 0u);
-        uint32_t total;
-        const uint32_t ex = block_excl_scan<BS>(v, s_wave, total);
-        if (v > 0 && carry + ex < (uint32_t)n_un) {
-            const int slot = atomicAdd(&s_nneed, 1);
-            d.recyc_need[2 * slot] = b;
-            d.recyc_need[2 * slot + 1] = (int)(carry + ex);
+    // the counts per 2^20 ids first (one load): ranges without a recyclable segment are passed over -- a pool of 134 M
+    // segments has 130 k per-1024 counts, and walking them 256 at a time took this block 0.3 ms per step
+    __shared__ int s_cnt2[256];
+    const int nb2 = (nb + 1023) >> 10;
+    for (int r0 = 0; r0 < nb2 && carry < (uint32_t)n_un; r0 += 256) {
+        __syncthreads();
+        s_cnt2[threadIdx.x & 255] = ((int)threadIdx.x < 256 && r0 + (int)threadIdx.x < nb2) ? d.recyc_cnt2[r0 + threadIdx.x] : 0;
+        __syncthreads();
+        for (int r = r0; r < min(r0 + 256, nb2) && carry < (uint32_t)n_un; ++r) {
+            if (s_cnt2[r - r0] == 0) continue;
+            for (int base = r << 10; base < min(nb, (r + 1) << 10); base += BS) {
+                const int b = base + threadIdx.x;
+                const uint32_t v = base == 0 ? recyc_first : ((b < nb && b < ((r + 1) << 10)) ? (uint32_t)d.recyc_cnt[b] : 0u);
+                uint32_t total;
+                const uint32_t ex = block_excl_scan<BS>(v, s_wave, total);
+                if (v > 0 && carry + ex < (uint32_t)n_un) {
+                    const int slot = atomicAdd(&s_nneed, 1);
+                    d.recyc_need[2 * slot] = b;
+                    d.recyc_need[2 * slot + 1] = (int)(carry + ex);
+                }
+                carry += total;
+                if (carry >= (uint32_t)n_un) break;
+            }
         }
-        carry += total;
-        if (carry >= (uint32_t)n_un) break;
     }
     __syncthreads();
     const int n_r = min(n_un, (int)carry);
@@ -342,7 +354,7 @@ __device__ __forceinline__ void role_mid(const Dev &d, int p, int n_active, int 
         }
         // the ids recycled out of this 1024-block leave its recyclable count if the learning role is going to grow
         // them past the matching threshold (known now: an empty row grows `grown` synapses) -- one update per block
-        if (whole && threadIdx.x == 0 && grown >= d.match_thr) atomicSub(&d.recyc_cnt[b], max(0, min((int)total, n_r - off)));
+        if (whole && threadIdx.x == 0 && grown >= d.match_thr) recyc_add(d, b, -max(0, min((int)total, n_r - off)));
     }
     if (whole) {
         // (the cells of eight bindings per thread first, clamped and unconditional, then their stores: with one load per
@@ -360,7 +372,7 @@ __device__ __forceinline__ void role_mid(const Dev &d, int p, int n_active, int 
         }
         if (n_new > 0 && grown < d.match_thr)      // fresh ids [S, S + n_new) that will stay below the matching threshold
             for (int b = (S >> 10) + (int)threadIdx.x; b <= (S + n_new - 1) >> 10; b += BS)
-                atomicAdd(&d.recyc_cnt[b], min(S + n_new, (b + 1) << 10) - max(S, b << 10));
+                recyc_add(d, b, min(S + n_new, (b + 1) << 10) - max(S, b << 10));
     } else {                                    // sharded: ids first, then rows given up, then rows taken
         __syncthreads();
         for (int pass = 0; pass < 2; ++pass) {
@@ -639,7 +651,7 @@ __device__ __forceinline__ void role_learn(const Dev &d, int p, int blk, int nbl
             // then; what becomes of a row bound this step every rank knew when it was bound (shard_bind).
             const bool was_dead = n < d.match_thr, is_dead = n_total < d.match_thr;
             if (d.world == 1) {
-                if (item < n_front && was_dead != is_dead) atomicAdd(&d.recyc_cnt[seg >> 10], is_dead ? 1 : -1);   // (bound this step: settled at binding)
+                if (item < n_front && was_dead != is_dead) recyc_add(d, seg >> 10, is_dead ? 1 : -1);   // (bound this step: settled at binding)
             } else if (!was_dead && is_dead) {
                 const int slot = atomicAdd(&d.dead_list[0], 1);
                 if (slot < DEAD_CAP) d.dead_list[1 + slot] = (int)gid; else atomicOr(&c->error, 8);
@@ -1140,7 +1152,10 @@ __global__ __launch_bounds__(256) void k_tm_recount(Dev d) {
     }
     if (v) atomicAdd(&s_recyc, v);
     __syncthreads();
-    if (threadIdx.x == 0) d.recyc_cnt[b] = s_recyc;
+    if (threadIdx.x == 0) {                        // (the second level was zeroed before the launch)
+        d.recyc_cnt[b] = s_recyc;
+        if (s_recyc) atomicAdd(&d.recyc_cnt2[b >> 10], s_recyc);
+    }
 }
 
 #endif
