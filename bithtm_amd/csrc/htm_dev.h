@@ -207,6 +207,15 @@ __device__ __forceinline__ int group8_sum_first(int v) {
     return t;
 }
 
+// Sum over each aligned group of 8 lanes, in every lane of the group (quad_perm xor 1, xor 2, then row_half_mirror:
+// lane i of a row's half reads lane 7 - i, which is in the other quad)
+__device__ __forceinline__ int group8_sum_all(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false);
+    return v;
+}
+
 template <int BS>
 __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *s_wave, uint32_t &total) {
     const int lane = lane_id(), wv = threadIdx.x >> 6;

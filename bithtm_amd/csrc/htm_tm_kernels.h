@@ -813,9 +813,9 @@ __device__ __forceinline__ void chunk_finish(const uint32_t *__restrict__ act, c
 // four, then one by one) those blocks took 9 us against the others' 5.
 struct ChunkHitsAll { uint32_t m; uint32_t aw[2]; };
 
-template <bool use_lds, int NOW>
-__device__ __forceinline__ ChunkHitsAll chunk_issue_all(const uint32_t *__restrict__ act, const uint32_t *s_colbits, const uint32_t (&e)[8],
-                                                        int first, int l, const int (&n)[2]) {
+// which of a lane's eight slots (four of each of its two rows) lie in active columns (all valid ones without the bitmap)
+template <bool use_lds>
+__device__ __forceinline__ uint32_t chunk_mask_all(const uint32_t *s_colbits, const uint32_t (&e)[8], int first, int l, const int (&n)[2]) {
     uint32_t m = 0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -831,6 +831,11 @@ __device__ __forceinline__ ChunkHitsAll chunk_issue_all(const uint32_t *__restri
         const int nv = min(max(n[u] - first - l * 4, 0), 4);
         m &= ~(((0xFu << nv) & 0xFu) << (4 * u));
     }
+    return m;
+}
+
+template <int NOW>
+__device__ __forceinline__ ChunkHitsAll chunk_read_all(const uint32_t *__restrict__ act, const uint32_t (&e)[8], uint32_t m) {
     ChunkHitsAll h;
     h.m = m;
     uint32_t mm = m;
@@ -841,6 +846,12 @@ __device__ __forceinline__ ChunkHitsAll chunk_issue_all(const uint32_t *__restri
         mm &= mm - 1;
     }
     return h;
+}
+
+template <bool use_lds, int NOW>
+__device__ __forceinline__ ChunkHitsAll chunk_issue_all(const uint32_t *__restrict__ act, const uint32_t *s_colbits, const uint32_t (&e)[8],
+                                                        int first, int l, const int (&n)[2]) {
+    return chunk_read_all<NOW>(act, e, chunk_mask_all<use_lds>(s_colbits, e, first, l, n));
 }
 
 // NOW = what chunk_issue_all has read; the rest is read here, three hits per pass (all three reads before any is used)
@@ -946,6 +957,23 @@ __device__ __forceinline__ void role_scan(const Dev &d, int p, int blk, int nblk
             n[u] = (ok && !(cur.n[u] & (int)SEG_BUSY)) ? cur.n[u] : 0;       // (a row the learning role is rewriting is its to scan)
             seg[u] = ok ? cur.seg[u] : S;
         }
+        uint32_t acc[U] = {0u, 0u};                  // this lane's share of potential (:247) | connected-active count << 16 (:171-172)
+        const uint32_t e1[8] = {(uint32_t)cur.ps[0].x, (uint32_t)cur.ps[0].y, (uint32_t)cur.ps[0].z, (uint32_t)cur.ps[0].w,
+                                (uint32_t)cur.ps[1].x, (uint32_t)cur.ps[1].y, (uint32_t)cur.ps[1].z, (uint32_t)cur.ps[1].w};
+        // Small pools: a row's later chunks are read only if it can still match -- its synapses in active columns among
+        // the first 32 (known from the bitmap in LDS, before any cell word is read) plus all of its later synapses must
+        // reach the matching threshold (:247).  A row that cannot is counted from its first chunk alone: its potential
+        // stays below the threshold either way, and nothing else of it is published.  35 % of the rows are longer than
+        // a chunk and four in five of those are of patterns that are not showing: their second lines were a fifth of
+        // the launch's traffic.
+        uint32_t m1 = 0;
+        if (!LARGE) {
+            m1 = chunk_mask_all<use_lds>(s_colbits, e1, 0, l, n);
+            const int hits = group8_sum_all((int)(__popc(m1 & 0xFu) | (__popc(m1 >> 4) << 8)));
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (n[u] > 32 && ((hits >> (8 * u)) & 0xFF) + n[u] - 32 < d.match_thr) n[u] = 32;
+        }
         // round trip 2 (only rows longer than one chunk): second chunk, in flight during the lookups of the first
         int4 ps2[U];
 #pragma unroll
@@ -954,13 +982,10 @@ __device__ __forceinline__ void role_scan(const Dev &d, int p, int blk, int nblk
             if (n[u] > 32) ps2[u] = *(const int4 *)(d.presyn + (size_t)seg[u] * d.E + 32 + l * 4);
         }
         SCAN_STAMP(2);                               // (synapse counts are here)
-        uint32_t acc[U] = {0u, 0u};                  // this lane's share of potential (:247) | connected-active count << 16 (:171-172)
-        const uint32_t e1[8] = {(uint32_t)cur.ps[0].x, (uint32_t)cur.ps[0].y, (uint32_t)cur.ps[0].z, (uint32_t)cur.ps[0].w,
-                                (uint32_t)cur.ps[1].x, (uint32_t)cur.ps[1].y, (uint32_t)cur.ps[1].z, (uint32_t)cur.ps[1].w};
         ChunkHits h1;
         ChunkHitsAll g1;
         if (LARGE) h1 = chunk_issue<use_lds>(act, s_colbits, e1, 0, l, n);
-        else g1 = chunk_issue_all<use_lds, 2>(act, s_colbits, e1, 0, l, n);
+        else g1 = chunk_read_all<2>(act, e1, m1);
         // large pools: the next iteration's rows are requested now, behind this iteration's cell-word reads (loads
         // return in issue order: requested earlier they would be waited for with those reads)
         const int b_next = b + gstride;
@@ -969,7 +994,7 @@ __device__ __forceinline__ void role_scan(const Dev &d, int p, int blk, int nblk
         // would make the compiler wait for them with everything else)
         Batch nxt = cur;
         if (LARGE) nxt = fetch(b_next);
-        const bool any_long = __any(n[0] > 32 || n[1] > 32);         // (most waves have a row that long: 35 % of the rows are)
+        const bool any_long = __any(n[0] > 32 || n[1] > 32);         // (a row that long which can still match: few waves have one)
         const uint32_t e2[8] = {(uint32_t)ps2[0].x, (uint32_t)ps2[0].y, (uint32_t)ps2[0].z, (uint32_t)ps2[0].w,
                                 (uint32_t)ps2[1].x, (uint32_t)ps2[1].y, (uint32_t)ps2[1].z, (uint32_t)ps2[1].w};
         if (!LARGE) {
