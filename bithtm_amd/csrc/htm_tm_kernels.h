@@ -713,10 +713,11 @@ __device__ __forceinline__ uint32_t select8(const uint32_t (&e)[8], int j) {
     return (j & 4) ? u1 : u0;
 }
 
+// bit i: slot i of this lane (four of each of its two rows) is valid and its column is active (all valid ones without the
+// bitmap); rows are packed: slots [0, n) are the valid ones
 template <bool use_lds>
-__device__ __forceinline__ ChunkHits chunk_issue(const uint32_t *__restrict__ act, const uint32_t *s_colbits, const uint32_t (&e)[8],
-                                                 int first, int l, const int (&n)[2]) {
-    uint32_t m = 0;                                  // bit i: slot i of this lane is valid and its column is active
+__device__ __forceinline__ uint32_t chunk_mask_all(const uint32_t *s_colbits, const uint32_t (&e)[8], int first, int l, const int (&n)[2]) {
+    uint32_t m = 0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         uint32_t on = 1u;
@@ -727,10 +728,14 @@ __device__ __forceinline__ ChunkHits chunk_issue(const uint32_t *__restrict__ ac
         m |= on << i;
     }
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {                    // rows are packed: slots [0, n) are the valid ones
+    for (int u = 0; u < 2; ++u) {
         const int nv = min(max(n[u] - first - l * 4, 0), 4);
         m &= ~(((0xFu << nv) & 0xFu) << (4 * u));
     }
+    return m;
+}
+
+__device__ __forceinline__ ChunkHits chunk_read(const uint32_t *__restrict__ act, const uint32_t (&e)[8], uint32_t m) {
     ChunkHits h;
     h.j1 = __ffs(m) - 1;                             // (-1 in lanes without a hit)
     const uint32_t m1 = m & (m - 1);
@@ -741,6 +746,12 @@ __device__ __forceinline__ ChunkHits chunk_issue(const uint32_t *__restrict__ ac
     h.aw1 = act[(h.e1 & SYN_CELL) >> 5];
     h.aw2 = act[(h.e2 & SYN_CELL) >> 5];
     return h;
+}
+
+template <bool use_lds>
+__device__ __forceinline__ ChunkHits chunk_issue(const uint32_t *__restrict__ act, const uint32_t *s_colbits, const uint32_t (&e)[8],
+                                                 int first, int l, const int (&n)[2]) {
+    return chunk_read(act, e, chunk_mask_all<use_lds>(s_colbits, e, first, l, n));
 }
 
 template <bool BATCH>
@@ -812,27 +823,6 @@ __device__ __forceinline__ void chunk_finish(const uint32_t *__restrict__ act, c
 // segment is active, so the lanes of two matching neighbours have eight hits each; read in dependent passes (two, then
 // four, then one by one) those blocks took 9 us against the others' 5.
 struct ChunkHitsAll { uint32_t m; uint32_t aw[2]; };
-
-// which of a lane's eight slots (four of each of its two rows) lie in active columns (all valid ones without the bitmap)
-template <bool use_lds>
-__device__ __forceinline__ uint32_t chunk_mask_all(const uint32_t *s_colbits, const uint32_t (&e)[8], int first, int l, const int (&n)[2]) {
-    uint32_t m = 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        uint32_t on = 1u;
-        if (use_lds) {
-            const uint32_t w = s_colbits[(e[i] & SYN_CELL) >> 10];
-            on = (w >> ((e[i] >> 5) & 31)) & 1u;
-        }
-        m |= on << i;
-    }
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int nv = min(max(n[u] - first - l * 4, 0), 4);
-        m &= ~(((0xFu << nv) & 0xFu) << (4 * u));
-    }
-    return m;
-}
 
 template <int NOW>
 __device__ __forceinline__ ChunkHitsAll chunk_read_all(const uint32_t *__restrict__ act, const uint32_t (&e)[8], uint32_t m) {
@@ -960,15 +950,14 @@ __device__ __forceinline__ void role_scan(const Dev &d, int p, int blk, int nblk
         uint32_t acc[U] = {0u, 0u};                  // this lane's share of potential (:247) | connected-active count << 16 (:171-172)
         const uint32_t e1[8] = {(uint32_t)cur.ps[0].x, (uint32_t)cur.ps[0].y, (uint32_t)cur.ps[0].z, (uint32_t)cur.ps[0].w,
                                 (uint32_t)cur.ps[1].x, (uint32_t)cur.ps[1].y, (uint32_t)cur.ps[1].z, (uint32_t)cur.ps[1].w};
-        // Small pools: a row's later chunks are read only if it can still match -- its synapses in active columns among
+        // A row's later chunks are read only if it can still match -- its synapses in active columns among
         // the first 32 (known from the bitmap in LDS, before any cell word is read) plus all of its later synapses must
         // reach the matching threshold (:247).  A row that cannot is counted from its first chunk alone: its potential
         // stays below the threshold either way, and nothing else of it is published.  35 % of the rows are longer than
         // a chunk and four in five of those are of patterns that are not showing: their second lines were a fifth of
         // the launch's traffic.
-        uint32_t m1 = 0;
-        if (!LARGE) {
-            m1 = chunk_mask_all<use_lds>(s_colbits, e1, 0, l, n);
+        const uint32_t m1 = chunk_mask_all<use_lds>(s_colbits, e1, 0, l, n);
+        if (use_lds) {
             const int hits = group8_sum_all((int)(__popc(m1 & 0xFu) | (__popc(m1 >> 4) << 8)));
 #pragma unroll
             for (int u = 0; u < U; ++u)
@@ -984,7 +973,7 @@ __device__ __forceinline__ void role_scan(const Dev &d, int p, int blk, int nblk
         SCAN_STAMP(2);                               // (synapse counts are here)
         ChunkHits h1;
         ChunkHitsAll g1;
-        if (LARGE) h1 = chunk_issue<use_lds>(act, s_colbits, e1, 0, l, n);
+        if (LARGE) h1 = chunk_read(act, e1, m1);
         else g1 = chunk_read_all<2>(act, e1, m1);
         // large pools: the next iteration's rows are requested now, behind this iteration's cell-word reads (loads
         // return in issue order: requested earlier they would be waited for with those reads)
