@@ -950,18 +950,22 @@ __device__ __forceinline__ void role_scan(const Dev &d, int p, int blk, int nblk
         uint32_t acc[U] = {0u, 0u};                  // this lane's share of potential (:247) | connected-active count << 16 (:171-172)
         const uint32_t e1[8] = {(uint32_t)cur.ps[0].x, (uint32_t)cur.ps[0].y, (uint32_t)cur.ps[0].z, (uint32_t)cur.ps[0].w,
                                 (uint32_t)cur.ps[1].x, (uint32_t)cur.ps[1].y, (uint32_t)cur.ps[1].z, (uint32_t)cur.ps[1].w};
-        // A row's later chunks are read only if it can still match -- its synapses in active columns among
-        // the first 32 (known from the bitmap in LDS, before any cell word is read) plus all of its later synapses must
-        // reach the matching threshold (:247).  A row that cannot is counted from its first chunk alone: its potential
-        // stays below the threshold either way, and nothing else of it is published.  35 % of the rows are longer than
-        // a chunk and four in five of those are of patterns that are not showing: their second lines were a fifth of
+        // A row is looked up in the cell words only if it can match at all, and its later chunks are read only then:
+        // its synapses in ACTIVE COLUMNS among the first 32 (known from the bitmap in LDS, before any cell word is read)
+        // plus all of its later synapses must reach the matching threshold (:247).  A row that cannot has a potential
+        // below the threshold whatever its cells do, and nothing else of it is published: its hits are dropped from the
+        // mask.  All but the rows of the patterns that are showing go that way -- their divergent cell-word reads
+        // were most of a wave's instructions, and the second lines of the 35 % of rows longer than a chunk a fifth of
         // the launch's traffic.
-        const uint32_t m1 = chunk_mask_all<use_lds>(s_colbits, e1, 0, l, n);
+        uint32_t m1 = chunk_mask_all<use_lds>(s_colbits, e1, 0, l, n);
         if (use_lds) {
             const int hits = group8_sum_all((int)(__popc(m1 & 0xFu) | (__popc(m1 >> 4) << 8)));
 #pragma unroll
             for (int u = 0; u < U; ++u)
-                if (n[u] > 32 && ((hits >> (8 * u)) & 0xFF) + n[u] - 32 < d.match_thr) n[u] = 32;
+                if (((hits >> (8 * u)) & 0xFF) + max(n[u] - 32, 0) < d.match_thr) {
+                    n[u] = min(n[u], 32);
+                    m1 &= ~(0xFu << (4 * u));
+                }
         }
         // round trip 2 (only rows longer than one chunk): second chunk, in flight during the lookups of the first
         int4 ps2[U];
@@ -973,8 +977,10 @@ __device__ __forceinline__ void role_scan(const Dev &d, int p, int blk, int nblk
         SCAN_STAMP(2);                               // (synapse counts are here)
         ChunkHits h1;
         ChunkHitsAll g1;
+        const bool any_hit = __any(m1 != 0);
+        g1.m = 0; g1.aw[0] = g1.aw[1] = 0;
         if (LARGE) h1 = chunk_read(act, e1, m1);
-        else g1 = chunk_read_all<2>(act, e1, m1);
+        else if (any_hit) g1 = chunk_read_all<2>(act, e1, m1);
         // large pools: the next iteration's rows are requested now, behind this iteration's cell-word reads (loads
         // return in issue order: requested earlier they would be waited for with those reads)
         const int b_next = b + gstride;
@@ -991,7 +997,7 @@ __device__ __forceinline__ void role_scan(const Dev &d, int p, int blk, int nblk
             // (its rows were requested before the first chunk's lookups): one round trip less on the blocks' chain
             ChunkHitsAll g2 = g1;
             if (any_long) g2 = chunk_issue_all<use_lds, 2>(act, s_colbits, e2, 32, l, n);
-            chunk_finish_all<2>(act, e1, g1, acc);
+            if (any_hit) chunk_finish_all<2>(act, e1, g1, acc);      // (most waves have no row that can match)
             if (any_long) chunk_finish_all<2>(act, e2, g2, acc);
         } else {
             chunk_finish<false>(act, e1, h1, acc);
