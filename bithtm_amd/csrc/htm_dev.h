@@ -135,6 +135,8 @@ struct Dev {
     uint8_t *bursting;        // [k]
     uint32_t *winw_idx;       // [k] winner word of the idx-th active column (same as win[active_cols[idx]])
     uint8_t *actcnt;          // [k] popc(active word) of the idx-th active column
+    uint32_t *act_list;       // [k] active word of the idx-th active column (same as act[p][active_cols[p][idx]])
+    uint16_t *col_rank[2];    // [colwords] active columns below each 32-column word of colbits[p] (written by the select's finish)
     uint32_t *unacc_word;     // [k]
     int *unacc_list;          // [k*32] winners without a matching segment, ascending
     int *seg_cell;            // [Scap] owning cell (enc)

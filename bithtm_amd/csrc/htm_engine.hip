@@ -178,6 +178,11 @@ static int prof_slot(htm_handle *h, const char *name) {
 static size_t learn_lds(int epl, int bs = RB) { return (size_t)(bs / 64) * CAND_CAP * 8 + (size_t)(bs / 64) * epl * 64 * 4 + (size_t)WIN_LDS * 4; }
 static int learn_epl(const Dev &d) { const int e = d.E / 64; return e <= 1 ? 1 : e == 2 ? 2 : e <= 4 ? 4 : 8; }
 static size_t scan_lds(const Dev &d, int use_lds) { return 16 + (use_lds ? (size_t)d.colwords * 4 : 0); }
+// ... with the rank of every bitmap word and the active words of the step's active columns behind the bitmap (the
+// three-launch schedule's scan looks the cells of active columns up in LDS: role_scan, TAB)
+static size_t scan_lds_tab(const Dev &d) {
+    return 16 + (size_t)((d.colwords + 3) & ~3) * 4 + (size_t)((d.colwords * 2 + 15) / 16) * 16 + (size_t)((d.k + 8 + 3) / 4) * 16;
+}
 static const int kClassifyBlocks = 384;           // x 256 segments per pass of the learn / punish classification
 static const int kLearnBlocks = 256;               // x RB/64 waves: one wave per learning / punished segment
 
@@ -288,7 +293,7 @@ static bool can_pipeline(const htm_handle *h) {
 // the three-launch schedule (htm_pipeline.h): the scan's LDS bitmap, one select histogram, the learning role and the
 // scan in one launch.  BITHTM_LEAN=0: the four-launch schedule below.
 static bool can_lean(const htm_handle *h) {
-    return h->knob_lean && can_pipeline(h) && scan_lds(h->d, 1) <= 64 * 1024 && h->emit_fits_lean;
+    return h->knob_lean && can_pipeline(h) && scan_lds_tab(h->d) <= 64 * 1024 && h->d.k < 65536 && h->emit_fits_lean;
 }
 
 // sp_done: the winner list of this step exists (the previous step's last launch, or the cold start).  next_sp: select
@@ -301,10 +306,10 @@ static void enqueue_lean(htm_handle *h, int p, int learning, const uint32_t *ban
     LAUNCH_ON(h, h->stream, (size_t)SEL_BINS * 4, "tm_mid+sp_overlap", k_mid_overlap, 1 + n_cls + n_ov + h->zero_blocks, 256, d, p, d.k, 1, learning, n_cls,
               bank, n_inputs, h->G, n_ov);
     const int epl = learn_epl(d), n_emit = plan.next_sp ? h->c256_blocks : 0, spec = scan_spec_blocks(h);
-    const size_t lds = std::max(std::max(learn_lds(epl, 256), scan_lds(d, 1)), sizeof(EmitShared));
+    const size_t lds = std::max(std::max(learn_lds(epl, 256), scan_lds_tab(d)), sizeof(EmitShared));
     const int n_learn = h->lean_learn_blocks, n_scan = h->lean_scan_blocks;
     const int grid = n_emit + n_learn + n_scan;
-#define LAUNCH_LSE(EPL_, MINW_) LAUNCH_ON(h, h->stream, lds, "tm_learn+tm_scan+sp_emit", (k_learn_scan_emit<EPL_, MINW_>), grid, 256, d, p, n_emit, n_learn, n_scan, spec)
+#define LAUNCH_LSE(EPL_, MINW_) LAUNCH_ON(h, h->stream, lds, "tm_learn+tm_scan+sp_emit", (k_learn_scan_emit<EPL_, MINW_, (MINW_ >= 6)>), grid, 256, d, p, n_emit, n_learn, n_scan, spec)
     if (scan_pool_is_large(h)) {
         switch (epl) { case 1: LAUNCH_LSE(1, 4); break; case 2: LAUNCH_LSE(2, 4); break; case 4: LAUNCH_LSE(4, 4); break; default: LAUNCH_LSE(8, 4); break; }
     } else {
@@ -539,6 +544,9 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
         rc |= dalloc(h, &d.bursting, k);
         rc |= dalloc(h, &d.winw_idx, k + 8);
         rc |= dalloc(h, &d.actcnt, k + 8);
+        rc |= dalloc(h, &d.act_list, k + 16);         // (staged into LDS in 16-byte units)
+        rc |= dalloc(h, &d.col_rank[0], colwords_padded);
+        rc |= dalloc(h, &d.col_rank[1], colwords_padded);
         rc |= dalloc(h, &d.unacc_word, k + 8);
         rc |= dalloc(h, &d.unacc_list, k * 32);
         rc |= dalloc(h, &d.seg_cell, S);
@@ -633,9 +641,9 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
                 h->emit_fits_open = h->emit_fits && c256 + (d.k * 32 + 255) / 256 <= std::min(1024, per_cu_open * cus);
                 // the three-launch schedule: the emit blocks come first in the grid of the learn + scan + emit kernel
                 int per_cu_lean = 0;
-                const size_t lean_lds = std::max(std::max(learn_lds(learn_epl(d), 256), scan_lds(d, 1)), sizeof(EmitShared));
-                const void *kern = learn_epl(d) == 1 ? (const void *)k_learn_scan_emit<1, 6> : learn_epl(d) == 2 ? (const void *)k_learn_scan_emit<2, 6>
-                                 : learn_epl(d) == 4 ? (const void *)k_learn_scan_emit<4, 6> : (const void *)k_learn_scan_emit<8, 6>;
+                const size_t lean_lds = std::max(std::max(learn_lds(learn_epl(d), 256), scan_lds_tab(d)), sizeof(EmitShared));
+                const void *kern = learn_epl(d) == 1 ? (const void *)k_learn_scan_emit<1, 6, true> : learn_epl(d) == 2 ? (const void *)k_learn_scan_emit<2, 6, true>
+                                 : learn_epl(d) == 4 ? (const void *)k_learn_scan_emit<4, 6, true> : (const void *)k_learn_scan_emit<8, 6, true>;
                 h->emit_fits_lean = cfg->enable_tm && h->emit_fits && lean_lds <= 64 * 1024 &&
                                     hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_lean, kern, 256, lean_lds) == hipSuccess &&
                                     c256 <= std::min(1024, per_cu_lean * cus);

@@ -194,7 +194,10 @@ __global__ __launch_bounds__(256) void k_mid_overlap(Dev d, int p, int n_active,
 
 // the emit blocks wait for each other's records: they come first in the grid (all resident whatever the others do);
 // then the learning role, whose items are the longest chains; then the scan
-template <int EPL, int MINW>
+// TAB: the scan looks active cells up in the LDS tables of the step's select finish and activation (role_scan) -- the
+// three-launch schedule, whose every step has them; the launch without emit blocks (enqueue_tm: stand-alone Temporal
+// Memory, shards) reads the cell words from memory
+template <int EPL, int MINW, bool TAB = false>
 __global__ __launch_bounds__(256, MINW) void k_learn_scan_emit(Dev d, int p, int n_emit_blocks, int n_learn_blocks, int n_scan_blocks, int n_spec) {
     TraceScope ts(d, 2 + 4 * p);
     int b = blockIdx.x;
@@ -208,7 +211,7 @@ __global__ __launch_bounds__(256, MINW) void k_learn_scan_emit(Dev d, int p, int
         return;
     }
     b -= n_learn_blocks;
-    role_scan<256, true, MINW < 6>(d, p, b, n_scan_blocks, n_spec, (uint32_t *)dyn_lds);      // (MINW < 6: the large-pool form)
+    role_scan<256, true, MINW < 6, TAB>(d, p, b, n_scan_blocks, n_spec, (uint32_t *)dyn_lds);      // (MINW < 6: the large-pool form)
 }
 
 #endif

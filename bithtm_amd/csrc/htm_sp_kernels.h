@@ -283,6 +283,7 @@ __device__ __forceinline__ void tm_store_column(const Dev &d, int p, bool col_ok
         d.unacc_word[idx] = w.unacc;
         d.winw_idx[idx] = w.winner;
         d.actcnt[idx] = (uint8_t)__popc(w.act);
+        d.act_list[idx] = w.act;
     }
 }
 
@@ -736,6 +737,9 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
     if (d.act[0] && !local) {
         const u64 mcol = __ballot(sel_any);
         if (lane_id() == 0) *(u64 *)&d.colbits[p][(cbase + (tid & ~63)) >> 5] = mcol;
+        // winners below each 32-column word of that bitmap = the word's first position in the winner list
+        // (role_scan, TAB: the active word of an active column is act_list[rank of the column])
+        if ((tid & 31) == 0) d.col_rank[p][c >> 5] = (uint16_t)(g_run + min(e_run, r));
     }
     if (c < d.sel_hi) {
         const bool sel = sel_any;

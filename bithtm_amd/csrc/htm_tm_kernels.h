@@ -877,20 +877,53 @@ __device__ __forceinline__ void chunk_finish_all(const uint32_t *__restrict__ ac
     }
 }
 
+// The same out of LDS (three-launch schedule): the active word of an ACTIVE column is act_list[its position in the
+// ascending winner list], and that position is col_rank[bitmap word] + the set bits below the column's in the word --
+// both tables written by the step's select finish and activation, staged beside the bitmap.  Three LDS reads per
+// slot instead of a divergent global read of 4 bytes in 64 different lines per instruction: a group of matching
+// segments (nearly every synapse a hit, 16 per lane over two chunks) took 6-8 us that way, the tail of the launch.
+// Every slot of the lane is looked up (no hit-by-hit passes: the reads are cheap), slots outside m count nothing.
+struct ScanTabs { const uint32_t *colbits; const uint16_t *rank; const uint32_t *actw; };
+
+__device__ __forceinline__ void chunk_count_tab(const ScanTabs &tb, const uint32_t (&e)[8], uint32_t m, uint32_t (&acc)[2]) {
+    uint32_t aw[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const uint32_t col = (e[i] & SYN_CELL) >> 5, cw = col >> 5;
+        const uint32_t w = tb.colbits[cw];
+        const uint32_t rk = (uint32_t)tb.rank[cw] + (uint32_t)__popc(w & ((1u << (col & 31)) - 1u));
+        const uint32_t on = (m >> i) & 1u;                 // (a slot outside m may name any column: entry 0 is read for it,
+        aw[i] = tb.actw[on ? rk : 0u] & (0u - on);         //  no branch -- a guarded read is waited for slot by slot)
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const uint32_t a = (aw[i] >> (e[i] & 31)) & 1u;
+        acc[i >> 2] += a + ((a & (e[i] >> 31)) << 16);
+    }
+}
+
 // diagnostic build (-DBITHTM_SCAN_STAMPS, handle created under BITHTM_TRACE=1): device clock at the phases of the first
 // iteration of every wave of the first 2048 scan blocks, d.trace[(block * 4 + wave) * 8 + phase] (tools/scan_phases.py)
 #ifdef BITHTM_SCAN_STAMPS
-#define SCAN_STAMP(i) do { if (d.trace && blk < 2048 && BS == 256 && (threadIdx.x & 63) == 0 && first_iter) d.trace[(size_t)(blk * 4 + wave) * 8 + (i)] = wall_clock64(); } while (0)
+// (-DBITHTM_SCAN_STAMPS=2: the phases of the wave's LAST iteration instead, slot 1 = when that iteration began)
+#define SCAN_STAMP(i) do { if (d.trace && blk < 2048 && BS == 256 && (threadIdx.x & 63) == 0 && (BITHTM_SCAN_STAMPS == 2 ? !first_iter : first_iter)) d.trace[(size_t)(blk * 4 + wave) * 8 + (i)] = wall_clock64(); } while (0)
 #else
 #define SCAN_STAMP(i) do { } while (0)
 #endif
 
 // LDS: from word 4: column bitmap [colwords] (words 0..3 unused)
-template <int BS, bool use_lds, bool LARGE>
+// TAB (small pools under the LDS bitmap, three-launch schedule): + rank [colwords] u16, active words [k + 8]
+template <int BS, bool use_lds, bool LARGE, bool TAB = false>
 __device__ __forceinline__ void role_scan(const Dev &d, int p, int blk, int nblk, int n_spec, uint32_t *lds) {
     static_assert(BS % 64 == 0, "whole waves of 16 segments");
+    static_assert(!TAB || (use_lds && !LARGE), "the tables go with the LDS bitmap of the small-pool form");
     constexpr int U = 2;                           // segments in flight per lane group
     uint32_t *s_colbits = lds + 4;
+    const int rank_q = (d.colwords * 2 + 15) / 16, actw_q = (d.k + 8 + 3) / 4;      // 16-byte units of the two tables
+    uint16_t *s_rank = (uint16_t *)(s_colbits + ((d.colwords + 3) & ~3));
+    uint32_t *s_actw = (uint32_t *)s_rank + rank_q * 4;
+    const ScanTabs tabs{s_colbits, s_rank, s_actw};
+    (void)tabs;
     constexpr bool need_cell = !LARGE;
     Counters *c = d.ctr;
     const int S = d.world > 1 ? c->L : c->S;         // rows to scan (a shard scans its local rows; a free row is empty)
@@ -933,10 +966,18 @@ __device__ __forceinline__ void role_scan(const Dev &d, int p, int blk, int nblk
     if (!speculative && g_first * 16 >= S) return;
     bool first_iter = true;
     (void)first_iter;
+#ifdef BITHTM_SCAN_STAMPS
+    int n_iter = 1;
+#endif
     SCAN_STAMP(0);
     Batch cur = fetch(g_first);
     if (use_lds)                                     // the bitmap staging overlaps with those loads
         for (int i = threadIdx.x; i < d.colwords; i += BS) s_colbits[i] = d.colbits[p][i];
+    if (TAB) {                                       // (16 bytes per load, no guard: both arrays are allocated in whole units and zero beyond their end)
+        const uint4 *rk = (const uint4 *)d.col_rank[p], *aw = (const uint4 *)d.act_list;
+        for (int i = threadIdx.x; i < rank_q; i += BS) ((uint4 *)s_rank)[i] = rk[i];
+        for (int i = threadIdx.x; i < actw_q; i += BS) ((uint4 *)s_actw)[i] = aw[i];
+    }
     __syncthreads();                                 // the only barrier: from here on the waves share nothing
     SCAN_STAMP(1);
     for (int b = g_first; b * 16 < S; b += gstride) {    // b = the block's first group of this iteration
@@ -980,7 +1021,7 @@ __device__ __forceinline__ void role_scan(const Dev &d, int p, int blk, int nblk
         const bool any_hit = __any(m1 != 0);
         g1.m = 0; g1.aw[0] = g1.aw[1] = 0;
         if (LARGE) h1 = chunk_read(act, e1, m1);
-        else if (any_hit) g1 = chunk_read_all<2>(act, e1, m1);
+        else if (!TAB && any_hit) g1 = chunk_read_all<2>(act, e1, m1);
         // large pools: the next iteration's rows are requested now, behind this iteration's cell-word reads (loads
         // return in issue order: requested earlier they would be waited for with those reads)
         const int b_next = b + gstride;
@@ -992,7 +1033,10 @@ __device__ __forceinline__ void role_scan(const Dev &d, int p, int blk, int nblk
         const bool any_long = __any(n[0] > 32 || n[1] > 32);         // (a row that long which can still match: few waves have one)
         const uint32_t e2[8] = {(uint32_t)ps2[0].x, (uint32_t)ps2[0].y, (uint32_t)ps2[0].z, (uint32_t)ps2[0].w,
                                 (uint32_t)ps2[1].x, (uint32_t)ps2[1].y, (uint32_t)ps2[1].z, (uint32_t)ps2[1].w};
-        if (!LARGE) {
+        if (TAB) {
+            if (any_hit) chunk_count_tab(tabs, e1, m1, acc);
+            if (any_long) chunk_count_tab(tabs, e2, chunk_mask_all<use_lds>(s_colbits, e2, 32, l, n), acc);
+        } else if (!LARGE) {
             // small pools: the second chunk's first cell-word reads go out before the first chunk's are waited for
             // (its rows were requested before the first chunk's lookups): one round trip less on the blocks' chain
             ChunkHitsAll g2 = g1;
@@ -1022,9 +1066,14 @@ __device__ __forceinline__ void role_scan(const Dev &d, int p, int blk, int nblk
                                     (uint32_t)pa[1].x, (uint32_t)pa[1].y, (uint32_t)pa[1].z, (uint32_t)pa[1].w};
             ChunkHits ha;
             ChunkHitsAll ga;
-            if (LARGE) ha = chunk_issue<use_lds>(act, s_colbits, ea, c * 32, l, n);
+            if (TAB) chunk_count_tab(tabs, ea, chunk_mask_all<use_lds>(s_colbits, ea, c * 32, l, n), acc);
+            else if (LARGE) ha = chunk_issue<use_lds>(act, s_colbits, ea, c * 32, l, n);
             else ga = chunk_issue_all<use_lds, 2>(act, s_colbits, ea, c * 32, l, n);
-            if (!LARGE) {
+            if (TAB) {
+                const uint32_t eb[8] = {(uint32_t)pb[0].x, (uint32_t)pb[0].y, (uint32_t)pb[0].z, (uint32_t)pb[0].w,
+                                        (uint32_t)pb[1].x, (uint32_t)pb[1].y, (uint32_t)pb[1].z, (uint32_t)pb[1].w};
+                chunk_count_tab(tabs, eb, chunk_mask_all<use_lds>(s_colbits, eb, (c + 1) * 32, l, n), acc);
+            } else if (!LARGE) {
                 const uint32_t eb[8] = {(uint32_t)pb[0].x, (uint32_t)pb[0].y, (uint32_t)pb[0].z, (uint32_t)pb[0].w,
                                         (uint32_t)pb[1].x, (uint32_t)pb[1].y, (uint32_t)pb[1].z, (uint32_t)pb[1].w};
                 const ChunkHitsAll gb = chunk_issue_all<use_lds, 2>(act, s_colbits, eb, (c + 1) * 32, l, n);
@@ -1035,22 +1084,35 @@ __device__ __forceinline__ void role_scan(const Dev &d, int p, int blk, int nblk
             }
         }
         SCAN_STAMP(3);                               // (every synapse counted)
+        // What the publication reads from memory (global ids on a shard, owner cells in the large-pool form) is read,
+        // and everything computed from it, for both segments before either is published: behind the first segment's
+        // atomics and stores the wait for such a read is a wait for them as well (the compiler cannot tell them
+        // apart across the branches) -- a microsecond per matching segment pair, in the waves that have them.
         bool matching[U];
+        int pot[U], conn[U], cell_of[U];
+        float jit[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const uint32_t sum = (uint32_t)group8_sum_first((int)acc[u]);     // (valid in the segment's first lane only)
-            const int pot = (int)(sum & 0xFFFFu), conn = (int)(sum >> 16);
-            matching[u] = l == 0 && seg[u] < S && pot >= d.match_thr;                 // :247
-            if (matching[u]) {
-                const bool active = conn >= d.act_thr;                                // :250
-                const int cell = need_cell ? cell_cur[u] : d.seg_cell[seg[u]];
-                const float jit = htm_jitter((float)pot, htm_draw24(base3, (uint32_t)seg_gid_of(d, seg[u]), 0u));   // :234-235
-                atomicMax(&d.cellmax[p][cell], __float_as_uint(jit));                // :237
-                if (active) atomicOr(&d.pred[p][cell >> 5], 1u << (cell & 31));       // :251, networks.py:122
-                d.seg_info[seg[u]] = (uint32_t)pot | ((uint32_t)conn << 12) | 0x40000000u | (active ? 0x80000000u : 0u);
-                d.seg_jit[seg[u]] = jit;
-            }
+            pot[u] = (int)(sum & 0xFFFFu);
+            conn[u] = (int)(sum >> 16);
+            matching[u] = l == 0 && seg[u] < S && pot[u] >= d.match_thr;              // :247
+            const uint32_t gid = matching[u] ? (uint32_t)seg_gid_of(d, seg[u]) : 0u;
+            cell_of[u] = need_cell ? cell_cur[u] : (matching[u] ? d.seg_cell[seg[u]] : 0);
+            jit[u] = htm_jitter((float)pot[u], htm_draw24(base3, gid, 0u));           // :234-235
         }
+        // (the compiler would sink the arithmetic back under the branches, and the wait with it)
+        asm volatile("" : "+v"(jit[0]), "+v"(jit[1]), "+v"(cell_of[0]), "+v"(cell_of[1]) : : "memory");
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (matching[u]) {
+                const bool active = conn[u] >= d.act_thr;                             // :250
+                const int cell = cell_of[u];
+                atomicMax(&d.cellmax[p][cell], __float_as_uint(jit[u]));             // :237
+                if (active) atomicOr(&d.pred[p][cell >> 5], 1u << (cell & 31));       // :251, networks.py:122
+                d.seg_info[seg[u]] = (uint32_t)pot[u] | ((uint32_t)conn[u] << 12) | 0x40000000u | (active ? 0x80000000u : 0u);
+                d.seg_jit[seg[u]] = jit[u];
+            }
         SCAN_STAMP(4);                               // (matching segments published)
         {   // the wave's 16 match bits: the ballots hold one bit per lane group at lane 8 * gi; a multiplication
             // gathers those eight bits into the top byte (all partial products fall on different bit positions)
@@ -1064,7 +1126,17 @@ __device__ __forceinline__ void role_scan(const Dev &d, int p, int blk, int nblk
         first_iter = false;
         if (b_next * 16 >= S) break;
         cur = LARGE ? nxt : fetch(b_next);
+#ifdef BITHTM_SCAN_STAMPS
+        ++n_iter;
+        SCAN_STAMP(1);
+#endif
     }
+#ifdef BITHTM_SCAN_STAMPS                            // when the wave left, and how many groups it took
+    if (d.trace && blk < 2048 && BS == 256 && (threadIdx.x & 63) == 0) {
+        d.trace[(size_t)(blk * 4 + wave) * 8 + 6] = wall_clock64();
+        d.trace[(size_t)(blk * 4 + wave) * 8 + 7] = (unsigned long long)n_iter;
+    }
+#endif
 }
 
 // use_lds is a compile-time switch: as a run-time flag it put a branch and a wait around every

@@ -26,7 +26,7 @@ def main():
     eng = htm.engine
     bank = eng.upload_bank(noisy)
     eng.run(bank, noisy.shape[0], 1500, learning=True)
-    eng.run(bank, noisy.shape[0], 33, learning=True, use_graph=True, pipeline=True)
+    eng.run(bank, noisy.shape[0], int(os.environ.get("SCAN_PHASES_STEPS", 33)), learning=True, use_graph=True, pipeline=True)
     eng.sync()
     t = eng.trace_read().reshape(-1)[: 2048 * 4 * 8].reshape(2048 * 4, 8).astype(np.float64) / 100.0
     S = eng.info().segments
@@ -53,6 +53,20 @@ def main():
         print(f"{label}: {int(sel.sum())}; wave time median {np.median(total[sel]):.2f} p95 {np.percentile(total[sel], 95):.2f} max {total[sel].max():.2f}")
         for i, nme in enumerate(names):
             print(f"    {nme:26s} median {np.median(ph[sel, i]):5.2f}  p95 {np.percentile(ph[sel, i], 95):5.2f}  max {ph[sel, i].max():5.2f}")
+    # the whole wave (all of its iterations): slot 6 = device clock when it left, slot 7 = groups it took
+    end, iters = t[:, 6] - t0, (t[:, 7] * 100.0).astype(int)
+    print(f"waves by groups taken: " + ", ".join(f"{k}: {int((iters == k).sum())} (left at median {np.median(end[iters == k]):.2f}, max {end[iters == k].max():.2f})" for k in sorted(set(iters.tolist()))))
+    last = np.argsort(end)[::-1][:12]
+    print("last waves to leave: group block wave matching(first group)  first iteration  groups taken  left at")
+    for wv in last:
+        print(f"  {wv:5d} {int(rows[wv]) // 4:5d} {int(rows[wv]) % 4:2d} {int(matching[wv]):3d}  {total[wv]:6.2f}  {iters[wv]:2d}  {end[wv]:6.2f}")
+    if os.environ.get("SCAN_PHASES_LAST") == "1":      # build with -DBITHTM_SCAN_STAMPS=2: slots 1..5 are of the last iteration
+        two = iters >= 2
+        ph2 = np.diff(t[:, 1:6], axis=1)
+        print("last iteration of the waves that took two groups: " + "  ".join(f"{n} {np.median(ph2[two, i]):.2f}/{ph2[two, i].max():.2f}" for i, n in enumerate(names[1:])))
+        for wv in last:
+            print(f"  group {wv:5d}: began {t[wv, 1] - t0:6.2f}  " + "  ".join(f"{x:6.2f}" for x in ph2[wv]))
+        return
     order = np.argsort(total)[::-1][:12]
     print("slowest waves: group block matching  start  " + "  ".join(n[:12] for n in names))
     for wv in order:

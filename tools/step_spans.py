@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Launch spans of many steady-state steps of the three-launch schedule (device clock, graph replay).
+
+tools/step_timeline.py shows two consecutive steps in detail; the trace holds no more than two.  This repeats the run
+with the traced pair moved along and prints, per step, the span of each launch and when the last block of each role
+of the third launch ended -- which role the launch waited for, and how often.
+
+    python tools/step_spans.py [pairs]
+"""
+import os
+import sys
+
+import numpy as np
+
+os.environ["BITHTM_TRACE"] = "1"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+
+WARMUP = 1500
+
+
+def main():
+    pairs = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+    w = dict(bench.WORKLOAD)
+    noisy, perm = bench.make_inputs(w)
+    c256, n_learn = (w["column_dim"] + 255) // 256, int(os.environ.get("BITHTM_LEAN_LEARN", 512))
+    rows = []
+    for u in range(pairs):
+        steps = 35 + 2 * u
+        os.environ["BITHTM_TRACE_UNTIL"] = str(WARMUP + steps - 2)
+        htm = bench.build_htm(w, perm, 0)
+        eng = htm.engine
+        bank = eng.upload_bank(noisy)
+        eng.run(bank, noisy.shape[0], WARMUP, learning=True)
+        eng.run(bank, noisy.shape[0], steps, learning=True, use_graph=True, pipeline=True)
+        eng.sync()
+        t = eng.trace_read()
+        for parity in (0, 1):
+            rec = {}
+            for launch in range(3):
+                tt = t[parity * 4 + launch]
+                blocks = np.nonzero(tt[:, 0] > 0)[0]
+                if not len(blocks):
+                    continue
+                first = tt[blocks, 0].min()
+                rec[launch] = (first, tt[blocks, 1].max())
+                if launch == 2:
+                    for lo, hi, name in ((0, c256, "emit"), (c256, c256 + n_learn, "learn"), (c256 + n_learn, 4096, "scan")):
+                        sel = blocks[(blocks >= lo) & (blocks < hi)]
+                        rec[name] = (tt[sel, 1].max() - first) / 100 if len(sel) else 0.0
+            if len(rec) >= 6:
+                rows.append((rec[0][0], [(rec[i][1] - rec[i][0]) / 100 for i in range(3)], rec["emit"], rec["learn"], rec["scan"]))
+        del htm, eng
+    print("launch spans (us): act_rows  mid_overlap  learn_scan_emit | last block of emit / learn / scan")
+    for _, sp, e, l, s in rows:
+        who = max((e, "emit"), (l, "learn"), (s, "scan"))[1]
+        print(f"  {sp[0]:6.2f} {sp[1]:6.2f} {sp[2]:6.2f} | {e:6.2f} {l:6.2f} {s:6.2f}  <- {who}")
+    a = np.array([r[1] for r in rows])
+    print(f"mean spans over {len(rows)} steps: {a[:, 0].mean():.2f} {a[:, 1].mean():.2f} {a[:, 2].mean():.2f} us; third launch: "
+          f"median {np.median(a[:, 2]):.2f}, above 11 us in {int((a[:, 2] > 11).sum())} steps")
+
+
+if __name__ == "__main__":
+    main()

@@ -15,7 +15,7 @@ import sys
 import numpy as np
 
 os.environ["BITHTM_TRACE"] = "1"
-WARMUP, STEPS = int(os.environ.get("TIMELINE_WARMUP", 1500)), 35      # (TIMELINE_WARMUP=0: the cold phase of a run from scratch)
+WARMUP, STEPS = int(os.environ.get("TIMELINE_WARMUP", 1500)), int(os.environ.get("TIMELINE_STEPS", 35))      # (TIMELINE_WARMUP=0: the cold phase of a run from scratch)
 os.environ["BITHTM_TRACE_UNTIL"] = str(WARMUP + STEPS - 2)      # the last two steps look ahead less: keep the steady state
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
