@@ -566,6 +566,8 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
         EMIT_STAMP(3);                               // (everybody's records read)
 #ifdef BITHTM_EMIT_STAMPS
         if (d.trace && wmode && tid == 0 && b < 1024) d.trace[(size_t)b * 8 + 7] = (unsigned long long)ne | ((unsigned long long)s_nraw << 32);
+        if (d.trace && wmode && b == 0 && ne > 160)      // the merged entries themselves, behind the emit blocks' rows
+            for (int e = tid; e < min(ne, 1024); e += 256) d.trace[(size_t)256 * 8 + e] = ((s_ek[e] & lowmask) >> d.low_zero) | ((unsigned long long)s_ec[e] << 32) | ((unsigned long long)s_eb[e] << 48);
 #endif
         if (!(s_flags & 1u) && ne <= CAND_MAX) {
             bool folded = false;

@@ -32,6 +32,12 @@ def main():
         t = raw[:, :6].astype(np.float64) / 100.0
         ne, nraw = raw[:, 7] & 0xFFFFFFFF, raw[:, 7] >> 32
         ph = np.diff(t, axis=1)
+        if int(ne.max()) > 160:
+            ent = eng.trace_read().reshape(-1)[256 * 8: 256 * 8 + int(ne.max())]
+            keys, cnt = ent & 0xFFFFFFFF, (ent >> 32) & 0xFFFF
+            uk = np.unique(keys)
+            print(f"    {len(uk)} distinct keys among {len(keys)} entries; (key bits above low_zero - smallest: weight, entries): "
+                  + " ".join(f"{int(k - uk[0])}:{int(cnt[keys == k].sum())},{int((keys == k).sum())}" for k in uk[::-1]))
         t0 = t[:, 0].min()
         print(f"step {step}: merged entries {int(ne.max())}, raw keys per block max {int(nraw.max())} mean {nraw.mean():.1f}; blocks end {(t[:, 5] - t0).min():.2f}..{(t[:, 5] - t0).max():.2f} us; "
               + "  ".join(f"{n} {np.median(ph[:, i]):.2f}/{ph[:, i].max():.2f}" for i, n in enumerate(names)))
