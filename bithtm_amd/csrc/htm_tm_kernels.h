@@ -1097,22 +1097,29 @@ __device__ __forceinline__ void role_scan(const Dev &d, int p, int blk, int nblk
             pot[u] = (int)(sum & 0xFFFFu);
             conn[u] = (int)(sum >> 16);
             matching[u] = l == 0 && seg[u] < S && pot[u] >= d.match_thr;              // :247
-            const uint32_t gid = matching[u] ? (uint32_t)seg_gid_of(d, seg[u]) : 0u;
-            cell_of[u] = need_cell ? cell_cur[u] : (matching[u] ? d.seg_cell[seg[u]] : 0);
-            jit[u] = htm_jitter((float)pot[u], htm_draw24(base3, gid, 0u));           // :234-235
+            jit[u] = 0.f;
+            cell_of[u] = 0;
         }
-        // (the compiler would sink the arithmetic back under the branches, and the wait with it)
-        asm volatile("" : "+v"(jit[0]), "+v"(jit[1]), "+v"(cell_of[0]), "+v"(cell_of[1]) : : "memory");
+        if (__any(matching[0] || matching[1])) {     // (few waves: the streaming forms must not pay for the arithmetic)
 #pragma unroll
-        for (int u = 0; u < U; ++u)
-            if (matching[u]) {
-                const bool active = conn[u] >= d.act_thr;                             // :250
-                const int cell = cell_of[u];
-                atomicMax(&d.cellmax[p][cell], __float_as_uint(jit[u]));             // :237
-                if (active) atomicOr(&d.pred[p][cell >> 5], 1u << (cell & 31));       // :251, networks.py:122
-                d.seg_info[seg[u]] = (uint32_t)pot[u] | ((uint32_t)conn[u] << 12) | 0x40000000u | (active ? 0x80000000u : 0u);
-                d.seg_jit[seg[u]] = jit[u];
+            for (int u = 0; u < U; ++u) {
+                const uint32_t gid = matching[u] ? (uint32_t)seg_gid_of(d, seg[u]) : 0u;
+                cell_of[u] = need_cell ? cell_cur[u] : (matching[u] ? d.seg_cell[seg[u]] : 0);
+                jit[u] = htm_jitter((float)pot[u], htm_draw24(base3, gid, 0u));       // :234-235
             }
+            // (the compiler would sink the arithmetic back under the branches, and the wait with it)
+            asm volatile("" : "+v"(jit[0]), "+v"(jit[1]), "+v"(cell_of[0]), "+v"(cell_of[1]) : : "memory");
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (matching[u]) {
+                    const bool active = conn[u] >= d.act_thr;                         // :250
+                    const int cell = cell_of[u];
+                    atomicMax(&d.cellmax[p][cell], __float_as_uint(jit[u]));         // :237
+                    if (active) atomicOr(&d.pred[p][cell >> 5], 1u << (cell & 31));   // :251, networks.py:122
+                    d.seg_info[seg[u]] = (uint32_t)pot[u] | ((uint32_t)conn[u] << 12) | 0x40000000u | (active ? 0x80000000u : 0u);
+                    d.seg_jit[seg[u]] = jit[u];
+                }
+        }
         SCAN_STAMP(4);                               // (matching segments published)
         {   // the wave's 16 match bits: the ballots hold one bit per lane group at lane 8 * gi; a multiplication
             // gathers those eight bits into the top byte (all partial products fall on different bit positions)
