@@ -11,6 +11,8 @@ cd $GRAFT_REPO_ROOT
 timeout -k 10 400 python bench.py > $OUT/bench.json 2> $OUT/bench.log; echo "bench exit=$?"
 timeout -k 10 300 python bench.py --steps 20 --warmup 5 --no-stress > $OUT/bench_driver_args.json 2> $OUT/bench_driver_args.log; echo "bench (driver args) exit=$?"
 timeout -k 10 200 python tools/step_timeline.py > $OUT/step_timeline.txt 2>&1
+timeout -k 10 300 python tools/step_spans.py 16 > $OUT/step_spans.txt 2>&1
+timeout -k 10 200 python tools/soak.py > $OUT/soak.txt 2>&1
 # the four-launch schedule, for comparison
 BITHTM_LEAN=0 timeout -k 10 300 python bench.py --no-cpu-baseline --no-stress > $OUT/bench_four_launches.json 2> $OUT/bench_four_launches.log; echo "bench (four launches) exit=$?"
 BITHTM_LEAN=0 timeout -k 10 200 python tools/step_timeline.py > $OUT/step_timeline_four_launches.txt 2>&1
