@@ -183,6 +183,9 @@ static size_t scan_lds(const Dev &d, int use_lds) { return 16 + (use_lds ? (size
 static size_t scan_lds_tab(const Dev &d) {
     return 16 + (size_t)((d.colwords + 3) & ~3) * 4 + (size_t)((d.colwords * 2 + 15) / 16) * 16 + (size_t)((d.k + 8 + 3) / 4) * 16;
 }
+// ... which needs them to fit (and the ranks 16 bits); otherwise the schedule's scan reads the cell words from memory
+static bool lean_tab(const Dev &d) { return scan_lds_tab(d) <= 64 * 1024 && d.k < 65536; }
+static size_t lean_scan_lds(const Dev &d) { return lean_tab(d) ? scan_lds_tab(d) : scan_lds(d, 1); }
 static const int kClassifyBlocks = 384;           // x 256 segments per pass of the learn / punish classification
 static const int kLearnBlocks = 256;               // x RB/64 waves: one wave per learning / punished segment
 
@@ -293,7 +296,7 @@ static bool can_pipeline(const htm_handle *h) {
 // the three-launch schedule (htm_pipeline.h): the scan's LDS bitmap, one select histogram, the learning role and the
 // scan in one launch.  BITHTM_LEAN=0: the four-launch schedule below.
 static bool can_lean(const htm_handle *h) {
-    return h->knob_lean && can_pipeline(h) && scan_lds_tab(h->d) <= 64 * 1024 && h->d.k < 65536 && h->emit_fits_lean;
+    return h->knob_lean && can_pipeline(h) && scan_lds(h->d, 1) <= 64 * 1024 && h->emit_fits_lean;
 }
 
 // sp_done: the winner list of this step exists (the previous step's last launch, or the cold start).  next_sp: select
@@ -306,14 +309,16 @@ static void enqueue_lean(htm_handle *h, int p, int learning, const uint32_t *ban
     LAUNCH_ON(h, h->stream, (size_t)SEL_BINS * 4, "tm_mid+sp_overlap", k_mid_overlap, 1 + n_cls + n_ov + h->zero_blocks, 256, d, p, d.k, 1, learning, n_cls,
               bank, n_inputs, h->G, n_ov);
     const int epl = learn_epl(d), n_emit = plan.next_sp ? h->c256_blocks : 0, spec = scan_spec_blocks(h);
-    const size_t lds = std::max(std::max(learn_lds(epl, 256), scan_lds_tab(d)), sizeof(EmitShared));
+    const size_t lds = std::max(std::max(learn_lds(epl, 256), lean_scan_lds(d)), sizeof(EmitShared));
     const int n_learn = h->lean_learn_blocks, n_scan = h->lean_scan_blocks;
     const int grid = n_emit + n_learn + n_scan;
-#define LAUNCH_LSE(EPL_, MINW_) LAUNCH_ON(h, h->stream, lds, "tm_learn+tm_scan+sp_emit", (k_learn_scan_emit<EPL_, MINW_, (MINW_ >= 6)>), grid, 256, d, p, n_emit, n_learn, n_scan, spec)
+#define LAUNCH_LSE(EPL_, MINW_, TAB_) LAUNCH_ON(h, h->stream, lds, "tm_learn+tm_scan+sp_emit", (k_learn_scan_emit<EPL_, MINW_, TAB_>), grid, 256, d, p, n_emit, n_learn, n_scan, spec)
     if (scan_pool_is_large(h)) {
-        switch (epl) { case 1: LAUNCH_LSE(1, 4); break; case 2: LAUNCH_LSE(2, 4); break; case 4: LAUNCH_LSE(4, 4); break; default: LAUNCH_LSE(8, 4); break; }
+        switch (epl) { case 1: LAUNCH_LSE(1, 4, false); break; case 2: LAUNCH_LSE(2, 4, false); break; case 4: LAUNCH_LSE(4, 4, false); break; default: LAUNCH_LSE(8, 4, false); break; }
+    } else if (lean_tab(d)) {
+        switch (epl) { case 1: LAUNCH_LSE(1, 6, true); break; case 2: LAUNCH_LSE(2, 6, true); break; case 4: LAUNCH_LSE(4, 6, true); break; default: LAUNCH_LSE(8, 6, true); break; }
     } else {
-        switch (epl) { case 1: LAUNCH_LSE(1, 6); break; case 2: LAUNCH_LSE(2, 6); break; case 4: LAUNCH_LSE(4, 6); break; default: LAUNCH_LSE(8, 6); break; }
+        switch (epl) { case 1: LAUNCH_LSE(1, 6, false); break; case 2: LAUNCH_LSE(2, 6, false); break; case 4: LAUNCH_LSE(4, 6, false); break; default: LAUNCH_LSE(8, 6, false); break; }
     }
 #undef LAUNCH_LSE
 }
@@ -641,7 +646,7 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
                 h->emit_fits_open = h->emit_fits && c256 + (d.k * 32 + 255) / 256 <= std::min(1024, per_cu_open * cus);
                 // the three-launch schedule: the emit blocks come first in the grid of the learn + scan + emit kernel
                 int per_cu_lean = 0;
-                const size_t lean_lds = std::max(std::max(learn_lds(learn_epl(d), 256), scan_lds_tab(d)), sizeof(EmitShared));
+                const size_t lean_lds = std::max(std::max(learn_lds(learn_epl(d), 256), lean_scan_lds(d)), sizeof(EmitShared));
                 const void *kern = learn_epl(d) == 1 ? (const void *)k_learn_scan_emit<1, 6, true> : learn_epl(d) == 2 ? (const void *)k_learn_scan_emit<2, 6, true>
                                  : learn_epl(d) == 4 ? (const void *)k_learn_scan_emit<4, 6, true> : (const void *)k_learn_scan_emit<8, 6, true>;
                 h->emit_fits_lean = cfg->enable_tm && h->emit_fits && lean_lds <= 64 * 1024 &&
