@@ -39,6 +39,9 @@ def main():
             print(f"    {len(uk)} distinct keys among {len(keys)} entries; (key bits above low_zero - smallest: weight, entries): "
                   + " ".join(f"{int(k - uk[0])}:{int(cnt[keys == k].sum())},{int((keys == k).sum())}" for k in uk[::-1]))
         t0 = t[:, 0].min()
+        pub = t[:, 2] - t0                            # when each block's record was out
+        print(f"    records published at median {np.median(pub):.2f} / last {pub.max():.2f} us (block {int(pub.argmax())}); all read {np.median(t[:, 3] - t0 - pub.max()):.2f} us after the last one; "
+              f"k-th key known {np.median(t[:, 4] - t[:, 3]):.2f} us later")
         print(f"step {step}: merged entries {int(ne.max())}, raw keys per block max {int(nraw.max())} mean {nraw.mean():.1f}; blocks end {(t[:, 5] - t0).min():.2f}..{(t[:, 5] - t0).max():.2f} us; "
               + "  ".join(f"{n} {np.median(ph[:, i]):.2f}/{ph[:, i].max():.2f}" for i, n in enumerate(names)))
 
