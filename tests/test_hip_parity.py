@@ -244,4 +244,3 @@ def test_emit_grid_too_large_for_the_pipelined_launch_falls_back():
     assert np.array_equal(htm.engine.read_sp_fields()["active_column"], o_sp.active_column)
     compare_store_with_oracle(steps - 1, ora, htm)
     htm.engine.check_capacity()
-
