@@ -128,9 +128,12 @@ def recorded_traffic(kernel):
     return dict(traffic=None)
 
 
-def cpu_baseline(w, htm, noisy, start_step, sample_steps):
+def cpu_baseline(w, htm, noisy, bank, start_step, sample_steps, run):
     """Time the NumPy oracle on this host from the GPU's learned state (a port of the
-    reference's CPU path: dense float64 `>=` + `&` + sum overlap, NumPy segment scan)."""
+    reference's CPU path: dense float64 `>=` + `&` + sum overlap, NumPy segment scan) -- and then let it check the
+    bench's own call pattern at the full size: the GPU runs the same timesteps the way the timed region made its calls
+    (streamed chunks with HTM_RUN_CONTINUE, graphs built ahead with htm_prepare) and must agree with the oracle at every
+    chunk boundary and, at the end, on the whole state."""
     from oracle import HTMOracle
     eng = htm.engine
     C, I, K = w["column_dim"], w["input_dim"], w["cell_dim"]
@@ -138,14 +141,87 @@ def cpu_baseline(w, htm, noisy, start_step, sample_steps):
     ora.spatial_pooler.duty_cycle = eng.read_duty_cycle().copy()
     ora.temporal_memory.import_state(eng.export_tm_state())
     n_bank = noisy.shape[0]
-    ora.step(noisy[start_step % n_bank])                 # untimed: page in / allocate
+    states = [ora.step(noisy[start_step % n_bank])]     # untimed: page in / allocate
     t0 = time.perf_counter()
     for t in range(1, sample_steps + 1):
-        ora.step(noisy[(start_step + t) % n_bank])
+        states.append(ora.step(noisy[(start_step + t) % n_bank]))
     dt = time.perf_counter() - t0
-    return dict(value=sample_steps / dt, unit="timesteps/s", cores=1, kind="port",
-                sample=f"{sample_steps} timesteps of the NumPy oracle from the GPU's learned state "
-                       f"(S={ora.temporal_memory.S} segments), single-threaded NumPy")
+    out = dict(value=sample_steps / dt, unit="timesteps/s", cores=1, kind="port",
+               sample=f"{sample_steps} timesteps of the NumPy oracle from the GPU's learned state "
+                      f"(S={ora.temporal_memory.S} segments), single-threaded NumPy")
+    try:
+        out.update(check_against_oracle(w, htm, noisy, bank, ora, states, run))
+    except AssertionError as e:
+        log(f"[bench] PARITY FAILURE against the oracle: {e}")
+        out.update(parity=f"FAILED: {e}")
+    return out
+
+
+def check_against_oracle(w, htm, noisy, bank, ora, states, run):
+    """The GPU's next len(states) timesteps, called as the timed region calls (run = its use_graph / pipeline flags),
+    against the oracle's: Temporal Memory outputs at every chunk boundary, everything at the end."""
+    from bithtm_amd import _lib as L
+    from bithtm_amd.engine import bool_to_words
+    eng = htm.engine
+    K, k = w["cell_dim"], htm.active_columns
+    n_bank = noisy.shape[0]
+    n = len(states)
+    cont = bool(run["pipeline"])
+    chunks, left = [], n                              # [5 warm-up, 20 timed] as the driver's arguments make them, then the rest
+    for c in (5, 20, 5):
+        if left > c:
+            chunks.append(c)
+            left -= c
+    chunks.append(left)
+    done = 0
+    for i, c in enumerate(chunks):
+        last = i == len(chunks) - 1
+        flags = dict(run, continuing=cont and not last)
+        eng.prepare(bank, n_bank, c, **flags)
+        eng.run(bank, n_bank, c, **flags)
+        done += c
+        o_sp, o_tm = states[done - 1]
+        od = o_tm.distal_state
+        info = eng.check_capacity()
+        assert info.segments == len(od.segment_potential), f"segment count after step {done}"
+        assert np.array_equal(eng.read(L.F_ACTIVE_COLUMN, np.int32, k), o_sp.active_column), f"active columns of step {done}"
+        assert np.array_equal(eng.read(L.F_CELL_ACTIVATION, np.uint32, w["column_dim"]), bool_to_words(o_tm.cell_activation)), f"cell activation of step {done}"
+        assert np.array_equal(eng.read(L.F_CELL_PREDICTION, np.uint32, w["column_dim"]), bool_to_words(o_tm.cell_prediction)), f"cell prediction of step {done}"
+        assert np.array_equal(eng.read(L.F_WINNER_CELL, np.int32, info.winner_cells), o_tm.winner_cell[0] * K + o_tm.winner_cell[1]), f"winner cells of step {done}"
+        assert np.array_equal(eng.read(L.F_BURSTING, np.uint8, k).astype(bool), o_tm.active_column_bursting[:, 0]), f"bursting columns of step {done}"
+        d = eng.read_distal()
+        assert np.array_equal(d["matching_segment"], od.matching_segment), f"matching segments of step {done}"
+        assert np.array_equal(d["matching_segment_activation"], od.matching_segment_activation), f"connected-active counts of step {done}"
+        assert np.array_equal(d["matching_segment_active"], od.matching_segment_active), f"active segments of step {done}"
+        assert np.array_equal(d["segment_potential"], od.segment_potential), f"segment potentials of step {done}"
+        assert np.array_equal(d["max_jittered_potential"].view(np.int32), od.max_jittered_potential.view(np.int32)), f"per-cell maxima of step {done}"
+    # the stream has ended: the Spatial Pooler's fields and the whole state
+    o_sp, o_tm = states[-1]
+    sp = eng.read_sp_fields()
+    assert np.array_equal(sp["overlaps"], o_sp.overlaps), "overlaps of the last step"
+    assert np.array_equal(sp["boosted_overlaps"].view(np.int64), o_sp.boosted_overlaps.view(np.int64)), "boosted overlaps of the last step"
+    otm, osp = ora.temporal_memory, ora.spatial_pooler
+    st = eng.read_store()
+    S = otm.S
+    assert st["S"] == S and np.array_equal(st["seg_cell"], otm.seg_cell[:S]) and np.array_equal(st["seg_nsyn"], otm.seg_nsyn[:S]), "segment owners / synapse counts"
+    assert np.array_equal(st["segcount"], otm.segcount), "segments per cell"
+
+    def canonical(presyn, perm, width):                # valid synapses first, by presynaptic id
+        key = np.where(presyn >= 0, presyn.astype(np.int64), np.int64(1) << 40)
+        order = np.argsort(key, axis=1, kind="stable")[:, :width]
+        return np.take_along_axis(presyn, order, axis=1), np.take_along_axis(perm, order, axis=1).view(np.int32)
+    width = int(max(st["seg_nsyn"].max(initial=0), 1))
+    a_ps, a_pm = canonical(st["presyn"], st["perm"], width)
+    b_ps, b_pm = canonical(otm.presyn[:S], otm.perm[:S], width)
+    assert np.array_equal(a_ps, b_ps), "presynaptic cells of the segment store"
+    assert np.array_equal(np.where(a_ps >= 0, a_pm, 0), np.where(b_ps >= 0, b_pm, 0)), "permanence bits of the segment store"
+    assert np.array_equal(eng.read_duty_cycle().view(np.int32), osp.duty_cycle.view(np.int32)), "duty cycle"
+    assert np.array_equal(eng.get_permanence().view(np.int64), osp.permanence.view(np.int64)), "Spatial Pooler permanences"
+    log(f"[bench] parity: {n} timesteps in chunks of {chunks} (streamed calls, prepared graphs) equal the oracle's at every chunk "
+        f"boundary; whole state equal at the end (S={S})")
+    return dict(parity="ok", parity_checked=f"{n} timesteps called as the timed region calls them (chunks {chunks}, HTM_RUN_CONTINUE={cont}, "
+                                            f"htm_prepare, hip_graph={bool(run['use_graph'])}): TM outputs at every chunk boundary, SP outputs and the whole "
+                                            f"state (segment store, permanence bits, duty cycle) at the end, bit for bit")
 
 
 STRESS = dict(input_dim=1024, column_dim=262144, cell_dim=16, world=8, segments_per_cell=255, synapses=32,
@@ -165,7 +241,44 @@ class LazyPermanence:
         return np.random.RandomState(self.seed + a).randn(b - a, self.shape[1]) * 0.1
 
 
-def stress_leg(steps=8, warmup=3):
+def check_stress_sample(eng, s, rows0, k, ranges=48, rows_per_range=256):
+    """Self-check of the configs[4] leg (the oracle's keyed generator as the checker): `ranges` x `rows_per_range` rows spread
+    over rank 0's pool are read back and compared with the rows the keyed generator gives those segment ids on the host --
+    presynaptic cells, permanence bits, owner cells; their potentials against the last step's active cells as the host
+    counts them; and the scan's verdict on each (the match word of k_tm_scan_wide: set, with that potential, exactly where
+    the potential reaches the matching threshold)."""
+    from oracle import populated_rows
+    from bithtm_amd import _lib as L
+    from bithtm_amd.engine import words_to_bool
+    C, K, spc, n_syn = s["column_dim"], s["cell_dim"], s["segments_per_cell"], s["synapses"]
+    act = words_to_bool(eng.read(L.F_CELL_ACTIVATION, np.uint32, C), K).reshape(-1)
+    assert int(act.sum()) >= k, "the last step has active cells"
+    starts = np.linspace(0, rows0 - rows_per_range, ranges).astype(np.int64)
+    n_rows = n_match = 0
+    for a in starts:
+        gid = eng.read_rows(L.F_SEG_GID, np.int32, a, rows_per_range).astype(np.int64)
+        assert np.array_equal(gid, np.arange(a, a + rows_per_range)), f"rows {a}..: global ids"
+        cells, perms = populated_rows(C * K, gid, n_syn, s["perm_lo"], s["perm_hi"], s["seed"])
+        presyn = eng.read_rows(L.F_SEG_PRESYN, np.int32, a, rows_per_range)
+        perm = eng.read_rows(L.F_SEG_PERM, np.float32, a, rows_per_range)
+        assert (presyn[:, n_syn:] == -1).all() and np.array_equal(presyn[:, :n_syn], cells), f"rows {a}..: presynaptic cells"
+        assert np.array_equal(perm[:, :n_syn].view(np.int32), perms.view(np.int32)), f"rows {a}..: permanence bits"
+        assert np.array_equal(eng.read_rows(L.F_SEG_CELL, np.int32, a, rows_per_range), gid // spc), f"rows {a}..: owner cells"
+        pot = act[cells].sum(axis=1)
+        assert np.array_equal(eng.read_rows(L.F_SEG_POTENTIAL, np.int32, a, rows_per_range), pot), f"rows {a}..: potentials"
+        conn = (act[cells] & (perms >= np.float32(0.5))).sum(axis=1)
+        matching = pot >= 15                           # PredictiveProjection defaults (projections.py:221-222)
+        want = np.where(matching, pot.astype(np.uint32) | (conn.astype(np.uint32) << 12) | ((conn >= 15).astype(np.uint32) << 31), 0).astype(np.uint32)
+        assert np.array_equal(eng.read_rows(L.F_MATCH_INFO, np.uint32, a, rows_per_range), want), f"rows {a}..: the scan's match words"
+        n_rows += rows_per_range
+        n_match += int(matching.sum())
+    log(f"[bench] configs[4] leg: self-check of {n_rows} sampled rows ok ({n_match} of them matching)")
+    return dict(checked=True, check=f"{n_rows} rows in {ranges} ranges over rank 0's pool: presynaptic cells, permanence bits and owner cells equal the "
+                                    f"keyed generator's for those ids; potentials and the scan's match words equal the host's count against the "
+                                    f"last step's active cells ({n_match} matching)")
+
+
+def stress_leg(steps=8, warmup=3, check=True):
     """BASELINE.json configs[4] (262 144 columns x 16 cells, 255 segments per cell, 8 GPUs: the HBM-bound scan stress of
     SURVEY section 8d) as far as one GPU can hold it: the whole 8-rank group runs in this process (bithtm_amd.distributed.
     LocalGroup: every sharded kernel, the all-gather as device copies), with the pre-populated pool generated on the
@@ -201,15 +314,23 @@ def stress_leg(steps=8, warmup=3):
     info = eng.check_capacity()
     rows = info.local_segments
     scan_bytes = (4 * s["synapses"] + 8) * rows0 + (4 * s["synapses"] + 8) * (rows - rows0)     # 4 B per synapse + 8 B per segment
-    scan_us = prof["tm_scan"]
+    scan_name = next(n for n in ("tm_scan_wide", "tm_scan_large", "tm_scan") if n in prof)
+    scan_us = prof[scan_name]
     ach = scan_bytes / scan_us / 1e3
     out = dict(workload=f"configs[4] on one GPU: rank 0 of {world} of {C} columns x {K} cells; its cells' {spc} segments x "
                         f"{s['synapses']} synapses each ({rows0} segments, generated on the device); all {world} ranks run in this process",
-               kernel="k_tm_scan_wide (tm_scan of rank 0)", segments=int(rows), bytes_per_launch=int(scan_bytes),
+               kernel={"tm_scan_wide": "k_tm_scan_wide", "tm_scan_large": "k_tm_scan<true, 1>", "tm_scan": "k_tm_scan<true, 6>"}[scan_name] + " (the scan of rank 0)",
+               segments=int(rows), bytes_per_launch=int(scan_bytes),
                avg_launch_us=round(scan_us, 1), achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4),
                rank0_launch_us={n: round(v, 1) for n, v in prof.items()}, rank0_step_us=round(sum(prof.values()), 1),
                exchange_bytes_per_rank=int(eng.shard_record_bytes()), setup_s=round(setup_s, 1))
     out.update(recorded_traffic("k_tm_scan_wide"))
+    if check:
+        try:
+            out.update(check_stress_sample(eng, s, rows0, k))
+        except AssertionError as e:
+            log(f"[bench] configs[4] leg: SELF-CHECK FAILED: {e}")
+            out.update(checked=False, check_error=str(e))
     log(f"[bench] configs[4] leg: rank 0 scans {rows} segments in {scan_us:.0f} us = {ach:.0f} GB/s ({ach / HBM_PEAK_GBS:.1%} of peak); "
         f"its step {out['rank0_step_us']:.0f} us; setup {setup_s:.1f} s")
     del group
@@ -314,8 +435,8 @@ def run_single(args):
 
     cpu = None
     if not args.no_cpu_baseline:
-        cpu = cpu_baseline(w, htm, noisy, int(eng.info().step_index), args.cpu_steps)
-        log(f"[bench] cpu baseline: {cpu['value']:.2f} timesteps/s")
+        cpu = cpu_baseline(w, htm, noisy, bank, int(eng.info().step_index), args.cpu_steps, run)
+        log(f"[bench] cpu baseline: {cpu['value']:.2f} timesteps/s; parity {cpu.get('parity')}")
     step_index, segments = int(info.step_index), int(info.segments)
     stress = None
     if not args.no_stress and not args.columns:
@@ -323,7 +444,7 @@ def run_single(args):
         import gc
         gc.collect()
         try:
-            stress = stress_leg()
+            stress = stress_leg(check=not args.no_cpu_baseline)
         except Exception as e:                          # a report beside the headline: never a reason to lose the line
             log(f"[bench] configs[4] leg failed: {e!r}")
             stress = dict(error=repr(e))
@@ -360,7 +481,7 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true", help="one role per launch (what the profiled replay always does)")
     args = ap.parse_args()
     if args.stress_only:
-        print(json.dumps(stress_leg()), flush=True)
+        print(json.dumps(stress_leg(check=not args.no_cpu_baseline)), flush=True)
         return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # started by hand without the launcher: start one process per GPU as a CHILD (this process has

@@ -6,7 +6,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libbithtm_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class HtmConfig(C.Structure):
@@ -72,6 +72,7 @@ EXPORTS = {
     "htm_sync": (C.c_int, [C.c_void_p]),
     "htm_get_info": (C.c_int, [C.c_void_p, C.POINTER(HtmInfo)]),
     "htm_read": (C.c_int64, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]),
+    "htm_read_rows": (C.c_int64, [C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_void_p, C.c_int64]),
     "htm_import_begin": (C.c_int, [C.c_void_p, C.c_int64]),
     "htm_write": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]),
     "htm_import_commit": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),

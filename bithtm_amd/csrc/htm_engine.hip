@@ -72,7 +72,9 @@ struct htm_handle {
     int sp_blocks, sel_blocks, c256_blocks, s1024_blocks, scan_blocks, zero_blocks, lean_learn_blocks, lean_scan_blocks, lean_overlap_blocks, cus;
     const uint32_t *ahead_bank;           // htm_run ended with HTM_RUN_CONTINUE on this bank: the SP has done the next step
     int ahead_n_inputs, ahead_learning;   //   and the front of the one after it
+    bool ahead_lean;                      //   ... in the three-launch schedule (else the four-launch one)
     int phase_active;                     // htm_sp_phase: length of the current winner list
+    bool import_keep;                     // htm_import_begin(HTM_IMPORT_PREV_STATE): the commit leaves the store, the step index and the sticky flags alone
     bool phase_open;                      // ... phases of the current (not yet closed) timestep have run: the Spatial Pooler
                                           // fields htm_read returns are that step's
     // graphs keyed by (parity, learning, bank, n_inputs)
@@ -218,12 +220,12 @@ static void launch_scan(htm_handle *h, int p, int use_lds) {
     if (scan_pool_is_large(h) && use_lds && scan_lds(d, 1) > 16 * 1024) {
         // a big column bitmap (32 KB at 262 144 columns): one copy per 1024-thread block, two blocks per CU
         const int blocks = std::max(1, std::min((d.Lcap + 255) / 256, 2 * h->cus));
-        LAUNCH_ON(h, h->stream, scan_lds(d, 1), "tm_scan", (k_tm_scan_wide<true>), blocks, 1024, d, p, 0);
+        LAUNCH_ON(h, h->stream, scan_lds(d, 1), "tm_scan_wide", (k_tm_scan_wide<true>), blocks, 1024, d, p, 0);
         return;
     }
     if (scan_pool_is_large(h)) {
-        if (use_lds) LAUNCH_ON(h, h->stream, scan_lds(d, 1), "tm_scan", (k_tm_scan<true, 1>), h->scan_blocks, 256, d, p, spec);
-        else LAUNCH_ON(h, h->stream, scan_lds(d, 0), "tm_scan", (k_tm_scan<false, 1>), h->scan_blocks, 256, d, p, spec);
+        if (use_lds) LAUNCH_ON(h, h->stream, scan_lds(d, 1), "tm_scan_large", (k_tm_scan<true, 1>), h->scan_blocks, 256, d, p, spec);
+        else LAUNCH_ON(h, h->stream, scan_lds(d, 0), "tm_scan_large", (k_tm_scan<false, 1>), h->scan_blocks, 256, d, p, spec);
     } else {
         if (use_lds) LAUNCH_ON(h, h->stream, scan_lds(d, 1), "tm_scan", (k_tm_scan<true, 6>), h->scan_blocks, 256, d, p, spec);
         else LAUNCH_ON(h, h->stream, scan_lds(d, 0), "tm_scan", (k_tm_scan<false, 6>), h->scan_blocks, 256, d, p, spec);
@@ -466,8 +468,10 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
     h->shard_send = h->shard_recv = nullptr;
     h->phase_active = 0;
     h->phase_open = false;
+    h->import_keep = false;
     h->ahead_bank = nullptr;
     h->ahead_n_inputs = h->ahead_learning = 0;
+    h->ahead_lean = false;
     hipError_t e = hipSetDevice(cfg->device);
     if (e != hipSuccess) return fail_create(h, std::string("hipSetDevice: ") + hipGetErrorString(e), HTM_ERR_HIP);
     if (cfg->use_caller_stream) {
@@ -645,13 +649,22 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
                 // the pipelined launch puts the activation blocks of the current step behind the emit blocks
                 h->emit_fits_open = h->emit_fits && c256 + (d.k * 32 + 255) / 256 <= std::min(1024, per_cu_open * cus);
                 // the three-launch schedule: the emit blocks come first in the grid of the learn + scan + emit kernel
-                int per_cu_lean = 0;
+                // (asked of every instantiation enqueue_lean may launch for this handle -- LDS tables or not, small-pool or
+                // large-pool scan: they differ in launch bounds and registers -- and the smallest answer counts)
+                int per_cu_lean = 1 << 30;
                 const size_t lean_lds = std::max(std::max(learn_lds(learn_epl(d), 256), lean_scan_lds(d)), sizeof(EmitShared));
-                const void *kern = learn_epl(d) == 1 ? (const void *)k_learn_scan_emit<1, 6, true> : learn_epl(d) == 2 ? (const void *)k_learn_scan_emit<2, 6, true>
-                                 : learn_epl(d) == 4 ? (const void *)k_learn_scan_emit<4, 6, true> : (const void *)k_learn_scan_emit<8, 6, true>;
-                h->emit_fits_lean = cfg->enable_tm && h->emit_fits && lean_lds <= 64 * 1024 &&
-                                    hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_lean, kern, 256, lean_lds) == hipSuccess &&
-                                    c256 <= std::min(1024, per_cu_lean * cus);
+                const int epl = learn_epl(d);
+#define LSE_VARIANTS(E_) {(const void *)k_learn_scan_emit<E_, 6, true>, (const void *)k_learn_scan_emit<E_, 6, false>, (const void *)k_learn_scan_emit<E_, 4, false>}
+                const void *kerns[4][3] = {LSE_VARIANTS(1), LSE_VARIANTS(2), LSE_VARIANTS(4), LSE_VARIANTS(8)};
+#undef LSE_VARIANTS
+                bool asked = cfg->enable_tm && h->emit_fits && lean_lds <= 64 * 1024;
+                for (int v = 0; asked && v < 3; ++v) {
+                    if (v == 0 && !lean_tab(d)) continue;           // (never launched without the tables)
+                    int per_cu = 0;
+                    asked = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kerns[epl == 1 ? 0 : epl == 2 ? 1 : epl == 4 ? 2 : 3][v], 256, lean_lds) == hipSuccess;
+                    per_cu_lean = std::min(per_cu_lean, per_cu);
+                }
+                h->emit_fits_lean = asked && c256 <= std::min(1024, per_cu_lean * cus);
             } else {
                 (void)hipGetLastError();
                 h->emit_fits = h->emit_fits_open = h->emit_fits_lean = false;
@@ -751,6 +764,20 @@ extern "C" int htm_sp_get_permanence(htm_handle *h, double *rows, int32_t row_be
     return HTM_OK;
 }
 
+// htm_sp_phase leaves the current (not yet closed) timestep half done: keys, boosted overlaps and the top-digit
+// histogram of parity step_host & 1 (DenseProjection.process / ExponentialBoosting.process called on their own on the
+// objects of a live SpatialPooler).  An entry point that runs the WHOLE step starts over: the histogram its overlap
+// accumulates into must be clean (only a select clears it), and the Spatial Pooler fields htm_read returns are the last
+// completed step's again.
+static int close_open_phases(htm_handle *h) {
+    if (!h->phase_open) return 0;
+    const int p = (int)(h->step_host & 1);
+    if (h->cfg.enable_sp) HIPCHK(h, hipMemsetAsync(h->d.hist0 + (size_t)p * HIST_REP * SEL_BINS, 0, (size_t)HIST_REP * SEL_BINS * 4, h->stream));
+    h->phase_open = false;
+    h->phase_active = 0;
+    return 0;
+}
+
 static int stage_input(htm_handle *h, const uint32_t *packed_input) {
     Dev &d = h->d;
     const int words = (d.I + 31) / 32;
@@ -765,7 +792,9 @@ extern "C" int htm_step(htm_handle *h, const uint32_t *packed_input, int32_t lea
     if (h->world > 1) { h->err = "sharded handle: use htm_shard_begin / htm_shard_finish"; return HTM_ERR_STATE; }
     HIPCHK(h, hipSetDevice(h->device));
     refresh_exchange_mode(h);
-    int rc = stage_input(h, packed_input);
+    int rc = close_open_phases(h);
+    if (rc) return rc;
+    rc = stage_input(h, packed_input);
     if (rc) return rc;
     return enqueue_step(h, h->d.input_stage, 1, learning ? 1 : 0, StepPlan{false, false, false});
 }
@@ -779,7 +808,9 @@ extern "C" int htm_sp_step(htm_handle *h, const uint32_t *packed_input, int32_t 
     if (h->cfg.enable_tm) { h->err = "htm_sp_step: the handle also has a Temporal Memory; use htm_step"; return HTM_ERR_STATE; }
     HIPCHK(h, hipSetDevice(h->device));
     refresh_exchange_mode(h);
-    int rc = stage_input(h, packed_input);
+    int rc = close_open_phases(h);
+    if (rc) return rc;
+    rc = stage_input(h, packed_input);
     if (rc) return rc;
     const int p = (int)(h->step_host & 1);
     enqueue_sp_front(h, h->d.input_stage, 1, p);
@@ -906,13 +937,34 @@ static int run_or_prepare(htm_handle *h, const uint32_t *device_inputs, int32_t 
     const bool graph = (use_graph & 1) && !h->profile;
     const bool pipeline = !(use_graph & 2) && can_pipeline(h);
     const bool resume = sp_is_ahead(h);            // the previous call left the SP one step (and a front) ahead
-    if (resume && (h->ahead_bank != device_inputs || h->ahead_n_inputs != n_inputs || h->ahead_learning != learning || !pipeline)) {
-        h->err = "htm_run: the previous call ended with HTM_RUN_CONTINUE; this one must use the same bank, n_inputs, learning and schedule";
+    if (resume && (h->ahead_bank != device_inputs || h->ahead_n_inputs != n_inputs || h->ahead_learning != learning)) {
+        h->err = "htm_run: the previous call ended with HTM_RUN_CONTINUE; this one must use the same bank, n_inputs and learning flag";
         return HTM_ERR_STATE;
     }
-    const bool cont = (use_graph & 4) && pipeline && n_steps > 0;      // keep looking ahead past the end of this call
-    if ((use_graph & 4) && !pipeline) { h->err = "htm_run: HTM_RUN_CONTINUE needs the pipelined schedule"; return HTM_ERR_STATE; }
+    // keep looking ahead past the end of this call -- where the pipelined schedule is available (the flag is a promise of
+    // the caller's, not a demand: without the schedule the call simply leaves nothing outstanding)
+    const bool cont = (use_graph & 4) && pipeline && n_steps > 0;
     if (dry && !graph) return HTM_OK;
+    if (!dry) { int rc = close_open_phases(h); if (rc) return rc; }
+    // The SP is ahead but the pipelined schedule is gone (another handle with its own stream has appeared on the device since,
+    // or this call asks for HTM_RUN_NO_PIPELINE): the coming step is run as the LAST step of the run that went ahead -- its
+    // launches hold no select finish, so nothing in them waits for another block -- and the rest of the call unpipelined.
+    if (resume && !pipeline && n_steps > 0) {
+        if (dry) return HTM_OK;                      // (that step is launched eagerly; the rest builds its graphs when it runs)
+        {
+            const int p = (int)(h->step_host & 1);
+            const StepPlan last{true, false, false};
+            if (h->ahead_lean) enqueue_lean(h, p, learning, device_inputs, n_inputs, last);
+            else enqueue_pipelined(h, p, learning, device_inputs, n_inputs, last);
+            h->step_host += 1;
+            // (the four-launch schedule had begun the step after it: that front is never consumed)
+            HIPCHK(h, hipMemsetAsync(h->d.hist0 + (size_t)(h->step_host & 1) * HIST_REP * SEL_BINS, 0, (size_t)HIST_REP * SEL_BINS * 4, h->stream));
+            h->ahead_bank = nullptr;
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) { h->err = std::string("kernel launch: ") + hipGetErrorString(e); return HTM_ERR_HIP; }
+        }
+        return run_or_prepare(h, device_inputs, n_inputs, n_steps - 1, learning, use_graph, false);
+    }
     // Graphs hold the launches of one step, or of up to kGraphSteps consecutive steady-state steps (a graph
     // launch boundary costs about 5 us more than a kernel boundary inside a graph: tools/step_timeline.py).
     // Nothing in a graph depends on the step index: kernels read it, and with it the bank row, from
@@ -969,6 +1021,7 @@ static int run_or_prepare(htm_handle *h, const uint32_t *device_inputs, int32_t 
         if (resume && !cont && n_steps == 1)        // the front computed for the step after this one is never consumed:
             HIPCHK(h, hipMemsetAsync(h->d.hist0 + (size_t)(h->step_host & 1) * HIST_REP * SEL_BINS, 0, (size_t)HIST_REP * SEL_BINS * 4, h->stream));    // its digit histogram
         h->ahead_bank = cont ? device_inputs : nullptr;
+        h->ahead_lean = cont && can_lean(h);
         h->ahead_n_inputs = n_inputs;
         h->ahead_learning = learning;
         // leave the segment count where the next call finds it (no wait: it may see the one before)
@@ -996,7 +1049,11 @@ extern "C" int64_t htm_shard_record_bytes(htm_handle *h) {
 
 static int shard_enqueue_begin(htm_handle *h, const uint32_t *bank, int n_inputs, void *send_device) {
     Dev &d = h->d;
-    if (!h->emit_fused) { h->err = "sharded handle: another handle with its own stream is live on this device"; return HTM_ERR_STATE; }
+    if (!h->emit_fused) {
+        h->err = h->emit_fits ? "sharded handle: another handle with its own stream is live on this device (the local select waits between blocks)"
+                              : "sharded handle: the local select's grid is not resident at once on this device (too many own columns)";
+        return HTM_ERR_STATE;
+    }
     const int p = (int)(h->step_host & 1);
     d.send = (unsigned char *)send_device;
     // own columns: overlap + boost + top digit, and the zeroing of the step's dense words; digit 1; local select finish
@@ -1362,7 +1419,7 @@ extern "C" int64_t htm_read(htm_handle *h, int32_t field, void *dst, int64_t cou
                 if (!c.has_distal) { memset(dst, 0, (size_t)S * 4); return S; }
                 int *tmp = nullptr;
                 if (hipMalloc((void **)&tmp, (size_t)S * 4) != hipSuccess) { h->err = "htm_read: hipMalloc failed"; return HTM_ERR_HIP; }
-                hipLaunchKernelGGL(k_tm_potentials, dim3((unsigned)std::min<int64_t>((S * 8 + 255) / 256, 8192)), dim3(256), 0, h->stream, d, q, tmp);
+                hipLaunchKernelGGL(k_tm_potentials, dim3((unsigned)std::min<int64_t>((S * 8 + 255) / 256, 8192)), dim3(256), 0, h->stream, d, q, tmp, 0, (int)S);
                 const bool ok = hipStreamSynchronize(h->stream) == hipSuccess && hipMemcpy(dst, tmp, (size_t)S * 4, hipMemcpyDeviceToHost) == hipSuccess;
                 hipFree(tmp);
                 if (!ok) { h->err = "htm_read: potentials kernel failed"; return HTM_ERR_HIP; }
@@ -1435,6 +1492,78 @@ extern "C" int64_t htm_read(htm_handle *h, int32_t field, void *dst, int64_t cou
     }
 }
 
+// Rows [row_begin, row_begin + row_count) of a per-segment field: what htm_read returns for the whole pool, for a pool
+// too large to read whole (configs[4]: 134 M rows).  HTM_F_MATCH_INFO comes back dense: one word per row, 0 = the row is
+// not matching.
+extern "C" int64_t htm_read_rows(htm_handle *h, int32_t field, int64_t row_begin, int64_t row_count, void *dst, int64_t count) {
+    if (!h || !dst || row_begin < 0 || row_count < 0) return HTM_ERR_ARGUMENT;
+    if (!h->cfg.enable_tm) { h->err = "htm_read_rows: handle has no Temporal Memory"; return HTM_ERR_STATE; }
+    Counters c;
+    int rc = read_counters(h, &c);
+    if (rc) return rc;
+    Dev &d = h->d;
+    const int q = (int)((h->step_host + 1) & 1);
+    const int64_t S = h->world > 1 ? c.L : c.S, E = d.E, K = d.K;
+    if (row_begin + row_count > S) { h->err = "htm_read_rows: rows out of range"; return HTM_ERR_ARGUMENT; }
+    const int64_t per = (field == HTM_F_SEG_PRESYN || field == HTM_F_SEG_PERM) ? E : 1, n = row_count * per;
+    if (count < n) { h->err = "htm_read_rows: buffer too small"; return HTM_ERR_ARGUMENT; }
+    if (n == 0) return 0;
+    auto copy = [&](const void *src, size_t bytes) -> bool {
+        if (hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost) != hipSuccess) { h->err = "htm_read_rows: hipMemcpy failed"; return false; }
+        return true;
+    };
+    switch (field) {
+        case HTM_F_SEG_NSYN: return copy(d.seg_nsyn + row_begin, (size_t)n * 4) ? n : HTM_ERR_HIP;
+        case HTM_F_SEG_GID: {
+            if (d.seg_gid) return copy(d.seg_gid + row_begin, (size_t)n * 4) ? n : HTM_ERR_HIP;
+            for (int64_t i = 0; i < n; ++i) ((int *)dst)[i] = (int)(row_begin + i);
+            return n;
+        }
+        case HTM_F_SEG_CELL: {
+            if (!copy(d.seg_cell + row_begin, (size_t)n * 4)) return HTM_ERR_HIP;
+            for (int64_t i = 0; i < n; ++i) ((int *)dst)[i] = enc_flat(((int *)dst)[i], (int)K);
+            return n;
+        }
+        case HTM_F_SEG_PRESYN:
+        case HTM_F_SEG_PERM: {
+            std::vector<int> nsyn((size_t)row_count);
+            if (hipMemcpy(nsyn.data(), d.seg_nsyn + row_begin, (size_t)row_count * 4, hipMemcpyDeviceToHost) != hipSuccess) { h->err = "htm_read_rows: hipMemcpy failed"; return HTM_ERR_HIP; }
+            if (!copy(field == HTM_F_SEG_PRESYN ? (const void *)(d.presyn + row_begin * E) : (const void *)(d.sperm + row_begin * E), (size_t)n * 4)) return HTM_ERR_HIP;
+            for (int64_t s = 0; s < row_count; ++s)
+                for (int64_t e = 0; e < E; ++e) {
+                    const bool valid = e < (nsyn[(size_t)s] & ~(int)SEG_BUSY);
+                    if (field == HTM_F_SEG_PRESYN) { int *v = (int *)dst + s * E + e; *v = valid ? enc_flat(*v & SYN_CELL, (int)K) : -1; }
+                    else if (!valid) ((float *)dst)[s * E + e] = -1.0f;
+                }
+            return n;
+        }
+        case HTM_F_SEG_POTENTIAL: {
+            if (!c.has_distal) { memset(dst, 0, (size_t)n * 4); return n; }
+            int *tmp = nullptr;
+            if (hipMalloc((void **)&tmp, (size_t)n * 4) != hipSuccess) { h->err = "htm_read_rows: hipMalloc failed"; return HTM_ERR_HIP; }
+            hipLaunchKernelGGL(k_tm_potentials, dim3((unsigned)std::min<int64_t>((n * 8 + 255) / 256, 8192)), dim3(256), 0, h->stream, d, q, tmp,
+                               (int)row_begin, (int)(row_begin + row_count));
+            const bool ok = hipStreamSynchronize(h->stream) == hipSuccess && hipMemcpy(dst, tmp, (size_t)n * 4, hipMemcpyDeviceToHost) == hipSuccess;
+            hipFree(tmp);
+            if (!ok) { h->err = "htm_read_rows: potentials kernel failed"; return HTM_ERR_HIP; }
+            return n;
+        }
+        case HTM_F_MATCH_INFO: {
+            const int64_t w0 = row_begin >> 5, w1 = (row_begin + row_count + 31) >> 5;
+            std::vector<uint32_t> bits((size_t)(w1 - w0), 0u);
+            if (c.has_distal && hipMemcpy(bits.data(), d.match_bits[q] + w0, bits.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) { h->err = "htm_read_rows: hipMemcpy failed"; return HTM_ERR_HIP; }
+            if (!copy(d.seg_info + row_begin, (size_t)n * 4)) return HTM_ERR_HIP;
+            for (int64_t i = 0; i < n; ++i) {
+                const int64_t r = row_begin + i;
+                const bool m = (bits[(size_t)((r >> 5) - w0)] >> (r & 31)) & 1u;
+                ((uint32_t *)dst)[i] = m ? (((uint32_t *)dst)[i] & ~0x40000000u) : 0u;
+            }
+            return n;
+        }
+        default: h->err = "htm_read_rows: not a per-segment field"; return HTM_ERR_ARGUMENT;
+    }
+}
+
 extern "C" int htm_write(htm_handle *h, int32_t field, const void *src, int64_t count) {
     if (!h || (!src && count > 0) || count < 0) return HTM_ERR_ARGUMENT;
     REJECT_WHEN_AHEAD(h);
@@ -1486,31 +1615,48 @@ extern "C" int htm_write(htm_handle *h, int32_t field, const void *src, int64_t 
 }
 
 extern "C" int htm_import_begin(htm_handle *h, int64_t step_index) {
-    if (!h || step_index < 0) return HTM_ERR_ARGUMENT;
+    if (!h || (step_index < 0 && step_index != HTM_IMPORT_PREV_STATE)) return HTM_ERR_ARGUMENT;
     REJECT_WHEN_AHEAD(h);
     if (h->world > 1) { h->err = "state import is not available on a column-sharded handle"; return HTM_ERR_STATE; }
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    h->step_host = step_index;
+    h->import_keep = step_index == HTM_IMPORT_PREV_STATE;
+    if (!h->import_keep) h->step_host = step_index;
+    int rc = close_open_phases(h);
+    if (rc) return rc;
     return HTM_OK;
+}
+
+// winner words (d.win[q], what HTM_F_WINNER_WORDS and State.winner_cell read) from the imported winner list
+__global__ __launch_bounds__(256) void k_tm_winner_words(Dev d, int q, int n) {
+    for (int c = blockIdx.x * 256 + threadIdx.x; c < d.C; c += gridDim.x * 256) d.win[q][c] = 0;
+}
+__global__ __launch_bounds__(256) void k_tm_winner_bits(Dev d, int q, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) { const int e = d.winners[q][i]; atomicOr(&d.win[q][e >> 5], 1u << (e & 31)); }
 }
 
 extern "C" int htm_import_commit(htm_handle *h, int32_t segments, int32_t matching_segments, int32_t winner_cells,
                                  int32_t has_distal_state, int32_t has_winner_cells) {
     if (!h) return HTM_ERR_ARGUMENT;
     Dev &d = h->d;
-    if (segments < 0 || segments > d.Scap || matching_segments < 0 || matching_segments > segments ||
-        winner_cells < 0 || winner_cells > d.k * 32) { h->err = "htm_import_commit: bad scalars"; return HTM_ERR_ARGUMENT; }
+    const bool keep = h->import_keep;              // TemporalMemory.process(prev_state=X): the previous step's State only
+    h->import_keep = false;
     Counters c;
     int rc = read_counters(h, &c);
     if (rc) return rc;
+    if (keep) segments = c.S;                       // (the store stays what it is)
+    if (segments < 0 || segments > d.Scap || matching_segments < 0 || matching_segments > segments ||
+        winner_cells < 0 || winner_cells > d.k * 32) { h->err = "htm_import_commit: bad scalars"; return HTM_ERR_ARGUMENT; }
     const int q = (int)((h->step_host + 1) & 1);
-    c.step[h->step_host & 1] = (uint32_t)h->step_host;
-    c.n_work[0] = c.n_work[1] = 0;
-    c.n_bind[0] = c.n_bind[1] = 0;
-    c.S = segments;
-    h->seg_hint = segments;                         // (the one place where the count can go down)
-    if (h->seg_pinned) *h->seg_pinned = segments;
+    if (!keep) {
+        c.step[h->step_host & 1] = (uint32_t)h->step_host;
+        c.n_work[0] = c.n_work[1] = 0;
+        c.n_bind[0] = c.n_bind[1] = 0;
+        c.S = segments;
+        h->seg_hint = segments;                     // (the one place where the count can go down)
+        if (h->seg_pinned) *h->seg_pinned = segments;
+    }
     {   // dense per-segment info from the staged PredictiveProjection.State lists
         const size_t M = (size_t)matching_segments;
         if (has_distal_state && (h->imp_pot.size() != (size_t)segments || h->imp_match_seg.size() != M ||
@@ -1545,12 +1691,28 @@ extern "C" int htm_import_commit(htm_handle *h, int32_t segments, int32_t matchi
     c.has_winner[q] = has_winner_cells ? 1 : 0;
     c.has_distal = has_distal_state ? 1 : 0;
     c.cm_dense_step = (uint32_t)h->step_host + 1u;
-    c.error = 0;
+    if (!keep) c.error = 0;                         // a checkpoint restore starts clean; an adopted previous State does not
+                                                    // forgive an overflow of the store it keeps
     HIPCHK(h, hipMemcpy(d.ctr, &c, sizeof(c), hipMemcpyHostToDevice));
     if (h->cfg.enable_tm) {
-        HIPCHK(h, hipMemsetAsync(d.recyc_cnt2, 0, ((size_t)(h->s1024_blocks + 1023) / 1024 + 1) * sizeof(int), h->stream));
-        hipLaunchKernelGGL(k_tm_recount, dim3(h->s1024_blocks), dim3(256), 0, h->stream, d);
-        hipLaunchKernelGGL(k_tm_flag_connected, dim3(std::min(4096, std::max(1, (int)(((long long)segments * d.E + 255) / 256)))), dim3(256), 0, h->stream, d);
+        // the previous step's active columns (State.active_cell / winner_cell index with them): the columns with an active cell
+        {
+            std::vector<uint32_t> act((size_t)d.C);
+            HIPCHK(h, hipMemcpy(act.data(), d.act[q], act.size() * 4, hipMemcpyDeviceToHost));
+            std::vector<int> cols((size_t)d.k, 0);
+            int n = 0;
+            for (int col = 0; col < d.C && n < d.k; ++col)
+                if (act[(size_t)col]) cols[(size_t)n++] = col;
+            HIPCHK(h, hipMemcpy(d.active_cols[q], cols.data(), cols.size() * 4, hipMemcpyHostToDevice));
+        }
+        // State.winner_cell / HTM_F_WINNER_WORDS read the winner words: rebuild them from the imported list
+        hipLaunchKernelGGL(k_tm_winner_words, dim3(std::min((d.C + 255) / 256, 1024)), dim3(256), 0, h->stream, d, q, winner_cells);
+        if (winner_cells > 0) hipLaunchKernelGGL(k_tm_winner_bits, dim3((winner_cells + 255) / 256), dim3(256), 0, h->stream, d, q, winner_cells);
+        if (!keep) {
+            HIPCHK(h, hipMemsetAsync(d.recyc_cnt2, 0, ((size_t)(h->s1024_blocks + 1023) / 1024 + 1) * sizeof(int), h->stream));
+            hipLaunchKernelGGL(k_tm_recount, dim3(h->s1024_blocks), dim3(256), 0, h->stream, d);
+            hipLaunchKernelGGL(k_tm_flag_connected, dim3(std::min(4096, std::max(1, (int)(((long long)segments * d.E + 255) / 256)))), dim3(256), 0, h->stream, d);
+        }
         HIPCHK(h, hipStreamSynchronize(h->stream));
     }
     return HTM_OK;

@@ -1024,7 +1024,7 @@ __global__ __launch_bounds__(1024) void k_shard_select(Dev d, const unsigned cha
     const int tid = threadIdx.x, lane = lane_id();
     const int KL = d.n_cand, n_tot = d.world * KL;
     const size_t rb = shard_record_bytes(KL);
-    const uint32_t inv_kl = (uint32_t)(((1ull << 32) + (uint32_t)KL - 1) / (uint32_t)KL);      // i / KL for i < 2^16-ish: one multiplication
+    const u64 inv_kl = ((1ull << 32) + (u64)KL - 1) / (u64)KL;      // i / KL for i < 2^16-ish: one multiplication (64 bits: KL = 1 gives 2^32)
     auto key_at = [&](int i) -> u64 {
         int r = (int)(((u64)(uint32_t)i * inv_kl) >> 32);
         if (r * KL > i) --r;

@@ -1207,12 +1207,14 @@ __global__ __launch_bounds__(256) void k_tm_populate(Dev d, long long cell_begin
 }
 
 // State.segment_potential (projections.py:246) for every segment, on demand: active presynaptic cells of the last
-// completed step (parity p), 8 lanes per segment (sharded handles: per local row).
-__global__ __launch_bounds__(256) void k_tm_potentials(Dev d, int p, int *out) {
-    const int S = d.world > 1 ? d.ctr->L : d.ctr->S;
+// completed step (parity p), 8 lanes per segment (sharded handles: per local row).  Rows [row_begin, row_end) into
+// out[row - row_begin].
+__global__ __launch_bounds__(256) void k_tm_potentials(Dev d, int p, int *out, int row_begin, int row_end) {
+    const int S = min(d.world > 1 ? d.ctr->L : d.ctr->S, row_end);
     const uint32_t *act = d.act[p];
     const int l = threadIdx.x & 7;
-    for (int seg = (blockIdx.x * 256 + threadIdx.x) >> 3; seg < S; seg += (gridDim.x * 256) >> 3) {
+    out -= row_begin;
+    for (int seg = row_begin + ((blockIdx.x * 256 + threadIdx.x) >> 3); seg < S; seg += (gridDim.x * 256) >> 3) {
         const int n = d.seg_nsyn[seg];
         const int *prow = d.presyn + (size_t)seg * d.E;
         int pot = 0;

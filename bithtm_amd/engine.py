@@ -135,7 +135,7 @@ class Engine:
         (or None) -- while the segment store and the step index stay what they are."""
         K = self.cell_dim
         S = self.info().segments
-        self._check(self.lib.htm_import_begin(self.h, int(self.steps)), "htm_import_begin")
+        self._check(self.lib.htm_import_begin(self.h, -1), "htm_import_begin")     # HTM_IMPORT_PREV_STATE: store, step index, flags stay
         self.write(L.F_CELL_PREDICTION, bool_to_words(np.asarray(prediction).reshape(self.column_dim, K)), np.uint32)
         self.write(L.F_CELL_ACTIVATION, bool_to_words(np.asarray(activation).reshape(self.column_dim, K)), np.uint32)
         winners = np.zeros(0, np.int32) if winner_flat is None else np.asarray(winner_flat, dtype=np.int32)
@@ -165,6 +165,14 @@ class Engine:
         out = np.empty(int(count), dtype=dtype)
         n = self._check(self.lib.htm_read(self.h, field, out.ctypes.data_as(C.c_void_p), out.size), "htm_read")
         return out[:n]
+
+    def read_rows(self, field, dtype, row_begin, row_count):
+        """Rows [row_begin, row_begin + row_count) of a per-segment field (htm_read_rows)."""
+        per = self.segment_slots if field in (L.F_SEG_PRESYN, L.F_SEG_PERM) else 1
+        out = np.empty(int(row_count) * per, dtype=dtype)
+        n = self._check(self.lib.htm_read_rows(self.h, field, int(row_begin), int(row_count), out.ctypes.data_as(C.c_void_p), out.size),
+                        "htm_read_rows")
+        return out[:n].reshape(int(row_count), per) if per > 1 else out[:n]
 
     def write(self, field, array, dtype):
         a = np.ascontiguousarray(array, dtype=dtype)

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define BITHTM_ABI_VERSION 2
+#define BITHTM_ABI_VERSION 3
 
 typedef struct htm_handle htm_handle;
 
@@ -198,9 +198,12 @@ int htm_run(htm_handle *h, const uint32_t *device_inputs, int32_t n_inputs, int3
 /* use_graph bit 2 (HTM_RUN_CONTINUE): a caller that streams its input in chunks promises that the next call is another
  * htm_run on the same bank, n_inputs and learning flag.  The Spatial Pooler then keeps working ahead across the end
  * of this call (the next step's overlaps and winner list are computed beside this call's last Temporal Memory
- * step) and the next call starts in the steady state instead of with a cold start of three more launches.  Until a later htm_run ends without the bit, every other call that needs the
- * Spatial Pooler's state (htm_step, htm_sp_*, htm_tm_step, state import, the Spatial Pooler fields of htm_read)
- * returns HTM_ERR_STATE; the Temporal Memory's state is that of exactly the steps run so far. */
+ * step) and the next call starts in the steady state instead of with a cold start of three more launches.  Until a
+ * later htm_run ends without the bit, every other call that needs the Spatial Pooler's state (htm_step, htm_sp_*,
+ * htm_tm_step, state import, the Spatial Pooler fields of htm_read) returns HTM_ERR_STATE; the Temporal Memory's state
+ * is that of exactly the steps run so far.  Where the pipelined schedule is not available the bit is ignored; a handle
+ * that is ahead when the schedule becomes unavailable (another handle with its own stream appears on the device)
+ * finishes the step it had begun in the schedule it began it in and goes on unpipelined -- never an error. */
 #define HTM_RUN_GRAPH 1
 #define HTM_RUN_NO_PIPELINE 2
 #define HTM_RUN_CONTINUE 4
@@ -271,11 +274,21 @@ int htm_get_info(htm_handle *h, htm_info *out);      /* synchronises; HTM_ERR_CA
  * number of elements written (>= 0) or a negative status. */
 int64_t htm_read(htm_handle *h, int32_t field, void *dst, int64_t count);
 
+/* Rows [row_begin, row_begin + row_count) of a per-segment field (HTM_F_SEG_CELL / _NSYN / _PRESYN / _PERM / _POTENTIAL /
+ * _GID, same element types as htm_read), for pools too large to read whole (the reference's `segment_bundle[a:b]`,
+ * `output_edge[a:b]`, `output_permanence[a:b]`: projections.py:226,43-44).  HTM_F_MATCH_INFO comes back DENSE here: one
+ * word per row, potential | activation<<12 | active<<31 for a matching row, 0 otherwise.  count = elements dst holds. */
+int64_t htm_read_rows(htm_handle *h, int32_t field, int64_t row_begin, int64_t row_count, void *dst, int64_t count);
+
 /* State import (checkpoint / hand-off from another implementation), in three steps:
  *   htm_import_begin(h, step_index)   the state being imported is "after step_index steps"
  *   htm_write(h, field, src, count)   the arrays of htm_read, same element types
  *   htm_import_commit(...)            the scalars that go with them; rebuilds derived state
- * SP permanences are imported with htm_sp_set_permanence. */
+ * SP permanences are imported with htm_sp_set_permanence.
+ * htm_import_begin(h, HTM_IMPORT_PREV_STATE): TemporalMemory.process(..., prev_state=X) (networks.py:92-93) -- only the
+ * fields of the previous step's State are written (cell words, winner cells, MATCH_* / SEG_POTENTIAL / CELL_MAX_JITTER);
+ * the segment store, the step index and the sticky capacity flags stay what they are (`segments` of the commit is ignored). */
+#define HTM_IMPORT_PREV_STATE (-1)
 int htm_import_begin(htm_handle *h, int64_t step_index);
 int htm_write(htm_handle *h, int32_t field, const void *src, int64_t count);
 int htm_import_commit(htm_handle *h, int32_t segments, int32_t matching_segments, int32_t winner_cells,

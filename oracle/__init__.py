@@ -5,7 +5,10 @@ This package is a NumPy restatement of the reference algorithm (cokwa/bitHTM,
 deterministic policies written down in DESIGN.md (stable top-k, documented float32 exp,
 keyed counter-based random draws).  It exists to CHECK the HIP path; it is never the thing
 shipped or measured.  Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s
-`cpu_baseline` leg may import it.  Nothing under `bithtm_amd/` imports it.
+`cpu_baseline` leg (the timed NumPy baseline and, with the same objects, the self-checks of
+the bench line: the GPU's next steps against the baseline's, the sampled rows of the
+configs[4] pool against the keyed generator) may import it -- there only as the checker.
+Nothing under `bithtm_amd/` imports it.
 
 Parity status: PINNED.  `tests/golden/generate_golden.py` runs the *unmodified* reference
 (imported read-only from /root/reference in the build container) through its own
@@ -21,5 +24,5 @@ from .keyed_rng import draw24, STREAM_LEAST_USED, STREAM_GROWTH, STREAM_SEGMENT_
 from .fexp import exp_f32  # noqa: F401
 from .htm_oracle import (  # noqa: F401
     SPParams, TMParams, SpatialPoolerOracle, TemporalMemoryOracle, HTMOracle, stable_topk,
-    canonical_synapses,
+    canonical_synapses, populated_rows,
 )

@@ -229,20 +229,11 @@ class TemporalMemoryOracle:
         self.seg_nsyn = np.full(S, n, dtype=np.int32)
         self.presyn = np.full((S, self.slots), -1, dtype=np.int32)
         self.perm = np.full((S, self.slots), -1.0, dtype=np.float32)
-        idx = np.arange(n)
         for lo in range(0, S, 1 << 18):                 # in slices: the intermediates stay small
             g = gid[lo:lo + (1 << 18)]
-            cells = ((draw32(seed, STREAM_POPULATE_CELL, 0, g[:, None], idx[None, :]).astype(np.uint64) * np.uint64(N))
-                     >> np.uint64(32)).astype(np.int64)
-            srt = np.sort(cells, axis=1)
-            for r in np.flatnonzero((srt[:, 1:] == srt[:, :-1]).any(axis=1)):      # rare: settle in synapse order
-                row = cells[r]
-                for i in range(1, n):
-                    while row[i] in row[:i]:
-                        row[i] = (row[i] + 1) % N
-            u = draw24(seed, STREAM_POPULATE_PERM, 0, g[:, None], idx[None, :]).astype(np.float64) * (1.0 / 16777216.0)
+            cells, perms = populated_rows(N, g, n, perm_lo, perm_hi, seed)
             self.presyn[lo:lo + len(g), :n] = cells
-            self.perm[lo:lo + len(g), :n] = (perm_lo + (perm_hi - perm_lo) * u).astype(np.float32)
+            self.perm[lo:lo + len(g), :n] = perms
         self.segcount[cell_begin:cell_end] = spc
         self.S = S
 
@@ -468,6 +459,25 @@ class TemporalMemoryOracle:
                 prediction=np.array(st["prediction"], dtype=np.float64))
         else:
             self.prev_distal = None
+
+
+def populated_rows(N, gid, synapses, perm_lo, perm_hi, seed):
+    """The synapses htm_populate / TemporalMemoryOracle.populate give the segments with ids `gid` (any subset, any order):
+    presynaptic flat cell ids int64[len(gid), synapses] and float32 permanences -- keyed by the segment id alone, so a
+    sample of a pool too large for the host can be regenerated and checked (bench.py's configs[4] leg)."""
+    g = np.asarray(gid, dtype=np.int64)
+    n = int(synapses)
+    idx = np.arange(n)
+    cells = ((draw32(seed, STREAM_POPULATE_CELL, 0, g[:, None], idx[None, :]).astype(np.uint64) * np.uint64(N))
+             >> np.uint64(32)).astype(np.int64)
+    srt = np.sort(cells, axis=1)
+    for r in np.flatnonzero((srt[:, 1:] == srt[:, :-1]).any(axis=1)):      # rare: settle in synapse order
+        row = cells[r]
+        for i in range(1, n):
+            while row[i] in row[:i]:
+                row[i] = (row[i] + 1) % N
+    u = draw24(seed, STREAM_POPULATE_PERM, 0, g[:, None], idx[None, :]).astype(np.float64) * (1.0 / 16777216.0)
+    return cells, (perm_lo + (perm_hi - perm_lo) * u).astype(np.float32)
 
 
 def canonical_synapses(seg_cell, presyn, perm):

@@ -133,3 +133,56 @@ def test_standalone_temporal_memory_takes_more_columns_later():
         got, want = tm.process(SimpleNamespace(active_column=cols)), ora.step(cols)
         assert np.array_equal(got.cell_prediction, want.cell_prediction) and np.array_equal(got.cell_activation, want.cell_activation), t
         assert np.array_equal(got.winner_cell[0], want.winner_cell[0]) and np.array_equal(got.winner_cell[1], want.winner_cell[1]), t
+
+
+def test_l1_methods_on_the_objects_of_a_live_pooler_do_not_disturb_its_steps():
+    """DenseProjection.process / ExponentialBoosting.process called on their own on the objects BOUND to a live
+    SpatialPooler / HierarchicalTemporalMemory use that pooler's engine (one phase of the current, unfinished timestep:
+    keys, boosted overlaps, the top-digit histogram).  The whole steps that follow -- sp.process(), htm.process(), htm.run()
+    -- must start over from a clean histogram and return the completed step's fields: interleaved here, against the oracle."""
+    import bithtm_amd as B
+    I, C, K, k, seed = 300, 2048, 8, 41, 71
+    np.random.seed(seed)
+    perm = np.random.randn(C, I) * 0.1
+    rng = np.random.RandomState(seed + 1)
+    bank = rng.rand(10, I) < 0.1
+    # a Spatial Pooler on its own
+    ora = SpatialPoolerOracle(I, C, k, permanence=perm)
+    prox = B.DenseProjection(I, C)
+    prox.permanence = perm
+    sp = B.SpatialPooler(I, C, k, proximal_projection=prox)
+    for t in range(40):
+        x = bank[t % 10] ^ (rng.rand(I) < 0.01)
+        if t % 3 == 1:
+            probe = bank[(t + 5) % 10]
+            assert np.array_equal(sp.proximal_projection.process(probe), ora.overlaps(probe)), t
+        if t % 4 == 2:
+            assert np.array_equal(sp.boosting.process(ora.overlaps(x)).view(np.int64), ora.boost(ora.overlaps(x)).view(np.int64)), t
+        want, got = ora.step(x), sp.process(x)
+        assert np.array_equal(got.active_column, want.active_column), t
+        assert np.array_equal(got.overlaps, want.overlaps), t
+        assert np.array_equal(got.boosted_overlaps.view(np.int64), want.boosted_overlaps.view(np.int64)), t
+    # the same inside a HierarchicalTemporalMemory, with batched runs in between
+    ora = HTMOracle(I, C, K, active_columns=k, seed=seed, permanence=perm)
+    prox = B.DenseProjection(I, C)
+    prox.permanence = perm
+    htm = B.HierarchicalTemporalMemory(I, C, K, active_columns=k, spatial_pooler=B.SpatialPooler(I, C, k, proximal_projection=prox),
+                                       temporal_memory=B.TemporalMemory(C, K, seed=seed))
+    t = 0
+    for rnd in range(12):
+        probe = bank[(rnd + 3) % 10]
+        assert np.array_equal(htm.spatial_pooler.proximal_projection.process(probe), ora.spatial_pooler.overlaps(probe)), rnd
+        if rnd % 2:
+            for _ in range(5):
+                o_sp, o_tm = ora.step(bank[t % 10])
+                t += 1
+            htm.run(bank, 5)
+            assert np.array_equal(htm.engine.read_sp_fields()["active_column"], o_sp.active_column), rnd
+            assert np.array_equal(htm.engine.read_sp_fields()["overlaps"], o_sp.overlaps), rnd
+        else:
+            o_sp, o_tm = ora.step(bank[t % 10])
+            s, m = htm.process(bank[t % 10])
+            t += 1
+            assert np.array_equal(s.active_column, o_sp.active_column), rnd
+            assert np.array_equal(s.overlaps, o_sp.overlaps), rnd
+            assert np.array_equal(m.cell_prediction, o_tm.cell_prediction), rnd

@@ -154,3 +154,120 @@ def test_populated_pool_column_sharded(world):
         a = canonical_synapses(st["seg_cell"][live], st["presyn"][live], st["perm"][live])
         b = canonical_synapses(otm.seg_cell[g], otm.presyn[g], otm.perm[g])
         assert all(x[0] == y[0] and np.array_equal(x[1], y[1]) and np.array_equal(x[2].view(np.int32), y[2].view(np.int32)) for x, y in zip(a, b))
+
+
+# ---- the large-pool scan under a big column bitmap: k_tm_scan_wide, the kernel of bench.py's configs[4] leg -------------
+# It is selected for more than 294 912 rows AND more than 131 072 columns (htm_engine.hip: launch_scan).  Random
+# synapses of a pre-populated pool reach the default matching threshold (15 of 32 on 2 % active cells) never, so the
+# thresholds are lowered here: about 3 % of the segments then match and a fifth of those are active -- potentials,
+# connected-active counts, per-cell maxima and prediction bits of the scan are all exercised.
+WIDE_TM = dict(segment_activation_threshold=4, segment_matching_threshold=3, segment_sampling_synapses=16)
+
+
+def _scan_outputs_equal(eng, od, want, rows, gid_of_row=None, own_cells=None):
+    """What the scan publishes for the handle's rows -- matching set, potential / connected-active count / active flag
+    of the matching segments, every row's potential, the per-cell maxima and the prediction words -- against the oracle's
+    PredictiveProjection.State (projections.py:245-255, :229-239)."""
+    from bithtm_amd import _lib as L
+    C, K = eng.column_dim, eng.cell_dim
+    info = eng.read_rows(L.F_MATCH_INFO, np.uint32, 0, rows)
+    gid = np.arange(rows) if gid_of_row is None else gid_of_row
+    live = np.flatnonzero(gid >= 0)
+    m = live[info[live] != 0]
+    order = np.argsort(gid[m], kind="stable")
+    m = m[order]
+    mine = np.ones(len(od.matching_segment), bool)
+    if own_cells is not None:
+        lo, hi = own_cells
+        cell = want["seg_cell"][od.matching_segment]
+        mine = (cell >= lo) & (cell < hi)
+    assert np.array_equal(gid[m], od.matching_segment[mine]), "matching segments"
+    assert np.array_equal((info[m] & 0xFFF).astype(np.int64), od.segment_potential[od.matching_segment[mine]]), "potentials of the matching segments"
+    assert np.array_equal(((info[m] >> 12) & 0xFFF).astype(np.int64), od.matching_segment_activation[mine]), "connected-active counts"
+    assert np.array_equal((info[m] >> 31).astype(bool), od.matching_segment_active[mine]), "active segments"
+    pot = eng.read_rows(L.F_SEG_POTENTIAL, np.int32, 0, rows)
+    assert np.array_equal(pot[live].astype(np.int64), od.segment_potential[gid[live]]), "every row's potential"
+    lo, hi = (0, C * K) if own_cells is None else own_cells
+    cm = eng.read(L.F_CELL_MAX_JITTER, np.float32, C * K)
+    assert np.array_equal(cm[lo:hi].view(np.int32), od.max_jittered_potential[lo:hi].view(np.int32)), "per-cell maxima"
+    pred = eng.read(L.F_CELL_PREDICTION, np.uint32, C)
+    assert np.array_equal(pred[lo // K:hi // K], _words(want["cell_prediction"])[lo // K:hi // K]), "prediction words"
+
+
+def test_wide_scan_kernel_262144_columns_unsharded():
+    """262 144 columns x 16 cells, 2 segments per cell = 8.4 M rows on one unsharded handle: the scan is k_tm_scan_wide
+    (asserted by the launch's name), compared with the oracle over learning steps."""
+    C, K, k = 262144, 16, 5243
+    tmp = TMParams(**WIDE_TM)
+    ora = TemporalMemoryOracle(C, K, tmp, seed=0)
+    ora.populate(2, synapses=32, seed=0)
+    eng = _engine(C, K, k, tmp, capacity=ora.S + (1 << 18), seed=0)
+    eng.populate(2, synapses=32, seed=0)
+    rng = np.random.RandomState(2)
+    seqs = [np.sort(rng.choice(C, k, replace=False)) for _ in range(2)]
+    eng.profile(True)
+    for t in range(3):
+        cols = seqs[t % 2]
+        want = ora.step(cols, learning=t > 0)
+        eng.tm_step(cols, learning=t > 0)
+        info = eng.check_capacity()
+        assert info.segments == ora.S
+        _scan_outputs_equal(eng, want.distal_state, dict(seg_cell=ora.seg_cell, cell_prediction=want.cell_prediction), info.local_segments)
+        assert len(want.distal_state.matching_segment) > 100000 and want.distal_state.matching_segment_active.sum() > 1000
+    names = eng.profile_read()
+    eng.profile(False)
+    assert names.get("tm_scan_wide", (0, 0))[1] == 3 and "tm_scan" not in names and "tm_scan_large" not in names, names
+    rng = np.random.RandomState(3)
+    _compare_store(eng, ora, sample=np.concatenate([rng.choice(C * K * 2, 3000, replace=False), np.arange(C * K * 2, ora.S)]))
+
+
+def test_wide_scan_kernel_as_rank_0_of_the_configs4_group():
+    """The 8-rank group of bench.py's configs[4] leg (LocalGroup, 262 144 columns x 16 cells, the pool generated for rank
+    0's cells only) with 8 segments per cell: rank 0 scans its 4.2 M rows with k_tm_scan_wide.  SP + TM with learning
+    against the unsharded oracle with the same generated pool."""
+    import bithtm_amd as B
+    from bithtm_amd import _lib as L
+    from bithtm_amd.distributed import LocalGroup
+    import bench
+    I, C, K, world, spc = 1024, 262144, 16, 8, 8
+    k = round(C * 0.02)
+    own_cells = C // world * K
+    rows0 = own_cells * spc
+    tmp = TMParams(**WIDE_TM)
+    lazy = bench.LazyPermanence(C, I, 12345)
+    per = C // world
+    perm = np.concatenate([lazy[slice(r * per, (r + 1) * per)] for r in range(world)])
+    ora = HTMOracle(I, C, K, active_columns=k, seed=0, tm_params=tmp, permanence=perm)
+    del perm
+    ora.temporal_memory.populate(spc, synapses=32, seed=0, cell_begin=0, cell_end=own_cells)
+
+    def parts(r):
+        return dict(distal=B.PredictiveProjection(C * K, segment_capacity=rows0 + 64 * k, segment_slots=64,
+                                                  segment_capacity_local=(rows0 if r == 0 else 0) + 64 * k,
+                                                  **{f: getattr(tmp, f) for f in tmp.__dataclass_fields__}))
+    group = LocalGroup(world, I, C, K, active_columns=k, permanence=lazy, make_parts=parts, seed=0)
+    for e in group.engines:
+        e.populate(spc, synapses=32, seed=0, cell_begin=0, cell_end=own_cells)
+    rng = np.random.RandomState(7)
+    bank = rng.rand(3, I) < 0.02
+    eng0 = group.engines[0]
+    otm = ora.temporal_memory
+    eng0.profile(True)
+    for t in range(3):
+        o_sp, o_tm = ora.step(bank[t % 3])
+        group.process(bank[t % 3])
+        for m in group.members:
+            info = m.engine.check_capacity()
+            assert info.segments == otm.S, (t, m.rank)
+            assert np.array_equal(m.engine.read(L.F_ACTIVE_COLUMN, np.int32, k), o_sp.active_column), (t, m.rank)
+            c0, c1 = m.column_range
+            pred = m.engine.read(L.F_CELL_PREDICTION, np.uint32, C)
+            assert np.array_equal(pred[c0:c1], _words(o_tm.cell_prediction)[c0:c1]), (t, m.rank)
+        info = eng0.info()
+        gid = eng0.read_rows(L.F_SEG_GID, np.int32, 0, info.local_segments)
+        _scan_outputs_equal(eng0, o_tm.distal_state, dict(seg_cell=otm.seg_cell, cell_prediction=o_tm.cell_prediction), info.local_segments,
+                            gid_of_row=gid, own_cells=(0, own_cells))
+        assert (o_tm.distal_state.matching_segment < rows0).sum() > 50000
+    names = eng0.profile_read()
+    eng0.profile(False)
+    assert names.get("tm_scan_wide", (0, 0))[1] == 3 and "tm_scan" not in names and "tm_scan_large" not in names, names

@@ -162,3 +162,26 @@ def test_random_sharded_configurations():
                            segment_sampling_synapses=int(rng.choice([8, 16])), permanence_punishment=float(rng.choice([0.01, 0.3])))
         _run(world, I=int(rng.choice([64, 200])), C=C, K=K, P=int(rng.choice([5, 12])), density=float(rng.choice([0.1, 0.3])),
              noise=float(rng.choice([0.0, 0.02])), steps=60, jump=float(rng.choice([0.0, 0.2])), seed=int(rng.randint(1 << 16)), tmp=tmp)
+
+
+def test_one_candidate_per_rank():
+    """active_columns = 1: every rank's record holds ONE candidate (the candidate -> (rank, entry) division of
+    k_shard_select with KL = 1)."""
+    import bithtm_amd as B
+    from bithtm_amd.distributed import LocalGroup
+    from bithtm_amd import _lib as L
+    I, C, K, world, seed = 64, 256, 4, 2, 5
+    np.random.seed(seed)
+    perm = np.random.randn(C, I) * 0.1
+    ora = HTMOracle(I, C, K, active_columns=1, seed=seed, permanence=perm)
+    group = LocalGroup(world, I, C, K, active_columns=1, permanence=perm, seed=seed)
+    rng = np.random.RandomState(seed + 1)
+    bank = rng.rand(7, I) < 0.2
+    for t in range(60):
+        o_sp, o_tm = ora.step(bank[t % 7])
+        group.process(bank[t % 7])
+        for m in group.members:
+            assert np.array_equal(m.engine.read(L.F_ACTIVE_COLUMN, np.int32, 1), o_sp.active_column), (t, m.rank)
+            info = m.engine.check_capacity()
+            assert info.segments == ora.temporal_memory.S, (t, m.rank)
+            assert np.array_equal(m.engine.read(L.F_WINNER_CELL, np.int32, info.winner_cells), o_tm.winner_cell[0] * K + o_tm.winner_cell[1]), (t, m.rank)

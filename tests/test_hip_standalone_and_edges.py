@@ -528,3 +528,75 @@ def test_random_small_configurations_agree_with_the_oracle():
         except CapacityError:                      # a configuration that outgrows its fixed pool: documented, not parity
             pass
     assert done >= 12
+
+
+def test_prev_state_adoption_keeps_the_sticky_capacity_flags():
+    """TemporalMemory.process(prev_state=X) writes X back through the state import; that must not forgive an overflow of
+    the segment pool the handle keeps (the import of a checkpoint, which replaces the store, does)."""
+    import bithtm_amd as B
+    from types import SimpleNamespace
+    C, K, k = 512, 8, 20                                # (20 winners: a new segment grows 20 synapses, past the matching threshold, so it is not recycled)
+    tm = B.TemporalMemory(C, K, distal_projection=B.PredictiveProjection(C * K, segment_capacity=64, segment_slots=64), seed=4)
+    rng = np.random.RandomState(5)
+    seqs = [np.sort(rng.choice(C, k, replace=False)) for _ in range(30)]
+    first = tm.process(SimpleNamespace(active_column=seqs[0]))
+    first.cell_prediction                               # (materialised: an earlier State of this object)
+    for cols in seqs[1:]:
+        tm.process(SimpleNamespace(active_column=cols))  # every column bursts: 20 new segments per step, the pool holds 64
+    with pytest.raises(B.CapacityError, match="segment pool"):
+        tm._engine.check_capacity()
+    st = tm.process(SimpleNamespace(active_column=seqs[3]), prev_state=first)
+    assert tm._engine.info().capacity_error & 1
+    with pytest.raises(B.CapacityError, match="segment pool"):
+        st.cell_prediction
+
+
+def test_winner_cells_survive_a_checkpoint_round_trip(tmp_path):
+    """State.winner_cell is read from the winner words; a state import fills them from the imported winner list."""
+    import bithtm_amd as B
+    rng = np.random.RandomState(21)
+    bank = rng.rand(12, 160) < 0.1
+    np.random.seed(22)
+    a = B.HierarchicalTemporalMemory(160, 1024, 8)
+    for t in range(40):
+        _, tm_state = a.process(bank[t % 12])
+    want = tm_state.winner_cell
+    a.save(str(tmp_path / "ckpt.npz"))
+    np.random.seed(23)
+    b = B.HierarchicalTemporalMemory(160, 1024, 8)
+    b.load(str(tmp_path / "ckpt.npz"))
+    got = b.temporal_memory.last_state.winner_cell
+    assert got is not None and np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    a.load(str(tmp_path / "ckpt.npz"))                  # into the handle that wrote it, too
+    got = a.temporal_memory.last_state.winner_cell
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    sa, ta = a.process(bank[4])
+    sb, tb = b.process(bank[4])
+    assert np.array_equal(ta.winner_cell[0], tb.winner_cell[0]) and np.array_equal(ta.cell_prediction, tb.cell_prediction)
+
+
+def test_a_stream_of_continuing_runs_survives_another_handle_appearing():
+    """A handle whose Spatial Pooler is ahead (HTM_RUN_CONTINUE) when another handle with its own stream is created on the
+    device loses the in-kernel select finish: the next htm_run must finish the step that was begun and go on unpipelined,
+    with the same results -- not return HTM_ERR_STATE for ever."""
+    import bithtm_amd as B
+    rng = np.random.RandomState(31)
+    bank = rng.rand(20, 200) < 0.08
+    np.random.seed(32)
+    twin = B.HierarchicalTemporalMemory(200, 2048, 16)
+    for t in range(57):
+        twin.process(bank[t % 20])
+    want = twin.engine.export_tm_state()
+    del twin
+    np.random.seed(32)
+    htm = B.HierarchicalTemporalMemory(200, 2048, 16)
+    htm.run(bank, 20, continuing=True)
+    np.random.seed(33)
+    other = B.HierarchicalTemporalMemory(200, 2048, 16)  # a second live handle, private stream
+    other.process(bank[0])
+    htm.run(bank, 17, continuing=True)                   # (the promise is kept; the schedule is gone)
+    htm.run(bank, 20)
+    got = htm.engine.export_tm_state()
+    for key in want:
+        assert np.array_equal(np.asarray(got[key]), np.asarray(want[key])), key
+    del other

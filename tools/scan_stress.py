@@ -56,7 +56,7 @@ def main():
             eng.tm_step(cols, learning=False)
         prof = eng.profile_read()
         eng.profile(False)
-        ms, n = prof["tm_scan"]
+        ms, n = next(prof[k] for k in ("tm_scan_wide", "tm_scan_large", "tm_scan") if k in prof)
         us = 1e3 * ms / n
         algo = 4 * S * n_syn + 8 * S
         info = eng.info()
