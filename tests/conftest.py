@@ -33,3 +33,10 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(autouse=True)
+def _graphs_for_short_runs_too(monkeypatch):
+    """htm_run launches calls of fewer than 64 steps eagerly whatever use_graph says (BITHTM_EAGER_BELOW, read when a
+    handle is created).  The tests ask for graphs to exercise every capture plan with short runs: switch the policy off."""
+    monkeypatch.setenv("BITHTM_EAGER_BELOW", "0")
