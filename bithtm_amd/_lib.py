@@ -57,6 +57,8 @@ EXPORTS = {
     "htm_sp_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     "htm_sp_phase": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]),
     "htm_tm_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
+    "htm_tm_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    "htm_tm_scan": (C.c_int, [C.c_void_p, C.c_void_p]),
     "htm_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "htm_prepare": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "htm_bank_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]),

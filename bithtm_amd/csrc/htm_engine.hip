@@ -931,6 +931,94 @@ extern "C" int htm_tm_step(htm_handle *h, const int32_t *active_column, int32_t 
     return HTM_OK;
 }
 
+// PredictiveProjection.update (projections.py:257-293) called on its own: learning with the learning cells, the
+// punishment mask and the previous State chosen by the caller.  The previous step's side -- prev_state, input_activation,
+// winner_input -- is what the handle holds as its previous step (written there with the state import if it is not the
+// handle's own: HTM_IMPORT_PREV_STATE).  columns[i] (distinct, any order, at most active_columns) has learning cells
+// winner_words[i] (bit j = cell j; `output_learning` of :261-262 for that column) of which unaccounted_words[i] need a new
+// segment (:271: learning_output cells whose max jittered potential is below epsilon); punish_words: one word per column
+// of the model, bit j = cell j of `output_punishment` (:269), or NULL for "every cell of a column not listed" (what
+// TemporalMemory passes, networks.py:107-108,111).  Does not close the timestep: htm_tm_scan does.
+extern "C" int htm_tm_update(htm_handle *h, const int32_t *columns, const uint32_t *winner_words, const uint32_t *unaccounted_words,
+                             int32_t n, const uint32_t *punish_words) {
+    if (!h || (n > 0 && (!columns || !winner_words || !unaccounted_words))) return HTM_ERR_ARGUMENT;
+    REJECT_WHEN_AHEAD(h);
+    if (!h->cfg.enable_tm) { h->err = "handle has no Temporal Memory"; return HTM_ERR_STATE; }
+    if (h->world > 1) { h->err = "htm_tm_update: not available on a column-sharded handle"; return HTM_ERR_STATE; }
+    Dev &d = h->d;
+    if (n < 0 || n > d.k) { h->err = "htm_tm_update: more columns with learning cells than active_columns"; return HTM_ERR_ARGUMENT; }
+    // ascending columns (the order of the winner list, networks.py:103-104 under the ascending-column policy)
+    std::vector<int> order((size_t)n);
+    for (int i = 0; i < n; ++i) order[(size_t)i] = i;
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return columns[a] < columns[b]; });
+    std::vector<int> cols((size_t)n);
+    std::vector<uint32_t> ww((size_t)n), uw((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        const int o = order[(size_t)i];
+        cols[(size_t)i] = columns[o];
+        ww[(size_t)i] = winner_words[o];
+        uw[(size_t)i] = unaccounted_words[o] & winner_words[o];
+        if (cols[(size_t)i] < 0 || cols[(size_t)i] >= d.C || (i && cols[(size_t)i] == cols[(size_t)i - 1])) { h->err = "htm_tm_update: bad column list"; return HTM_ERR_ARGUMENT; }
+    }
+    HIPCHK(h, hipSetDevice(h->device));
+    const int p = (int)(h->step_host & 1);
+    int *d_cols = nullptr;
+    uint32_t *d_ww = nullptr, *d_uw = nullptr, *d_pun = nullptr;
+    auto release = [&]() { if (d_cols) hipFree(d_cols); if (d_ww) hipFree(d_ww); if (d_uw) hipFree(d_uw); if (d_pun) hipFree(d_pun); };
+    const size_t nb = (size_t)std::max(n, 1) * 4;
+    if (hipMalloc((void **)&d_cols, nb) != hipSuccess || hipMalloc((void **)&d_ww, nb) != hipSuccess || hipMalloc((void **)&d_uw, nb) != hipSuccess ||
+        (punish_words && hipMalloc((void **)&d_pun, (size_t)d.C * 4) != hipSuccess)) { release(); h->err = "htm_tm_update: hipMalloc failed"; return HTM_ERR_HIP; }
+    bool ok = true;
+    if (n) ok = hipMemcpyAsync(d_cols, cols.data(), nb, hipMemcpyHostToDevice, h->stream) == hipSuccess &&
+                hipMemcpyAsync(d_ww, ww.data(), nb, hipMemcpyHostToDevice, h->stream) == hipSuccess &&
+                hipMemcpyAsync(d_uw, uw.data(), nb, hipMemcpyHostToDevice, h->stream) == hipSuccess;
+    if (ok && punish_words) ok = hipMemcpyAsync(d_pun, punish_words, (size_t)d.C * 4, hipMemcpyHostToDevice, h->stream) == hipSuccess;
+    if (!ok) { release(); h->err = "htm_tm_update: hipMemcpy failed"; return HTM_ERR_HIP; }
+    hipLaunchKernelGGL(k_tm_ext_winners, dim3(std::min((d.C + 255) / 256, 1024)), dim3(256), 0, h->stream, d, p, d_cols, d_ww, d_uw, n, 0);
+    if (n) hipLaunchKernelGGL(k_tm_ext_winners, dim3((n + 255) / 256), dim3(256), 0, h->stream, d, p, d_cols, d_ww, d_uw, n, 1);
+    d.punish = d_pun;                               // (kernels take Dev by value: set for the middle launch only)
+    LAUNCH(h, "tm_mid", k_mid_rows, 1 + kClassifyBlocks + h->zero_blocks, 256, d, p, n, 1, 1, kClassifyBlocks, nullptr, 1, 0, 0, 0);
+    d.punish = nullptr;
+    launch_learn(h, p);
+    hipError_t e = hipGetLastError();
+    const bool synced = hipStreamSynchronize(h->stream) == hipSuccess;       // (the staging buffers are this call's)
+    release();
+    if (e != hipSuccess || !synced) { h->err = std::string("htm_tm_update: ") + hipGetErrorString(e != hipSuccess ? e : hipGetLastError()); return HTM_ERR_HIP; }
+    h->phase_open = false;
+    return HTM_OK;
+}
+
+// PredictiveProjection.process (projections.py:245-255) called on its own: the segment scan against the active cells the
+// caller names (active_words: one word per column of the model, bit j = cell j), which become the step's cell activation;
+// closes the timestep.  The State is read with htm_read (MATCH_*, SEG_POTENTIAL, CELL_MAX_JITTER, CELL_PREDICTION).
+extern "C" int htm_tm_scan(htm_handle *h, const uint32_t *active_words) {
+    if (!h || !active_words) return HTM_ERR_ARGUMENT;
+    REJECT_WHEN_AHEAD(h);
+    if (!h->cfg.enable_tm) { h->err = "handle has no Temporal Memory"; return HTM_ERR_STATE; }
+    if (h->world > 1) { h->err = "htm_tm_scan: not available on a column-sharded handle"; return HTM_ERR_STATE; }
+    Dev &d = h->d;
+    HIPCHK(h, hipSetDevice(h->device));
+    const int p = (int)(h->step_host & 1);
+    uint32_t *d_act = nullptr;
+    if (hipMalloc((void **)&d_act, (size_t)d.C * 4) != hipSuccess) { h->err = "htm_tm_scan: hipMalloc failed"; return HTM_ERR_HIP; }
+    bool ok = hipMemcpyAsync(d_act, active_words, (size_t)d.C * 4, hipMemcpyHostToDevice, h->stream) == hipSuccess;
+    // clean accumulators: the scan sets match bits, per-cell maxima and prediction bits with atomics (in a whole timestep the
+    // middle launch and the learning role of the step before leave them clean)
+    ok = ok && hipMemsetAsync(d.match_bits[p], 0, (size_t)(d.Lcap + 255) / 256 * 8 * 4, h->stream) == hipSuccess &&
+         hipMemsetAsync(d.cellmax[p], 0, (size_t)d.C * 32 * 4, h->stream) == hipSuccess &&
+         hipMemsetAsync(&d.ctr->n_active_cells, 0, sizeof(int), h->stream) == hipSuccess;
+    if (!ok) { hipFree(d_act); h->err = "htm_tm_scan: staging failed"; return HTM_ERR_HIP; }
+    hipLaunchKernelGGL(k_tm_ext_active, dim3(std::min((d.C + 255) / 256, 1024)), dim3(256), 0, h->stream, d, p, d_act);
+    launch_scan(h, p, scan_lds(d, 1) <= 64 * 1024);
+    hipError_t e = hipGetLastError();
+    const bool synced = hipStreamSynchronize(h->stream) == hipSuccess;
+    hipFree(d_act);
+    if (e != hipSuccess || !synced) { h->err = std::string("htm_tm_scan: ") + hipGetErrorString(e != hipSuccess ? e : hipGetLastError()); return HTM_ERR_HIP; }
+    h->step_host += 1;
+    h->phase_open = false;
+    return HTM_OK;
+}
+
 // htm_run, or (dry) only the capture + instantiation of every hipGraph that htm_run call would replay
 static int run_or_prepare(htm_handle *h, const uint32_t *device_inputs, int32_t n_inputs, int32_t n_steps, int32_t learning,
                           int32_t use_graph, bool dry) {

@@ -28,6 +28,35 @@ __global__ __launch_bounds__(256) void k_tm_activate(Dev d, int p, int n_active,
     tm_activate_column(d, p, want_winner, ok, a, idx, ok ? d.pred[p ^ 1][a] : 0u);
 }
 
+// PredictiveProjection.update called on its own (htm_tm_update): the learning cells come from the caller, grouped by
+// column -- pass 0 clears the step's winner words, pass 1 stores the n columns' lists and words where the middle launch
+// looks for them
+__global__ __launch_bounds__(256) void k_tm_ext_winners(Dev d, int p, const int *cols, const uint32_t *winw, const uint32_t *unacc, int n, int pass) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (pass == 0) { for (int c = i; c < d.C; c += gridDim.x * 256) d.win[p][c] = 0; return; }
+    if (i < n) {
+        d.active_cols[p][i] = cols[i];
+        d.win[p][cols[i]] = winw[i];
+        d.winw_idx[i] = winw[i];
+        d.unacc_word[i] = unacc[i];
+        d.actcnt[i] = 0;
+    }
+}
+
+// PredictiveProjection.process called on its own (htm_tm_scan): the active cells come from the caller as one word per
+// column; the column bitmap, the count of active cells and clean accumulators for the scan
+__global__ __launch_bounds__(256) void k_tm_ext_active(Dev d, int p, const uint32_t *actw) {
+    for (int c0 = (blockIdx.x * 256 + (threadIdx.x & ~63)); c0 < ((d.C + 63) & ~63); c0 += gridDim.x * 256) {
+        const int c = c0 + lane_id();
+        const uint32_t w = c < d.C ? actw[c] & cell_mask(d.K) : 0u;
+        if (c < d.C) { d.act[p][c] = w; d.pred[p][c] = 0; }
+        const u64 m = __ballot(w != 0);
+        if (lane_id() == 0) *(u64 *)&d.colbits[p][c0 >> 5] = m;
+        const uint32_t cells = wave_sum((uint32_t)__popc(w));
+        if (lane_id() == 0 && cells) atomicAdd(&d.ctr->n_active_cells, (int)cells);
+    }
+}
+
 __device__ __forceinline__ bool col_is_local(const Dev &d, int cell) { const int col = cell >> 5; return col >= d.c0 && col < d.c1; }
 
 // the global id of a local row (unsharded handles: the row IS the id)
@@ -162,7 +191,7 @@ __device__ __forceinline__ void role_mid(const Dev &d, int p, int n_active, int 
             const bool unpred = !((d.pred[q][col] >> cb) & 1u);                          // :266
             const bool best = fabsf(jit - __uint_as_float(d.cellmax[q][cell])) < d.eps;  // :267
             learn = is_winner && ((info >> 31) || (unpred && best));                     // :268
-            punish = d.act[p][col] == 0;                                                 // :269
+            punish = d.punish ? (d.punish[col] >> cb) & 1u : d.act[p][col] == 0;         // :269
         };
         if (n <= 8 * n_cls * BS) {
             // small pools: one row per thread, so that the rows of a word -- segments created together match together --

@@ -75,6 +75,7 @@ class Engine:
             cfg.segment_sampling_synapses = distal.segment_sampling_synapses
             cap = distal.segment_capacity
             cfg.segment_capacity = int(cap) if cap is not None else max(4096, 512 * self.active_columns)
+            self._auto_grow = cap is None           # a default-sized pool grows like the reference's arrays (networks._grow_if_needed)
             cfg.segment_slots = int(distal.segment_slots)
             cfg.segment_capacity_local = int(getattr(distal, "segment_capacity_local", None) or 0)
         cfg.seed = int(seed) & 0xFFFFFFFF
@@ -224,6 +225,22 @@ class Engine:
         cols = np.ascontiguousarray(active_column, dtype=np.int32)
         self._check(self.lib.htm_tm_step(self.h, cols.ctypes.data_as(C.c_void_p), cols.size, int(bool(learning)),
                                          int(bool(return_winner_cell))), "htm_tm_step")
+        self.steps += 1
+
+    def tm_update(self, columns, winner_words, unaccounted_words, punish_words=None):
+        """PredictiveProjection.update on its own (htm_tm_update, include/bithtm_hip.h)."""
+        cols = np.ascontiguousarray(columns, dtype=np.int32)
+        ww = np.ascontiguousarray(winner_words, dtype=np.uint32)
+        uw = np.ascontiguousarray(unaccounted_words, dtype=np.uint32)
+        pw = None if punish_words is None else np.ascontiguousarray(punish_words, dtype=np.uint32)
+        self._check(self.lib.htm_tm_update(self.h, cols.ctypes.data_as(C.c_void_p), ww.ctypes.data_as(C.c_void_p), uw.ctypes.data_as(C.c_void_p),
+                                           cols.size, None if pw is None else pw.ctypes.data_as(C.c_void_p)), "htm_tm_update")
+
+    def tm_scan(self, active_words):
+        """PredictiveProjection.process on its own (htm_tm_scan); closes the timestep."""
+        aw = np.ascontiguousarray(active_words, dtype=np.uint32)
+        assert aw.size == self.column_dim
+        self._check(self.lib.htm_tm_scan(self.h, aw.ctypes.data_as(C.c_void_p)), "htm_tm_scan")
         self.steps += 1
 
     def upload_bank(self, inputs):

@@ -146,22 +146,102 @@ class PredictiveProjection:
     # state views (copy_custom-style consumers: reference_implementations.py:51-66)
     @property
     def segment_bundle(self):
-        return self._engine.read_store()["seg_cell"][:, None]
+        from . import _lib as L
+        eng = self._ensure_engine()
+        return eng.read(L.F_SEG_CELL, np.int32, eng.info().local_segments)[:, None]
 
     @property
     def bundle_segments(self):
-        return self._engine.read_store()["segcount"]
+        from . import _lib as L
+        eng = self._ensure_engine()
+        return eng.read(L.F_SEGCOUNT, np.int32, eng.column_dim * eng.cell_dim)
 
     @property
     def segment_projection(self):
         """A snapshot of the synapse store in the reference's SparseProjection layout (see SegmentProjectionView):
         `reference_implementations.TemporalMemory().copy_custom(tm)` accepts a bithtm_amd TemporalMemory through it."""
-        st = self._engine.read_store()
+        st = self._ensure_engine().read_store()
         return SegmentProjectionView(st["presyn"], st["perm"], self.output_dim)
 
-    def process(self, active_input, return_jittered_potential_info=True):
-        raise NotImplementedError("PredictiveProjection.process / update work on the previous State objects of the "
-                                  "TemporalMemory that owns the projection; on the device they run inside "
-                                  "TemporalMemory.process (kernels k_tm_scan, k_mid_rows, k_tm_learn)")
+    # ---- the reference's methods, callable on their own (projections.py:229-293): a caller's own TemporalMemory around
+    # the device's segment store.  Inside bithtm_amd.TemporalMemory they are not called: its timestep is fused on the device.
+    class State:
+        """projections.py:195-203."""
 
-    update = process
+        def __init__(self, d, jitter=True):
+            self.prediction = d["prediction"]
+            self.segment_potential = d["segment_potential"]
+            self.matching_segment = d["matching_segment"]
+            self.matching_segment_activation = d["matching_segment_activation"]
+            self.matching_segment_active = d["matching_segment_active"]
+            self.max_jittered_potential = d["max_jittered_potential"] if jitter else None
+            self.matching_segment_jittered_potential = d["matching_segment_jittered_potential"] if jitter else None
+            self._jitter = (d["max_jittered_potential"], d["matching_segment_jittered_potential"])
+
+    def _ensure_engine(self):
+        if self._engine is None:
+            from .engine import Engine
+            cell_dim = int(getattr(self, "cell_dim", None) or 32)
+            if self.output_dim % cell_dim:
+                raise ValueError("PredictiveProjection used on its own: output_dim must be a multiple of cell_dim (default 32; set .cell_dim)")
+            C = self.output_dim // cell_dim
+            self._engine = Engine(0, C, cell_dim, int(getattr(self, "active_columns", None) or C), distal=self,
+                                  seed=int(getattr(self, "seed", 0)))
+            self._last_state = None
+        return self._engine
+
+    def fill_jittered_potential_info(self, state, matching_segment_bundle=None):
+        """projections.py:229-239 (the scan computed both with the keyed draws)."""
+        if state.max_jittered_potential is None or state.matching_segment_jittered_potential is None:
+            state.max_jittered_potential, state.matching_segment_jittered_potential = state._jitter
+
+    def get_jittered_potential_info(self, state, matching_segment_bundle=None):
+        """projections.py:241-243."""
+        self.fill_jittered_potential_info(state)
+        return state.max_jittered_potential, state.matching_segment_jittered_potential
+
+    def process(self, active_input, return_jittered_potential_info=True):
+        """projections.py:245-255 on the device (the segment scan): `active_input` = flat ids of the active cells."""
+        from .engine import CapacityError  # noqa: F401
+        eng = self._ensure_engine()
+        K, C = eng.cell_dim, eng.column_dim
+        flat = np.asarray(active_input, dtype=np.int64).reshape(-1)
+        words = np.zeros(C, dtype=np.uint32)
+        np.bitwise_or.at(words, flat // K, (np.uint32(1) << (flat % K).astype(np.uint32)))
+        eng.tm_scan(words)
+        eng.check_capacity()
+        st = PredictiveProjection.State(eng.read_distal(), jitter=return_jittered_potential_info)
+        self._last_state = st
+        return st
+
+    def update(self, prev_state, input_activation, learning_output, output_punishment, winner_input=None, output_learning=None,
+               epsilon=1e-8):
+        """projections.py:257-293 on the device (segment allocation, learn / punish classification, permanence updates,
+        growth).  `prev_state`: the State this object's process() returned last -- or any earlier one, which is then
+        written back as the device's previous step (a host round trip, like TemporalMemory.process(prev_state=))."""
+        if prev_state is None:                                                    # :258-259
+            return
+        eng = self._ensure_engine()
+        K, C = eng.cell_dim, eng.column_dim
+        if getattr(eng, "_epsilon", 1e-8) != epsilon:
+            eng.set_epsilon(epsilon)
+            eng._epsilon = epsilon
+        self.fill_jittered_potential_info(prev_state)
+        learning_output = np.asarray(learning_output, dtype=np.int64).reshape(-1)
+        input_activation = np.asarray(input_activation, dtype=np.bool_).reshape(C, K)
+        # the previous step's side of the call: prev_state, input_activation, winner_input
+        eng.import_prev_state(np.asarray(prev_state.prediction).reshape(C, K) > epsilon, input_activation,
+                              None if winner_input is None else np.asarray(winner_input, dtype=np.int64), prev_state)
+        learn_mask = np.zeros(C * K, dtype=np.bool_)
+        if output_learning is None:
+            learn_mask[learning_output] = True                                    # :261-262
+        else:
+            learn_mask[:] = np.asarray(output_learning, dtype=np.bool_).reshape(-1)
+        unacc = learning_output[np.asarray(prev_state.max_jittered_potential)[learning_output] < np.float32(epsilon)]      # :271
+        need = np.zeros(C * K, dtype=np.bool_)
+        need[unacc] = True
+        learn_mask |= need                          # (a cell that gets a segment is a learning cell: :281 learns on the new segment)
+        from .engine import bool_to_words
+        ww, uw = bool_to_words(learn_mask.reshape(C, K)), bool_to_words(need.reshape(C, K))
+        cols = np.flatnonzero(ww)
+        eng.tm_update(cols, ww[cols], uw[cols], bool_to_words(np.asarray(output_punishment, dtype=np.bool_).reshape(C, K)))

@@ -163,6 +163,20 @@ int htm_sp_step(htm_handle *h, const uint32_t *packed_input, int32_t learning);
 int htm_tm_step(htm_handle *h, const int32_t *active_column, int32_t n, int32_t learning,
                 int32_t return_winner_cell);
 
+/* PredictiveProjection.update / .process (projections.py:257-293, :245-255) called on their own -- a caller that writes its
+ * own TemporalMemory.process around the device's segment store (its own winner-cell rule, its own punishment mask).
+ *   htm_tm_update  learning: columns[i] (distinct, at most active_columns of them) has the learning cells winner_words[i]
+ *                  (bit j = cell j: `learning_output` / `output_learning`), of which unaccounted_words[i] get a new segment
+ *                  (:271-281); punish_words = `output_punishment` as one word per column of the model, or NULL = every cell
+ *                  of a column not listed (what TemporalMemory.process passes, networks.py:107-108,111).  prev_state,
+ *                  input_activation and winner_input of the reference's signature are the handle's previous step (its own
+ *                  last one, or whatever was written with htm_import_begin(HTM_IMPORT_PREV_STATE) / htm_write).
+ *   htm_tm_scan    the scan against the cells of active_words (one word per column of the model), which become the
+ *                  step's cell activation; closes the timestep.  PredictiveProjection.State is read with htm_read. */
+int htm_tm_update(htm_handle *h, const int32_t *columns, const uint32_t *winner_words, const uint32_t *unaccounted_words,
+                  int32_t n, const uint32_t *punish_words);
+int htm_tm_scan(htm_handle *h, const uint32_t *active_words);
+
 /* SpatialPooler.process (networks.py:26-35) one phase per call, for handles whose plug-in objects (proximal_projection=,
  * boosting=, inhibition=: networks.py:16,22-24) partly live on the host: the binding interleaves these calls with the
  * user's `process` / `update` methods.  The phases work on the current timestep and do not close it: on a handle with

@@ -186,3 +186,178 @@ def test_l1_methods_on_the_objects_of_a_live_pooler_do_not_disturb_its_steps():
             assert np.array_equal(s.active_column, o_sp.active_column), rnd
             assert np.array_equal(s.overlaps, o_sp.overlaps), rnd
             assert np.array_equal(m.cell_prediction, o_tm.cell_prediction), rnd
+
+
+# ---- distal_projection= / temporal_memory= / spatial_pooler= (networks.py:50,55,134,143-144) ------------------------------
+class OracleProjection:
+    """A user's own PredictiveProjection with the reference's interface (projections.py:194-293), living on the host: the
+    oracle's learning and scan behind `update` / `process` / `get_jittered_potential_info` / `bundle_segments`."""
+
+    def __init__(self, column_dim, cell_dim, seed, params=None):
+        from oracle import TMParams, TemporalMemoryOracle
+        self.o = TemporalMemoryOracle(column_dim, cell_dim, params or TMParams(), seed)
+        self.segment_matching_threshold = self.o.params.segment_matching_threshold
+        self.C, self.K = column_dim, cell_dim
+        self.calls = dict(process=0, update=0)
+
+    @property
+    def bundle_segments(self):
+        return self.o.segcount
+
+    def get_jittered_potential_info(self, state, matching_segment_bundle=None):
+        return state.max_jittered_potential, state.matching_segment_jittered_potential
+
+    def process(self, active_input, return_jittered_potential_info=True):
+        self.calls["process"] += 1
+        act = np.zeros(self.C * self.K, dtype=np.bool_)
+        act[active_input] = True
+        d = self.o._scan(act.reshape(self.C, self.K), self.o.step_index)
+        self.o.step_index += 1
+        return d
+
+    def update(self, prev_state, input_activation, learning_output, output_punishment, winner_input=None, output_learning=None, epsilon=1e-8):
+        if prev_state is None:
+            return
+        self.calls["update"] += 1
+        o = self.o
+        o.prev_distal, o.prev_activation, o.prev_winner = prev_state, np.asarray(input_activation).reshape(self.C, self.K), winner_input
+        active_column = np.flatnonzero(~np.asarray(output_punishment).reshape(self.C, self.K).any(axis=1))
+        o._learn(np.asarray(learning_output, dtype=np.int64), active_column, o.step_index)
+
+
+def _tm_states_equal(t, got, want, K):
+    assert np.array_equal(got.cell_activation, want.cell_activation), t
+    assert np.array_equal(got.cell_prediction, want.cell_prediction), t
+    assert np.array_equal(got.active_column_bursting[:, 0], want.active_column_bursting[:, 0]), t
+    assert np.array_equal(got.winner_cell[0] * K + got.winner_cell[1], want.winner_cell[0] * K + want.winner_cell[1]), t
+    assert np.array_equal(got.active_cell[0] * K + got.active_cell[1], want.active_cell[0] * K + want.active_cell[1]), t
+    gd, wd = got.distal_state, want.distal_state
+    assert np.array_equal(gd.matching_segment, wd.matching_segment), t
+    assert np.array_equal(gd.segment_potential, wd.segment_potential), t
+    assert np.array_equal(gd.matching_segment_activation, wd.matching_segment_activation), t
+    assert np.array_equal(gd.matching_segment_active, wd.matching_segment_active), t
+    assert np.array_equal(np.asarray(gd.max_jittered_potential).view(np.int32), wd.max_jittered_potential.view(np.int32)), t
+    assert np.array_equal(np.asarray(gd.prediction), wd.prediction), t
+
+
+def _column_sequences(C, k, n, seed):
+    rng = np.random.RandomState(seed)
+    return [np.sort(rng.choice(C, k, replace=False)) for _ in range(n)]
+
+
+def test_temporal_memory_with_a_host_side_distal_projection():
+    """TemporalMemory(distal_projection=<any object with the reference's interface>): TemporalMemory.process runs on the host
+    (networks.py:91-128) and calls the user's update / process / get_jittered_potential_info where the reference does."""
+    import bithtm_amd as B
+    from types import SimpleNamespace
+    from oracle import TemporalMemoryOracle
+    C, K, k, seed = 512, 8, 20, 81
+    proj = OracleProjection(C, K, seed)
+    tm = B.TemporalMemory(C, K, distal_projection=proj, seed=seed)
+    ora = TemporalMemoryOracle(C, K, seed=seed)
+    seqs = _column_sequences(C, k, 9, 82)
+    rng = np.random.RandomState(83)
+    for t in range(80):
+        cols = seqs[t % 9]
+        learning = t % 11 != 6
+        want = ora.step(cols, learning=learning)
+        shuffled = cols[rng.permutation(k)]                         # (any order: per-column results come back in the caller's)
+        got = tm.process(SimpleNamespace(active_column=shuffled), learning=learning)
+        assert np.array_equal(got.active_column_bursting[np.argsort(shuffled, kind="stable"), 0], want.active_column_bursting[:, 0]), t
+        got.active_column_bursting = got.active_column_bursting[np.argsort(shuffled, kind="stable")]
+        _tm_states_equal(t, got, want, K)
+        assert tm.last_state is got
+    assert proj.calls["process"] == 80 and proj.calls["update"] > 60
+    assert np.array_equal(proj.o.seg_nsyn[:proj.o.S], ora.seg_nsyn[:ora.S]) and proj.o.S == ora.S > 100
+
+
+def test_predictive_projection_methods_on_their_own_drive_the_device():
+    """PredictiveProjection.process / .update / .get_jittered_potential_info (projections.py:229-293) called on their own: a
+    subclass of the device's projection is not the fused kind, so TemporalMemory orchestrates on the host and every call
+    lands on the device through htm_tm_update / htm_tm_scan -- learning, allocation, recycling, scan -- against the oracle."""
+    import bithtm_amd as B
+    from types import SimpleNamespace
+    from oracle import TMParams, TemporalMemoryOracle, canonical_synapses
+
+    class MyProjection(B.PredictiveProjection):
+        pass
+
+    C, K, k, seed = 1024, 16, 21, 91
+    tmp = TMParams(segment_activation_threshold=9, segment_matching_threshold=7, segment_sampling_synapses=18, permanence_punishment=0.15,
+                   permanence_decrement=0.12)
+    proj = MyProjection(C * K, segment_slots=64, **{f: getattr(tmp, f) for f in tmp.__dataclass_fields__})
+    tm = B.TemporalMemory(C, K, distal_projection=proj, seed=seed)
+    assert not tm._own_distal
+    ora = TemporalMemoryOracle(C, K, tmp, seed=seed)
+    seqs = _column_sequences(C, k, 11, 92)
+    rng = np.random.RandomState(93)
+    for t in range(120):
+        cols = seqs[int(rng.randint(11))] if rng.rand() < 0.15 else seqs[t % 11]
+        learning = t % 13 != 5
+        want = ora.step(cols, learning=learning)
+        got = tm.process(SimpleNamespace(active_column=cols), learning=learning)
+        _tm_states_equal(t, got, want, K)
+    eng = proj._engine
+    eng.check_capacity()
+    st = eng.read_store()
+    S = ora.S
+    assert st["S"] == S and np.array_equal(st["seg_cell"], ora.seg_cell[:S]) and np.array_equal(st["seg_nsyn"], ora.seg_nsyn[:S])
+    assert np.array_equal(st["segcount"], ora.segcount)
+    a, b = canonical_synapses(st["seg_cell"], st["presyn"], st["perm"]), canonical_synapses(ora.seg_cell[:S], ora.presyn[:S], ora.perm[:S])
+    assert all(np.array_equal(x[1], y[1]) and np.array_equal(x[2].view(np.int32), y[2].view(np.int32)) for x, y in zip(a, b))
+    assert (ora.seg_nsyn[:S] < 7).any()               # segments died: recycling was exercised
+    # the methods by hand, with an earlier State (written back as the device's previous step)
+    d1 = proj.process(np.flatnonzero(want.cell_activation.reshape(-1)))
+    assert np.array_equal(d1.matching_segment, ora._scan(want.cell_activation, ora.step_index).matching_segment)
+
+
+@pytest.mark.parametrize("foreign", ["temporal_memory", "spatial_pooler", "both"])
+def test_htm_with_foreign_layers(foreign):
+    """HierarchicalTemporalMemory(spatial_pooler=, temporal_memory=) with objects that are not the device's own
+    (networks.py:134,143-149; example.py:7-12 swaps the Temporal Memory): the two `process` calls of the reference, the
+    device-backed layer stepping an engine of its own."""
+    import bithtm_amd as B
+    from types import SimpleNamespace
+    from oracle import TemporalMemoryOracle
+    I, C, K, k, seed = 200, 2048, 8, 41, 97
+    np.random.seed(seed)
+    perm = np.random.randn(C, I) * 0.1
+    ora = HTMOracle(I, C, K, active_columns=k, seed=seed, permanence=perm)
+
+    class UserTM:
+        def __init__(self):
+            self.o = TemporalMemoryOracle(C, K, seed=seed)
+
+        def process(self, sp_state, learning=True):
+            return self.o.step(np.sort(np.asarray(sp_state.active_column)), learning=learning)
+
+    class UserSP:
+        def __init__(self):
+            self.o = SpatialPoolerOracle(I, C, k, permanence=perm)
+
+        def process(self, input, learning=True):
+            return self.o.step(input, learning=learning)
+
+    kw = {}
+    if foreign in ("temporal_memory", "both"):
+        kw["temporal_memory"] = UserTM()
+    else:
+        kw["temporal_memory"] = B.TemporalMemory(C, K, seed=seed)
+    if foreign in ("spatial_pooler", "both"):
+        kw["spatial_pooler"] = UserSP()
+    else:
+        prox = B.DenseProjection(I, C)
+        prox.permanence = perm
+        kw["spatial_pooler"] = B.SpatialPooler(I, C, k, proximal_projection=prox)
+    htm = B.HierarchicalTemporalMemory(I, C, K, active_columns=k, **kw)
+    rng = np.random.RandomState(seed + 1)
+    bank = rng.rand(10, I) < 0.1
+    for t in range(70):
+        x = bank[t % 10] ^ (rng.rand(I) < 0.01)
+        o_sp, o_tm = ora.step(x)
+        s, m = htm.process(x)
+        assert np.array_equal(np.sort(s.active_column), o_sp.active_column), t
+        assert np.array_equal(m.cell_prediction, o_tm.cell_prediction), t
+        assert np.array_equal(m.winner_cell[0] * K + m.winner_cell[1], o_tm.winner_cell[0] * K + o_tm.winner_cell[1]), t
+    with pytest.raises(RuntimeError):
+        htm.run(bank, 3)

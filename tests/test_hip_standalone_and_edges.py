@@ -349,7 +349,9 @@ def test_random_call_patterns_equal_step_by_step():
 
     def digest(htm):
         st, d = htm.engine.read_store(), htm.engine.read_distal()
-        return (htm.engine.read_sp_fields()["active_column"], st["seg_cell"], st["seg_nsyn"], st["presyn"], st["perm"],
+        w = max(int(st["seg_nsyn"].max(initial=0)), 1)      # (rows are packed; a default-sized pool may have grown its rows)
+        assert (st["presyn"][:, w:] == -1).all()
+        return (htm.engine.read_sp_fields()["active_column"], st["seg_cell"], st["seg_nsyn"], st["presyn"][:, :w], st["perm"][:, :w],
                 htm.temporal_memory.last_state.cell_prediction, htm.engine.read_duty_cycle(), d["matching_segment"], d["max_jittered_potential"])
 
     for seed in range(int(os.environ.get("BITHTM_CALL_FUZZ_SEQUENCES", "12"))):
@@ -600,3 +602,51 @@ def test_a_stream_of_continuing_runs_survives_another_handle_appearing():
     for key in want:
         assert np.array_equal(np.asarray(got[key]), np.asarray(want[key])), key
     del other
+
+
+def test_default_sized_pools_grow_like_the_references_arrays():
+    """utils.py:113-135: the reference's segment store grows on demand.  A pool whose size the user did not fix follows it
+    (the engine is re-created with a larger pool and the state handed over, between host-fed steps and between the batches
+    of a run()): more segments than the first pool held, more synapses than its rows held, the oracle's result throughout."""
+    from hip_impl import compare_store_with_oracle, make_htm
+    from oracle import HTMOracle, TMParams
+    I, C, K, seed = 96, 1024, 4, 41
+    k = round(C * 0.02)
+    tmp = TMParams(segment_activation_threshold=3, segment_matching_threshold=3, segment_sampling_synapses=32, permanence_decrement=0.0)
+    np.random.seed(seed)
+    ora = HTMOracle(I, C, K, active_columns=k, seed=seed, tm_params=tmp)
+    htm = make_htm(I, C, K, k, seed, ora.spatial_pooler.permanence.copy(), None, tmp, segment_capacity=None, segment_slots=128)
+    first = htm.engine
+    assert first.segment_capacity == 10240 and first.segment_slots == 128
+    rng = np.random.RandomState(seed + 1)
+    t = 0
+    for rnd in range(2):                                # novel input throughout: every column bursts, 20 new segments per step
+        bank = rng.rand(300, I) < 0.15
+        for _ in range(150):                            # host-fed steps
+            ora.step(bank[t % 300])
+            htm.process(bank[t % 300])
+            t += 1
+        for _ in range(150):                            # and a device-side batch
+            ora.step(bank[t % 300])
+            t += 1
+        htm.run(bank, 150)
+        compare_store_with_oracle(t, ora, htm)
+    assert htm.engine is not first and htm.engine.segment_capacity > 10240 and ora.temporal_memory.S > 10240
+    small = rng.rand(6, I) < 0.15                       # a few patterns in random order, nothing ever pruned: the segments fill up
+    for _ in range(400):
+        x = small[rng.randint(6)]
+        ora.step(x)
+        htm.process(x)
+        t += 1
+    compare_store_with_oracle(t, ora, htm)
+    assert htm.engine.segment_slots > 128 and ora.temporal_memory.seg_nsyn.max() > 128
+    # an explicit capacity stays a hard limit
+    import bithtm_amd as B
+    fixed = B.HierarchicalTemporalMemory(I, C, K, temporal_memory=B.TemporalMemory(C, K, distal_projection=B.PredictiveProjection(
+        C * K, segment_capacity=512, segment_activation_threshold=3, segment_matching_threshold=3)))
+    bank = rng.rand(200, I) < 0.15
+    with pytest.raises(B.CapacityError):
+        for i in range(200):
+            fixed.process(bank[i])
+            if i % 20 == 0:
+                fixed.engine.check_capacity()
