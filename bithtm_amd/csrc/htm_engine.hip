@@ -83,6 +83,10 @@ struct htm_handle {
     std::map<std::tuple<int, int, const void *, int>, hipGraphExec_t> graphs;
     // state import staging (htm_write of the MATCH_* / SEG_POTENTIAL fields, applied at commit)
     std::vector<int> imp_pot, imp_match_seg;
+    // ... on a column-sharded handle also the per-segment arrays (written for ALL segment ids; the commit keeps the rows of
+    // the segments this rank's cells own)
+    std::vector<int> imp_seg_cell, imp_seg_nsyn, imp_presyn;
+    std::vector<float> imp_perm;
     std::vector<uint32_t> imp_match_info;
     std::vector<float> imp_match_jit;
     // profiling
@@ -1149,24 +1153,22 @@ extern "C" int64_t htm_shard_record_bytes(htm_handle *h) {
 
 static int shard_enqueue_begin(htm_handle *h, const uint32_t *bank, int n_inputs, void *send_device) {
     Dev &d = h->d;
-    if (!h->emit_fused) {
-        h->err = h->emit_fits ? "sharded handle: another handle with its own stream is live on this device (the local select waits between blocks)"
-                              : "sharded handle: the local select's grid is not resident at once on this device (too many own columns)";
-        return HTM_ERR_STATE;
-    }
     const int p = (int)(h->step_host & 1);
     d.send = (unsigned char *)send_device;
     // own columns: overlap + boost + top digit, and the zeroing of the step's dense words; digit 1; local select finish
     // + speculative cell words of the candidates, packed into the record
     const int n_word_blocks = ((d.c1 - d.c0) * 32 + RB - 1) / RB;        // one own column per half-wave
     // (the local select: one windowed histogram pass beside the overlap, finished inside the candidates kernel;
-    // BITHTM_SHARD_WINDOW=0: two launched digits)
-    const int wmode = h->knob_shard_window;
+    // BITHTM_SHARD_WINDOW=0: two launched digits.  While another handle with a stream of its own is live on the device the
+    // blocks of a grid must not wait for each other: every digit by a launch, the counts by k_sp_count -- same candidates)
+    const int fused = h->emit_fused ? 1 : 0;
+    const int wmode = fused ? h->knob_shard_window : 0;
     LAUNCH(h, "shard_overlap", k_shard_overlap, h->sp_blocks + n_word_blocks + std::min((d.C + RB - 1) / RB, 64), RB, d, bank, n_inputs, h->G, p,
            h->sp_blocks, n_word_blocks, wmode);
     if (!wmode)
         for (int pass = 1; pass < d.sel_passes; ++pass) LAUNCH(h, "sp_select", k_sel_pass, h->sel_blocks, RB, d, pass, p);
-    LAUNCH(h, "shard_candidates", k_sp_emit, h->c256_blocks, 256, d, p, 1, 1, EMIT_LOCAL, wmode);
+    if (!fused) LAUNCH(h, "sp_count", k_sp_count, h->c256_blocks, 256, d, p);
+    LAUNCH(h, "shard_candidates", k_sp_emit, h->c256_blocks, 256, d, p, 1, fused, EMIT_LOCAL, wmode);
     return 0;
 }
 
@@ -1682,6 +1684,17 @@ extern "C" int htm_write(htm_handle *h, int32_t field, const void *src, int64_t 
         h->err = "htm_write: field not available on this handle";
         return HTM_ERR_STATE;
     }
+    if (h->world > 1 && (field == HTM_F_SEG_CELL || field == HTM_F_SEG_NSYN || field == HTM_F_SEG_PRESYN || field == HTM_F_SEG_PERM)) {
+        // a column-sharded handle is given the arrays of ALL segment ids (what an unsharded handle exports, or the merged
+        // export of a sharded group) and keeps its own cells' rows at the commit
+        const int64_t per = (field == HTM_F_SEG_PRESYN || field == HTM_F_SEG_PERM) ? E : 1;
+        if (count > (int64_t)d.Scap * per) { h->err = "htm_write: too many elements"; return HTM_ERR_ARGUMENT; }
+        if (field == HTM_F_SEG_PERM) { h->imp_perm.assign((const float *)src, (const float *)src + count); return HTM_OK; }
+        std::vector<int> &v = field == HTM_F_SEG_CELL ? h->imp_seg_cell : field == HTM_F_SEG_NSYN ? h->imp_seg_nsyn : h->imp_presyn;
+        v.assign((const int *)src, (const int *)src + count);
+        if (field != HTM_F_SEG_NSYN) for (auto &x : v) x = x < 0 ? 0 : flat_enc(x, (int)K);
+        return HTM_OK;
+    }
     switch (field) {
         case HTM_F_DUTY_CYCLE: return put(d.duty, src, count, 4, C);
         case HTM_F_CELL_ACTIVATION: return put(d.act[q], src, count, 4, C);
@@ -1717,7 +1730,8 @@ extern "C" int htm_write(htm_handle *h, int32_t field, const void *src, int64_t 
 extern "C" int htm_import_begin(htm_handle *h, int64_t step_index) {
     if (!h || (step_index < 0 && step_index != HTM_IMPORT_PREV_STATE)) return HTM_ERR_ARGUMENT;
     REJECT_WHEN_AHEAD(h);
-    if (h->world > 1) { h->err = "state import is not available on a column-sharded handle"; return HTM_ERR_STATE; }
+    if (h->world > 1 && step_index == HTM_IMPORT_PREV_STATE) { h->err = "prev_state adoption is not available on a column-sharded handle"; return HTM_ERR_STATE; }
+    if (h->shard_open) { h->err = "htm_import_begin: a step opened with htm_shard_begin is not finished"; return HTM_ERR_STATE; }
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->import_keep = step_index == HTM_IMPORT_PREV_STATE;
@@ -1749,13 +1763,62 @@ extern "C" int htm_import_commit(htm_handle *h, int32_t segments, int32_t matchi
     if (segments < 0 || segments > d.Scap || matching_segments < 0 || matching_segments > segments ||
         winner_cells < 0 || winner_cells > d.k * 32) { h->err = "htm_import_commit: bad scalars"; return HTM_ERR_ARGUMENT; }
     const int q = (int)((h->step_host + 1) & 1);
+    std::vector<int> g2l;                           // column-sharded: local row of every id this rank owns, -1 otherwise
+    if (h->world > 1) {
+        const size_t S = (size_t)segments, E = (size_t)d.E;
+        if (h->imp_seg_cell.size() != S || h->imp_seg_nsyn.size() != S || h->imp_presyn.size() != S * E || h->imp_perm.size() != S * E) {
+            h->err = "htm_import_commit: a column-sharded handle needs SEG_CELL / SEG_NSYN / SEG_PRESYN / SEG_PERM of all segment ids";
+            return HTM_ERR_ARGUMENT;
+        }
+        g2l.assign((size_t)d.Scap, -1);
+        std::vector<int> gid_of_row;
+        std::vector<uint32_t> dead(((size_t)d.Scap + 31) / 32 + 32, 0u);
+        const size_t nb1 = ((size_t)d.Scap + 1023) / 1024, nb2 = (nb1 + 1023) / 1024 + 1;
+        std::vector<int> cnt1(nb1, 0), cnt2(nb2, 0);
+        for (size_t g = 0; g < S; ++g) {
+            if (h->imp_seg_nsyn[g] < d.match_thr) { dead[g >> 5] |= 1u << (g & 31); cnt1[g >> 10] += 1; cnt2[g >> 20] += 1; }
+            const int col = h->imp_seg_cell[g] >> 5;
+            if (col >= d.c0 && col < d.c1) { g2l[g] = (int)gid_of_row.size(); gid_of_row.push_back((int)g); }
+        }
+        const size_t L = gid_of_row.size();
+        if (L > (size_t)d.Lcap) { h->err = "htm_import_commit: more segments of this rank's cells than segment_capacity_local"; return HTM_ERR_CAPACITY; }
+        std::vector<int> cell(L), nsyn(L), presyn(L * E);
+        std::vector<float> perm(L * E);
+        for (size_t r = 0; r < L; ++r) {
+            const size_t g = (size_t)gid_of_row[r];
+            cell[r] = h->imp_seg_cell[g];
+            nsyn[r] = h->imp_seg_nsyn[g];
+            memcpy(&presyn[r * E], &h->imp_presyn[g * E], E * 4);
+            memcpy(&perm[r * E], &h->imp_perm[g * E], E * 4);
+        }
+        HIPCHK(h, hipMemset(d.seg_gid, 0xFF, (size_t)d.Lcap * 4));
+        HIPCHK(h, hipMemset(d.seg_nsyn, 0, (size_t)d.Lcap * 4));
+        if (L) {
+            HIPCHK(h, hipMemcpy(d.seg_gid, gid_of_row.data(), L * 4, hipMemcpyHostToDevice));
+            HIPCHK(h, hipMemcpy(d.seg_cell, cell.data(), L * 4, hipMemcpyHostToDevice));
+            HIPCHK(h, hipMemcpy(d.seg_nsyn, nsyn.data(), L * 4, hipMemcpyHostToDevice));
+            HIPCHK(h, hipMemcpy(d.presyn, presyn.data(), L * E * 4, hipMemcpyHostToDevice));
+            HIPCHK(h, hipMemcpy(d.sperm, perm.data(), L * E * 4, hipMemcpyHostToDevice));
+        }
+        HIPCHK(h, hipMemcpy(d.g2l, g2l.data(), g2l.size() * 4, hipMemcpyHostToDevice));
+        HIPCHK(h, hipMemcpy(d.dead_bits, dead.data(), dead.size() * 4, hipMemcpyHostToDevice));
+        HIPCHK(h, hipMemcpy(d.recyc_cnt, cnt1.data(), cnt1.size() * 4, hipMemcpyHostToDevice));
+        HIPCHK(h, hipMemcpy(d.recyc_cnt2, cnt2.data(), cnt2.size() * 4, hipMemcpyHostToDevice));
+        HIPCHK(h, hipMemset(d.dead_list, 0, sizeof(int)));
+        c.L = (int32_t)L;
+        c.n_lfree = 0;
+        h->imp_seg_cell.clear(); h->imp_seg_nsyn.clear(); h->imp_presyn.clear(); h->imp_perm.clear();
+        h->imp_seg_cell.shrink_to_fit(); h->imp_presyn.shrink_to_fit(); h->imp_perm.shrink_to_fit();
+    }
+    const int rows = h->world > 1 ? c.L : segments;     // rows of the per-row arrays (info words, jitter, match bits)
+    auto row_of = [&](int gid) { return h->world > 1 ? g2l[(size_t)gid] : gid; };
     if (!keep) {
         c.step[h->step_host & 1] = (uint32_t)h->step_host;
         c.n_work[0] = c.n_work[1] = 0;
         c.n_bind[0] = c.n_bind[1] = 0;
         c.S = segments;
-        h->seg_hint = segments;                     // (the one place where the count can go down)
-        if (h->seg_pinned) *h->seg_pinned = segments;
+        h->seg_hint = rows;                         // (the one place where the count can go down)
+        if (h->seg_pinned) *h->seg_pinned = rows;
     }
     {   // dense per-segment info from the staged PredictiveProjection.State lists
         const size_t M = (size_t)matching_segments;
@@ -1764,18 +1827,19 @@ extern "C" int htm_import_commit(htm_handle *h, int32_t segments, int32_t matchi
             h->err = "htm_import_commit: SEG_POTENTIAL / MATCH_* fields missing or of the wrong length";
             return HTM_ERR_ARGUMENT;
         }
-        std::vector<uint32_t> info((size_t)segments, 0u), bits((size_t)(d.Lcap + 255) / 256 * 8, 0u);
-        std::vector<float> jit((size_t)segments, 0.f);
+        std::vector<uint32_t> info((size_t)rows, 0u), bits((size_t)(d.Lcap + 255) / 256 * 8, 0u);
+        std::vector<float> jit((size_t)rows, 0.f);
         if (has_distal_state) {
             for (size_t i = 0; i < M; ++i) {
-                const int sgm = h->imp_match_seg[i];
-                if (sgm < 0 || sgm >= segments) { h->err = "htm_import_commit: matching segment id out of range"; return HTM_ERR_ARGUMENT; }
+                if (h->imp_match_seg[i] < 0 || h->imp_match_seg[i] >= segments) { h->err = "htm_import_commit: matching segment id out of range"; return HTM_ERR_ARGUMENT; }
+                const int sgm = row_of(h->imp_match_seg[i]);
+                if (sgm < 0) continue;              // (another rank's segment)
                 info[(size_t)sgm] = (h->imp_match_info[i] & ~0x40000000u) | 0x40000000u;
                 jit[(size_t)sgm] = h->imp_match_jit[i];
                 bits[(size_t)sgm >> 5] |= 1u << (sgm & 31);
             }
         }
-        if (segments) {
+        if (rows) {
             HIPCHK(h, hipMemcpy(d.seg_info, info.data(), info.size() * 4, hipMemcpyHostToDevice));
             HIPCHK(h, hipMemcpy(d.seg_jit, jit.data(), jit.size() * 4, hipMemcpyHostToDevice));
         }
@@ -1809,9 +1873,11 @@ extern "C" int htm_import_commit(htm_handle *h, int32_t segments, int32_t matchi
         hipLaunchKernelGGL(k_tm_winner_words, dim3(std::min((d.C + 255) / 256, 1024)), dim3(256), 0, h->stream, d, q, winner_cells);
         if (winner_cells > 0) hipLaunchKernelGGL(k_tm_winner_bits, dim3((winner_cells + 255) / 256), dim3(256), 0, h->stream, d, q, winner_cells);
         if (!keep) {
-            HIPCHK(h, hipMemsetAsync(d.recyc_cnt2, 0, ((size_t)(h->s1024_blocks + 1023) / 1024 + 1) * sizeof(int), h->stream));
-            hipLaunchKernelGGL(k_tm_recount, dim3(h->s1024_blocks), dim3(256), 0, h->stream, d);
-            hipLaunchKernelGGL(k_tm_flag_connected, dim3(std::min(4096, std::max(1, (int)(((long long)segments * d.E + 255) / 256)))), dim3(256), 0, h->stream, d);
+            if (h->world == 1) {                    // (a shard's counts came with its dead bits, above)
+                HIPCHK(h, hipMemsetAsync(d.recyc_cnt2, 0, ((size_t)(h->s1024_blocks + 1023) / 1024 + 1) * sizeof(int), h->stream));
+                hipLaunchKernelGGL(k_tm_recount, dim3(h->s1024_blocks), dim3(256), 0, h->stream, d);
+            }
+            hipLaunchKernelGGL(k_tm_flag_connected, dim3(std::min(4096, std::max(1, (int)(((long long)rows * d.E + 255) / 256)))), dim3(256), 0, h->stream, d);
         }
         HIPCHK(h, hipStreamSynchronize(h->stream));
     }

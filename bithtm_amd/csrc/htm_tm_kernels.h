@@ -1259,7 +1259,7 @@ __global__ __launch_bounds__(256) void k_tm_potentials(Dev d, int p, int *out, i
 // after a state import: derive the connected flag of every valid synapse from its permanence
 // (the scan reads the flag instead of the permanence row)
 __global__ __launch_bounds__(256) void k_tm_flag_connected(Dev d) {
-    const int S = d.ctr->S;
+    const int S = d.world > 1 ? d.ctr->L : d.ctr->S;      // (rows)
     const long long total = (long long)S * d.E;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const int seg = (int)(i / d.E), slot = (int)(i % d.E);

@@ -29,6 +29,51 @@ def env_rank_world():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
 
 
+def merge_shard_states(parts, column_dim, cell_dim):
+    """The ranks' `engine.export_tm_state()` dictionaries (local rows under global ids, own cells, own columns) put
+    together into the state an unsharded handle exports -- what `import_tm_state` takes on any handle, sharded or not
+    (a sharded one keeps the rows of its own cells).  Checkpoint / hand-off of a column-sharded run."""
+    parts = sorted(parts, key=lambda p: int(p["column_range"][0]))
+    S, E, K = int(parts[0]["S"]), int(parts[0]["slots"]), cell_dim
+    out = dict(S=np.int64(S), slots=np.int64(E), step_index=parts[0]["step_index"],
+               seg_cell=np.zeros(S, np.int32), seg_nsyn=np.zeros(S, np.int32), presyn=np.full((S, E), -1, np.int32),
+               perm=np.full((S, E), -1.0, np.float32), segcount=np.zeros(column_dim * K, np.int32),
+               prev_prediction=np.zeros((column_dim, K), np.bool_), prev_activation=parts[0]["prev_activation"],
+               prev_winner=parts[0]["prev_winner"], has_prev_winner=parts[0]["has_prev_winner"], has_distal=parts[0]["has_distal"])
+    has_distal = bool(parts[0]["has_distal"])
+    if has_distal:
+        out.update(segment_potential=np.zeros(S, np.int64), max_jittered_potential=np.zeros(column_dim * K, np.float32),
+                   prediction=np.zeros(column_dim * K, np.float64))
+    match = []
+    seen = np.zeros(S, np.bool_)
+    for p in parts:
+        assert int(p["S"]) == S, "the ranks disagree on the number of segment ids"
+        c0, c1 = (int(x) for x in p["column_range"])
+        gid = np.asarray(p["seg_gid"])
+        live = np.flatnonzero(gid >= 0)
+        g = gid[live]
+        assert not seen[g].any(), "a segment id is owned by two ranks"
+        seen[g] = True
+        out["seg_cell"][g], out["seg_nsyn"][g] = p["seg_cell"][live], p["seg_nsyn"][live]
+        out["presyn"][g], out["perm"][g] = p["presyn"][live], p["perm"][live]
+        out["segcount"][c0 * K:c1 * K] = p["segcount"][c0 * K:c1 * K]
+        out["prev_prediction"][c0:c1] = p["prev_prediction"][c0:c1]
+        if has_distal:
+            out["segment_potential"][g] = p["segment_potential"][live]
+            out["max_jittered_potential"][c0 * K:c1 * K] = p["max_jittered_potential"][c0 * K:c1 * K]
+            out["prediction"][c0 * K:c1 * K] = p["prediction"][c0 * K:c1 * K]
+            rows = np.asarray(p["matching_segment"])
+            match.append((gid[rows], p["matching_segment_activation"], p["matching_segment_active"], p["matching_segment_jittered_potential"]))
+    assert seen.all(), "a segment id is owned by no rank"
+    if has_distal:
+        seg = np.concatenate([m[0] for m in match]).astype(np.int64)
+        order = np.argsort(seg, kind="stable")
+        out.update(matching_segment=seg[order], matching_segment_activation=np.concatenate([m[1] for m in match])[order],
+                   matching_segment_active=np.concatenate([m[2] for m in match])[order],
+                   matching_segment_jittered_potential=np.concatenate([m[3] for m in match])[order])
+    return out
+
+
 class ShardedHTM:
     """The reference's HierarchicalTemporalMemory.process (networks.py:146-149) over `world` GPUs.
 
@@ -81,6 +126,24 @@ class ShardedHTM:
         eng.shard_finish(self.recv.data_ptr(), learning=learning)
 
     compute = process
+
+    # ---- checkpoint / hand-off: the state of the whole model, as an unsharded handle exports and imports it
+    def export_tm_state(self):
+        """Collective: every rank contributes its part (torch.distributed.all_gather_object; not a fast path)."""
+        import torch.distributed as dist
+        parts = [None] * self.world
+        dist.all_gather_object(parts, self.engine.export_tm_state())
+        return merge_shard_states(parts, self.column_dim, self.cell_dim)
+
+    def import_state(self, tm_state, permanence, duty_cycle):
+        """The whole model's state (HierarchicalTemporalMemory.state_dict of an unsharded run, or export_tm_state of a
+        sharded one + the Spatial Pooler's arrays): this rank keeps its own columns' rows, cells and segments."""
+        from . import _lib as L
+        eng = self.engine
+        c0, c1 = self.column_range
+        eng.set_permanence(np.asarray(permanence)[c0:c1], row_begin=c0)
+        eng.write(L.F_DUTY_CYCLE, np.asarray(duty_cycle, dtype=np.float32), np.float32)
+        eng.import_tm_state(tm_state)
 
     def run(self, device_bank, n_inputs, steps, learning=True):
         eng = self.engine
@@ -140,6 +203,18 @@ class LocalGroup:
         self._check(self.lib.htm_shard_group_step(self._handles, self.world, None, 1, packed.ctypes.data_as(C.c_void_p), int(bool(learning))))
         for e in self.engines:
             e.steps += 1
+
+    def export_tm_state(self):
+        return merge_shard_states([e.export_tm_state() for e in self.engines], self.column_dim, self.cell_dim)
+
+    def import_state(self, tm_state, permanence, duty_cycle):
+        """See ShardedHTM.import_state: every rank is handed the whole model's state and keeps its own share."""
+        from . import _lib as L
+        for e in self.engines:
+            c0, c1 = e.column_range
+            e.set_permanence(np.asarray(permanence)[c0:c1], row_begin=c0)
+            e.write(L.F_DUTY_CYCLE, np.asarray(duty_cycle, dtype=np.float32), np.float32)
+            e.import_tm_state(tm_state)
 
     def upload_bank(self, inputs):
         import ctypes as C

@@ -383,6 +383,8 @@ class Engine:
             prev_activation=words_to_bool(self.read(L.F_CELL_ACTIVATION, np.uint32, self.column_dim), K),
             prev_winner=self.read(L.F_WINNER_CELL, np.int32, info.winner_cells).astype(np.int64),
             has_prev_winner=np.bool_(info.has_winner_cells), has_distal=np.bool_(info.has_distal_state))
+        if self.shard_world > 1:                    # rows are local: distributed.merge_shard_states puts the ranks' parts together
+            out.update(seg_gid=st["seg_gid"], column_range=np.asarray(self.column_range))
         d = self.read_distal()
         if d is not None:
             out.update(d)
@@ -390,6 +392,8 @@ class Engine:
 
     def import_tm_state(self, st):
         K, S, E = self.cell_dim, int(st["S"]), self.segment_slots
+        if "seg_gid" in st:
+            raise HtmError("import_tm_state: this is one rank's part of a sharded state; merge the parts first (distributed.merge_shard_states)")
         if S > self.segment_capacity:
             raise CapacityError(f"state has {S} segments, pool holds {self.segment_capacity}")
         self._check(self.lib.htm_import_begin(self.h, int(st["step_index"])), "htm_import_begin")

@@ -185,3 +185,55 @@ def test_one_candidate_per_rank():
             info = m.engine.check_capacity()
             assert info.segments == ora.temporal_memory.S, (t, m.rank)
             assert np.array_equal(m.engine.read(L.F_WINNER_CELL, np.int32, info.winner_cells), o_tm.winner_cell[0] * K + o_tm.winner_cell[1]), (t, m.rank)
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_state_import_into_a_sharded_group_and_merged_export(world):
+    """A learned state of an unsharded run handed to a column-sharded group (every rank is given the whole state and keeps
+    the rows of its own cells' segments, under their global ids, with the replicated dead bits and recyclable counts), the
+    group stepped on, and its merged export against the unsharded run stepped the same way -- recycling included."""
+    from hip_impl import make_htm
+    from bithtm_amd.distributed import LocalGroup
+    import bithtm_amd as B
+    I, C, K, P, seed = 160, 2048, 8, 14, 33
+    k = round(C * 0.02)
+    tmp = TMParams(permanence_punishment=0.2, permanence_decrement=0.14, segment_activation_threshold=9, segment_matching_threshold=7,
+                   segment_sampling_synapses=18)
+    np.random.seed(seed)
+    perm = np.random.randn(C, I) * 0.1
+    solo = make_htm(I, C, K, k, seed, perm, None, tmp)
+    rng = np.random.RandomState(seed + 1)
+    bank = rng.rand(P, I) < 0.1
+    steps = [bank[int(rng.randint(P))] if rng.rand() < 0.15 else bank[t % P] for t in range(260)]
+    for x in steps[:160]:
+        solo.process(x)
+    state = solo.state_dict()
+
+    def parts(r):
+        prox = B.DenseProjection.__new__(B.DenseProjection)
+        prox.input_dim, prox.output_dim = I, C
+        prox.permanence_threshold, prox.permanence_increment, prox.permanence_decrement = 0.0, 0.03, 0.015
+        prox._engine, prox._permanence = None, np.zeros((C, I))
+        return dict(proximal=prox, distal=B.PredictiveProjection(C * K, **{f: getattr(tmp, f) for f in tmp.__dataclass_fields__}))
+    group = LocalGroup(world, I, C, K, active_columns=k, make_parts=parts, seed=seed)
+    group.import_state({key[3:]: v for key, v in state.items() if key.startswith("tm_")}, state["sp_permanence"], state["sp_duty_cycle"])
+    for x in steps[160:]:
+        solo.process(x)
+        group.process(x)
+    for e in group.engines:
+        e.check_capacity()
+    want, got = solo.engine.export_tm_state(), group.export_tm_state()
+    assert set(want) == set(got)
+    assert (want["seg_nsyn"] < 7).any() and int(want["S"]) > int(state["tm_S"])       # deaths and growth after the import
+    for key in want:
+        a, b = np.asarray(got[key]), np.asarray(want[key])
+        if key in ("perm", "max_jittered_potential", "matching_segment_jittered_potential"):
+            a, b = a.view(np.int32), b.view(np.int32)
+        if key in ("presyn", "perm"):                  # (slot order within a row is free)
+            order_a, order_b = np.argsort(np.asarray(got["presyn"]), axis=1, kind="stable"), np.argsort(np.asarray(want["presyn"]), axis=1, kind="stable")
+            a, b = np.take_along_axis(a, order_a, axis=1), np.take_along_axis(b, order_b, axis=1)
+        assert a.shape == b.shape and np.array_equal(a, b), key
+    for e in group.engines:
+        c0, c1 = e.column_range
+        assert np.array_equal(e.get_permanence(c0, c1 - c0).view(np.int64), solo.engine.get_permanence(c0, c1 - c0).view(np.int64))
+        assert np.array_equal(e.read_duty_cycle()[c0:c1].view(np.int32), solo.engine.read_duty_cycle()[c0:c1].view(np.int32))
