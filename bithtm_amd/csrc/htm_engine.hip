@@ -58,6 +58,8 @@ struct htm_handle {
     const uint32_t *shard_bank;           // input of the step between htm_shard_begin and _finish
     int shard_n_inputs;
     bool shard_open;
+    int shard_front_wmode;                // htm_shard_run: the histogram form of the overlap computed ahead for the coming step
+    std::map<std::tuple<int, int, const void *, int>, hipGraphExec_t> shard_graphs;      // (on rank 0's handle for a group in one process)
     void *rccl_comm;                      // ncclComm_t of htm_shard_comm_init (the exchange of htm_shard_step)
     unsigned char *shard_send, *shard_recv;   // ... and its device buffers
     int G;                                // lanes per SP row
@@ -261,16 +263,28 @@ static void enqueue_sp_back(htm_handle *h, const uint32_t *bank, int n_inputs, i
 
 // TemporalMemory.process after the per-column activation, one role per launch.  sp_rows: the SP
 // permanence update of this step rides along in the middle launch.
+// front_wmode >= 0 (column-sharded handles inside htm_shard_run): the overlap of the COMING step on the rank's own
+// columns rides in the last launch (wmode = front_wmode: windowed histogram or top digit)
 static void enqueue_tm(htm_handle *h, int n_active, int learning, int want_winner, int p,
-                       const uint32_t *bank, int n_inputs, bool sp_rows) {
+                       const uint32_t *bank, int n_inputs, bool sp_rows, int front_wmode = -1) {
     Dev &d = h->d;
     const int n_cls = learning ? kClassifyBlocks : 0;
     const int n_sp_rows = (sp_rows && learning && h->cfg.enable_sp) ? d.k : 0;
     const int n_duty = h->world > 1 ? (d.c1 - d.c0 + 255) / 256 : 0;      // (unsharded: the emit role updates the duty cycle)
     LAUNCH(h, "tm_mid", k_mid_rows, 1 + n_cls + n_sp_rows + n_duty + h->zero_blocks, 256, d, p, n_active, want_winner, learning, n_cls, bank, n_inputs, n_sp_rows, 0, n_duty);
-    // the learning role and the scan: one launch (k_learn_scan_emit without emit blocks: the learning waves scan their own
-    // rows), unless the pool is large (the streaming scan kernels) or somebody is timing the roles one by one
-    if (h->knob_fuse_tm && !h->profile && !scan_pool_is_large(h) && scan_lds(d, 1) <= 64 * 1024) {
+    // the learning role and the scan: one launch (the learning waves scan their own rows), unless the pool is large (the
+    // streaming scan kernels) or somebody is timing the roles one by one (unsharded handles under htm_profile)
+    const bool fuse = h->knob_fuse_tm && !(h->profile && h->world == 1) && !scan_pool_is_large(h) && scan_lds(d, 1) <= 64 * 1024;
+    if (fuse && front_wmode >= 0) {
+        const int epl = learn_epl(d), n_learn = h->lean_learn_blocks, n_scan = h->lean_scan_blocks, spec = scan_spec_blocks(h);
+        const size_t lds = std::max(std::max(learn_lds(epl, 256), scan_lds(d, 1)), (size_t)SEL_BINS * 4);
+        const int grid = n_learn + n_scan + h->lean_overlap_blocks;
+#define LAUNCH_LSO(E_) LAUNCH_ON(h, h->stream, lds, "tm_learn+tm_scan+shard_overlap", (k_learn_scan_overlap<E_>), grid, 256, d, p, n_learn, n_scan, spec, bank, n_inputs, h->G, front_wmode)
+        switch (epl) { case 1: LAUNCH_LSO(1); break; case 2: LAUNCH_LSO(2); break; case 4: LAUNCH_LSO(4); break; default: LAUNCH_LSO(8); break; }
+#undef LAUNCH_LSO
+        return;
+    }
+    if (fuse) {
         const int epl = learn_epl(d), n_learn = h->lean_learn_blocks, n_scan = h->lean_scan_blocks, spec = scan_spec_blocks(h);
         const size_t lds = std::max(learn_lds(epl, 256), scan_lds(d, 1));
         switch (epl) {
@@ -279,10 +293,13 @@ static void enqueue_tm(htm_handle *h, int n_active, int learning, int want_winne
             case 4: LAUNCH_ON(h, h->stream, lds, "tm_learn+tm_scan", (k_learn_scan_emit<4, 6>), n_learn + n_scan, 256, d, p, 0, n_learn, n_scan, spec); break;
             default: LAUNCH_ON(h, h->stream, lds, "tm_learn+tm_scan", (k_learn_scan_emit<8, 6>), n_learn + n_scan, 256, d, p, 0, n_learn, n_scan, spec); break;
         }
-        return;
+    } else {
+        launch_learn(h, p);
+        launch_scan(h, p, scan_lds(d, 1) <= 64 * 1024);
     }
-    launch_learn(h, p);
-    launch_scan(h, p, scan_lds(d, 1) <= 64 * 1024);
+    // (a large pool streams through kernels of its own: the front as a launch behind them)
+    if (front_wmode >= 0)
+        LAUNCH(h, "shard_overlap", k_shard_overlap, h->sp_blocks, RB, d, bank, n_inputs, h->G, p, h->sp_blocks, 0, front_wmode, 1);
 }
 
 // How a step is launched inside htm_run.
@@ -416,6 +433,7 @@ extern "C" void htm_destroy(htm_handle *h) {
     hipSetDevice(h->device);
     hipStreamSynchronize(h->stream);
     for (auto &kv : h->graphs) hipGraphExecDestroy(kv.second);
+    for (auto &kv : h->shard_graphs) hipGraphExecDestroy(kv.second);
     for (auto &v : h->prof_events)
         for (auto &pr : v) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     for (hipEvent_t e : h->prof_all) hipEventDestroy(e);
@@ -470,6 +488,7 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
     h->shard_bank = nullptr;
     h->shard_n_inputs = 1;
     h->shard_open = false;
+    h->shard_front_wmode = 0;
     h->rccl_comm = nullptr;
     h->shard_send = h->shard_recv = nullptr;
     h->phase_active = 0;
@@ -716,6 +735,12 @@ extern "C" int htm_set_epsilon(htm_handle *h, float epsilon) {
     for (auto &kv : h->graphs) hipGraphExecDestroy(kv.second);
     h->graphs.clear();
     h->d.eps = epsilon;
+    return HTM_OK;
+}
+
+extern "C" int htm_get_stream(htm_handle *h, void **stream) {
+    if (!h || !stream) return HTM_ERR_ARGUMENT;
+    *stream = (void *)h->stream;
     return HTM_OK;
 }
 
@@ -1151,7 +1176,8 @@ extern "C" int64_t htm_shard_record_bytes(htm_handle *h) {
     return (int64_t)shard_record_bytes(h->d.n_cand);
 }
 
-static int shard_enqueue_begin(htm_handle *h, const uint32_t *bank, int n_inputs, void *send_device) {
+// front_done: this step's overlap (own columns) was computed beside the previous step's learning and scan (htm_shard_run)
+static int shard_enqueue_begin(htm_handle *h, const uint32_t *bank, int n_inputs, void *send_device, bool front_done = false) {
     Dev &d = h->d;
     const int p = (int)(h->step_host & 1);
     d.send = (unsigned char *)send_device;
@@ -1163,8 +1189,12 @@ static int shard_enqueue_begin(htm_handle *h, const uint32_t *bank, int n_inputs
     // blocks of a grid must not wait for each other: every digit by a launch, the counts by k_sp_count -- same candidates)
     const int fused = h->emit_fused ? 1 : 0;
     const int wmode = fused ? h->knob_shard_window : 0;
-    LAUNCH(h, "shard_overlap", k_shard_overlap, h->sp_blocks + n_word_blocks + std::min((d.C + RB - 1) / RB, 64), RB, d, bank, n_inputs, h->G, p,
-           h->sp_blocks, n_word_blocks, wmode);
+    if (front_done && h->shard_front_wmode != wmode) {       // the exchange mode changed since the front was computed: start over
+        HIPCHK(h, hipMemsetAsync(d.hist0 + (size_t)p * HIST_REP * SEL_BINS, 0, (size_t)HIST_REP * SEL_BINS * 4, h->stream));
+        front_done = false;
+    }
+    LAUNCH(h, "shard_overlap", k_shard_overlap, (front_done ? 0 : h->sp_blocks) + n_word_blocks + std::min((d.C + RB - 1) / RB, 64), RB, d, bank, n_inputs, h->G, p,
+           front_done ? 0 : h->sp_blocks, n_word_blocks, wmode, 0);
     if (!wmode)
         for (int pass = 1; pass < d.sel_passes; ++pass) LAUNCH(h, "sp_select", k_sel_pass, h->sel_blocks, RB, d, pass, p);
     if (!fused) LAUNCH(h, "sp_count", k_sp_count, h->c256_blocks, 256, d, p);
@@ -1172,11 +1202,14 @@ static int shard_enqueue_begin(htm_handle *h, const uint32_t *bank, int n_inputs
     return 0;
 }
 
-static int shard_enqueue_finish(htm_handle *h, const uint32_t *bank, int n_inputs, const void *recv_device, int learning) {
+// front_next: compute the coming step's overlap beside this step's learning and scan (same bank: htm_shard_run)
+static int shard_enqueue_finish(htm_handle *h, const uint32_t *bank, int n_inputs, const void *recv_device, int learning, bool front_next = false) {
     Dev &d = h->d;
     const int p = (int)(h->step_host & 1);
     LAUNCH(h, "shard_select", k_shard_select, h->world, 1024, d, (const unsigned char *)recv_device, p);
-    enqueue_tm(h, d.k, learning, 1, p, bank, n_inputs, true);
+    const int wmode = h->emit_fused ? h->knob_shard_window : 0;
+    enqueue_tm(h, d.k, learning, 1, p, bank, n_inputs, true, front_next ? wmode : -1);
+    if (front_next) h->shard_front_wmode = wmode;
     h->step_host += 1;
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { h->err = std::string("kernel launch: ") + hipGetErrorString(e); return HTM_ERR_HIP; }
@@ -1277,12 +1310,31 @@ extern "C" int htm_rccl_selftest(int32_t device) {
               hipMalloc((void **)&b, n) == hipSuccess && hipMemcpy(a, src.data(), n, hipMemcpyHostToDevice) == hipSuccess;
     ok = ok && g_rccl.all_gather(a, b, n, 0, comm, stream) == 0 && hipStreamSynchronize(stream) == hipSuccess &&
          hipMemcpy(dst.data(), b, n, hipMemcpyDeviceToHost) == hipSuccess && dst == src;
+    // and the same collective captured into a hipGraph and replayed (what htm_shard_run does with whole timesteps)
+    int captured = 0;
+    if (ok) {
+        hipGraph_t graph_obj = nullptr;
+        hipGraphExec_t exec = nullptr;
+        std::fill(dst.begin(), dst.end(), 0);
+        bool cap = hipMemset(b, 0, n) == hipSuccess && hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+        if (cap) {
+            const bool in = g_rccl.all_gather(a, b, n, 0, comm, stream) == 0;
+            cap = hipStreamEndCapture(stream, &graph_obj) == hipSuccess && in && graph_obj &&
+                  hipGraphInstantiate(&exec, graph_obj, nullptr, nullptr, 0) == hipSuccess;
+        }
+        if (cap) cap = hipGraphLaunch(exec, stream) == hipSuccess && hipStreamSynchronize(stream) == hipSuccess &&
+                       hipMemcpy(dst.data(), b, n, hipMemcpyDeviceToHost) == hipSuccess && dst == src;
+        if (exec) hipGraphExecDestroy(exec);
+        if (graph_obj) hipGraphDestroy(graph_obj);
+        (void)hipGetLastError();
+        captured = cap ? 1 : 0;
+    }
     g_rccl.comm_destroy(comm);
     if (a) hipFree(a);
     if (b) hipFree(b);
     hipStreamDestroy(stream);
     if (!ok) { g_create_error = "RCCL all-gather self-test failed"; return HTM_ERR_HIP; }
-    return HTM_OK;
+    return captured ? HTM_OK : 1;                   // 1: the collective works but this runtime does not capture it (htm_shard_run then launches eagerly)
 }
 
 extern "C" int htm_shard_comm_init(htm_handle *h, const void *unique_id128) {
@@ -1372,6 +1424,128 @@ extern "C" int htm_shard_step(htm_handle *h, const uint32_t *device_inputs, int3
     const int nrc = g_rccl.all_gather(h->shard_send, h->shard_recv, rb, /* ncclChar */ 0, h->rccl_comm, h->stream);
     if (nrc != 0) { h->err = std::string("ncclAllGather: ") + (g_rccl.get_error_string ? g_rccl.get_error_string(nrc) : "failed"); return HTM_ERR_HIP; }
     return shard_enqueue_finish(h, bank, n_inputs, h->shard_recv, learning ? 1 : 0);
+}
+
+// ---- n timesteps of the column-sharded step without the host in the loop (htm_shard_run, htm_shard_group_run) ----
+// Inside a run the overlap of step t + 1 (own columns) rides in the last launch of step t, and the launches of whole
+// steps -- the collective included: RCCL's all-gather is captured like a kernel -- are replayed as hipGraphs (two parities
+// per graph, up to 16 steps).  hs = the handles stepped together (one: this process's rank, the exchange by RCCL;
+// several: all ranks of a group in one process, the exchange as device copies).
+static int shard_exchange(htm_handle *const *hs, int n) {
+    if (n == 1) {
+        htm_handle *h = hs[0];
+        const int nrc = g_rccl.all_gather(h->shard_send, h->shard_recv, shard_record_bytes(h->d.n_cand), /* ncclChar */ 0, h->rccl_comm, h->stream);
+        if (nrc != 0) { h->err = std::string("ncclAllGather: ") + (g_rccl.get_error_string ? g_rccl.get_error_string(nrc) : "failed"); return HTM_ERR_HIP; }
+        return 0;
+    }
+    const size_t rb = shard_record_bytes(hs[0]->d.n_cand);
+    for (int r = 0; r < n; ++r)
+        for (int q = 0; q < n; ++q)
+            HIPCHK(hs[r], hipMemcpyAsync(hs[r]->shard_recv + (size_t)q * rb, hs[q]->shard_send, rb, hipMemcpyDeviceToDevice, hs[r]->stream));
+    return 0;
+}
+
+// `count` consecutive steps; first_front_done: the first one's overlap exists already; last_front_next: the last one
+// computes the overlap of the step after it
+static int shard_enqueue_steps(htm_handle *const *hs, int n, const uint32_t *const *banks, int n_inputs, int learning, int count,
+                               bool first_front_done, bool last_front_next) {
+    for (int i = 0; i < count; ++i) {
+        const bool fd = i > 0 || first_front_done, fn = i + 1 < count || last_front_next;
+        for (int r = 0; r < n; ++r) {
+            int rc = shard_enqueue_begin(hs[r], banks[r], n_inputs, hs[r]->shard_send, fd);
+            if (rc) return rc;
+        }
+        int rc = shard_exchange(hs, n);
+        if (rc) return rc;
+        for (int r = 0; r < n; ++r) {
+            rc = shard_enqueue_finish(hs[r], banks[r], n_inputs, hs[r]->shard_recv, learning, fn);
+            if (rc) return rc;
+        }
+    }
+    return 0;
+}
+
+static int shard_run(htm_handle *const *hs, int n, const uint32_t *const *banks, int n_inputs, int n_steps, int learning, int use_graph) {
+    htm_handle *h0 = hs[0];
+    learning = learning ? 1 : 0;
+    bool pipeline = !(use_graph & 2), graph = (use_graph & 1) != 0;
+    for (int r = 0; r < n; ++r) {
+        htm_handle *h = hs[r];
+        HIPCHK(h, hipSetDevice(h->device));
+        refresh_exchange_mode(h);
+        int rc = ensure_shard_buffers(h);
+        if (rc) return rc;
+        if (h->seg_pinned) { const int seen = *(volatile int *)h->seg_pinned; h->seg_hint = std::max(h->seg_hint, seen); }
+        if (h->profile) graph = false;
+    }
+    const int kSpan = 16;
+    for (int t = 0; t < n_steps;) {
+        // steady state: steps whose overlap was computed ahead and that compute the next one's; the first and the last step
+        // of a call are launched on their own
+        const bool fd = pipeline && t > 0, steady = fd && t + 1 < n_steps;
+        int span = 1;
+        if (steady && graph) span = std::min(kSpan, (n_steps - 1 - t) & ~1) > 0 ? std::min(kSpan, (n_steps - 1 - t) & ~1) : 1;
+        const bool fn = pipeline && t + span < n_steps;
+        if (!graph) {
+            int rc = shard_enqueue_steps(hs, n, banks, n_inputs, learning, span, fd, fn);
+            if (rc) return rc;
+            t += span;
+            continue;
+        }
+        int flags = (int)(h0->step_host & 1) | learning << 1 | (fd ? 4 : 0) | (fn ? 8 : 0) | span << 4;
+        for (int r = 0; r < n; ++r)           // what the launches of a rank depend on besides its arguments
+            flags ^= (int)((scan_spec_blocks(hs[r]) * 2654435761u + (scan_pool_is_large(hs[r]) ? 97u : 0u) + (hs[r]->emit_fused ? 193u : 0u)) << 10) * (r + 1);
+        auto key = std::make_tuple(flags, n, (const void *)banks[0], n_inputs);
+        auto it = h0->shard_graphs.find(key);
+        if (it == h0->shard_graphs.end()) {
+            std::vector<long long> saved((size_t)n);
+            for (int r = 0; r < n; ++r) saved[(size_t)r] = hs[r]->step_host;
+            hipGraph_t graph_obj = nullptr;
+            hipError_t e = hipStreamBeginCapture(h0->stream, hipStreamCaptureModeThreadLocal);
+            int rc = e == hipSuccess ? shard_enqueue_steps(hs, n, banks, n_inputs, learning, span, fd, fn) : HTM_ERR_HIP;
+            hipError_t e2 = e == hipSuccess ? hipStreamEndCapture(h0->stream, &graph_obj) : e;
+            for (int r = 0; r < n; ++r) hs[r]->step_host = saved[(size_t)r];      // (captured, not run)
+            hipGraphExec_t exec = nullptr;
+            if (rc == 0 && e2 == hipSuccess && graph_obj && hipGraphInstantiate(&exec, graph_obj, nullptr, nullptr, 0) != hipSuccess) exec = nullptr;
+            if (graph_obj) hipGraphDestroy(graph_obj);
+            if (!exec) {                            // (a collective that cannot be captured on this runtime: launch eagerly from here on)
+                (void)hipGetLastError();
+                graph = false;
+                h0->err.clear();
+                continue;
+            }
+            it = h0->shard_graphs.emplace(key, exec).first;
+        }
+        HIPCHK(h0, hipGraphLaunch(it->second, h0->stream));
+        for (int r = 0; r < n; ++r) hs[r]->step_host += span;
+        t += span;
+    }
+    if (n_steps > 0)
+        for (int r = 0; r < n; ++r)
+            if (hs[r]->seg_pinned) HIPCHK(hs[r], hipMemcpyAsync(hs[r]->seg_pinned, &hs[r]->d.ctr->L, sizeof(int), hipMemcpyDeviceToHost, hs[r]->stream));
+    return HTM_OK;
+}
+
+extern "C" int htm_shard_run(htm_handle *h, const uint32_t *device_inputs, int32_t n_inputs, int32_t n_steps, int32_t learning, int32_t use_graph) {
+    if (!h || !device_inputs || n_inputs < 1 || n_steps < 0) return HTM_ERR_ARGUMENT;
+    if (h->world < 2 || !h->rccl_comm) { h->err = "htm_shard_run: needs a sharded handle after htm_shard_comm_init"; return HTM_ERR_STATE; }
+    if (h->shard_open) { h->err = "htm_shard_run: a step opened with htm_shard_begin is not finished"; return HTM_ERR_STATE; }
+    htm_handle *hs[1] = {h};
+    const uint32_t *banks[1] = {device_inputs};
+    return shard_run(hs, 1, banks, n_inputs, n_steps, learning, use_graph);
+}
+
+extern "C" int htm_shard_group_run(htm_handle *const *handles, int32_t n, const uint32_t *const *device_inputs, int32_t n_inputs, int32_t n_steps,
+                                   int32_t learning, int32_t use_graph) {
+    if (!handles || n < 2 || !device_inputs || n_inputs < 1 || n_steps < 0) return HTM_ERR_ARGUMENT;
+    for (int r = 0; r < n; ++r) {
+        htm_handle *h = handles[r];
+        if (!h || h->world != n || h->rank != r || h->stream != handles[0]->stream || h->device != handles[0]->device || !device_inputs[r]) {
+            if (h) h->err = "htm_shard_group_run: handles must be ranks 0..n-1 of one group on one stream, each with its bank";
+            return HTM_ERR_ARGUMENT;
+        }
+    }
+    return shard_run(handles, n, device_inputs, n_inputs, n_steps, learning, use_graph);
 }
 
 // Pre-populated pool (BASELINE.json configs[4]: a pure scan stress, not a learned state): every cell with flat id in

@@ -30,6 +30,26 @@ struct TraceScope {                                 // BITHTM_TRACE=1: first / l
 #if defined(BITHTM_LEARN_STAMPS) || defined(BITHTM_SCAN_STAMPS) || defined(BITHTM_EMIT_STAMPS) || defined(BITHTM_SHARD_STAMPS)
         t = nullptr;                                // the diagnostic builds of the learning role and of the scan use the buffer
         return;
+// The column-sharded step's last launch (enqueue_tm, world > 1): the learning role, the scan of the rank's own rows, and --
+// inside htm_shard_run -- the overlap of the COMING step on the rank's own columns (its permanence rows and duty cycle were
+// updated by this step's middle launch; nothing of the Temporal Memory is read): one launch less on the rank's chain.
+template <int EPL>
+__global__ __launch_bounds__(256, 6) void k_learn_scan_overlap(Dev d, int p, int n_learn_blocks, int n_scan_blocks, int n_spec,
+                                                               const uint32_t *__restrict__ bank, int n_inputs, int G, int wmode) {
+    int b = blockIdx.x;
+    if (b < n_learn_blocks) {
+        role_learn<EPL, 256, true>(d, p, b, n_learn_blocks, (LearnShared<EPL, 256> *)dyn_lds);
+        return;
+    }
+    b -= n_learn_blocks;
+    if (b < n_scan_blocks) {
+        role_scan<256, true, false, false>(d, p, b, n_scan_blocks, n_spec, (uint32_t *)dyn_lds);
+        return;
+    }
+    b -= n_scan_blocks;
+    role_overlap<256>(d, bank, n_inputs, G, p, p ^ 1, 1, b, (int)gridDim.x - n_learn_blocks - n_scan_blocks, (uint32_t *)dyn_lds, wmode);
+}
+
 #endif
         t = (d.trace && blockIdx.x < 4096 && d.ctr->step[slot >> 2] < d.trace_until) ? d.trace + ((size_t)slot * 4096 + blockIdx.x) * 2 : nullptr;
         if (t && threadIdx.x == 0) t[0] = wall_clock64();
@@ -212,6 +232,26 @@ __global__ __launch_bounds__(256, MINW) void k_learn_scan_emit(Dev d, int p, int
     }
     b -= n_learn_blocks;
     role_scan<256, true, MINW < 6, TAB>(d, p, b, n_scan_blocks, n_spec, (uint32_t *)dyn_lds);      // (MINW < 6: the large-pool form)
+}
+
+// The column-sharded step's last launch (enqueue_tm, world > 1): the learning role, the scan of the rank's own rows, and --
+// inside htm_shard_run -- the overlap of the COMING step on the rank's own columns (its permanence rows and duty cycle were
+// updated by this step's middle launch; nothing of the Temporal Memory is read): one launch less on the rank's chain.
+template <int EPL>
+__global__ __launch_bounds__(256, 6) void k_learn_scan_overlap(Dev d, int p, int n_learn_blocks, int n_scan_blocks, int n_spec,
+                                                               const uint32_t *__restrict__ bank, int n_inputs, int G, int wmode) {
+    int b = blockIdx.x;
+    if (b < n_learn_blocks) {
+        role_learn<EPL, 256, true>(d, p, b, n_learn_blocks, (LearnShared<EPL, 256> *)dyn_lds);
+        return;
+    }
+    b -= n_learn_blocks;
+    if (b < n_scan_blocks) {
+        role_scan<256, true, false, false>(d, p, b, n_scan_blocks, n_spec, (uint32_t *)dyn_lds);
+        return;
+    }
+    b -= n_scan_blocks;
+    role_overlap<256>(d, bank, n_inputs, G, p, p ^ 1, 1, b, (int)gridDim.x - n_learn_blocks - n_scan_blocks, (uint32_t *)dyn_lds, wmode);
 }
 
 #endif

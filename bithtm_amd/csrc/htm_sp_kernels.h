@@ -874,13 +874,15 @@ __global__ void k_sp_commit(Dev d, int p) { d.ctr->step[p ^ 1] = d.ctr->step[p] 
 // ---- column sharding: the kernels on either side of the exchange -----------------------------
 // before the exchange, first launch: overlap + boost + top key digit of the OWN columns, the speculative cell words of
 // the own columns, and the zeroing of the step's dense per-column words (the winners' words are written after the exchange)
-__global__ __launch_bounds__(RB) void k_shard_overlap(Dev d, const uint32_t *__restrict__ bank, int n_inputs, int G, int p, int n_overlap_blocks, int n_word_blocks, int wmode) {
+// (front: only the overlap blocks, for the COMING step -- parity p ^ 1, the bank row after this step's)
+__global__ __launch_bounds__(RB) void k_shard_overlap(Dev d, const uint32_t *__restrict__ bank, int n_inputs, int G, int p, int n_overlap_blocks, int n_word_blocks, int wmode, int front) {
     __shared__ uint32_t h[SEL_BINS];
     int b = blockIdx.x;
     if (b < n_overlap_blocks) {
-        role_overlap<RB>(d, bank, n_inputs, G, p, p, 0, b, n_overlap_blocks, h, wmode);
+        role_overlap<RB>(d, bank, n_inputs, G, p, front ? p ^ 1 : p, front ? 1 : 0, b, n_overlap_blocks, h, wmode);
         return;
     }
+    if (front) return;
     b -= n_overlap_blocks;
     if (b < n_word_blocks) {
         // the cell words every OWN column would have if it became active (networks.py:95-104; they only depend on the

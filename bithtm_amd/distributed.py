@@ -145,11 +145,10 @@ class ShardedHTM:
         eng.write(L.F_DUTY_CYCLE, np.asarray(duty_cycle, dtype=np.float32), np.float32)
         eng.import_tm_state(tm_state)
 
-    def run(self, device_bank, n_inputs, steps, learning=True):
+    def run(self, device_bank, n_inputs, steps, learning=True, use_graph=True, pipeline=True):
         eng = self.engine
-        if self.all_gather is None:
-            for _ in range(steps):
-                eng.shard_step(device_bank=device_bank, n_inputs=n_inputs, learning=learning)
+        if self.all_gather is None:                 # the loop, the exchange and the graphs inside the library
+            eng.shard_run(device_bank, n_inputs, steps, learning=learning, use_graph=use_graph, pipeline=pipeline)
             return
         send, recv = self.send.data_ptr(), self.recv.data_ptr()
         for _ in range(steps):
@@ -178,10 +177,15 @@ class LocalGroup:
                 proximal.input_dim, proximal.output_dim = input_dim, column_dim
                 proximal.permanence_threshold, proximal.permanence_increment, proximal.permanence_decrement = 0.0, 0.03, 0.015
                 proximal._engine, proximal._permanence = None, permanence
-            self.engines.append(Engine(input_dim, column_dim, cell_dim, active_columns, proximal=proximal,
-                                       boosting=parts.get("boosting") or ExponentialBoosting(column_dim, active_columns),
-                                       distal=parts.get("distal") or PredictiveProjection(column_dim * cell_dim),
-                                       seed=seed, device=device, stream="default", shard_rank=r, shard_world=world))
+            # rank 0's engine creates a stream of its own, the others enqueue on it (one in-order stream for the whole group:
+            # what a graph capture of the group's step needs -- the default stream cannot be captured)
+            eng = Engine(input_dim, column_dim, cell_dim, active_columns, proximal=proximal,
+                         boosting=parts.get("boosting") or ExponentialBoosting(column_dim, active_columns),
+                         distal=parts.get("distal") or PredictiveProjection(column_dim * cell_dim),
+                         seed=seed, device=device, stream=(self.engines[0].stream_handle() if r else None), shard_rank=r, shard_world=world)
+            if r:
+                eng._stream_owner = self.engines[0]
+            self.engines.append(eng)
         self._handles = (C.c_void_p * world)(*[e.h for e in self.engines])
         self._banks = None
         self.lib = self.engines[0].lib
@@ -221,9 +225,15 @@ class LocalGroup:
         self._banks = (C.c_void_p * self.world)(*[e.upload_bank(inputs) for e in self.engines])
         self._n_inputs = len(inputs)
 
-    def run(self, steps, learning=True):
-        """`steps` timesteps over the bank of upload_bank (every rank holds its copy)."""
-        for _ in range(steps):
-            self._check(self.lib.htm_shard_group_step(self._handles, self.world, self._banks, self._n_inputs, None, int(bool(learning))))
+    def run(self, steps, learning=True, use_graph=True, pipeline=True, stepwise=False):
+        """`steps` timesteps over the bank of upload_bank (every rank holds its copy): the loop inside the library
+        (htm_shard_group_run: whole timesteps replayed as hipGraphs, each rank's next overlap computed beside its learning and
+        scan).  stepwise: one htm_shard_group_step call per timestep instead."""
+        if stepwise:
+            for _ in range(steps):
+                self._check(self.lib.htm_shard_group_step(self._handles, self.world, self._banks, self._n_inputs, None, int(bool(learning))))
+        else:
+            flags = (1 if use_graph else 0) | (0 if pipeline else 2)
+            self._check(self.lib.htm_shard_group_run(self._handles, self.world, self._banks, self._n_inputs, int(steps), int(bool(learning)), flags))
         for e in self.engines:
             e.steps += steps

@@ -83,6 +83,7 @@ class Engine:
         # stream: None = a private stream; "default" = the device's default stream; else a hipStream_t of the caller
         cfg.use_caller_stream = int(stream is not None)
         cfg.stream = stream if (stream and stream != "default") else None
+        self._stream_owner = None                   # (an engine created on another engine's stream keeps that engine alive)
         self.shard_rank, self.shard_world = int(shard_rank), max(int(shard_world), 1)
         per = self.column_dim // self.shard_world
         self.column_range = (self.shard_rank * per, (self.shard_rank + 1) * per)
@@ -129,6 +130,18 @@ class Engine:
 
     def sync(self):
         self._check(self.lib.htm_sync(self.h), "htm_sync")
+
+    def stream_handle(self):
+        """The hipStream_t this engine enqueues on (an integer; 0 = the default stream)."""
+        out = C.c_void_p()
+        self._check(self.lib.htm_get_stream(self.h, C.byref(out)), "htm_get_stream")
+        return out.value or 0
+
+    def shard_run(self, device_bank, n_inputs, n_steps, learning=True, use_graph=True, pipeline=True):
+        """n_steps column-sharded timesteps, the exchange (RCCL) and the loop inside the library (htm_shard_run)."""
+        flags = (1 if use_graph else 0) | (0 if pipeline else 2)
+        self._check(self.lib.htm_shard_run(self.h, C.c_void_p(device_bank), int(n_inputs), int(n_steps), int(bool(learning)), flags), "htm_shard_run")
+        self.steps += n_steps
 
     def import_prev_state(self, prediction, activation, winner_flat, distal):
         """TemporalMemory.process(prev_state=X) (networks.py:92-93): X's fields become the handle's "previous step" --

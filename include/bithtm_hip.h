@@ -260,8 +260,18 @@ int htm_shard_unique_id(void *out128);
 int htm_shard_comm_init(htm_handle *h, const void *unique_id128);
 int htm_shard_step(htm_handle *h, const uint32_t *device_inputs, int32_t n_inputs, const uint32_t *packed_input,
                    int32_t learning);
-/* RCCL round trip at world size 1 on `device` (communicator, all-gather on a stream, compare): what a box with one
- * GPU can verify of the path htm_shard_step takes. */
+/* n_steps of htm_shard_step over a bank resident in device memory, without the host in the loop: the launches of whole
+ * timesteps, the collective included, are replayed as hipGraphs (use_graph bit 0; RCCL's all-gather is captured like a
+ * kernel -- where the runtime refuses, the call launches eagerly instead), and inside the call the overlap of step t + 1 on
+ * the rank's own columns rides in the last launch of step t (bit 1, HTM_RUN_NO_PIPELINE: not).  The state a call leaves
+ * behind is that of n_steps htm_shard_step calls.  htm_shard_group_run: the same for all the ranks of a group inside one
+ * process (see htm_shard_group_step). */
+int htm_shard_run(htm_handle *h, const uint32_t *device_inputs, int32_t n_inputs, int32_t n_steps, int32_t learning, int32_t use_graph);
+int htm_shard_group_run(htm_handle *const *handles, int32_t n, const uint32_t *const *device_inputs, int32_t n_inputs, int32_t n_steps,
+                        int32_t learning, int32_t use_graph);
+/* RCCL round trip at world size 1 on `device` (communicator, all-gather on a stream, compare; then the same collective
+ * captured into a hipGraph and replayed): what a box with one GPU can verify of the path htm_shard_step / htm_shard_run
+ * take.  0: both work; 1: the collective works but is not capturable on this runtime; negative: failure. */
 int htm_rccl_selftest(int32_t device);
 
 /* All the shards of one model inside ONE process on one device: handles[r] = rank r of n = shard_world, created on
@@ -280,6 +290,9 @@ int htm_populate(htm_handle *h, int64_t cell_begin, int64_t cell_end, int32_t se
                  double perm_lo, double perm_hi, uint32_t seed);
 
 int htm_sync(htm_handle *h);
+/* the hipStream_t the handle enqueues on (its own, or the caller's: htm_config.use_caller_stream) -- for callers that order
+ * their own work against it, and for creating further handles on the same stream */
+int htm_get_stream(htm_handle *h, void **stream);
 int htm_get_info(htm_handle *h, htm_info *out);      /* synchronises; HTM_ERR_CAPACITY (with *out filled
                                                          in) once a fixed-capacity pool has overflowed */
 

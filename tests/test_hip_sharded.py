@@ -110,7 +110,8 @@ def test_rccl_all_gather_through_the_library_at_world_size_one():
     from bithtm_amd import _lib
     lib = _lib.load()
     rc = lib.htm_rccl_selftest(0)
-    assert rc == 0, lib.htm_last_error(None)
+    assert rc in (0, 1), lib.htm_last_error(None)      # 0: the collective also replays from a captured hipGraph (htm_shard_run's form)
+    print("RCCL all-gather captured into a hipGraph and replayed" if rc == 0 else "RCCL all-gather works eagerly; NOT capturable on this runtime")
 
 
 def test_two_shards_default_parameters():
@@ -237,3 +238,48 @@ def test_state_import_into_a_sharded_group_and_merged_export(world):
         c0, c1 = e.column_range
         assert np.array_equal(e.get_permanence(c0, c1 - c0).view(np.int64), solo.engine.get_permanence(c0, c1 - c0).view(np.int64))
         assert np.array_equal(e.read_duty_cycle()[c0:c1].view(np.int32), solo.engine.read_duty_cycle()[c0:c1].view(np.int32))
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_sharded_runs_inside_the_library_equal_step_by_step(world):
+    """htm_shard_group_run (the loop inside the library: whole timesteps replayed as hipGraphs, the next step's overlap riding
+    in the last launch of the current one) == one htm_shard_group_step call per timestep == the oracle, for run lengths
+    that exercise every plan (first / steady / last steps, odd and even graph spans, eager)."""
+    import bithtm_amd as B
+    from bithtm_amd.distributed import LocalGroup
+    from bithtm_amd import _lib as L
+    I, C, K, P, seed = 200, 4096, 8, 13, 44
+    k = round(C * 0.02)
+    np.random.seed(seed)
+    perm = np.random.randn(C, I) * 0.1
+    ora = HTMOracle(I, C, K, active_columns=k, seed=seed, permanence=perm)
+    bank = np.random.RandomState(seed + 1).rand(P, I) < 0.1
+    lengths = [1, 2, 3, 40, 5, 17, 18, 1, 34]
+    groups = {}
+    for mode in ("graph", "eager", "nopipe", "stepwise"):
+        g = LocalGroup(world, I, C, K, active_columns=k, permanence=perm, seed=seed)
+        g.upload_bank(bank)
+        for n in lengths:
+            if mode == "stepwise":
+                g.run(n, stepwise=True)
+            else:
+                g.run(n, use_graph=mode == "graph", pipeline=mode != "nopipe")
+        groups[mode] = g
+    for t in range(sum(lengths)):
+        o_sp, o_tm = ora.step(bank[t % P])
+    want = None
+    for mode, g in groups.items():
+        for e in g.engines:
+            info = e.check_capacity()
+            assert info.step_index == sum(lengths) and info.segments == ora.temporal_memory.S, mode
+            assert np.array_equal(e.read(L.F_ACTIVE_COLUMN, np.int32, k), o_sp.active_column), mode
+        got = g.export_tm_state()
+        if want is None:
+            want = got
+            assert np.array_equal(got["prev_prediction"], o_tm.cell_prediction) and np.array_equal(got["seg_nsyn"], ora.temporal_memory.seg_nsyn[:ora.temporal_memory.S])
+            continue
+        for key in want:
+            a, b = np.asarray(got[key]), np.asarray(want[key])
+            if a.dtype.kind == "f":
+                a, b = a.view(np.int32 if a.itemsize == 4 else np.int64), b.view(np.int32 if b.itemsize == 4 else np.int64)
+            assert a.shape == b.shape and np.array_equal(a, b), (mode, key)
