@@ -110,12 +110,12 @@ def role_bytes(w, k, seg_nsyn, n_work, n_match):
     }
 
 
-def recorded_traffic(kernel):
+def recorded_traffic(kernel, files=("r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json")):
     """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r02_pmc_summary.json:
     rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs of this same workload and schedule; KB
     units; FETCH_SIZE doubled as MI355X_MICROARCH.md section HBM prescribes for gfx950).  PMC counters cannot
     be read from inside this process, so this is a recorded value, not a live one."""
-    for name in ("r02_pmc_summary.json", "r01_pmc_summary.json"):
+    for name in files:
         path = os.path.join(ROOT, "profiles", name)
         try:
             d = json.load(open(path))

@@ -167,8 +167,6 @@ struct Dev {
     int *lfree;               // [Lcap]  stack of free local rows
     int *asg_gid;             // [k*32]  ids assigned to this step's new segment requests, in request order
     int *cand_cols;           // [sel_k] own candidate columns of this step, ascending
-    uint32_t *spec_win, *spec_unacc;      // [c1 - c0] winner / needs-a-segment word each own column would have if it became active
-    uint8_t *spec_burst;      // [c1 - c0] ... and whether it would burst
     int *dead_list;           // [1 + DEAD_CAP]: count, global ids of own segments that died while learning
     const uint32_t *punish;   // htm_tm_update: per-cell punishment mask, one word per column (projections.py:269's output_punishment);
                               // null: the cells of columns that are not active (networks.py:107-108,111)

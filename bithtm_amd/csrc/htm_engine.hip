@@ -255,7 +255,7 @@ static void enqueue_sp_back(htm_handle *h, const uint32_t *bank, int n_inputs, i
     Dev &d = h->d;
     const int fused = h->emit_fused;               // all blocks co-resident: count inside emit
     if (!fused) LAUNCH(h, "sp_count", k_sp_count, h->c256_blocks, 256, d, p);
-    LAUNCH(h, "sp_emit", k_sp_emit, h->c256_blocks, 256, d, p, want_winner, fused, mode, 0);
+    LAUNCH(h, "sp_emit", k_sp_emit, h->c256_blocks, 256, d, p, want_winner, fused, mode, 0, h->c256_blocks);
     // (a forked graph branch for this independent update was measured at +17..29 us per step on
     // this runtime, against 2.3 us for one more kernel in the chain: tools/launch_overhead.hip)
     if (sp_learn) LAUNCH(h, "sp_learn", k_sp_learn, d.k, 256, d, bank, n_inputs, p);
@@ -299,7 +299,7 @@ static void enqueue_tm(htm_handle *h, int n_active, int learning, int want_winne
     }
     // (a large pool streams through kernels of its own: the front as a launch behind them)
     if (front_wmode >= 0)
-        LAUNCH(h, "shard_overlap", k_shard_overlap, h->sp_blocks, RB, d, bank, n_inputs, h->G, p, h->sp_blocks, 0, front_wmode, 1);
+        LAUNCH(h, "shard_overlap", k_shard_overlap, h->sp_blocks, RB, d, bank, n_inputs, h->G, p, front_wmode, 1);
 }
 
 // How a step is launched inside htm_run.
@@ -606,9 +606,6 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
             rc |= dalloc(h, &d.lfree, S);
             rc |= dalloc(h, &d.asg_gid, k * 32);
             rc |= dalloc(h, &d.cand_cols, (size_t)d.n_cand + 8);
-            rc |= dalloc(h, &d.spec_win, (size_t)(d.c1 - d.c0));
-            rc |= dalloc(h, &d.spec_unacc, (size_t)(d.c1 - d.c0));
-            rc |= dalloc(h, &d.spec_burst, (size_t)(d.c1 - d.c0));
             if (!rc && (hipMemsetAsync(d.seg_gid, 0xFF, S * 4, h->stream) != hipSuccess ||
                         hipMemsetAsync(d.g2l, 0xFF, G * 4, h->stream) != hipSuccess)) { h->err = "hipMemsetAsync failed"; rc = HTM_ERR_HIP; }
         }
@@ -1181,9 +1178,9 @@ static int shard_enqueue_begin(htm_handle *h, const uint32_t *bank, int n_inputs
     Dev &d = h->d;
     const int p = (int)(h->step_host & 1);
     d.send = (unsigned char *)send_device;
-    // own columns: overlap + boost + top digit, and the zeroing of the step's dense words; digit 1; local select finish
-    // + speculative cell words of the candidates, packed into the record
-    const int n_word_blocks = ((d.c1 - d.c0) * 32 + RB - 1) / RB;        // one own column per half-wave
+    // own columns: overlap + boost + histogram (unless computed ahead); the local select's finish, the cell words each
+    // candidate would have if it became active, the record -- and, in further blocks of that launch, the zeroing of the step's
+    // dense words
     // (the local select: one windowed histogram pass beside the overlap, finished inside the candidates kernel;
     // BITHTM_SHARD_WINDOW=0: two launched digits.  While another handle with a stream of its own is live on the device the
     // blocks of a grid must not wait for each other: every digit by a launch, the counts by k_sp_count -- same candidates)
@@ -1193,12 +1190,11 @@ static int shard_enqueue_begin(htm_handle *h, const uint32_t *bank, int n_inputs
         HIPCHK(h, hipMemsetAsync(d.hist0 + (size_t)p * HIST_REP * SEL_BINS, 0, (size_t)HIST_REP * SEL_BINS * 4, h->stream));
         front_done = false;
     }
-    LAUNCH(h, "shard_overlap", k_shard_overlap, (front_done ? 0 : h->sp_blocks) + n_word_blocks + std::min((d.C + RB - 1) / RB, 64), RB, d, bank, n_inputs, h->G, p,
-           front_done ? 0 : h->sp_blocks, n_word_blocks, wmode, 0);
+    if (!front_done) LAUNCH(h, "shard_overlap", k_shard_overlap, h->sp_blocks, RB, d, bank, n_inputs, h->G, p, wmode, 0);
     if (!wmode)
         for (int pass = 1; pass < d.sel_passes; ++pass) LAUNCH(h, "sp_select", k_sel_pass, h->sel_blocks, RB, d, pass, p);
     if (!fused) LAUNCH(h, "sp_count", k_sp_count, h->c256_blocks, 256, d, p);
-    LAUNCH(h, "shard_candidates", k_sp_emit, h->c256_blocks, 256, d, p, 1, fused, EMIT_LOCAL, wmode);
+    LAUNCH(h, "shard_candidates", k_sp_emit, h->c256_blocks + std::min((d.C + 255) / 256, 64), 256, d, p, 1, fused, EMIT_LOCAL, wmode, h->c256_blocks);
     return 0;
 }
 
@@ -1206,7 +1202,7 @@ static int shard_enqueue_begin(htm_handle *h, const uint32_t *bank, int n_inputs
 static int shard_enqueue_finish(htm_handle *h, const uint32_t *bank, int n_inputs, const void *recv_device, int learning, bool front_next = false) {
     Dev &d = h->d;
     const int p = (int)(h->step_host & 1);
-    LAUNCH(h, "shard_select", k_shard_select, h->world, 1024, d, (const unsigned char *)recv_device, p);
+    LAUNCH(h, "shard_select", k_shard_select, h->world + 1, 1024, d, (const unsigned char *)recv_device, p);      // (+ 1: the death reports)
     const int wmode = h->emit_fused ? h->knob_shard_window : 0;
     enqueue_tm(h, d.k, learning, 1, p, bank, n_inputs, true, front_next ? wmode : -1);
     if (front_next) h->shard_front_wmode = wmode;
@@ -1256,6 +1252,7 @@ struct RcclApi {
     int (*comm_init_rank)(void **, int, ncclUniqueIdBytes, int) = nullptr;
     int (*all_gather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
     int (*comm_destroy)(void *) = nullptr;
+    int (*comm_count)(void *, int *) = nullptr;
     const char *(*get_error_string)(int) = nullptr;
 };
 RcclApi g_rccl;
@@ -1275,6 +1272,7 @@ const char *load_rccl() {
     api.all_gather = (int (*)(const void *, void *, size_t, int, void *, hipStream_t))dlsym(lib, "ncclAllGather");
     api.comm_destroy = (int (*)(void *))dlsym(lib, "ncclCommDestroy");
     api.get_error_string = (const char *(*)(int))dlsym(lib, "ncclGetErrorString");
+    api.comm_count = (int (*)(void *, int *))dlsym(lib, "ncclCommCount");
     if (!api.get_unique_id || !api.comm_init_rank || !api.all_gather || !api.comm_destroy) return "librccl.so lacks an expected symbol";
     g_rccl = api;
     g_rccl_destroy = api.comm_destroy;
@@ -1353,6 +1351,15 @@ extern "C" int htm_shard_comm_init(htm_handle *h, const void *unique_id128) {
     if (rc2) return rc2;
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return HTM_OK;
+}
+
+// ranks of the RCCL communicator htm_shard_step / htm_shard_run exchange over (ncclCommCount): what a scaling run reports
+extern "C" int htm_shard_comm_size(htm_handle *h) {
+    if (!h) return HTM_ERR_ARGUMENT;
+    if (!h->rccl_comm || !g_rccl.comm_count) { h->err = "htm_shard_comm_size: no communicator (htm_shard_comm_init)"; return HTM_ERR_STATE; }
+    int n = 0;
+    if (g_rccl.comm_count(h->rccl_comm, &n) != 0) { h->err = "ncclCommCount failed"; return HTM_ERR_HIP; }
+    return n;
 }
 
 static int ensure_shard_buffers(htm_handle *h) {

@@ -241,15 +241,29 @@ __global__ __launch_bounds__(256) void k_sp_count(Dev d, int sp) {
 // least-used cell (:84-89).  idx = position of column a in the ascending active list.
 struct ColumnWords { uint32_t act, winner, unacc; bool burst; };
 
+// what a lane (cell j of column a) reads from memory for tm_column_words: fetched for several columns at once where a
+// half-wave handles more than one (the loads of all of them in flight together)
+struct ColumnLoads { float cm; int segcount; };
+
+__device__ __forceinline__ ColumnLoads tm_column_loads(const Dev &d, int p, bool col_ok, int a, int has_distal) {
+    const int j = lane_id() & 31;
+    const bool valid = col_ok && j < d.K;
+    ColumnLoads l;
+    const int idx = valid ? a * 32 + j : 0;          // (clamped and unconditional: a guarded load is waited for on its own)
+    const float cm = __uint_as_float(d.cellmax[p ^ 1][idx]);
+    l.cm = (valid && has_distal) ? cm : -1.0f;
+    l.segcount = d.segcount[idx];
+    return l;
+}
+
 // pw = prev_state.cell_prediction row of column a (0 when !col_ok)
-__device__ __forceinline__ ColumnWords tm_column_words(const Dev &d, int p, int want_winner, bool col_ok, int a, uint32_t pw) {
+__device__ __forceinline__ ColumnWords tm_column_compute(const Dev &d, int want_winner, bool col_ok, int a, uint32_t pw, const ColumnLoads &l,
+                                                         int has_distal, uint32_t step) {
     const int lane = lane_id(), half = lane >> 5, j = lane & 31;
     const bool valid = col_ok && j < d.K;
     const bool burst = pw == 0;
     const uint32_t act = burst ? cell_mask(d.K) : pw;        // networks.py:115
-    const int has_distal = d.ctr->has_distal;
-    float cm = -1.0f;
-    if (valid && has_distal) cm = __uint_as_float(d.cellmax[p ^ 1][a * 32 + j]);
+    const float cm = l.cm;
     uint32_t winner = pw, unacc = 0;
     if (want_winner) {
         float colmax = cm;
@@ -258,8 +272,8 @@ __device__ __forceinline__ ColumnWords tm_column_words(const Dev &d, int p, int 
         const bool best = valid && has_distal && fabsf(cm - colmax) < d.eps;       // :81
         float jit = 3.0e38f;
         if (valid) {
-            uint32_t base = htm_stream_base(d.seed, HTM_STREAM_LEAST_USED, d.ctr->step[p]);
-            jit = htm_jitter((float)d.segcount[a * 32 + j], htm_draw24(base, (uint32_t)(a * d.K + j), 0u));   // :86-87
+            uint32_t base = htm_stream_base(d.seed, HTM_STREAM_LEAST_USED, step);
+            jit = htm_jitter((float)l.segcount, htm_draw24(base, (uint32_t)(a * d.K + j), 0u));   // :86-87
         }
         float mn = jit;
         for (int o = 16; o > 0; o >>= 1) mn = fminf(mn, __shfl_xor(mn, o));
@@ -272,6 +286,12 @@ __device__ __forceinline__ ColumnWords tm_column_words(const Dev &d, int p, int 
         unacc = has_distal ? (winner & ~(uint32_t)(bm >> (half * 32))) : 0u;       // projections.py:271
     }
     return ColumnWords{act, want_winner ? winner : 0u, unacc, burst};
+}
+
+__device__ __forceinline__ ColumnWords tm_column_words(const Dev &d, int p, int want_winner, bool col_ok, int a, uint32_t pw) {
+    const int has_distal = d.ctr->has_distal;
+    const ColumnLoads l = tm_column_loads(d, p, col_ok, a, has_distal);
+    return tm_column_compute(d, want_winner, col_ok, a, pw, l, has_distal, d.ctr->step[p]);
 }
 
 // store the words of active column a, the idx-th of the ascending active list
@@ -416,7 +436,7 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
     const bool own_col = c < d.sel_hi && c >= d.c0 && c < d.c1;
     const float my_duty = (own_col && (mode & EMIT_DUTY)) ? d.duty[c] : 0.f;
     const bool tm_here = d.act[0] && (mode & EMIT_ACTIVATE);
-    s_predw[tid] = (c < d.sel_hi && tm_here) ? d.pred[p ^ 1][c] : 0u;
+    s_predw[tid] = (c < d.sel_hi && (tm_here || local)) ? d.pred[p ^ 1][c] : 0u;
     u64 T;
     uint32_t r;                                     // how many of the keys == T are selected
     bool second_round = false;                      // per-block counts still to be exchanged
@@ -769,12 +789,36 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
     if (local) {                                   // this block's candidates into the exchange record
         double *r_boost = (double *)d.send;
         uint32_t *r_col = (uint32_t *)(d.send + (size_t)d.n_cand * 8), *r_win = r_col + d.n_cand, *r_unacc = r_win + d.n_cand;
-        for (int i = tid; i < n_sel; i += 256) {   // (the words of every own column were computed beside the overlap)
-            const int a = s_col[i], pos = first_pos + i;
-            r_boost[pos] = d.boosted[p][a];
-            r_col[pos] = (uint32_t)a | (d.spec_burst[a - d.c0] ? 0x80000000u : 0u);
-            r_win[pos] = d.spec_win[a - d.c0];
-            r_unacc[pos] = d.spec_unacc[a - d.c0];
+        // with the cell words each would have if it became active (networks.py:95-104: they only depend on the owner's previous
+        // predictions, segment maxima and segment counts): one candidate per half-wave, four per half-wave and pass with all
+        // their loads in flight together
+        const int has_distal = d.ctr->has_distal;
+        const uint32_t step = d.ctr->step[p];
+        constexpr int CPP = 4;
+        for (int i0 = 0; i0 < n_sel; i0 += 8 * CPP) {
+            int a[CPP];
+            bool ok[CPP];
+            ColumnLoads l[CPP];
+            double bo[CPP];
+#pragma unroll
+            for (int u = 0; u < CPP; ++u) {
+                const int i = i0 + u * 8 + (tid >> 5);
+                ok[u] = i < n_sel;
+                a[u] = ok[u] ? s_col[i] : d.c0;
+                l[u] = tm_column_loads(d, p, ok[u], a[u], has_distal);
+                bo[u] = d.boosted[p][a[u]];
+            }
+#pragma unroll
+            for (int u = 0; u < CPP; ++u) {
+                const ColumnWords w = tm_column_compute(d, 1, ok[u], a[u], ok[u] ? s_predw[a[u] - cbase] : 0u, l[u], has_distal, step);
+                const int pos = first_pos + i0 + u * 8 + (tid >> 5);
+                if (ok[u] && (lane & 31) == 0) {
+                    r_boost[pos] = bo[u];
+                    r_col[pos] = (uint32_t)a[u] | (w.burst ? 0x80000000u : 0u);
+                    r_win[pos] = w.winner;
+                    r_unacc[pos] = w.unacc;
+                }
+            }
         }
         if (b == 0) {                              // and the segments that died while the previous step learned
             uint32_t *r_dead = r_unacc + d.n_cand;
@@ -792,9 +836,21 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
     }
 }
 
-__global__ __launch_bounds__(256) void k_sp_emit(Dev d, int p, int want_winner, int fused, int mode, int wmode) {
+// blocks [0, n_emit_blocks): the role; further blocks (a shard's candidates launch): zero the step's dense per-column words and
+// the column bitmap (the winners' words are written after the exchange)
+__global__ __launch_bounds__(256) void k_sp_emit(Dev d, int p, int want_winner, int fused, int mode, int wmode, int n_emit_blocks) {
     __shared__ EmitShared sh;
-    role_emit(d, p, want_winner, fused, mode, blockIdx.x, gridDim.x, &sh, wmode);
+    if ((int)blockIdx.x >= n_emit_blocks) {
+        const int nb = (int)gridDim.x - n_emit_blocks;
+        for (int c = ((int)blockIdx.x - n_emit_blocks) * 256 + (int)threadIdx.x; c < d.C; c += nb * 256) {
+            d.act[p][c] = 0;
+            d.win[p][c] = 0;
+            d.pred[p][c] = 0;
+            if (c < d.colwords) d.colbits[p][c] = 0;
+        }
+        return;
+    }
+    role_emit(d, p, want_winner, fused, mode, blockIdx.x, n_emit_blocks, &sh, wmode);
 }
 
 // DenseProjection.update (projections.py:23-24) on the k winner rows, fused with the rebuild
@@ -872,41 +928,11 @@ __global__ __launch_bounds__(256) void k_sp_duty_list(Dev d, int p, int n, int p
 __global__ void k_sp_commit(Dev d, int p) { d.ctr->step[p ^ 1] = d.ctr->step[p] + 1; }
 
 // ---- column sharding: the kernels on either side of the exchange -----------------------------
-// before the exchange, first launch: overlap + boost + top key digit of the OWN columns, the speculative cell words of
-// the own columns, and the zeroing of the step's dense per-column words (the winners' words are written after the exchange)
-// (front: only the overlap blocks, for the COMING step -- parity p ^ 1, the bank row after this step's)
-__global__ __launch_bounds__(RB) void k_shard_overlap(Dev d, const uint32_t *__restrict__ bank, int n_inputs, int G, int p, int n_overlap_blocks, int n_word_blocks, int wmode, int front) {
+// before the exchange: overlap + boost + histogram of the OWN columns (front: for the COMING step -- parity p ^ 1, the bank
+// row after this step's -- where it does not ride in the previous step's last launch, k_learn_scan_overlap)
+__global__ __launch_bounds__(RB) void k_shard_overlap(Dev d, const uint32_t *__restrict__ bank, int n_inputs, int G, int p, int wmode, int front) {
     __shared__ uint32_t h[SEL_BINS];
-    int b = blockIdx.x;
-    if (b < n_overlap_blocks) {
-        role_overlap<RB>(d, bank, n_inputs, G, p, front ? p ^ 1 : p, front ? 1 : 0, b, n_overlap_blocks, h, wmode);
-        return;
-    }
-    if (front) return;
-    b -= n_overlap_blocks;
-    if (b < n_word_blocks) {
-        // the cell words every OWN column would have if it became active (networks.py:95-104; they only depend on the
-        // previous step's predictions, segment maxima and segment counts): one column per half-wave.  The local select
-        // that follows copies the words of its candidates into the exchange record.
-        const int i = (b * RB + (int)threadIdx.x) >> 5, cl = d.c1 - d.c0;
-        const bool ok = i < cl;
-        const int a = d.c0 + (ok ? i : 0);
-        const ColumnWords w = tm_column_words(d, p, 1, ok, a, ok ? d.pred[p ^ 1][a] : 0u);
-        if (ok && (lane_id() & 31) == 0) {
-            d.spec_win[i] = w.winner;
-            d.spec_unacc[i] = w.unacc;
-            d.spec_burst[i] = w.burst ? 1 : 0;
-        }
-        return;
-    }
-    b -= n_word_blocks;
-    const int nb = (int)gridDim.x - n_overlap_blocks - n_word_blocks;
-    for (int c = b * RB + (int)threadIdx.x; c < d.C; c += nb * RB) {
-        d.act[p][c] = 0;
-        d.win[p][c] = 0;
-        d.pred[p][c] = 0;
-        if (c < d.colwords) d.colbits[p][c] = 0;
-    }
+    role_overlap<RB>(d, bank, n_inputs, G, p, front ? p ^ 1 : p, front ? 1 : 0, blockIdx.x, gridDim.x, h, wmode);
 }
 
 // after the exchange: the exact global top-k over the world x KL candidates, computed by every block for itself
@@ -928,31 +954,15 @@ __device__ __forceinline__ void block_select_regs(const u64 (&kreg)[KPT], uint32
                                                   const BlockSelLds &L, u64 *T_out, uint32_t *r_out, bool *missed) {
     const int tid = threadIdx.x, lane = lane_id();
     uint32_t *h = L.h;
-    if (tid == 0) { *L.s_or = 0; *L.s_and = ~0ull; }
-    __syncthreads();
-    {
-        u64 vo = 0, va = ~0ull;
-#pragma unroll
-        for (int j = 0; j < KPT; ++j)
-            if ((vmask >> j) & 1u) { vo |= kreg[j]; va &= kreg[j]; }
-        for (int o = 32; o > 0; o >>= 1) {
-            vo |= ((u64)__shfl_xor((uint32_t)(vo >> 32), o) << 32) | __shfl_xor((uint32_t)vo, o);
-            va &= ((u64)__shfl_xor((uint32_t)(va >> 32), o) << 32) | __shfl_xor((uint32_t)va, o);
-        }
-        if (lane == 0) { atomicOr((unsigned long long *)L.s_or, vo); atomicAnd((unsigned long long *)L.s_and, va); }
-    }
-    __syncthreads();
-    const u64 differ = *L.s_or ^ *L.s_and;
-    const int top0 = differ ? 64 - __clzll((long long)differ) : 0;       // bits [top0, 64) are the same in every key
-    u64 P = top0 < 64 ? (*L.s_and >> top0) << top0 : 0ull;
+    u64 P = 0;
     uint32_t krem = k;
     bool done = false;
     u64 T = 0;
-    int top_start = top0;
+    int top_start = 64, top0 = 64;
+    bool outside = false;
     {
-        __syncthreads();
         for (int i = tid; i < SEL_BINS; i += 1024) h[i] = 0;
-        if (tid == 0) { L.s_cnt[0] = 0; L.s_out[0] = 0; }
+        if (tid == 0) { L.s_cnt[0] = 0; L.s_out[0] = 0; *L.s_or = 0; *L.s_and = ~0ull; }
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < KPT; ++j) hist_add_tie(h, win_bin(kreg[j], base), (vmask >> j) & 1u);
@@ -990,6 +1000,25 @@ __device__ __forceinline__ void block_select_regs(const u64 (&kreg)[KPT], uint32
             krem = L.s_out[1];
             done = true;
             __syncthreads();
+        } else {
+            // the k-th key is outside the window: everything is left to the digit passes, which start below the keys' common
+            // prefix (the bits that are the same in every key; only computed here, where they are needed)
+            u64 vo = 0, va = ~0ull;
+#pragma unroll
+            for (int j = 0; j < KPT; ++j)
+                if ((vmask >> j) & 1u) { vo |= kreg[j]; va &= kreg[j]; }
+            for (int o = 32; o > 0; o >>= 1) {
+                vo |= ((u64)__shfl_xor((uint32_t)(vo >> 32), o) << 32) | __shfl_xor((uint32_t)vo, o);
+                va &= ((u64)__shfl_xor((uint32_t)(va >> 32), o) << 32) | __shfl_xor((uint32_t)va, o);
+            }
+            if (lane == 0) { atomicOr((unsigned long long *)L.s_or, vo); atomicAnd((unsigned long long *)L.s_and, va); }
+            __syncthreads();
+            const u64 differ = *L.s_or ^ *L.s_and;
+            top0 = differ ? 64 - __clzll((long long)differ) : 0;       // bits [top0, 64) are the same in every key
+            P = top0 < 64 ? (*L.s_and >> top0) << top0 : 0ull;
+            top_start = top0;
+            outside = true;
+            __syncthreads();
         }
     }
     for (int top = top_start; !done && top > low_zero;) {
@@ -1011,7 +1040,7 @@ __device__ __forceinline__ void block_select_regs(const u64 (&kreg)[KPT], uint32
     }
     *T_out = done ? T : P;
     *r_out = krem;
-    *missed = !done && top_start == top0;
+    *missed = outside;
 }
 
 #ifdef BITHTM_SHARD_STAMPS                       // diagnostic build: device clock at the phases of block 0, d.trace[phase]
@@ -1026,6 +1055,30 @@ __global__ __launch_bounds__(1024) void k_shard_select(Dev d, const unsigned cha
     const int tid = threadIdx.x, lane = lane_id();
     const int KL = d.n_cand, n_tot = d.world * KL;
     const size_t rb = shard_record_bytes(KL);
+    if ((int)blockIdx.x == d.world) {
+        // one block beside the select (it used to be the tail of block 0, 2-3 us): every rank's death reports, all at once
+        // (rank after rank, each with its dependent loads and atomics, this was 8 x 2 round trips): thread -> (rank, entry)
+        // through the counts
+        __shared__ int s_dead[64 + 1];
+        if (tid <= 64) s_dead[tid] = 0;
+        __syncthreads();
+        const int nr = min(d.world, 64);
+        if (tid < nr) s_dead[tid + 1] = min((int)((const uint32_t *)(recv + (size_t)tid * rb + (size_t)KL * 20))[0], DEAD_CAP);
+        __syncthreads();
+        if (tid == 0) for (int r = 0; r < nr; ++r) s_dead[r + 1] += s_dead[r];
+        __syncthreads();
+        const int total_dead = s_dead[nr];
+        for (int e = tid; e < total_dead; e += 1024) {
+            int r = 0;
+            while (s_dead[r + 1] <= e) ++r;
+            const uint32_t *r_dead = (const uint32_t *)(recv + (size_t)r * rb + (size_t)KL * 20);
+            const int gid = (int)r_dead[1 + e - s_dead[r]];
+            const uint32_t old = atomicOr(&d.dead_bits[gid >> 5], 1u << (gid & 31));
+            if (!((old >> (gid & 31)) & 1u)) recyc_add(d, gid >> 10, 1);
+        }
+        if (tid == 0) d.dead_list[0] = 0;          // reported; the coming learning role collects this step's
+        return;
+    }
     const u64 inv_kl = ((1ull << 32) + (u64)KL - 1) / (u64)KL;      // i / KL for i < 2^16-ish: one multiplication (64 bits: KL = 1 gives 2^32)
     auto key_at = [&](int i) -> u64 {
         int r = (int)(((u64)(uint32_t)i * inv_kl) >> 32);
@@ -1152,28 +1205,6 @@ __global__ __launch_bounds__(1024) void k_shard_select(Dev d, const unsigned cha
         eq_run += total >> 16;
     }
     SHARD_STAMP(4);                                // (own winners emitted)
-    if (b == 0) {
-        // every rank's death reports, all at once (rank after rank, each with its dependent loads and atomics, this was
-        // 8 x 2 round trips at the end of the step's longest kernel): thread -> (rank, entry) through the counts
-        __shared__ int s_dead[64 + 1];
-        if (tid <= 64) s_dead[tid] = 0;
-        __syncthreads();
-        const int nr = min(d.world, 64);
-        if (tid < nr) s_dead[tid + 1] = min((int)((const uint32_t *)(recv + (size_t)tid * rb + (size_t)KL * 20))[0], DEAD_CAP);
-        __syncthreads();
-        if (tid == 0) for (int r = 0; r < nr; ++r) s_dead[r + 1] += s_dead[r];
-        __syncthreads();
-        const int total_dead = s_dead[nr];
-        for (int e = tid; e < total_dead; e += 1024) {
-            int r = 0;
-            while (s_dead[r + 1] <= e) ++r;
-            const uint32_t *r_dead = (const uint32_t *)(recv + (size_t)r * rb + (size_t)KL * 20);
-            const int gid = (int)r_dead[1 + e - s_dead[r]];
-            const uint32_t old = atomicOr(&d.dead_bits[gid >> 5], 1u << (gid & 31));
-            if (!((old >> (gid & 31)) & 1u)) recyc_add(d, gid >> 10, 1);
-        }
-        if (tid == 0) d.dead_list[0] = 0;          // reported; the coming learning role collects this step's
-    }
     SHARD_STAMP(5);
 }
 

@@ -309,6 +309,9 @@ class Engine:
         buf = C.create_string_buffer(bytes(unique_id), 128)
         self._check(self.lib.htm_shard_comm_init(self.h, buf), "htm_shard_comm_init")
 
+    def shard_comm_size(self):
+        return int(self._check(self.lib.htm_shard_comm_size(self.h), "htm_shard_comm_size"))
+
     def shard_step(self, input_bits=None, device_bank=None, n_inputs=1, learning=True):
         """One column-sharded timestep with the exchange (RCCL) inside the library."""
         if input_bits is not None:

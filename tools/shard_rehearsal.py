@@ -40,11 +40,13 @@ def main():
     wall = (time.perf_counter() - t0) / 200
     eng.profile(True)
     group.run(200)
-    prof = {n: 1e3 * ms / cnt for n, (ms, cnt) in eng.profile_read().items() if cnt}
+    raw = {n: v for n, v in eng.profile_read().items() if v[1]}
     eng.profile(False)
+    prof = {n: 1e3 * ms / cnt for n, (ms, cnt) in raw.items()}
+    steady = {n: v for n, v in prof.items() if raw[n][1] >= 100}         # the launches every step has (a call's first and last step differ)
     info = eng.check_capacity()
-    print(json.dumps(dict(world=args.world, rank0_launch_us={n: round(v, 1) for n, v in prof.items()},
-                          rank0_kernels_us=round(sum(prof.values()), 1), all_ranks_wall_us_per_step=round(1e6 * wall, 1),
+    print(json.dumps(dict(world=args.world, rank0_launch_us={n: round(v, 1) for n, v in prof.items()}, launches_per_step=len(steady),
+                          rank0_kernels_us=round(sum(steady.values()), 1), all_ranks_wall_us_per_step=round(1e6 * wall, 1),
                           segments=info.segments, rank0_rows=info.local_segments, record_bytes=eng.shard_record_bytes(),
                           select_fallbacks=info.select_fallbacks, steps=info.step_index)))
 
