@@ -68,7 +68,8 @@ struct htm_handle {
     int first_graph_steps;                // ... of the first graph of a call (BITHTM_FIRST_GRAPH_STEPS; 0 = like the others)
     bool emit_fused, emit_fused_open;     // the emit grid is resident at once in k_sp_emit / in k_open_emit (refreshed per call)
     bool emit_fits_lean;                  // ... and in k_learn_scan_emit
-    int knob_lean, knob_fuse_tm, knob_shard_window, knob_scan_large;      // environment knobs, read when the handle is created
+    int knob_lean, knob_fuse_tm, knob_shard_window, knob_scan_large, knob_step_window, knob_tail_rows;
+    bool window_known;                    // a select has run on this handle since it was created / imported into: Counters::sel_win is meaningful      // environment knobs, read when the handle is created
     bool emit_fits, emit_fits_open;       // ... as far as this handle's own grids go (fixed at creation)
     int sel_passes_fused, sel_passes_full; // launched select digits with / without the in-kernel finish
     int seg_hint;                         // a lower bound of the segment count (see scan_spec_blocks)
@@ -240,22 +241,37 @@ static void launch_scan(htm_handle *h, int p, int use_lds) {
     }
 }
 
-// Front of SpatialPooler.process for the step with parity sp: overlap + boost (+ select digit 0)
-// and the remaining select digits.
-static void enqueue_sp_front(htm_handle *h, const uint32_t *bank, int n_inputs, int p) {
+// the windowed one-pass select (win_bin) outside the three-launch schedule too: the histogram is finished inside the emit
+// grid, so only where that grid's blocks may wait for each other (BITHTM_STEP_WINDOW=0: two launched digits, as before)
+// (and only once a select has left a window behind: the first step of a handle, or after a state import, takes the digits)
+static int step_wmode(const htm_handle *h) { return h->emit_fused && h->knob_step_window && h->world == 1 && h->window_known ? 1 : 0; }
+
+// Front of SpatialPooler.process for the step with parity sp: overlap + boost + histogram (the windowed one, or the top
+// key digit and then the remaining select digits).  host_input: the packed input of a host-fed step (it rides in the
+// launch's arguments where it fits); else the bank in device memory.
+static void enqueue_sp_front(htm_handle *h, const uint32_t *bank, int n_inputs, int p, int wmode, const uint32_t *host_input = nullptr) {
     Dev &d = h->d;
-    LAUNCH(h, "sp_overlap", k_sp_overlap, h->sp_blocks, RB, d, bank, n_inputs, h->G, p, p, 0);
-    for (int pass = 1; pass < d.sel_passes; ++pass) LAUNCH(h, "sp_select", k_sel_pass, h->sel_blocks, RB, d, pass, p);
+    if (host_input && d.W <= ARG_INPUT_WORDS) {
+        PackedInputArg in;
+        memset(&in, 0, sizeof(in));
+        memcpy(in.w, host_input, (size_t)((d.I + 31) / 32) * 4);
+        LAUNCH(h, "sp_overlap", k_sp_overlap_arg, h->sp_blocks, RB, d, in, h->G, p, wmode);
+    } else {
+        LAUNCH(h, "sp_overlap", k_sp_overlap, h->sp_blocks, RB, d, bank, n_inputs, h->G, p, p, 0, wmode);
+    }
+    if (!wmode)
+        for (int pass = 1; pass < d.sel_passes; ++pass) LAUNCH(h, "sp_select", k_sel_pass, h->sel_blocks, RB, d, pass, p);
 }
 
 // Rest of SpatialPooler.process: count + emit.  mode = EMIT_ALL: all of it, with the TM's per-column
 // activation when the handle has a Temporal Memory.  sp_learn: the permanence update as a launch of
 // its own (handles without a Temporal Memory, and the first step of a pipelined run).
-static void enqueue_sp_back(htm_handle *h, const uint32_t *bank, int n_inputs, int p, int want_winner, int mode, bool sp_learn) {
+static void enqueue_sp_back(htm_handle *h, const uint32_t *bank, int n_inputs, int p, int want_winner, int mode, bool sp_learn, int wmode = 0) {
     Dev &d = h->d;
     const int fused = h->emit_fused;               // all blocks co-resident: count inside emit
     if (!fused) LAUNCH(h, "sp_count", k_sp_count, h->c256_blocks, 256, d, p);
-    LAUNCH(h, "sp_emit", k_sp_emit, h->c256_blocks, 256, d, p, want_winner, fused, mode, 0, h->c256_blocks);
+    LAUNCH(h, "sp_emit", k_sp_emit, h->c256_blocks, 256, d, p, want_winner, fused, mode, fused ? wmode : 0, h->c256_blocks);
+    h->window_known = true;                         // (every select leaves the next step's window behind)
     // (a forked graph branch for this independent update was measured at +17..29 us per step on
     // this runtime, against 2.3 us for one more kernel in the chain: tools/launch_overhead.hip)
     if (sp_learn) LAUNCH(h, "sp_learn", k_sp_learn, d.k, 256, d, bank, n_inputs, p);
@@ -269,19 +285,24 @@ static void enqueue_tm(htm_handle *h, int n_active, int learning, int want_winne
                        const uint32_t *bank, int n_inputs, bool sp_rows, int front_wmode = -1) {
     Dev &d = h->d;
     const int n_cls = learning ? kClassifyBlocks : 0;
-    const int n_sp_rows = (sp_rows && learning && h->cfg.enable_sp) ? d.k : 0;
-    const int n_duty = h->world > 1 ? (d.c1 - d.c0 + 255) / 256 : 0;      // (unsharded: the emit role updates the duty cycle)
-    LAUNCH(h, "tm_mid", k_mid_rows, 1 + n_cls + n_sp_rows + n_duty + h->zero_blocks, 256, d, p, n_active, want_winner, learning, n_cls, bank, n_inputs, n_sp_rows, 0, n_duty);
     // the learning role and the scan: one launch (the learning waves scan their own rows), unless the pool is large (the
     // streaming scan kernels) or somebody is timing the roles one by one (unsharded handles under htm_profile)
     const bool fuse = h->knob_fuse_tm && !(h->profile && h->world == 1) && !scan_pool_is_large(h) && scan_lds(d, 1) <= 64 * 1024;
-    if (fuse && front_wmode >= 0) {
+    int n_sp_rows = (sp_rows && learning && h->cfg.enable_sp) ? d.k : 0;
+    // an unsharded step's permanence rows ride in that launch (the middle launch is left with the Temporal Memory's chain);
+    // a shard's stay in the middle launch: the coming step's overlap, which reads them, may ride in the last one
+    const int n_tail_rows = (fuse && h->world == 1 && h->knob_tail_rows) ? n_sp_rows : 0;
+    if (n_tail_rows) n_sp_rows = 0;
+    const int n_duty = h->world > 1 ? (d.c1 - d.c0 + 255) / 256 : 0;      // (unsharded: the emit role updates the duty cycle)
+    LAUNCH(h, "tm_mid", k_mid_rows, 1 + n_cls + n_sp_rows + n_duty + h->zero_blocks, 256, d, p, n_active, want_winner, learning, n_cls, bank, n_inputs, n_sp_rows, 0, n_duty);
+    if (fuse && (front_wmode >= 0 || n_tail_rows)) {
         const int epl = learn_epl(d), n_learn = h->lean_learn_blocks, n_scan = h->lean_scan_blocks, spec = scan_spec_blocks(h);
         const size_t lds = std::max(std::max(learn_lds(epl, 256), scan_lds(d, 1)), (size_t)SEL_BINS * 4);
-        const int grid = n_learn + n_scan + h->lean_overlap_blocks;
-#define LAUNCH_LSO(E_) LAUNCH_ON(h, h->stream, lds, "tm_learn+tm_scan+shard_overlap", (k_learn_scan_overlap<E_>), grid, 256, d, p, n_learn, n_scan, spec, bank, n_inputs, h->G, front_wmode)
-        switch (epl) { case 1: LAUNCH_LSO(1); break; case 2: LAUNCH_LSO(2); break; case 4: LAUNCH_LSO(4); break; default: LAUNCH_LSO(8); break; }
-#undef LAUNCH_LSO
+        const int grid = n_learn + n_scan + (n_tail_rows ? n_tail_rows : h->lean_overlap_blocks);
+        const char *name = n_tail_rows ? "tm_learn+tm_scan+sp_learn" : "tm_learn+tm_scan+shard_overlap";
+#define LAUNCH_LST(E_) LAUNCH_ON(h, h->stream, lds, name, (k_learn_scan_tail<E_>), grid, 256, d, p, n_learn, n_scan, spec, bank, n_inputs, h->G, front_wmode, n_tail_rows)
+        switch (epl) { case 1: LAUNCH_LST(1); break; case 2: LAUNCH_LST(2); break; case 4: LAUNCH_LST(4); break; default: LAUNCH_LST(8); break; }
+#undef LAUNCH_LST
         return;
     }
     if (fuse) {
@@ -388,14 +409,15 @@ static void enqueue_cold_start(htm_handle *h, const uint32_t *bank, int n_inputs
     Dev &d = h->d;
     const int p = (int)(h->step_host & 1);
     if (plan.sp_done || !plan.next_sp) return;
+    const int wmode = step_wmode(h);
     if (can_lean(h)) {                              // the winner list of this step, nothing else
-        enqueue_sp_front(h, bank, n_inputs, p);
-        enqueue_sp_back(h, bank, n_inputs, p, 1, 0, false);
+        enqueue_sp_front(h, bank, n_inputs, p, wmode);
+        enqueue_sp_back(h, bank, n_inputs, p, 1, 0, false, wmode);
         return;
     }
-    enqueue_sp_front(h, bank, n_inputs, p);
-    enqueue_sp_back(h, bank, n_inputs, p, 1, EMIT_DUTY | EMIT_CLEAR, learning != 0);
-    LAUNCH(h, "sp_overlap", k_sp_overlap, h->sp_blocks, RB, d, bank, n_inputs, h->G, p, p ^ 1, 1);
+    enqueue_sp_front(h, bank, n_inputs, p, wmode);
+    enqueue_sp_back(h, bank, n_inputs, p, 1, EMIT_DUTY | EMIT_CLEAR, learning != 0, wmode);
+    LAUNCH(h, "sp_overlap", k_sp_overlap, h->sp_blocks, RB, d, bank, n_inputs, h->G, p, p ^ 1, 1, 0);
     LAUNCH(h, "sp_select", k_sel_pass, h->sel_blocks, RB, d, 1, p ^ 1);
 }
 
@@ -405,13 +427,13 @@ static void enqueue_rest(htm_handle *h, int p, const uint32_t *bank, int n_input
     } else if (plan.sp_done || plan.next_sp) {
         enqueue_pipelined(h, p, learning, bank, n_inputs, plan);
     } else {                                        // one role per launch
-        enqueue_sp_back(h, bank, n_inputs, p, 1, EMIT_ALL, false);
+        enqueue_sp_back(h, bank, n_inputs, p, 1, EMIT_ALL, false, step_wmode(h));
         enqueue_tm(h, h->d.k, learning, 1, p, bank, n_inputs, true);
     }
 }
 
-static int enqueue_step(htm_handle *h, const uint32_t *bank, int n_inputs, int learning, StepPlan plan) {
-    if (!plan.sp_done && !plan.next_sp) enqueue_sp_front(h, bank, n_inputs, (int)(h->step_host & 1));
+static int enqueue_step(htm_handle *h, const uint32_t *bank, int n_inputs, int learning, StepPlan plan, const uint32_t *host_input = nullptr) {
+    if (!plan.sp_done && !plan.next_sp) enqueue_sp_front(h, bank, n_inputs, (int)(h->step_host & 1), step_wmode(h), host_input);
     enqueue_cold_start(h, bank, n_inputs, learning, plan);
     enqueue_rest(h, (int)(h->step_host & 1), bank, n_inputs, learning, plan);
     h->step_host += 1;
@@ -488,6 +510,7 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
     h->shard_bank = nullptr;
     h->shard_n_inputs = 1;
     h->shard_open = false;
+    h->window_known = false;
     h->shard_front_wmode = 0;
     h->rccl_comm = nullptr;
     h->shard_send = h->shard_recv = nullptr;
@@ -643,6 +666,8 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
     h->knob_fuse_tm = getenv("BITHTM_FUSE_TM") ? atoi(getenv("BITHTM_FUSE_TM")) != 0 : 1;
     h->knob_shard_window = getenv("BITHTM_SHARD_WINDOW") ? atoi(getenv("BITHTM_SHARD_WINDOW")) != 0 : 1;
     h->knob_scan_large = getenv("BITHTM_SCAN_LARGE") ? atoi(getenv("BITHTM_SCAN_LARGE")) : -1;
+    h->knob_step_window = getenv("BITHTM_STEP_WINDOW") ? atoi(getenv("BITHTM_STEP_WINDOW")) != 0 : 1;
+    h->knob_tail_rows = getenv("BITHTM_TAIL_ROWS") ? atoi(getenv("BITHTM_TAIL_ROWS")) != 0 : 1;
     h->lean_overlap_blocks = getenv("BITHTM_LEAN_OVERLAP") ? std::max(1, atoi(getenv("BITHTM_LEAN_OVERLAP"))) : h->sp_blocks * (RB / 256);
     h->lean_learn_blocks = getenv("BITHTM_LEAN_LEARN") ? std::max(1, atoi(getenv("BITHTM_LEAN_LEARN"))) : 512;
     h->lean_scan_blocks = getenv("BITHTM_LEAN_SCAN") ? std::max(1, atoi(getenv("BITHTM_LEAN_SCAN"))) : (h->scan_blocks > 512 ? std::max(256, (h->scan_blocks * 3 / 8 + 255) & ~255) : h->scan_blocks);
@@ -826,9 +851,11 @@ extern "C" int htm_step(htm_handle *h, const uint32_t *packed_input, int32_t lea
     refresh_exchange_mode(h);
     int rc = close_open_phases(h);
     if (rc) return rc;
-    rc = stage_input(h, packed_input);
-    if (rc) return rc;
-    return enqueue_step(h, h->d.input_stage, 1, learning ? 1 : 0, StepPlan{false, false, false});
+    if (h->d.W > ARG_INPUT_WORDS) {                 // (an input too wide for the launch's arguments: staged by a copy)
+        rc = stage_input(h, packed_input);
+        if (rc) return rc;
+    }
+    return enqueue_step(h, h->d.input_stage, 1, learning ? 1 : 0, StepPlan{false, false, false}, packed_input);
 }
 
 extern "C" int htm_sp_step(htm_handle *h, const uint32_t *packed_input, int32_t learning) {
@@ -845,8 +872,8 @@ extern "C" int htm_sp_step(htm_handle *h, const uint32_t *packed_input, int32_t 
     rc = stage_input(h, packed_input);
     if (rc) return rc;
     const int p = (int)(h->step_host & 1);
-    enqueue_sp_front(h, h->d.input_stage, 1, p);
-    enqueue_sp_back(h, h->d.input_stage, 1, p, 0, EMIT_ALL, learning && !h->cfg.enable_tm);
+    enqueue_sp_front(h, h->d.input_stage, 1, p, step_wmode(h));
+    enqueue_sp_back(h, h->d.input_stage, 1, p, 0, EMIT_ALL, learning && !h->cfg.enable_tm, step_wmode(h));
     h->step_host += 1;
     return HTM_OK;
 }
@@ -872,7 +899,7 @@ extern "C" int htm_sp_phase(htm_handle *h, int32_t phase, const void *data, int6
             if (!data) return HTM_ERR_ARGUMENT;
             int rc = stage_input(h, (const uint32_t *)data);
             if (rc) return rc;
-            LAUNCH(h, "sp_overlap", k_sp_overlap, h->sp_blocks, RB, d, d.input_stage, 1, h->G, p, p, 0);
+            LAUNCH(h, "sp_overlap", k_sp_overlap, h->sp_blocks, RB, d, d.input_stage, 1, h->G, p, p, 0, 0);
             break;
         }
         case HTM_SP_BOOST: {                       // ExponentialBoosting.process on overlaps from the host; data = int32[C]
@@ -1118,10 +1145,10 @@ static int run_or_prepare(htm_handle *h, const uint32_t *device_inputs, int32_t 
             if (t == 0 && h->first_graph_steps > 0 && span > h->first_graph_steps) span = h->first_graph_steps;
         }
         if (!dry) {
-            if (!plan.sp_done && !plan.next_sp) enqueue_sp_front(h, device_inputs, n_inputs, p);    // eager
+            if (!plan.sp_done && !plan.next_sp) enqueue_sp_front(h, device_inputs, n_inputs, p, step_wmode(h));    // eager
             enqueue_cold_start(h, device_inputs, n_inputs, learning, plan);                         // eager: first step of a pipelined run
         }
-        auto key = std::make_tuple(p, learning * 16 + (plan.sp_done ? 4 : 0) + (plan.next_sp ? 2 : 0) + (plan.next_front ? 1 : 0) + 32 * scan_spec_blocks(h) + (scan_pool_is_large(h) ? (1 << 20) : 0) + (h->emit_fused ? (1 << 21) : 0) + (span << 22) + (lean ? 8 : 0),
+        auto key = std::make_tuple(p, learning * 16 + (plan.sp_done ? 4 : 0) + (plan.next_sp ? 2 : 0) + (plan.next_front ? 1 : 0) + 32 * scan_spec_blocks(h) + (scan_pool_is_large(h) ? (1 << 20) : 0) + (h->emit_fused ? (1 << 21) : 0) + (span << 22) + (lean ? 8 : 0) + (step_wmode(h) ? (1 << 19) : 0),
                                    (const void *)device_inputs, n_inputs);
         auto it = h->graphs.find(key);
         if (it == h->graphs.end()) {
@@ -2036,6 +2063,7 @@ extern "C" int htm_import_commit(htm_handle *h, int32_t segments, int32_t matchi
     c.has_winner[q] = has_winner_cells ? 1 : 0;
     c.has_distal = has_distal_state ? 1 : 0;
     c.cm_dense_step = (uint32_t)h->step_host + 1u;
+    if (!keep) h->window_known = false;
     if (!keep) c.error = 0;                         // a checkpoint restore starts clean; an adopted previous State does not
                                                     // forgive an overflow of the store it keeps
     HIPCHK(h, hipMemcpy(d.ctr, &c, sizeof(c), hipMemcpyHostToDevice));

@@ -30,12 +30,14 @@ struct TraceScope {                                 // BITHTM_TRACE=1: first / l
 #if defined(BITHTM_LEARN_STAMPS) || defined(BITHTM_SCAN_STAMPS) || defined(BITHTM_EMIT_STAMPS) || defined(BITHTM_SHARD_STAMPS)
         t = nullptr;                                // the diagnostic builds of the learning role and of the scan use the buffer
         return;
-// The column-sharded step's last launch (enqueue_tm, world > 1): the learning role, the scan of the rank's own rows, and --
-// inside htm_shard_run -- the overlap of the COMING step on the rank's own columns (its permanence rows and duty cycle were
-// updated by this step's middle launch; nothing of the Temporal Memory is read): one launch less on the rank's chain.
+// The last launch of a step run role by role (enqueue_tm): the learning role, the scan, and a streaming role behind them --
+//   n_rows > 0   the Spatial Pooler's permanence rows of THIS step (a host-fed step, htm_step: they used to share the middle
+//                launch, whose block 0 is the step's longest chain; beside the learning role and the scan they are free)
+//   else         the overlap of the COMING step on a shard's own columns (htm_shard_run; their permanence rows and duty
+//                cycle were updated by this step's middle launch; nothing of the Temporal Memory is read)
 template <int EPL>
-__global__ __launch_bounds__(256, 6) void k_learn_scan_overlap(Dev d, int p, int n_learn_blocks, int n_scan_blocks, int n_spec,
-                                                               const uint32_t *__restrict__ bank, int n_inputs, int G, int wmode) {
+__global__ __launch_bounds__(256, 6) void k_learn_scan_tail(Dev d, int p, int n_learn_blocks, int n_scan_blocks, int n_spec,
+                                                            const uint32_t *__restrict__ bank, int n_inputs, int G, int wmode, int n_rows) {
     int b = blockIdx.x;
     if (b < n_learn_blocks) {
         role_learn<EPL, 256, true>(d, p, b, n_learn_blocks, (LearnShared<EPL, 256> *)dyn_lds);
@@ -47,7 +49,8 @@ __global__ __launch_bounds__(256, 6) void k_learn_scan_overlap(Dev d, int p, int
         return;
     }
     b -= n_scan_blocks;
-    role_overlap<256>(d, bank, n_inputs, G, p, p ^ 1, 1, b, (int)gridDim.x - n_learn_blocks - n_scan_blocks, (uint32_t *)dyn_lds, wmode);
+    if (n_rows > 0) role_sp_row<256>(d, p, bank, n_inputs, 0, b, threadIdx.x);
+    else role_overlap<256>(d, bank, n_inputs, G, p, p ^ 1, 1, b, (int)gridDim.x - n_learn_blocks - n_scan_blocks, (uint32_t *)dyn_lds, wmode);
 }
 
 #endif
@@ -234,12 +237,14 @@ __global__ __launch_bounds__(256, MINW) void k_learn_scan_emit(Dev d, int p, int
     role_scan<256, true, MINW < 6, TAB>(d, p, b, n_scan_blocks, n_spec, (uint32_t *)dyn_lds);      // (MINW < 6: the large-pool form)
 }
 
-// The column-sharded step's last launch (enqueue_tm, world > 1): the learning role, the scan of the rank's own rows, and --
-// inside htm_shard_run -- the overlap of the COMING step on the rank's own columns (its permanence rows and duty cycle were
-// updated by this step's middle launch; nothing of the Temporal Memory is read): one launch less on the rank's chain.
+// The last launch of a step run role by role (enqueue_tm): the learning role, the scan, and a streaming role behind them --
+//   n_rows > 0   the Spatial Pooler's permanence rows of THIS step (a host-fed step, htm_step: they used to share the middle
+//                launch, whose block 0 is the step's longest chain; beside the learning role and the scan they are free)
+//   else         the overlap of the COMING step on a shard's own columns (htm_shard_run; their permanence rows and duty
+//                cycle were updated by this step's middle launch; nothing of the Temporal Memory is read)
 template <int EPL>
-__global__ __launch_bounds__(256, 6) void k_learn_scan_overlap(Dev d, int p, int n_learn_blocks, int n_scan_blocks, int n_spec,
-                                                               const uint32_t *__restrict__ bank, int n_inputs, int G, int wmode) {
+__global__ __launch_bounds__(256, 6) void k_learn_scan_tail(Dev d, int p, int n_learn_blocks, int n_scan_blocks, int n_spec,
+                                                            const uint32_t *__restrict__ bank, int n_inputs, int G, int wmode, int n_rows) {
     int b = blockIdx.x;
     if (b < n_learn_blocks) {
         role_learn<EPL, 256, true>(d, p, b, n_learn_blocks, (LearnShared<EPL, 256> *)dyn_lds);
@@ -251,7 +256,8 @@ __global__ __launch_bounds__(256, 6) void k_learn_scan_overlap(Dev d, int p, int
         return;
     }
     b -= n_scan_blocks;
-    role_overlap<256>(d, bank, n_inputs, G, p, p ^ 1, 1, b, (int)gridDim.x - n_learn_blocks - n_scan_blocks, (uint32_t *)dyn_lds, wmode);
+    if (n_rows > 0) role_sp_row<256>(d, p, bank, n_inputs, 0, b, threadIdx.x);
+    else role_overlap<256>(d, bank, n_inputs, G, p, p ^ 1, 1, b, (int)gridDim.x - n_learn_blocks - n_scan_blocks, (uint32_t *)dyn_lds, wmode);
 }
 
 #endif

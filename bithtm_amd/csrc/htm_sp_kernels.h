@@ -103,9 +103,26 @@ __device__ __forceinline__ void role_overlap(const Dev &d, const uint32_t *__res
         if (h[i]) atomicAdd(&g0[i], h[i]);
 }
 
-__global__ __launch_bounds__(RB) void k_sp_overlap(Dev d, const uint32_t *__restrict__ bank, int n_inputs, int G, int p, int sp, int step_offset) {
-    __shared__ uint32_t h[SEL_BINS];               // histogram of the top key digit (select pass 0)
-    role_overlap<RB>(d, bank, n_inputs, G, p, sp, step_offset, blockIdx.x, gridDim.x, h);
+__global__ __launch_bounds__(RB) void k_sp_overlap(Dev d, const uint32_t *__restrict__ bank, int n_inputs, int G, int p, int sp, int step_offset, int wmode) {
+    __shared__ uint32_t h[SEL_BINS];               // histogram of the top key digit (select pass 0), or the windowed one
+    role_overlap<RB>(d, bank, n_inputs, G, p, sp, step_offset, blockIdx.x, gridDim.x, h, wmode);
+}
+
+// The same for ONE input that comes from the host with the launch itself (htm_step and its kin, input_dim <= 2048): the packed
+// input travels in the kernel's arguments -- no copy to stage, nothing to wait for -- every block reads it from there (through
+// LDS), and block 0 leaves it in d.input_stage for the launches that follow (the permanence rows of the step).
+#define ARG_INPUT_WORDS 64
+struct PackedInputArg { uint32_t w[ARG_INPUT_WORDS]; };
+__global__ __launch_bounds__(RB) void k_sp_overlap_arg(Dev d, PackedInputArg in, int G, int p, int wmode) {
+    __shared__ uint32_t h[SEL_BINS];
+    __shared__ __attribute__((aligned(16))) uint32_t s_in[ARG_INPUT_WORDS];
+    if (threadIdx.x < ARG_INPUT_WORDS) {
+        const uint32_t v = threadIdx.x < d.W ? in.w[threadIdx.x] : 0u;
+        s_in[threadIdx.x] = v;
+        if (blockIdx.x == 0 && threadIdx.x < d.W) d.input_stage[threadIdx.x] = v;
+    }
+    __syncthreads();
+    role_overlap<RB>(d, s_in, 1, G, p, p, 0, blockIdx.x, gridDim.x, h, wmode);
 }
 
 // GlobalInhibition.process (regularizations.py:28-29) as an exact radix select of the k-th

@@ -17,7 +17,10 @@ class CapacityError(HtmError):
 
 
 def pack_bits(bits, words):
-    """bool[I] -> uint32[words], bit i of the input = bit (i & 31) of word (i >> 5)."""
+    """bool[I] -> uint32[words], bit i of the input = bit (i & 31) of word (i >> 5).  An input that is packed already (a
+    contiguous uint32 array of `words` words: a caller that keeps its inputs packed, or packs them once) goes through as it is."""
+    if type(bits) is np.ndarray and bits.dtype == np.uint32 and bits.ndim == 1 and bits.size == words and bits.flags.c_contiguous:
+        return bits
     bits = np.asarray(bits)
     if bits.dtype != np.bool_:
         bits = bits.astype(np.bool_)
@@ -212,7 +215,9 @@ class Engine:
     # ---- stepping
     def step(self, input_bits, learning=True):
         packed = pack_bits(input_bits, self.words)
-        self._check(self.lib.htm_step(self.h, packed.ctypes.data_as(C.c_void_p), int(bool(learning))), "htm_step")
+        rc = self.lib.htm_step(self.h, packed.ctypes.data, 1 if learning else 0)
+        if rc < 0:
+            self._check(rc, "htm_step")
         self.steps += 1
 
     def sp_step(self, input_bits, learning=True):

@@ -41,7 +41,7 @@ class _Lazy:
         self._engine = engine
         self._step = step
         self._cache = {}
-        engine_states(engine).add(self)
+        engine_states(engine).append(weakref.ref(self))
 
     def _fetch(self):
         raise NotImplementedError
@@ -68,17 +68,23 @@ class _Lazy:
 
 
 def engine_states(engine):
+    """Weak references to the States of the engine's current step (a plain list: a host-fed step creates two and retires
+    two, and this is on its path)."""
     s = getattr(engine, "_live_states", None)
     if s is None:
-        s = engine._live_states = weakref.WeakSet()
+        s = engine._live_states = []
     return s
 
 
 def retire_states(engine):
     """Called before a new step is enqueued: pin down every State somebody still holds."""
-    for st in list(engine_states(engine)):
-        st._materialize()
-    engine_states(engine).clear()
+    live = getattr(engine, "_live_states", None)
+    if live:
+        for ref in live:
+            st = ref()
+            if st is not None:
+                st._materialize()
+        live.clear()
 
 
 class SpatialPooler:
@@ -354,7 +360,7 @@ class TemporalMemory:
         if getattr(eng, "_epsilon", 1e-8) != epsilon:
             eng.set_epsilon(epsilon)
             eng._epsilon = epsilon
-        if _grow_if_needed(eng, 2 * max(len(active_column), 1)):
+        if _grow_if_needed(eng, max(len(active_column), 1)):
             self.grow_pool(*eng._grow_to)
             eng = self._engine
             if getattr(eng, "_epsilon", 1e-8) != epsilon:
@@ -494,7 +500,7 @@ class HierarchicalTemporalMemory:
             sp_state = self.spatial_pooler.process(input, learning=learning)
             return sp_state, self.temporal_memory.process(sp_state, learning=learning)
         retire_states(eng)
-        if _grow_if_needed(eng, 2 * self.active_columns):
+        if _grow_if_needed(eng, self.active_columns):
             self.grow_pool(*eng._grow_to)
             eng = self._engine
         if not self.spatial_pooler._plain:          # plug-in objects on the host: SP phase by phase, then the TM with its winners
@@ -578,11 +584,12 @@ class HierarchicalTemporalMemory:
         eng.check_capacity()
 
 
-def _grow_if_needed(eng, per_step, every=32, force_check=False):
+def _grow_if_needed(eng, per_step, every=128, force_check=False):
     """Pools whose size the user did not fix (`segment_capacity=None`) follow the reference's growing arrays
-    (utils.py:113-135): every `every` host-fed steps the engine is asked how full it is, and True comes back -- with the
-    sizes to grow to in eng._grow_to -- when the free segments would not last another `every` steps at `per_step` new
-    segments each, or a segment is within one sample of its slots.  (Never in the middle of a device-side batch.)"""
+    (utils.py:113-135): every `every` host-fed steps the engine is asked how full it is (a synchronisation and a read-back:
+    not more often), and True comes back -- with the sizes to grow to in eng._grow_to -- when the free segments would not
+    last another `every` steps at `per_step` new segments each (every active column bursting), or a segment has filled three
+    quarters of its slots.  (Never in the middle of a device-side batch.)"""
     if not getattr(eng, "_auto_grow", False) or not eng.has_tm:
         return False
     eng._since_check = getattr(eng, "_since_check", every) + 1
