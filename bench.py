@@ -110,11 +110,12 @@ def role_bytes(w, k, seg_nsyn, n_work, n_match):
     }
 
 
-def recorded_traffic(kernel, files=("r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json")):
-    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r02_pmc_summary.json:
-    rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs of this same workload and schedule; KB
-    units; FETCH_SIZE doubled as MI355X_MICROARCH.md section HBM prescribes for gfx950).  PMC counters cannot
-    be read from inside this process, so this is a recorded value, not a live one."""
+def recorded_traffic(kernel, files=("r03_pmc_summary.json",), sum_nsyn=None):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r03_pmc_summary.json: rocprofv3 --pmc
+    FETCH_SIZE and --pmc WRITE_SIZE in separate runs of this same command and schedule; KB units; FETCH_SIZE doubled as
+    MI355X_MICROARCH.md section HBM prescribes for gfx950).  PMC counters cannot be read from inside this process, so this is a
+    recorded value, not a live one -- and only used where the recorded pass saw the model in the state this run is in
+    (the synapses in the pool, which the scan's traffic follows, within 5 %): otherwise traffic is null and says why."""
     for name in files:
         path = os.path.join(ROOT, "profiles", name)
         try:
@@ -122,7 +123,11 @@ def recorded_traffic(kernel, files=("r03_pmc_summary.json", "r02_pmc_summary.jso
             key = next(k for k in d["FETCH_SIZE"] if kernel in k)          # template kernels: "void k_scan_sel<true, 6>"
             f = d["FETCH_SIZE"][key]["mean_last150_KB"]
             wr = d["WRITE_SIZE"][key]["mean_last150_KB"]
-            return dict(traffic=int((2 * f + wr) * 1024), traffic_source=f"profiles/{name} (recorded PMC pass, 2*FETCH_SIZE + WRITE_SIZE)")
+            rec = d.get("state", {}).get("sum_nsyn")
+            if sum_nsyn is not None and rec is not None and abs(rec - sum_nsyn) > 0.05 * sum_nsyn:
+                return dict(traffic=None, traffic_source=f"profiles/{name} was recorded with {rec} synapses in the pool, this run has {sum_nsyn}: not comparable")
+            return dict(traffic=int((2 * f + wr) * 1024), traffic_source=f"profiles/{name} (recorded PMC pass of this command, 2*FETCH_SIZE + WRITE_SIZE"
+                                                                          + (f"; pool of {rec} synapses then, {sum_nsyn} now)" if rec is not None and sum_nsyn is not None else ")"))
         except Exception:
             continue
     return dict(traffic=None)
@@ -324,7 +329,7 @@ def stress_leg(steps=8, warmup=3, check=True):
                avg_launch_us=round(scan_us, 1), achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4),
                rank0_launch_us={n: round(v, 1) for n, v in prof.items()}, rank0_step_us=round(sum(prof.values()), 1),
                exchange_bytes_per_rank=int(eng.shard_record_bytes()), setup_s=round(setup_s, 1))
-    out.update(recorded_traffic("k_tm_scan_wide"))
+    out.update(recorded_traffic("k_tm_scan_wide"))         # (a generated pool: the same in every run)
     if check:
         try:
             out.update(check_stress_sample(eng, s, rows0, k))
@@ -431,7 +436,9 @@ def run_single(args):
                     launches={n: dict(kernel=kernel_of[n], us=round(launch_us[n], 2), bytes=int(launch_bytes[n]),
                                       frac=round(launch_bytes[n] / (launch_us[n] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4))
                               for n in launch_us})
-    roofline.update(recorded_traffic(kernel_of[dominant]))
+    sum_nsyn = int(store["seg_nsyn"].astype(np.int64).sum())
+    roofline.update(recorded_traffic(kernel_of[dominant], sum_nsyn=sum_nsyn))
+    roofline["state"] = dict(step_index=int(info.step_index), segments=int(info.segments), sum_nsyn=sum_nsyn)
 
     cpu = None
     if not args.no_cpu_baseline:

@@ -30,29 +30,6 @@ struct TraceScope {                                 // BITHTM_TRACE=1: first / l
 #if defined(BITHTM_LEARN_STAMPS) || defined(BITHTM_SCAN_STAMPS) || defined(BITHTM_EMIT_STAMPS) || defined(BITHTM_SHARD_STAMPS)
         t = nullptr;                                // the diagnostic builds of the learning role and of the scan use the buffer
         return;
-// The last launch of a step run role by role (enqueue_tm): the learning role, the scan, and a streaming role behind them --
-//   n_rows > 0   the Spatial Pooler's permanence rows of THIS step (a host-fed step, htm_step: they used to share the middle
-//                launch, whose block 0 is the step's longest chain; beside the learning role and the scan they are free)
-//   else         the overlap of the COMING step on a shard's own columns (htm_shard_run; their permanence rows and duty
-//                cycle were updated by this step's middle launch; nothing of the Temporal Memory is read)
-template <int EPL>
-__global__ __launch_bounds__(256, 6) void k_learn_scan_tail(Dev d, int p, int n_learn_blocks, int n_scan_blocks, int n_spec,
-                                                            const uint32_t *__restrict__ bank, int n_inputs, int G, int wmode, int n_rows) {
-    int b = blockIdx.x;
-    if (b < n_learn_blocks) {
-        role_learn<EPL, 256, true>(d, p, b, n_learn_blocks, (LearnShared<EPL, 256> *)dyn_lds);
-        return;
-    }
-    b -= n_learn_blocks;
-    if (b < n_scan_blocks) {
-        role_scan<256, true, false, false>(d, p, b, n_scan_blocks, n_spec, (uint32_t *)dyn_lds);
-        return;
-    }
-    b -= n_scan_blocks;
-    if (n_rows > 0) role_sp_row<256>(d, p, bank, n_inputs, 0, b, threadIdx.x);
-    else role_overlap<256>(d, bank, n_inputs, G, p, p ^ 1, 1, b, (int)gridDim.x - n_learn_blocks - n_scan_blocks, (uint32_t *)dyn_lds, wmode);
-}
-
 #endif
         t = (d.trace && blockIdx.x < 4096 && d.ctr->step[slot >> 2] < d.trace_until) ? d.trace + ((size_t)slot * 4096 + blockIdx.x) * 2 : nullptr;
         if (t && threadIdx.x == 0) t[0] = wall_clock64();

@@ -31,11 +31,12 @@ def main():
     group = LocalGroup(args.world, I, C, K, permanence=perm,
                        make_parts=lambda r: dict(distal=B.PredictiveProjection(C * K, segment_slots=w["segment_slots"])))
     group.upload_bank(noisy)
-    group.run(args.steps)
+    graph = "ROCP_TOOL_LIBRARIES" not in os.environ      # (rocprofv3 crashes inside hipGraph replay on this image)
+    group.run(args.steps, use_graph=graph)
     eng = group.engines[0]
     eng.sync()
     t0 = time.perf_counter()
-    group.run(200)
+    group.run(200, use_graph=graph)
     eng.sync()
     wall = (time.perf_counter() - t0) / 200
     eng.profile(True)
