@@ -730,6 +730,7 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
         d.cand_pairwise = CAND_PAIRWISE;
         if (const char *e = getenv("BITHTM_CAND_PAIRWISE")) d.cand_pairwise = std::max(0, atoi(e));     // test knobs
         d.win_offset = getenv("BITHTM_SEL_WINDOW_OFFSET") ? std::max(0, atoi(getenv("BITHTM_SEL_WINDOW_OFFSET"))) : 0;
+        d.cand_speculate = getenv("BITHTM_CAND_SPECULATE") ? atoi(getenv("BITHTM_CAND_SPECULATE")) != 0 : 1;     // (test knob: 0 = always the general path)
         d.cand_others = CAND_OTHERS;
         if (const char *e = getenv("BITHTM_CAND_OTHERS")) d.cand_others = std::max(0, std::min(CAND_OTHERS, atoi(e)));
     }

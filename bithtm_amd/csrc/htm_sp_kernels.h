@@ -356,7 +356,7 @@ __host__ __device__ __forceinline__ size_t shard_record_bytes(int n_cand) {
 #define CAND_D 15             // distinct bucket keys one block can publish (head + 15 granules = its 128-byte record)
 #define CAND_RAW 64           // ... and collect from its waves before merging duplicates
 #define CAND_MAX 1024         // bucket entries a block can merge
-#define CAND_OTHERS 160         // ... after folding the copies of one key, if at most this many others remain
+#define CAND_OTHERS 160         // ... after folding the copies of one key, if at most this many others remain (<= 256: one per thread)
 #define CAND_PAIRWISE 160      // ... by comparing all pairs; above that, by radix refinement in LDS
 
 // pick the bucket that contains the krem-th largest key of a histogram held in LDS
@@ -445,7 +445,7 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
     static_assert(2 * CAND_MAX <= SEL_BINS, "bucket keys must fit the histogram");
     const int tid = threadIdx.x, lane = lane_id();
     EMIT_STAMP(0);
-    if (tid == 0) { s_gt = 0; s_eq = 0; s_n = 0; s_nraw = 0; s_ne = 0; s_flags = 0; }
+    if (tid == 0) { s_gt = 0; s_eq = 0; s_n = 0; s_nraw = 0; s_ne = 0; s_flags = 0; s_T = 0; }
     const int cbase = d.sel_lo + b * 256, c = cbase + tid;      // the select covers columns [sel_lo, sel_hi)
     const bool local = mode & EMIT_LOCAL;
     // independent of everything below: in flight while the select state is resolved
@@ -564,6 +564,7 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
         // ---- everybody's records: the head granule is polled alone (one lane-load per spin keeps the
         // polling traffic low); further pairs, if any, are fetched in one batch; each granule validates itself
         uint32_t gthi_before = 0;
+        u64 heaviest = 0;                            // multiplicity:12 | unresolved key bits:40 of the heaviest pair this thread has read
         for (int rb = tid; rb < nblk; rb += 256) {
             const u64 *rr = (const u64 *)(d.sel_rec + (size_t)rb * 32);
             u64 g[CAND_D];
@@ -586,17 +587,36 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
             }
             if (rb < b) gthi_before += (uint32_t)((g[0] >> 38) & 0x1FFu);
             if ((g[0] >> 51) & 1ull) atomicOr(&s_flags, 1u);
+            // the pairs into the merged list: one reservation per wave and pair index (a reservation per lane is a same-address
+            // LDS atomic served lane by lane: 400-570 of them in a crowded bin, microseconds)
 #pragma unroll
-            for (int j = 0; j < CAND_D; ++j)
-                if (j < np) {
-                    const int slot = atomicAdd(&s_ne, 1);
+            for (int j = 0; j < CAND_D; ++j) {
+                const bool has = j < np;
+                const u64 mh = __ballot(has);
+                if (!mh) break;                       // (wave-uniform: np only shrinks with j)
+                int base = 0;
+                if (lane == __ffsll((long long)mh) - 1) base = atomicAdd(&s_ne, __popcll(mh));
+                base = __shfl(base, __ffsll((long long)mh) - 1);
+                if (has) {
+                    const int slot = base + __popcll(mh & lanemask_lt());
                     if (slot < CAND_MAX) {
-                        const u64 low = (j == 0 ? g[0] & 0x1FFFFFFFull : g[j] & 0xFFFFFFFFFFull) << d.low_zero;
-                        s_ek[slot] = (lowbits < 64 ? hiP << lowbits : 0ull) | low;
-                        s_ec[slot] = (uint16_t)(j == 0 ? (g[0] >> 29) & 0x1FFu : (g[j] >> 40) & 0xFFFu);
+                        const u64 low40 = j == 0 ? g[0] & 0x1FFFFFFFull : g[j] & 0xFFFFFFFFFFull;
+                        const u64 cnt = j == 0 ? (g[0] >> 29) & 0x1FFu : (g[j] >> 40) & 0xFFFu;
+                        s_ek[slot] = (lowbits < 64 ? hiP << lowbits : 0ull) | (low40 << d.low_zero);
+                        s_ec[slot] = (uint16_t)cnt;
                         s_eb[slot] = (uint16_t)rb;
+                        heaviest = max(heaviest, (cnt << 40) | low40);
                     }
                 }
+            }
+        }
+        // (the heaviest pair of all: for the many-way tie below -- settled here, before the barrier everybody needs anyway)
+        if (__any(heaviest != 0)) {
+            for (int o = 32; o > 0; o >>= 1) {
+                const u64 other = ((u64)__shfl_xor((uint32_t)(heaviest >> 32), o) << 32) | __shfl_xor((uint32_t)heaviest, o);
+                heaviest = max(heaviest, other);
+            }
+            if (lane == 0) atomicMax((unsigned long long *)&s_T, heaviest);
         }
         __syncthreads();
         const int ne = s_ne;
@@ -624,43 +644,98 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
                 T = s_T;
                 r = s_r;
             } else {
-                // many entries: overlaps tie and most blocks report the same key.  Fold the copies of the
-                // first entry's key into one entry; if few others remain, all pairs again
-                const u64 K0 = s_ek[0];
-                if (tid == 0) { sh->n_others = 0; sh->c0 = 0; }
+                // many entries: overlaps tie and most blocks report the same key -- the columns of one learned pattern, equal
+                // overlaps and equal duty histories, a thousand of them behind one key, and a few dozen stragglers around it.
+                // K0 = the key of the heaviest pair any block published (the largest key among equally heavy ones: found while the
+                // records were read).  One pass folds its copies, counts the keys above it and sets the others aside;
+                // nearly always the k-th key IS K0 (it straddles the k-th position) and that pass is all there is to do.
+                const u64 K0 = (lowbits < 64 ? hiP << lowbits : 0ull) | ((s_T & 0xFFFFFFFFFFull) << d.low_zero);
+                if (tid == 0) { sh->n_others = 0; sh->c0 = 0; s_mh[1] = 0; s_mh[2] = 0; }
                 __syncthreads();
-                uint32_t c0 = 0;
-                for (int e = tid; e < ne; e += 256) {
-                    const u64 ke = s_ek[e];
-                    if (ke == K0) {
-                        c0 += s_ec[e];
-                    } else {
-                        const int pos = atomicAdd(&sh->n_others, 1);
-                        if (pos < CAND_OTHERS) { sh->ok[pos] = ke; sh->oc[pos] = s_ec[e]; }
+                // (the keys above K0 are set aside from the front of the list, the keys below it from its end)
+                uint32_t c0 = 0, g0 = 0;
+                for (int e0 = tid & ~63; e0 < ne; e0 += 256) {        // (whole waves: the appends are reserved once per wave)
+                    const int e = e0 + lane;
+                    const u64 ke = e < ne ? s_ek[e] : K0;
+                    const uint32_t ce = e < ne ? (uint32_t)s_ec[e] : 0u;
+                    const bool up = ke > K0, dn = ke < K0;
+                    c0 += ke == K0 ? ce : 0u;
+                    g0 += up ? ce : 0u;
+                    const u64 mu = __ballot(up), md = __ballot(dn);
+                    int bu = 0, bd = 0;
+                    if (lane == 0) {
+                        if (mu) bu = atomicAdd(&sh->n_others, __popcll(mu));
+                        if (md) bd = (int)atomicAdd(&s_mh[2], (uint32_t)__popcll(md));
+                    }
+                    bu = __shfl(bu, 0);
+                    bd = __shfl(bd, 0);
+                    if (up) {
+                        const int pos = bu + __popcll(mu & lanemask_lt());
+                        if (pos < CAND_OTHERS) { sh->ok[pos] = ke; sh->oc[pos] = ce; }
+                    } else if (dn) {
+                        const int pos = CAND_OTHERS - 1 - (bd + __popcll(md & lanemask_lt()));
+                        if (pos >= 0) { sh->ok[pos] = ke; sh->oc[pos] = ce; }
                     }
                 }
                 c0 = wave_sum(c0);
-                if (lane == 0 && c0) atomicAdd(&sh->c0, c0);
+                g0 = wave_sum(g0);
+                if (lane == 0) { if (c0) atomicAdd(&sh->c0, c0); if (g0) atomicAdd(&s_mh[1], g0); }
                 __syncthreads();
-                const int no = sh->n_others;
-                folded = no < d.cand_others;
-                if (folded) {
-                    if (tid == 0) { sh->ok[no] = K0; sh->oc[no] = sh->c0; }
-                    __syncthreads();
-                    for (int e = tid; e <= no; e += 256) {
-                        const u64 ke = sh->ok[e];
+                const int n_above = sh->n_others, n_below = (int)s_mh[2];
+                const uint32_t G = s_mh[1], E0 = sh->c0;
+                if (d.cand_speculate && G < krem && krem <= G + E0) {         // the k-th key is K0
+                    T = K0;
+                    r = krem - G;
+                    folded = true;
+                } else if (d.cand_speculate && n_above + n_below <= d.cand_others) {
+                    // the k-th key is one of the stragglers on ONE side of K0 (the pattern's columns fill most of the k places, the
+                    // rest go to the best of the others): all pairs among that side's entries only
+                    const bool up = krem <= G;
+                    const int first = up ? 0 : CAND_OTHERS - n_below, n_side = up ? n_above : n_below;
+                    const uint32_t kside = up ? krem : krem - G - E0;
+                    for (int e = tid; e < n_side; e += 256) {
+                        const u64 ke = sh->ok[first + e];
                         uint32_t ng = 0, nq = 0;
-                        for (int f = 0; f <= no; ++f) {
-                            const u64 kf = sh->ok[f];
-                            const uint32_t cf = sh->oc[f];
+                        for (int f = 0; f < n_side; ++f) {
+                            const u64 kf = sh->ok[first + f];
+                            const uint32_t cf = sh->oc[first + f];
                             ng += kf > ke ? cf : 0u;
                             nq += kf == ke ? cf : 0u;
                         }
-                        if (ng < krem && krem <= ng + nq) { s_T = ke; s_r = krem - ng; }
+                        if (ng < kside && kside <= ng + nq) { s_T = ke; s_r = kside - ng; }
                     }
                     __syncthreads();
                     T = s_T;
                     r = s_r;
+                    folded = true;
+                } else {
+                    // (BITHTM_CAND_SPECULATE=0, the form of round 2: K0 joins the others, all pairs among them all)
+                    const int no = n_above + n_below;
+                    folded = no < d.cand_others;
+                    if (folded) {
+                        // close the gap between the two ends (at most CAND_OTHERS <= 256 entries: one per thread, read before any is written)
+                        const bool mv = tid < n_below;
+                        const u64 kk = mv ? sh->ok[CAND_OTHERS - 1 - tid] : 0ull;
+                        const uint32_t cc = mv ? sh->oc[CAND_OTHERS - 1 - tid] : 0u;
+                        __syncthreads();
+                        if (mv) { sh->ok[n_above + tid] = kk; sh->oc[n_above + tid] = cc; }
+                        if (tid == 0) { sh->ok[no] = K0; sh->oc[no] = E0; }
+                        __syncthreads();
+                        for (int e = tid; e <= no; e += 256) {
+                            const u64 ke = sh->ok[e];
+                            uint32_t ng = 0, nq = 0;
+                            for (int f = 0; f <= no; ++f) {
+                                const u64 kf = sh->ok[f];
+                                const uint32_t cf = sh->oc[f];
+                                ng += kf > ke ? cf : 0u;
+                                nq += kf == ke ? cf : 0u;
+                            }
+                            if (ng < krem && krem <= ng + nq) { s_T = ke; s_r = krem - ng; }
+                        }
+                        __syncthreads();
+                        T = s_T;
+                        r = s_r;
+                    }
                 }
             }
             if (ne > d.cand_pairwise && !folded) {    // still many distinct keys: 8-bit radix refinement
@@ -687,6 +762,7 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
                 T = (lowbits < 64 ? hiP << lowbits : 0ull) | pref;
                 r = rem;
             }
+            EMIT_STAMP(6);                            // (the k-th key itself; what follows counts the earlier blocks' winners)
             uint32_t g = gthi_before, e2 = 0;         // winners of the blocks before this one
             for (int e = tid; e < ne; e += 256)
                 if (s_eb[e] < b) {

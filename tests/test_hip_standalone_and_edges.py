@@ -303,6 +303,8 @@ def test_batched_run_equals_step_by_step():
 
 @pytest.mark.parametrize("env", [{}, {"BITHTM_LEAN": "0"}, {"BITHTM_SEL_WINDOW_OFFSET": "4000"}, {"BITHTM_CAND_D": "0"}, {"BITHTM_CAND_D": "1"},
                                  {"BITHTM_CAND_PAIRWISE": "0", "BITHTM_CAND_OTHERS": "0"}, {"BITHTM_CAND_PAIRWISE": "0", "BITHTM_CAND_OTHERS": "4"},
+                                 {"BITHTM_CAND_PAIRWISE": "0", "BITHTM_CAND_OTHERS": "0", "BITHTM_CAND_SPECULATE": "0"},
+                                 {"BITHTM_CAND_PAIRWISE": "0", "BITHTM_CAND_OTHERS": "4", "BITHTM_CAND_SPECULATE": "0"},
                                  {"BITHTM_LEAN_SCAN": "1", "BITHTM_LEAN_LEARN": "1"}, {"BITHTM_LEAN_SCAN": "3", "BITHTM_LEAN_LEARN": "2", "BITHTM_LEAN_OVERLAP": "3"},
                                  {"BITHTM_FUSE_TM": "0"}],
                          ids=lambda e: ",".join(f"{k[7:]}={v}" for k, v in e.items()) or "default")
@@ -310,7 +312,8 @@ def test_pipelined_schedules_and_select_paths_equal_step_by_step(env, monkeypatc
     """htm.run in its pipelined schedules -- three launches per step (the learning role scanning its own rows beside the
     scan, the one-pass windowed select) and the four-launch one -- against process(), with the select forced down every
     path: a window that always misses (exact fallback each step), records that overflow (slots 0 / 1), the tie merge
-    (pairwise 0; others 0 = radix refinement only), and grids of a few blocks (every wave loops)."""
+    (pairwise 0; others 0 = radix refinement only; SPECULATE 0 = without the shortcut "the k-th key is the heaviest key"), and
+    grids of a few blocks (every wave loops)."""
     import bithtm_amd as B
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -443,21 +446,23 @@ def test_batched_run_with_learning_switched_off_and_on():
             assert np.array_equal(a, b)
 
 
-@pytest.mark.parametrize("digits,slots,pairwise,others", [("2", "8", "160", "128"), ("3", "8", "160", "128"), ("2", "0", "160", "128"),
-                                                          ("2", "1", "160", "128"), ("2", "8", "0", "128"), ("2", "8", "0", "4"), ("2", "8", "0", "0")])
-def test_select_is_exact_on_the_record_path_and_on_the_fallback(digits, slots, pairwise, others, monkeypatch):
+@pytest.mark.parametrize("digits,slots,pairwise,others,spec", [("2", "8", "160", "128", "1"), ("3", "8", "160", "128", "1"), ("2", "0", "160", "128", "1"),
+                                                               ("2", "1", "160", "128", "1"), ("2", "8", "0", "128", "1"), ("2", "8", "0", "4", "1"), ("2", "8", "0", "0", "1"),
+                                                               ("2", "8", "0", "128", "0"), ("2", "8", "0", "4", "0"), ("2", "8", "0", "0", "0")])
+def test_select_is_exact_on_the_record_path_and_on_the_fallback(digits, slots, pairwise, others, spec, monkeypatch):
     """k_sp_emit finishes the top-k select from per-block bucket records.  slots=0 makes every block
     with a bucket key overflow its record, so the exact in-kernel fallback runs every step; slots=1
     mixes both paths; 3 launched digits is the variant with smaller buckets; pairwise=0 merges the
     records on every step the way a many-way tie is merged (the copies of one key folded into one
     entry, then all pairs if fewer than `others` other entries remain, else radix refinement:
-    others=4 mixes both, others=0 is radix only)."""
+    others=4 mixes both, others=0 is radix only; spec=0: without the shortcut that tries the heaviest key first)."""
     import bithtm_amd as B
     from oracle import HTMOracle
     monkeypatch.setenv("BITHTM_SEL_LAUNCH_DIGITS", digits)
     monkeypatch.setenv("BITHTM_CAND_D", slots)
     monkeypatch.setenv("BITHTM_CAND_PAIRWISE", pairwise)
     monkeypatch.setenv("BITHTM_CAND_OTHERS", others)
+    monkeypatch.setenv("BITHTM_CAND_SPECULATE", spec)
     np.random.seed(31)
     htm = B.HierarchicalTemporalMemory(300, 4096, 8)
     ora = HTMOracle(300, 4096, 8, seed=0, permanence=htm.spatial_pooler.proximal_projection.permanence.copy())

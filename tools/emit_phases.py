@@ -42,6 +42,8 @@ def main():
         pub = t[:, 2] - t0                            # when each block's record was out
         print(f"    records published at median {np.median(pub):.2f} / last {pub.max():.2f} us (block {int(pub.argmax())}); all read {np.median(t[:, 3] - t0 - pub.max()):.2f} us after the last one; "
               f"k-th key known {np.median(t[:, 4] - t[:, 3]):.2f} us later")
+        kth = (raw[:, 6].astype(np.float64) / 100.0 - t[:, 3])
+        print(f"    (k-th key itself {np.median(kth):.2f}/{kth.max():.2f} us of that phase)")
         print(f"step {step}: merged entries {int(ne.max())}, raw keys per block max {int(nraw.max())} mean {nraw.mean():.1f}; blocks end {(t[:, 5] - t0).min():.2f}..{(t[:, 5] - t0).max():.2f} us; "
               + "  ".join(f"{n} {np.median(ph[:, i]):.2f}/{ph[:, i].max():.2f}" for i, n in enumerate(names)))
 
