@@ -10,6 +10,12 @@ typedef unsigned long long u64;
 #define SEL_DIGIT 12
 #define SEL_BINS 4096         // 1 << SEL_DIGIT
 #define HIST_REP 4            // copies of the digit-0 histogram (its few hot bins take one atomic per block; 8 and 2 measured no better)
+#define SEL_COARSE 64         // ... and the sums of the 64 runs of 64 bins, in COARSE_REP copies of their own (every block of the overlap adds
+#define COARSE_REP 16         // to a few hot runs: block b to copy b % COARSE_REP): the windowed select picks the run first, then the bin
+                              // inside it -- two reads of a few kilobytes instead of one of 64 KB by every block of the select's finish
+#define COARSE_STRIDE 1024    // words between two coarse copies (a page each: the copies' atomics go to different memory channels)
+#define HIST0_FINE (HIST_REP * SEL_BINS)
+#define HIST0_PAR (HIST0_FINE + COARSE_REP * COARSE_STRIDE)      // words per step parity: fine copies, then coarse copies
 #define RB 512                // threads per block of the role kernels (overlap, select, learn, scan)
 #define SCAN_SEGS 64          // segments per 256-thread block iteration of the segment scan
 #define DEAD_CAP 256          // newly dead segment ids one rank can report per exchange
@@ -120,7 +126,7 @@ struct Dev {
     double *boosted[2];       // [C]
     u64 *key[2];              // [C] bits of boosted (non-negative doubles order like uint64)
     uint32_t *hist;           // [2][SEL_MAX_PASSES][SEL_BINS]  (digits 1..)
-    uint32_t *hist0;          // [2][HIST_REP][SEL_BINS]        digit 0: block b adds to copy b % HIST_REP
+    uint32_t *hist0;          // [2][HIST_REP][SEL_BINS + SEL_COARSE]   digit 0 (or the window's bins): block b adds to copy b % HIST_REP
     uint32_t *sel_blk;        // [ceil(C/256)] packed (greater, equal) counts per 256-column block
     uint32_t *sel_rec;        // [ceil(C/256)][32] per-block bucket records of k_sp_emit (16 granules)
     int *active_cols[2];      // [k] ascending; parity double buffer (the pipelined schedule emits step t+1's

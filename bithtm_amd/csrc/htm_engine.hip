@@ -579,7 +579,7 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
             rc |= dalloc(h, &d.key[q], C);
         }
         rc |= dalloc(h, &d.hist, (size_t)2 * SEL_MAX_PASSES * SEL_BINS);
-        rc |= dalloc(h, &d.hist0, (size_t)2 * HIST_REP * SEL_BINS);
+        rc |= dalloc(h, &d.hist0, (size_t)2 * HIST0_PAR);
         rc |= dalloc(h, &d.sel_blk, (C + 255) / 256);
         rc |= dalloc(h, &d.sel_rec, (C + 255) / 256 * 32);
         rc |= dalloc(h, &d.input_stage, (size_t)d.W);
@@ -830,7 +830,7 @@ extern "C" int htm_sp_get_permanence(htm_handle *h, double *rows, int32_t row_be
 static int close_open_phases(htm_handle *h) {
     if (!h->phase_open) return 0;
     const int p = (int)(h->step_host & 1);
-    if (h->cfg.enable_sp) HIPCHK(h, hipMemsetAsync(h->d.hist0 + (size_t)p * HIST_REP * SEL_BINS, 0, (size_t)HIST_REP * SEL_BINS * 4, h->stream));
+    if (h->cfg.enable_sp) HIPCHK(h, hipMemsetAsync(h->d.hist0 + (size_t)p * HIST0_PAR, 0, (size_t)HIST0_PAR * 4, h->stream));
     h->phase_open = false;
     h->phase_active = 0;
     return 0;
@@ -894,7 +894,7 @@ extern "C" int htm_sp_phase(htm_handle *h, int32_t phase, const void *data, int6
     // the top-digit histogram of this step's keys is accumulated by the phase that makes the keys and consumed (and
     // cleared) by the select: a phase that makes keys starts from a clean one, whatever ran before it in this step
     if (phase == HTM_SP_OVERLAP || phase == HTM_SP_BOOST || (phase == HTM_SP_SELECT && data))
-        HIPCHK(h, hipMemsetAsync(d.hist0 + (size_t)p * HIST_REP * SEL_BINS, 0, (size_t)HIST_REP * SEL_BINS * 4, h->stream));
+        HIPCHK(h, hipMemsetAsync(d.hist0 + (size_t)p * HIST0_PAR, 0, (size_t)HIST0_PAR * 4, h->stream));
     switch (phase) {
         case HTM_SP_OVERLAP: {                     // DenseProjection.process + ExponentialBoosting.process; data = packed input
             if (!data) return HTM_ERR_ARGUMENT;
@@ -1109,7 +1109,7 @@ static int run_or_prepare(htm_handle *h, const uint32_t *device_inputs, int32_t 
             else enqueue_pipelined(h, p, learning, device_inputs, n_inputs, last);
             h->step_host += 1;
             // (the four-launch schedule had begun the step after it: that front is never consumed)
-            HIPCHK(h, hipMemsetAsync(h->d.hist0 + (size_t)(h->step_host & 1) * HIST_REP * SEL_BINS, 0, (size_t)HIST_REP * SEL_BINS * 4, h->stream));
+            HIPCHK(h, hipMemsetAsync(h->d.hist0 + (size_t)(h->step_host & 1) * HIST0_PAR, 0, (size_t)HIST0_PAR * 4, h->stream));
             h->ahead_bank = nullptr;
             hipError_t e = hipGetLastError();
             if (e != hipSuccess) { h->err = std::string("kernel launch: ") + hipGetErrorString(e); return HTM_ERR_HIP; }
@@ -1173,7 +1173,7 @@ static int run_or_prepare(htm_handle *h, const uint32_t *device_inputs, int32_t 
     if (dry) return HTM_OK;
     if (n_steps > 0) {
         if (resume && !cont && n_steps == 1)        // the front computed for the step after this one is never consumed:
-            HIPCHK(h, hipMemsetAsync(h->d.hist0 + (size_t)(h->step_host & 1) * HIST_REP * SEL_BINS, 0, (size_t)HIST_REP * SEL_BINS * 4, h->stream));    // its digit histogram
+            HIPCHK(h, hipMemsetAsync(h->d.hist0 + (size_t)(h->step_host & 1) * HIST0_PAR, 0, (size_t)HIST0_PAR * 4, h->stream));    // its digit histogram
         h->ahead_bank = cont ? device_inputs : nullptr;
         h->ahead_lean = cont && can_lean(h);
         h->ahead_n_inputs = n_inputs;
@@ -1215,7 +1215,7 @@ static int shard_enqueue_begin(htm_handle *h, const uint32_t *bank, int n_inputs
     const int fused = h->emit_fused ? 1 : 0;
     const int wmode = fused ? h->knob_shard_window : 0;
     if (front_done && h->shard_front_wmode != wmode) {       // the exchange mode changed since the front was computed: start over
-        HIPCHK(h, hipMemsetAsync(d.hist0 + (size_t)p * HIST_REP * SEL_BINS, 0, (size_t)HIST_REP * SEL_BINS * 4, h->stream));
+        HIPCHK(h, hipMemsetAsync(d.hist0 + (size_t)p * HIST0_PAR, 0, (size_t)HIST0_PAR * 4, h->stream));
         front_done = false;
     }
     if (!front_done) LAUNCH(h, "shard_overlap", k_shard_overlap, h->sp_blocks, RB, d, bank, n_inputs, h->G, p, wmode, 0);

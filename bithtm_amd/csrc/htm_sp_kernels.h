@@ -48,6 +48,8 @@ __device__ __forceinline__ void role_overlap(const Dev &d, const uint32_t *__res
         __syncthreads();
     }
     const uint32_t wbase = wmode ? d.ctr->sel_win[sp] : 0u;
+    static_assert(WIN_BINS <= SEL_BINS - SEL_COARSE, "the runs' sums live behind the window's bins in the LDS histogram");
+    uint32_t *hc = h + SEL_BINS - SEL_COARSE;       // (window mode only)
     const uint4 *in4 = (const uint4 *)(bank + (size_t)((d.ctr->step[p] + (uint32_t)step_offset) % (uint32_t)n_inputs) * d.W);
     const uint4 *mask4 = (const uint4 *)d.mask;
     const int lane = lane_id();
@@ -93,14 +95,24 @@ __device__ __forceinline__ void role_overlap(const Dev &d, const uint32_t *__res
             }
             // (plain LDS atomics: only the 64 / G row owners of the wave take part, and hist_add's loop over the
             // distinct digits, a dependent shuffle + ballot + atomic each, cost 0.3 us per call here)
-            if (do_hist && owner) atomicAdd(&h[wmode ? win_bin(key, wbase) : (uint32_t)(key >> sel_shift(0))], 1u);
+            // (the windowed histogram leaves out the bin below the window, where most columns are: the select counts from the
+            // top and never gets there -- if it would, the k-th key is outside the window and the exact fallback takes over)
+            const uint32_t bin = wmode ? win_bin(key, wbase) : (uint32_t)(key >> sel_shift(0));
+            if (do_hist && owner && (!wmode || bin != 0u)) {
+                atomicAdd(&h[bin], 1u);
+                if (wmode) atomicAdd(&hc[bin >> 6], 1u);
+            }
         }
     }
     if (!do_hist) return;
     __syncthreads();
-    uint32_t *g0 = d.hist0 + (size_t)(sp * HIST_REP + (blk & (HIST_REP - 1))) * SEL_BINS;
-    for (int i = threadIdx.x; i < SEL_BINS; i += BS)
+    uint32_t *g0 = d.hist0 + (size_t)sp * HIST0_PAR + (size_t)(blk & (HIST_REP - 1)) * SEL_BINS;
+    uint32_t *gc = d.hist0 + (size_t)sp * HIST0_PAR + HIST0_FINE + (size_t)(blk & (COARSE_REP - 1)) * COARSE_STRIDE;
+    const int n_fine = wmode ? SEL_BINS - SEL_COARSE : SEL_BINS;
+    for (int i = threadIdx.x; i < n_fine; i += BS)
         if (h[i]) atomicAdd(&g0[i], h[i]);
+    // the runs' sums were counted beside the bins (in the words of the LDS histogram the window never uses: bins >= WIN_BINS)
+    if (wmode && threadIdx.x < SEL_COARSE && hc[threadIdx.x]) atomicAdd(&gc[threadIdx.x], hc[threadIdx.x]);
 }
 
 __global__ __launch_bounds__(RB) void k_sp_overlap(Dev d, const uint32_t *__restrict__ bank, int n_inputs, int G, int p, int sp, int step_offset, int wmode) {
@@ -149,7 +161,7 @@ __device__ __forceinline__ void sel_resolve(const Dev &d, int sp, int prev, uint
             v[j] = (prev > 0 && b < nb) ? *(const uint4 *)(gh + b) : make_uint4(0, 0, 0, 0);
         }
         if (prev == 0) {                            // digit 0: sum the copies
-            const uint32_t *g0 = d.hist0 + (size_t)sp * HIST_REP * SEL_BINS;
+            const uint32_t *g0 = d.hist0 + (size_t)sp * HIST0_PAR;
             for (int r = 0; r < HIST_REP; ++r)
 #pragma unroll
                 for (int j = 0; j < PER / 4; ++j) {
@@ -241,7 +253,7 @@ __global__ __launch_bounds__(256) void k_sp_count(Dev d, int sp) {
         d.ctr->sel_win[sp ^ 1] = min(win_base_for(T) + (uint32_t)d.win_offset, 4096u - WIN_COARSE);
     }
     if (d.sel_passes > 1)                       // pass-0 histogram is consumed: clear it for its next use
-        for (int i = blockIdx.x * 256 + threadIdx.x; i < HIST_REP * SEL_BINS; i += gridDim.x * 256) d.hist0[(size_t)sp * HIST_REP * SEL_BINS + i] = 0;
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < HIST0_PAR; i += gridDim.x * 256) d.hist0[(size_t)sp * HIST0_PAR + i] = 0;
     const int c = d.sel_lo + blockIdx.x * 256 + threadIdx.x;
     uint32_t v = 0;
     if (c < d.sel_hi) {
@@ -463,24 +475,32 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
         uint32_t krem;
         int lowbits = sel_shift(d.sel_passes - 1);              // key bits not resolved by launches
         if (wmode) {
-            {   // the histogram: sum of the copies (16-byte loads, all in flight)
-                constexpr int PER4 = SEL_BINS / 256 / 4;
-                const uint32_t *g0 = d.hist0 + (size_t)p * HIST_REP * SEL_BINS;
-                uint4 v[PER4];
+            // The bin of the k-th key, and the keys above it: from the runs' sums first (64 of them, one wave, one read of the
+            // copies), then from the 64 bins of the chosen run -- two dependent reads of a kilobyte each, no block-wide scan.
+            // (Round 2 had every block fetch the copies whole, 64 KB, and scan 4 096 bins: 3.0-4.5 us at the head of the
+            // select finish's chain.)
+            if (tid < 64) {
+                const uint32_t *g0 = d.hist0 + (size_t)p * HIST0_PAR;
+                const int idx = 63 - tid;            // (from the top: the scan then gives "keys above")
+                uint32_t v = 0;
 #pragma unroll
-                for (int j = 0; j < PER4; ++j) v[j] = make_uint4(0, 0, 0, 0);
-                for (int r = 0; r < HIST_REP; ++r)
+                for (int r = 0; r < COARSE_REP; ++r) v += g0[HIST0_FINE + r * COARSE_STRIDE + idx];
+                uint32_t incl = wave_incl_scan(v);
+                const uint32_t kk = (uint32_t)d.sel_k;
+                const u64 hit = __ballot(incl >= kk);          // the first run (from the top) at which k keys have been seen
+                const int lane_r = hit ? __ffsll((long long)hit) - 1 : 63;
+                const int run = 63 - lane_r;
+                const uint32_t above_run = (uint32_t)__builtin_amdgcn_readlane((int)(incl - v), lane_r);
+                uint32_t f = 0;
 #pragma unroll
-                    for (int j = 0; j < PER4; ++j) {
-                        const uint4 a = *(const uint4 *)(g0 + (size_t)r * SEL_BINS + 4 * (j * 256 + tid));
-                        v[j].x += a.x; v[j].y += a.y; v[j].z += a.z; v[j].w += a.w;
-                    }
-#pragma unroll
-                for (int j = 0; j < PER4; ++j) *(uint4 *)(h + 4 * (j * 256 + tid)) = v[j];
+                for (int r = 0; r < HIST_REP; ++r) f += g0[(size_t)r * SEL_BINS + run * 64 + idx];
+                const uint32_t incl_f = above_run + wave_incl_scan(f);
+                const u64 hit_f = __ballot(incl_f >= kk);
+                const int lane_f = hit_f ? __ffsll((long long)hit_f) - 1 : 63;
+                if (tid == lane_f) { s_out[0] = hit && hit_f ? (uint32_t)(run * 64 + 63 - lane_f) : 0u; s_out[1] = incl_f - f; }
             }
             __syncthreads();
-            uint32_t bucket, above;
-            sel_pick<256>(h, WIN_BINS, (uint32_t)d.sel_k, s_wave, s_out, &bucket, &above);
+            const uint32_t bucket = s_out[0], above = s_out[1];
             __syncthreads();
             if (bucket >= 1u && bucket <= (WIN_COARSE << WIN_FINE)) {
                 const uint32_t fine = bucket - 1u;
@@ -803,7 +823,7 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
         // the pass-0 histogram is consumed: clear it for its next use (here, not earlier: a barrier
         // waits for outstanding stores, and the record exchange above is the critical chain)
         if (d.sel_passes > 1)
-            for (int i = b * 256 + tid; i < HIST_REP * SEL_BINS; i += nblk * 256) d.hist0[(size_t)p * HIST_REP * SEL_BINS + i] = 0;
+            for (int i = b * 256 + tid; i < HIST0_PAR; i += nblk * 256) d.hist0[(size_t)p * HIST0_PAR + i] = 0;
     } else {
         T = d.ctr->sel_prefix[p];
         r = d.ctr->sel_krem[p];
@@ -997,7 +1017,7 @@ __global__ __launch_bounds__(RB) void k_sp_keys(Dev d, int p, int from_overlap) 
         atomicAdd(&h[(uint32_t)(key >> sel_shift(0))], 1u);
     }
     __syncthreads();
-    uint32_t *g0 = d.hist0 + (size_t)(p * HIST_REP + (blockIdx.x & (HIST_REP - 1))) * SEL_BINS;
+    uint32_t *g0 = d.hist0 + (size_t)p * HIST0_PAR + (size_t)(blockIdx.x & (HIST_REP - 1)) * SEL_BINS;
     for (int i = threadIdx.x; i < SEL_BINS; i += RB)
         if (h[i]) atomicAdd(&g0[i], h[i]);
 }
