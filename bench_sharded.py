@@ -99,6 +99,7 @@ def run_sharded(args):
     c0, c1 = htm.column_range
     bank = eng.upload_bank(noisy)
     ranks_seen = eng.shard_comm_size() if backend == "nccl" else dist.get_world_size()
+    in_graph = backend == "nccl" and eng.shard_graph_ok()
     log(f"[bench_sharded] setup {time.perf_counter() - t_setup:.1f}s incl. {pretrain} untimed pre-training steps (unsharded, on every rank) and the "
         f"hand-over to {world} shards; S={eng.info().segments} segments, {eng.info().local_segments} rows on rank 0; communicator of {ranks_seen} ranks")
 
@@ -218,8 +219,8 @@ def run_sharded(args):
                         patterns=w["patterns"], input_density=w["density"], flip_noise=w["noise"], pretrain_steps=pretrain,
                         segments=int(info.segments), segment_slots=w["segment_slots"], backend=backend, ranks_seen=int(ranks_seen),
                         exchange_bytes_per_rank=int(eng.shard_record_bytes()),
-                        exchange="in-library ncclAllGather, captured in the step's hipGraph" if backend == "nccl" else "host-staged gloo",
-                        hip_graph=backend == "nccl", launches_per_step=4, repetitions=reps, ranks_consistent=consistent),
+                        exchange=("in-library ncclAllGather, " + ("captured in the step's hipGraph" if in_graph else "launched eagerly (the preflight found it not capturable)")) if backend == "nccl" else "host-staged gloo",
+                        hip_graph=in_graph, launches_per_step=4, repetitions=reps, ranks_consistent=consistent),
             repetitions=[round(args.steps / t, 1) for t in times],
             roofline=roofline, cpu_baseline=cpu)
     dist.barrier()

@@ -69,6 +69,7 @@ EXPORTS = {
     "htm_shard_comm_init": (C.c_int, [C.c_void_p, C.c_void_p]),
     "htm_shard_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]),
     "htm_shard_comm_size": (C.c_int, [C.c_void_p]),
+    "htm_shard_graph_ok": (C.c_int, [C.c_void_p]),
     "htm_shard_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "htm_shard_group_run": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "htm_rccl_selftest": (C.c_int, [C.c_int32]),

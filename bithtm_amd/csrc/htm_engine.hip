@@ -58,6 +58,7 @@ struct htm_handle {
     const uint32_t *shard_bank;           // input of the step between htm_shard_begin and _finish
     int shard_n_inputs;
     bool shard_open;
+    bool shard_graph_ok;                  // htm_shard_comm_init's preflight: this communicator's all-gather replays correctly from a captured hipGraph
     int shard_front_wmode;                // htm_shard_run: the histogram form of the overlap computed ahead for the coming step
     std::map<std::tuple<int, int, const void *, int>, hipGraphExec_t> shard_graphs;      // (on rank 0's handle for a group in one process)
     void *rccl_comm;                      // ncclComm_t of htm_shard_comm_init (the exchange of htm_shard_step)
@@ -512,6 +513,7 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
     h->shard_open = false;
     h->window_known = false;
     h->shard_front_wmode = 0;
+    h->shard_graph_ok = false;
     h->rccl_comm = nullptr;
     h->shard_send = h->shard_recv = nullptr;
     h->phase_active = 0;
@@ -1378,7 +1380,54 @@ extern "C" int htm_shard_comm_init(htm_handle *h, const void *unique_id128) {
     int rc2 = ensure_shard_buffers(h);
     if (rc2) return rc2;
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    // Preflight on THIS communicator and THESE buffers, collectively (every rank runs the same two gathers): the exchange of a
+    // timestep launched eagerly -- its result checked: rank q's part of the gathered buffer must hold q's pattern -- and the same
+    // collective captured into a hipGraph and replayed.  htm_shard_run replays whole timesteps as graphs only if the second
+    // check passes here (a rank that launches eagerly and one that replays issue the same collective: the modes may differ).
+    {
+        const size_t rb = shard_record_bytes(h->d.n_cand);
+        std::vector<unsigned char> got(rb * (size_t)h->world);
+        auto check = [&]() -> bool {
+            if (hipStreamSynchronize(h->stream) != hipSuccess || hipMemcpy(got.data(), h->shard_recv, got.size(), hipMemcpyDeviceToHost) != hipSuccess) return false;
+            for (int q = 0; q < h->world; ++q)
+                for (size_t i = 0; i < rb; i += 997)
+                    if (got[(size_t)q * rb + i] != (unsigned char)(q + 1)) return false;
+            return true;
+        };
+        HIPCHK(h, hipMemsetAsync(h->shard_send, h->rank + 1, rb, h->stream));
+        HIPCHK(h, hipMemsetAsync(h->shard_recv, 0, rb * (size_t)h->world, h->stream));
+        int nrc = g_rccl.all_gather(h->shard_send, h->shard_recv, rb, 0, comm, h->stream);
+        if (nrc != 0 || !check()) { h->err = "htm_shard_comm_init: the all-gather over this communicator does not deliver the ranks' records"; return HTM_ERR_HIP; }
+        bool ok = h->stream != nullptr && hipMemsetAsync(h->shard_recv, 0, rb * (size_t)h->world, h->stream) == hipSuccess &&
+                  hipStreamSynchronize(h->stream) == hipSuccess;      // (the default stream cannot be captured)
+        hipGraph_t graph_obj = nullptr;
+        hipGraphExec_t exec = nullptr;
+        if (ok && hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            const bool in = g_rccl.all_gather(h->shard_send, h->shard_recv, rb, 0, comm, h->stream) == 0;
+            ok = hipStreamEndCapture(h->stream, &graph_obj) == hipSuccess && in && graph_obj && hipGraphInstantiate(&exec, graph_obj, nullptr, nullptr, 0) == hipSuccess;
+        } else {
+            ok = false;
+        }
+        // (every rank must issue the second gather, captured or not: the others are waiting in theirs)
+        if (ok) ok = hipGraphLaunch(exec, h->stream) == hipSuccess;
+        else ok = g_rccl.all_gather(h->shard_send, h->shard_recv, rb, 0, comm, h->stream) == 0 && false;
+        const bool delivered = check();
+        if (exec) hipGraphExecDestroy(exec);
+        if (graph_obj) hipGraphDestroy(graph_obj);
+        (void)hipGetLastError();
+        h->shard_graph_ok = ok && delivered;
+        HIPCHK(h, hipMemsetAsync(h->shard_send, 0, rb, h->stream));
+        HIPCHK(h, hipMemsetAsync(h->shard_recv, 0, rb * (size_t)h->world, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
     return HTM_OK;
+}
+
+// 1: htm_shard_run replays whole timesteps (the all-gather included) as hipGraphs on this handle; 0: it launches eagerly
+// (the preflight of htm_shard_comm_init found the collective not capturable, or the handle enqueues on the default stream)
+extern "C" int htm_shard_graph_ok(htm_handle *h) {
+    if (!h) return HTM_ERR_ARGUMENT;
+    return h->shard_graph_ok ? 1 : 0;
 }
 
 // ranks of the RCCL communicator htm_shard_step / htm_shard_run exchange over (ncclCommCount): what a scaling run reports
@@ -1513,6 +1562,7 @@ static int shard_run(htm_handle *const *hs, int n, const uint32_t *const *banks,
         if (h->seg_pinned) { const int seen = *(volatile int *)h->seg_pinned; h->seg_hint = std::max(h->seg_hint, seen); }
         if (h->profile) graph = false;
     }
+    if (n == 1 && !h0->shard_graph_ok) graph = false;      // (this communicator's collective does not replay from a graph: the preflight said so)
     const int kSpan = 16;
     for (int t = 0; t < n_steps;) {
         // steady state: steps whose overlap was computed ahead and that compute the next one's; the first and the last step

@@ -101,7 +101,9 @@ class ShardedHTM:
         boosting = boosting or ExponentialBoosting(column_dim, active_columns)
         distal = distal or PredictiveProjection(column_dim * cell_dim)
         torch.cuda.set_device(device)
-        self.stream = torch.cuda.current_stream()
+        # a stream of its own when the exchange is the library's (the default stream cannot be captured into a hipGraph); the
+        # caller's current stream when the caller gathers (its collective is ordered on that stream)
+        self.stream = torch.cuda.Stream(device=device) if all_gather is None else torch.cuda.current_stream()
         self.engine = Engine(input_dim, column_dim, cell_dim, active_columns, proximal=proximal, boosting=boosting,
                              distal=distal, seed=seed, device=device, stream=self.stream.cuda_stream,
                              shard_rank=rank, shard_world=world)

@@ -317,6 +317,10 @@ class Engine:
     def shard_comm_size(self):
         return int(self._check(self.lib.htm_shard_comm_size(self.h), "htm_shard_comm_size"))
 
+    def shard_graph_ok(self):
+        """Whether shard_run replays whole timesteps, the all-gather included, as hipGraphs (htm_shard_comm_init's preflight)."""
+        return bool(self._check(self.lib.htm_shard_graph_ok(self.h), "htm_shard_graph_ok"))
+
     def shard_step(self, input_bits=None, device_bank=None, n_inputs=1, learning=True):
         """One column-sharded timestep with the exchange (RCCL) inside the library."""
         if input_bits is not None:

@@ -261,6 +261,9 @@ int htm_shard_comm_init(htm_handle *h, const void *unique_id128);
 int htm_shard_step(htm_handle *h, const uint32_t *device_inputs, int32_t n_inputs, const uint32_t *packed_input,
                    int32_t learning);
 int htm_shard_comm_size(htm_handle *h);              /* ranks of that communicator (ncclCommCount), or a negative status */
+int htm_shard_graph_ok(htm_handle *h);               /* 1: htm_shard_comm_init's preflight (a record-sized all-gather over this
+                                                        communicator, checked, then captured into a hipGraph, replayed and checked
+                                                        again) passed and htm_shard_run replays graphs; 0: it launches eagerly */
 /* n_steps of htm_shard_step over a bank resident in device memory, without the host in the loop: the launches of whole
  * timesteps, the collective included, are replayed as hipGraphs (use_graph bit 0; RCCL's all-gather is captured like a
  * kernel -- where the runtime refuses, the call launches eagerly instead), and inside the call the overlap of step t + 1 on
