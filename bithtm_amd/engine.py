@@ -25,6 +25,8 @@ def pack_bits(bits, words):
     if bits.dtype != np.bool_:
         bits = bits.astype(np.bool_)
     packed = np.packbits(bits, bitorder="little")
+    if packed.size == words * 4:                    # (an input_dim that fills its words: no padding to add)
+        return packed.view(np.uint32)
     out = np.zeros(words * 4, dtype=np.uint8)
     out[:len(packed)] = packed
     return out.view(np.uint32)
