@@ -248,7 +248,10 @@ class TemporalMemory:
         self.distal_projection = distal_projection or PredictiveProjection(self.column_dim * self.cell_dim)     # networks.py:55
         # the device's own kind (exact type: a subclass may override the methods the fused step would skip) -- or any object
         # with the reference's PredictiveProjection interface, which is then called on the host (_process_host)
-        self._own_distal = type(self.distal_projection) is PredictiveProjection
+        # (more than 32 cells per column: the device's Temporal Memory step is built on one 32-bit word of cells per column;
+        # the segment store is not -- it lives in cell space -- so such a model keeps its projection on the device and runs
+        # the per-column part of TemporalMemory.process, networks.py:95-119, on the host: correct, not fast)
+        self._own_distal = type(self.distal_projection) is PredictiveProjection and cell_dim <= 32
         if not self._own_distal:
             if isinstance(self.distal_projection, PredictiveProjection):      # a subclass of the device's: tell it the model's shape
                 self.distal_projection.cell_dim, self.distal_projection.seed = cell_dim, seed

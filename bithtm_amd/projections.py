@@ -154,7 +154,7 @@ class PredictiveProjection:
     def bundle_segments(self):
         from . import _lib as L
         eng = self._ensure_engine()
-        return eng.read(L.F_SEGCOUNT, np.int32, eng.column_dim * eng.cell_dim)
+        return eng.read(L.F_SEGCOUNT, np.int32, eng.column_dim * eng.cell_dim)[:self.output_dim]
 
     @property
     def segment_projection(self):
@@ -179,16 +179,32 @@ class PredictiveProjection:
             self._jitter = (d["max_jittered_potential"], d["matching_segment_jittered_potential"])
 
     def _ensure_engine(self):
+        """An engine of its own for a projection used outside a fused TemporalMemory.  The projection lives in CELL space
+        (segments belong to cells, synapses point at cells; what a column is matters to TemporalMemory.process only), so
+        any model shape fits the device's layout of 32 cells per word: `cell_dim` <= 32 dividing output_dim keeps the
+        model's own columns, anything else -- 33 cells per column and more -- is laid out as ceil(output_dim / 32) words
+        of 32 cells, flat cell ids unchanged."""
         if self._engine is None:
             from .engine import Engine
             cell_dim = int(getattr(self, "cell_dim", None) or 32)
-            if self.output_dim % cell_dim:
-                raise ValueError("PredictiveProjection used on its own: output_dim must be a multiple of cell_dim (default 32; set .cell_dim)")
-            C = self.output_dim // cell_dim
+            if cell_dim > 32 or self.output_dim % cell_dim:
+                cell_dim = 32
+            C = -(-self.output_dim // cell_dim)
             self._engine = Engine(0, C, cell_dim, int(getattr(self, "active_columns", None) or C), distal=self,
                                   seed=int(getattr(self, "seed", 0)))
             self._last_state = None
         return self._engine
+
+    def _padded(self, a, fill=0):
+        """A per-cell array of the model (output_dim entries) in the engine's length (whole words of cells)."""
+        eng = self._ensure_engine()
+        a = np.asarray(a).reshape(-1)
+        n = eng.column_dim * eng.cell_dim
+        if len(a) == n:
+            return a
+        out = np.full(n, fill, dtype=a.dtype)
+        out[:len(a)] = a
+        return out
 
     def fill_jittered_potential_info(self, state, matching_segment_bundle=None):
         """projections.py:229-239 (the scan computed both with the keyed draws)."""
@@ -210,7 +226,9 @@ class PredictiveProjection:
         np.bitwise_or.at(words, flat // K, (np.uint32(1) << (flat % K).astype(np.uint32)))
         eng.tm_scan(words)
         eng.check_capacity()
-        st = PredictiveProjection.State(eng.read_distal(), jitter=return_jittered_potential_info)
+        d = eng.read_distal()
+        d["prediction"], d["max_jittered_potential"] = d["prediction"][:self.output_dim], d["max_jittered_potential"][:self.output_dim]
+        st = PredictiveProjection.State(d, jitter=return_jittered_potential_info)
         self._last_state = st
         return st
 
@@ -228,15 +246,21 @@ class PredictiveProjection:
             eng._epsilon = epsilon
         self.fill_jittered_potential_info(prev_state)
         learning_output = np.asarray(learning_output, dtype=np.int64).reshape(-1)
-        input_activation = np.asarray(input_activation, dtype=np.bool_).reshape(C, K)
+        input_activation = self._padded(np.asarray(input_activation, dtype=np.bool_)).reshape(C, K)
         # the previous step's side of the call: prev_state, input_activation, winner_input
-        eng.import_prev_state(np.asarray(prev_state.prediction).reshape(C, K) > epsilon, input_activation,
-                              None if winner_input is None else np.asarray(winner_input, dtype=np.int64), prev_state)
+        from types import SimpleNamespace
+        prev = SimpleNamespace(matching_segment=prev_state.matching_segment, segment_potential=prev_state.segment_potential,
+                               matching_segment_activation=prev_state.matching_segment_activation,
+                               matching_segment_active=prev_state.matching_segment_active,
+                               matching_segment_jittered_potential=prev_state.matching_segment_jittered_potential,
+                               max_jittered_potential=self._padded(np.asarray(prev_state.max_jittered_potential, dtype=np.float32)))
+        eng.import_prev_state(self._padded(np.asarray(prev_state.prediction)).reshape(C, K) > epsilon, input_activation,
+                              None if winner_input is None else np.asarray(winner_input, dtype=np.int64), prev)
         learn_mask = np.zeros(C * K, dtype=np.bool_)
         if output_learning is None:
             learn_mask[learning_output] = True                                    # :261-262
         else:
-            learn_mask[:] = np.asarray(output_learning, dtype=np.bool_).reshape(-1)
+            learn_mask[:] = self._padded(np.asarray(output_learning, dtype=np.bool_))
         unacc = learning_output[np.asarray(prev_state.max_jittered_potential)[learning_output] < np.float32(epsilon)]      # :271
         need = np.zeros(C * K, dtype=np.bool_)
         need[unacc] = True
@@ -244,4 +268,4 @@ class PredictiveProjection:
         from .engine import bool_to_words
         ww, uw = bool_to_words(learn_mask.reshape(C, K)), bool_to_words(need.reshape(C, K))
         cols = np.flatnonzero(ww)
-        eng.tm_update(cols, ww[cols], uw[cols], bool_to_words(np.asarray(output_punishment, dtype=np.bool_).reshape(C, K)))
+        eng.tm_update(cols, ww[cols], uw[cols], bool_to_words(self._padded(np.asarray(output_punishment, dtype=np.bool_)).reshape(C, K)))

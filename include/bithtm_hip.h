@@ -45,7 +45,8 @@ typedef struct htm_config {
     int32_t device;                     /* HIP device ordinal */
     int32_t input_dim;                  /* SpatialPooler.input_dim   (networks.py:18) */
     int32_t column_dim;                 /* column_dim                (networks.py:19,52) */
-    int32_t cell_dim;                   /* TemporalMemory.cell_dim   (networks.py:53), 1..32 */
+    int32_t cell_dim;                   /* TemporalMemory.cell_dim   (networks.py:53), 1..32 (a model with more cells per column keeps
+                                           its segment store on an engine of ceil(N / 32) columns of 32 cells: DESIGN.md section 7) */
     int32_t active_columns;             /* k                         (networks.py:20,137) */
     int32_t enable_sp;                  /* 0: handle is a stand-alone TemporalMemory */
     int32_t enable_tm;                  /* 0: handle is a stand-alone SpatialPooler */

@@ -242,8 +242,6 @@ def test_capacity_overflow_is_reported_not_truncated():
 
 def test_bad_arguments_fail_loudly():
     import bithtm_amd as B
-    with pytest.raises(B.HtmError):
-        B.HierarchicalTemporalMemory(64, 256, 33)                      # cell_dim > 32
     tm = B.TemporalMemory(256, 4)
     from types import SimpleNamespace
     with pytest.raises(B.HtmError):
@@ -655,3 +653,51 @@ def test_default_sized_pools_grow_like_the_references_arrays():
             fixed.process(bank[i])
             if i % 20 == 0:
                 fixed.engine.check_capacity()
+
+
+@pytest.mark.parametrize("K", [33, 64])
+def test_more_than_32_cells_per_column(K):
+    """networks.py:53 has no cap on cell_dim.  The device's fused Temporal Memory step is built on one 32-bit word of cells per
+    column; beyond that the segment store stays on the device (it lives in cell space: htm_tm_update / htm_tm_scan on an engine
+    laid out as words of 32 cells, flat cell ids unchanged) and the per-column part of TemporalMemory.process runs on the host.
+    Stand-alone and inside a HierarchicalTemporalMemory, against the oracle."""
+    import bithtm_amd as B
+    from types import SimpleNamespace
+    from oracle import HTMOracle, TMParams, TemporalMemoryOracle, canonical_synapses
+    C, k, seed = 320, 10, 17                               # (320 x 33 cells: not a whole number of 32-cell words)
+    tmp = TMParams(segment_activation_threshold=6, segment_matching_threshold=5, segment_sampling_synapses=12, permanence_punishment=0.1)
+    tm = B.TemporalMemory(C, K, distal_projection=B.PredictiveProjection(C * K, segment_slots=64, **{f: getattr(tmp, f) for f in tmp.__dataclass_fields__}), seed=seed)
+    assert not tm._own_distal
+    ora = TemporalMemoryOracle(C, K, tmp, seed=seed)
+    rng = np.random.RandomState(seed)
+    seqs = [np.sort(rng.choice(C, k, replace=False)) for _ in range(7)]
+    for t in range(70):
+        cols = seqs[int(rng.randint(7))] if rng.rand() < 0.1 else seqs[t % 7]
+        want = ora.step(cols, learning=t % 11 != 4)
+        got = tm.process(SimpleNamespace(active_column=cols), learning=t % 11 != 4)
+        assert got.cell_prediction.shape == (C, K)
+        assert np.array_equal(got.cell_prediction, want.cell_prediction) and np.array_equal(got.cell_activation, want.cell_activation), t
+        assert np.array_equal(got.winner_cell[0] * K + got.winner_cell[1], want.winner_cell[0] * K + want.winner_cell[1]), t
+        assert np.array_equal(got.distal_state.matching_segment, want.distal_state.matching_segment), t
+        assert np.array_equal(got.distal_state.segment_potential, want.distal_state.segment_potential), t
+        assert np.array_equal(np.asarray(got.distal_state.max_jittered_potential).view(np.int32), want.distal_state.max_jittered_potential.view(np.int32)), t
+    st = tm.distal_projection._engine.read_store()
+    S = ora.S
+    assert st["S"] == S > 50 and np.array_equal(st["seg_cell"], ora.seg_cell[:S]) and np.array_equal(st["seg_nsyn"], ora.seg_nsyn[:S])
+    a, b = canonical_synapses(st["seg_cell"], st["presyn"], st["perm"]), canonical_synapses(ora.seg_cell[:S], ora.presyn[:S], ora.perm[:S])
+    assert all(np.array_equal(x[1], y[1]) and np.array_equal(x[2].view(np.int32), y[2].view(np.int32)) for x, y in zip(a, b))
+    assert np.array_equal(tm.distal_projection.bundle_segments, ora.segcount)
+    # and as the Temporal Memory of a HierarchicalTemporalMemory (the Spatial Pooler steps an engine of its own)
+    I = 128
+    np.random.seed(seed)
+    full = HTMOracle(I, C, K, active_columns=k, seed=seed)
+    prox = B.DenseProjection(I, C)
+    prox.permanence = full.spatial_pooler.permanence.copy()
+    htm = B.HierarchicalTemporalMemory(I, C, K, active_columns=k, spatial_pooler=B.SpatialPooler(I, C, k, proximal_projection=prox), seed=seed)
+    assert htm.engine is None
+    bank = rng.rand(6, I) < 0.15
+    for t in range(40):
+        o_sp, o_tm = full.step(bank[t % 6])
+        s, m = htm.process(bank[t % 6])
+        assert np.array_equal(s.active_column, o_sp.active_column) and np.array_equal(m.cell_prediction, o_tm.cell_prediction), t
+        assert np.array_equal(m.active_column_bursting[:, 0], o_tm.active_column_bursting[:, 0]), t
