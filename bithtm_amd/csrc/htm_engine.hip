@@ -66,7 +66,6 @@ struct htm_handle {
     int G;                                // lanes per SP row
     int graph_steps;                      // steady-state steps per captured graph (BITHTM_GRAPH_STEPS)
     int eager_below;                      // calls of fewer steps than this launch eagerly (BITHTM_EAGER_BELOW)
-    int first_graph_steps;                // ... of the first graph of a call (BITHTM_FIRST_GRAPH_STEPS; 0 = like the others)
     bool emit_fused, emit_fused_open;     // the emit grid is resident at once in k_sp_emit / in k_open_emit (refreshed per call)
     bool emit_fits_lean;                  // ... and in k_learn_scan_emit
     int knob_lean, knob_fuse_tm, knob_shard_window, knob_scan_large, knob_step_window, knob_tail_rows;
@@ -642,10 +641,8 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
     h->seg_hint = 0;
     h->graph_steps = 16;
     if (const char *e = getenv("BITHTM_GRAPH_STEPS")) h->graph_steps = std::max(1, std::min(256, atoi(e)));
-    h->first_graph_steps = 0;
     h->eager_below = 64;
     if (const char *e = getenv("BITHTM_EAGER_BELOW")) h->eager_below = std::max(0, atoi(e));
-    if (const char *e = getenv("BITHTM_FIRST_GRAPH_STEPS")) h->first_graph_steps = std::max(0, std::min(256, atoi(e)));
     h->seg_pinned = nullptr;
     if (hipHostMalloc((void **)&h->seg_pinned, sizeof(int), hipHostMallocDefault) == hipSuccess) *h->seg_pinned = 0; else h->seg_pinned = nullptr;
     while (h->G < d.W4 && h->G < 64) h->G <<= 1;
@@ -1143,9 +1140,6 @@ static int run_or_prepare(htm_handle *h, const uint32_t *device_inputs, int32_t 
             const int steady = cont ? n_steps - t : n_steps - t - (lean ? 1 : 2);       // steps from here on that look ahead fully
             if (cont && steady > 1 && steady < 2 * kGraphSteps) span = steady;      // a continuing call's (last) stretch: one graph
             else if (steady >= kGraphSteps) span = kGraphSteps;
-            // the first graph of a call is a short one: the device starts on it while the host is still submitting the
-            // launches of the long one behind it (a graph's launches reach the device together: tools/first_graph.py)
-            if (t == 0 && h->first_graph_steps > 0 && span > h->first_graph_steps) span = h->first_graph_steps;
         }
         if (!dry) {
             if (!plan.sp_done && !plan.next_sp) enqueue_sp_front(h, device_inputs, n_inputs, p, step_wmode(h));    // eager
