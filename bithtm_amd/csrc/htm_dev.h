@@ -34,10 +34,8 @@ typedef unsigned long long u64;
 // moves up by 3: two launched 12-bit digits then resolve 3 more mantissa bits, and the bucket the select
 // finishes in-kernel is 8 times narrower (a crowded bucket is what makes `emit` slow).
 #define KEY_SHIFT 3
-__device__ __forceinline__ u64 select_key(double boosted) {
-    const u64 bits = (u64)__double_as_longlong(boosted);
-    return bits ? (bits - ((u64)(1023 - 150) << 52)) << KEY_SHIFT : 0ull;
-}
+__device__ __forceinline__ u64 select_key_bits(u64 bits) { return bits ? (bits - ((u64)(1023 - 150) << 52)) << KEY_SHIFT : 0ull; }
+__device__ __forceinline__ u64 select_key(double boosted) { return select_key_bits((u64)__double_as_longlong(boosted)); }
 
 // The windowed select of the three-launch schedule: ONE histogram pass.  The bins are not the key's top 12 bits but a
 // monotone function of the key that spends them where the k-th key is expected -- WIN_COARSE values of the top digit
@@ -60,6 +58,16 @@ __host__ __device__ __forceinline__ uint32_t win_bin(u64 key, uint32_t base) {
 __host__ __device__ __forceinline__ uint32_t win_base_for(u64 kth_key) {
     const uint32_t c = (uint32_t)(kth_key >> 52);
     return c > WIN_COARSE / 2 ? min(c - WIN_COARSE / 2, 4096u - WIN_COARSE) : 0u;
+}
+
+// The window of the column-sharded step's GLOBAL select (k_shard_select) starts 8 values of the top digit -- a factor of two:
+// the digit holds three mantissa bits -- below the previous step's k-th key (the k-th key of a new pattern is 1.5 times
+// lower at most), because there the keys below the window are not counted at all: of a step's 10-13 thousand candidates
+// (every rank's top-1 311) a tenth can win, and the histogram pass of one block is bound by its CU's LDS atomics.
+#define WIN_GLOBAL_BELOW 8
+__host__ __device__ __forceinline__ uint32_t win_base_global(u64 kth_key) {
+    const uint32_t c = (uint32_t)(kth_key >> 52);
+    return c > WIN_GLOBAL_BELOW ? min(c - WIN_GLOBAL_BELOW, 4096u - WIN_COARSE) : 0u;
 }
 
 // radix-select digit p covers key bits [shift, shift + bits): 12 bits from the top, the last one 4
@@ -86,6 +94,8 @@ struct Counters {
     int32_t n_bind[2];        // newly bound segments of the step (back of the work array, growing down)
     alignas(128) int32_t n_work_last;      // ... of the last completed step (telemetry)
     int32_t sel_fallbacks;    // steps whose top-k select took the in-kernel fallback (telemetry)
+    int32_t cand_exact;       // sharded: steps whose LOCAL select cut the threshold bin exactly (record exchange) instead of
+                              // handing the whole bin over (telemetry)
     uint32_t emit_epoch;      // bumped by every overlap launch: tags the records k_sp_emit's blocks exchange
     int32_t n_un;             // winners needing a new segment
     int32_t n_recycled, n_new, S_old;
@@ -104,12 +114,14 @@ struct Counters {
 };
 
 struct Dev {
-    int I, W, W4, Ipad, C, K, k, E, Scap, work_cap, sel_passes, colwords, low_zero, cand_d, cand_pairwise, cand_others, cand_speculate;
+    int I, W, W4, Ipad, C, K, k, E, Scap, work_cap, sel_passes, colwords, low_zero, cand_d, cand_pairwise, cand_others, cand_speculate, cand_take_all;
     int win_offset;           // test knob: added to the select window's base (a window that misses: the fallback every step)
     int world, c0, c1;        // this rank owns columns [c0, c1) (world == 1: everything)
     int sel_lo, sel_hi, sel_k; // the select works on the keys of columns [sel_lo, sel_hi) and finds their sel_k largest
                               // (unsharded: all columns, k; a shard selects its own candidates: [c0, c1), min(k, c1 - c0))
-    int Lcap, n_cand;         // sharded: local row capacity; candidates per rank in the exchange record = sel_k
+    int Lcap, n_cand;         // sharded: local row capacity; candidates a rank must offer = sel_k = min(k, own columns)
+    int cand_cap;             // ... and the candidate slots of its exchange record (>= n_cand: the local select may hand over the
+                              // whole threshold bin instead of cutting it, see role_emit)
     double sp_thr, sp_don, sp_doff;
     float coef, mom, dinc;
     double lrn_act, lrn_inact, pun_act, pun_inact;
@@ -204,6 +216,42 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(v), 63); }
 
+// The value lane `src` holds, src the same in every lane (a ballot's first set bit, a constant): v_readlane -- __shfl
+// compiles to ds_bpermute, a round trip through the LDS crossbar, whatever the source lane is.
+#ifdef BITHTM_BISECT_A
+__device__ __forceinline__ uint32_t wave_read(uint32_t v, int src) { return (uint32_t)__shfl((int)v, src); }
+__device__ __forceinline__ int wave_read(int v, int src) { return __shfl(v, src); }
+#else
+__device__ __forceinline__ uint32_t wave_read(uint32_t v, int src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, src); }
+__device__ __forceinline__ int wave_read(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
+#endif
+__device__ __forceinline__ u64 wave_read(u64 v, int src) {
+#ifdef BITHTM_BISECT_A
+    return ((u64)(uint32_t)__shfl((int)(v >> 32), src) << 32) | (uint32_t)__shfl((int)(uint32_t)v, src);
+#endif
+    return ((u64)(uint32_t)__builtin_amdgcn_readlane((int)(v >> 32), src) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src);
+}
+
+// op over the 64 lanes' 64-bit values (op associative and commutative, ident its identity), the result in every lane: the
+// DPP pattern of wave_incl_scan, two moves and one op per step, instead of six pairs of ds_bpermute.
+template <typename Op>
+__device__ __forceinline__ u64 wave_reduce64(u64 v, u64 ident, Op op) {
+    const int il = (int)(uint32_t)ident, ih = (int)(ident >> 32);
+#define BITHTM_DPP64(src, ctrl, rm, bm) \
+    (((u64)(uint32_t)__builtin_amdgcn_update_dpp(ih, (int)((src) >> 32), ctrl, rm, bm, false) << 32) | \
+     (uint32_t)__builtin_amdgcn_update_dpp(il, (int)(uint32_t)(src), ctrl, rm, bm, false))
+    u64 t = v;
+    t = op(t, BITHTM_DPP64(v, 0x111, 0xf, 0xf));
+    t = op(t, BITHTM_DPP64(v, 0x112, 0xf, 0xf));
+    t = op(t, BITHTM_DPP64(v, 0x113, 0xf, 0xf));
+    t = op(t, BITHTM_DPP64(t, 0x114, 0xf, 0xe));
+    t = op(t, BITHTM_DPP64(t, 0x118, 0xf, 0xc));
+    t = op(t, BITHTM_DPP64(t, 0x142, 0xa, 0xf));
+    t = op(t, BITHTM_DPP64(t, 0x143, 0xc, 0xf));
+#undef BITHTM_DPP64
+    return wave_read(t, 63);
+}
+
 // Sum over each aligned group of 8 lanes, valid in the group's FIRST lane only (row_shl:1,2,3 then 4:
 // four VALU ops instead of three ds_bpermute round trips).
 __device__ __forceinline__ int group8_sum_first(int v) {
@@ -224,12 +272,19 @@ __device__ __forceinline__ int group8_sum_all(int v) {
     return v;
 }
 
-template <int BS>
+// A block barrier that orders LDS traffic only.  __syncthreads() is a workgroup-scope release + barrier + acquire: the
+// release waits for EVERY outstanding vector-memory operation of the wave -- gfx9's vmcnt counts loads, stores and atomics
+// alike --, so a barrier behind a global store (a published record, a cleared histogram, a winner's words) or behind
+// loads that are not needed yet costs their round trip, about a microsecond.  Where the threads of a block only talk
+// through LDS, this is the barrier: LDS (and scalar) operations drained, then s_barrier.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int BS, bool LDS_ONLY = false>
 __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *s_wave, uint32_t &total) {
     const int lane = lane_id(), wv = threadIdx.x >> 6;
     const uint32_t x = wave_incl_scan(v);
     if (lane == 63) s_wave[wv] = x;
-    __syncthreads();
+    if (LDS_ONLY) lds_barrier(); else __syncthreads();
     uint32_t woff = 0, tot = 0;
 #pragma unroll
     for (int i = 0; i < BS / 64; ++i) {
@@ -237,7 +292,7 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *s_wave
         if (i < wv) woff += t;
         tot += t;
     }
-    __syncthreads();
+    if (LDS_ONLY) lds_barrier(); else __syncthreads();
     total = tot;
     return woff + x - v;
 }
@@ -249,7 +304,7 @@ __device__ __forceinline__ int wave_append(int *counter, bool pred) {
     int leader = __ffsll((long long)m) - 1;
     int base = 0;
     if (lane_id() == leader) base = atomicAdd(counter, __popcll(m));
-    base = __shfl(base, leader);
+    base = wave_read(base, leader);
     return pred ? base + __popcll(m & lanemask_lt()) : -1;
 }
 
@@ -266,7 +321,7 @@ __device__ __forceinline__ void hist_add(uint32_t *h, uint32_t digit, bool activ
     u64 todo = __ballot(active);
     while (todo) {
         const int leader = __ffsll((long long)todo) - 1;
-        const uint32_t dl = __shfl(digit, leader);
+        const uint32_t dl = wave_read(digit, leader);
         const u64 same = __ballot(active && digit == dl) & todo;
         if (lane_id() == leader) atomicAdd(&h[dl], (uint32_t)__popcll(same));
         todo &= ~same;
@@ -280,7 +335,7 @@ __device__ __forceinline__ void hist_add_tie(uint32_t *h, uint32_t digit, bool a
     const u64 act = __ballot(active);
     if (!act) return;
     const int leader = __ffsll((long long)act) - 1;
-    const uint32_t dl = __shfl(digit, leader);
+    const uint32_t dl = wave_read(digit, leader);
     const u64 same = __ballot(active && digit == dl);
     if (lane_id() == leader) atomicAdd(&h[dl], (uint32_t)__popcll(same));
     if (active && digit != dl) atomicAdd(&h[digit], 1u);

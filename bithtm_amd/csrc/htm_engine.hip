@@ -554,6 +554,7 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
     // the select: all columns and their k largest; a shard selects its own candidates for the exchange
     d.sel_lo = d.c0; d.sel_hi = d.c1;
     d.sel_k = d.n_cand = std::min(d.k, d.c1 - d.c0);
+    d.cand_cap = shard_cand_cap(d.n_cand, d.c1 - d.c0);
     d.sp_thr = cfg->sp_permanence_threshold; d.sp_don = cfg->sp_delta_on; d.sp_doff = cfg->sp_delta_off;
     d.coef = cfg->boost_coefficient; d.mom = cfg->duty_momentum; d.dinc = cfg->duty_increment;
     d.lrn_act = cfg->tm_learn_active; d.lrn_inact = cfg->tm_learn_inactive;
@@ -730,6 +731,7 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
         if (const char *e = getenv("BITHTM_CAND_PAIRWISE")) d.cand_pairwise = std::max(0, atoi(e));     // test knobs
         d.win_offset = getenv("BITHTM_SEL_WINDOW_OFFSET") ? std::max(0, atoi(getenv("BITHTM_SEL_WINDOW_OFFSET"))) : 0;
         d.cand_speculate = getenv("BITHTM_CAND_SPECULATE") ? atoi(getenv("BITHTM_CAND_SPECULATE")) != 0 : 1;     // (test knob: 0 = always the general path)
+        d.cand_take_all = getenv("BITHTM_CAND_TAKE_ALL") ? atoi(getenv("BITHTM_CAND_TAKE_ALL")) != 0 : 1;      // (test knob: 0 = a shard's local select always cuts exactly)
         d.cand_others = CAND_OTHERS;
         if (const char *e = getenv("BITHTM_CAND_OTHERS")) d.cand_others = std::max(0, std::min(CAND_OTHERS, atoi(e)));
     }
@@ -1194,7 +1196,7 @@ static int ensure_shard_buffers(htm_handle *h);
 
 extern "C" int64_t htm_shard_record_bytes(htm_handle *h) {
     if (!h) return HTM_ERR_ARGUMENT;
-    return (int64_t)shard_record_bytes(h->d.n_cand);
+    return (int64_t)shard_record_bytes(h->d.cand_cap);
 }
 
 // front_done: this step's overlap (own columns) was computed beside the previous step's learning and scan (htm_shard_run)
@@ -1379,7 +1381,7 @@ extern "C" int htm_shard_comm_init(htm_handle *h, const void *unique_id128) {
     // collective captured into a hipGraph and replayed.  htm_shard_run replays whole timesteps as graphs only if the second
     // check passes here (a rank that launches eagerly and one that replays issue the same collective: the modes may differ).
     {
-        const size_t rb = shard_record_bytes(h->d.n_cand);
+        const size_t rb = shard_record_bytes(h->d.cand_cap);
         std::vector<unsigned char> got(rb * (size_t)h->world);
         auto check = [&]() -> bool {
             if (hipStreamSynchronize(h->stream) != hipSuccess || hipMemcpy(got.data(), h->shard_recv, got.size(), hipMemcpyDeviceToHost) != hipSuccess) return false;
@@ -1435,7 +1437,7 @@ extern "C" int htm_shard_comm_size(htm_handle *h) {
 
 static int ensure_shard_buffers(htm_handle *h) {
     if (h->shard_send) return 0;
-    const size_t rb = shard_record_bytes(h->d.n_cand);
+    const size_t rb = shard_record_bytes(h->d.cand_cap);
     int rc = dalloc(h, &h->shard_send, rb);
     rc |= dalloc(h, &h->shard_recv, rb * (size_t)h->world);
     return rc;
@@ -1470,7 +1472,7 @@ extern "C" int htm_shard_group_step(htm_handle *const *handles, int32_t n, const
         rc = shard_enqueue_begin(h, h->shard_bank, h->shard_n_inputs, h->shard_send);
         if (rc) return rc;
     }
-    const size_t rb = shard_record_bytes(handles[0]->d.n_cand);
+    const size_t rb = shard_record_bytes(handles[0]->d.cand_cap);
     for (int r = 0; r < n; ++r)
         for (int q = 0; q < n; ++q)
             HIPCHK(handles[r], hipMemcpyAsync(handles[r]->shard_recv + (size_t)q * rb, handles[q]->shard_send, rb, hipMemcpyDeviceToDevice, handles[r]->stream));
@@ -1498,7 +1500,7 @@ extern "C" int htm_shard_step(htm_handle *h, const uint32_t *device_inputs, int3
     }
     int rc = shard_enqueue_begin(h, bank, n_inputs, h->shard_send);
     if (rc) return rc;
-    const size_t rb = shard_record_bytes(h->d.n_cand);
+    const size_t rb = shard_record_bytes(h->d.cand_cap);
     const int nrc = g_rccl.all_gather(h->shard_send, h->shard_recv, rb, /* ncclChar */ 0, h->rccl_comm, h->stream);
     if (nrc != 0) { h->err = std::string("ncclAllGather: ") + (g_rccl.get_error_string ? g_rccl.get_error_string(nrc) : "failed"); return HTM_ERR_HIP; }
     return shard_enqueue_finish(h, bank, n_inputs, h->shard_recv, learning ? 1 : 0);
@@ -1512,11 +1514,11 @@ extern "C" int htm_shard_step(htm_handle *h, const uint32_t *device_inputs, int3
 static int shard_exchange(htm_handle *const *hs, int n) {
     if (n == 1) {
         htm_handle *h = hs[0];
-        const int nrc = g_rccl.all_gather(h->shard_send, h->shard_recv, shard_record_bytes(h->d.n_cand), /* ncclChar */ 0, h->rccl_comm, h->stream);
+        const int nrc = g_rccl.all_gather(h->shard_send, h->shard_recv, shard_record_bytes(h->d.cand_cap), /* ncclChar */ 0, h->rccl_comm, h->stream);
         if (nrc != 0) { h->err = std::string("ncclAllGather: ") + (g_rccl.get_error_string ? g_rccl.get_error_string(nrc) : "failed"); return HTM_ERR_HIP; }
         return 0;
     }
-    const size_t rb = shard_record_bytes(hs[0]->d.n_cand);
+    const size_t rb = shard_record_bytes(hs[0]->d.cand_cap);
     for (int r = 0; r < n; ++r)
         for (int q = 0; q < n; ++q)
             HIPCHK(hs[r], hipMemcpyAsync(hs[r]->shard_recv + (size_t)q * rb, hs[q]->shard_send, rb, hipMemcpyDeviceToDevice, hs[r]->stream));
@@ -1715,6 +1717,7 @@ extern "C" int htm_get_info(htm_handle *h, htm_info *out) {
     out->appended_segments = c.n_un ? c.n_new : 0;
     out->work_items = c.n_work_last;
     out->select_fallbacks = c.sel_fallbacks;
+    out->candidate_exact_steps = c.cand_exact;
     if (c.error) {
         h->err = std::string("capacity exhausted:") + ((c.error & 1) ? " segment pool (segment_capacity)" : "") +
                  ((c.error & 2) ? " synapse slots (segment_slots)" : "") + ((c.error & 4) ? " work list / growth staging" : "") +

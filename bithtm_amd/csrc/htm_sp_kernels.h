@@ -45,8 +45,8 @@ __device__ __forceinline__ void role_overlap(const Dev &d, const uint32_t *__res
             d.ctr->sel_pass_prefix[sp][0] = 0;
             d.ctr->sel_pass_krem[sp][0] = (uint32_t)d.sel_k;
         }
-        __syncthreads();
-    }
+        lds_barrier();                             // (LDS only: the zeroing stores above are for later launches -- the rows' loads
+    }                                              // below do not wait for them)
     const uint32_t wbase = wmode ? d.ctr->sel_win[sp] : 0u;
     static_assert(WIN_BINS <= SEL_BINS - SEL_COARSE, "the runs' sums live behind the window's bins in the LDS histogram");
     uint32_t *hc = h + SEL_BINS - SEL_COARSE;       // (window mode only)
@@ -105,7 +105,7 @@ __device__ __forceinline__ void role_overlap(const Dev &d, const uint32_t *__res
         }
     }
     if (!do_hist) return;
-    __syncthreads();
+    lds_barrier();                                 // (LDS only: the flush does not wait for the stores of the keys)
     uint32_t *g0 = d.hist0 + (size_t)sp * HIST0_PAR + (size_t)(blk & (HIST_REP - 1)) * SEL_BINS;
     uint32_t *gc = d.hist0 + (size_t)sp * HIST0_PAR + HIST0_FINE + (size_t)(blk & (COARSE_REP - 1)) * COARSE_STRIDE;
     const int n_fine = wmode ? SEL_BINS - SEL_COARSE : SEL_BINS;
@@ -342,16 +342,26 @@ __device__ __forceinline__ void tm_activate_column(const Dev &d, int p, int want
 
 // ---- column sharding: the exchange record ----------------------------------------------------
 // One fixed-size record per rank and timestep (oracle/sharded.py record_nbytes): the rank's own
-// top-min(k, own columns) candidates, in ascending column order, each with the cell words the column WOULD have if
-// it became active (they only depend on the owner's previous predictions, segment maxima and segment counts), and
-// the global ids of own segments that fell below the matching threshold while learning (the lowest-id-first
-// recycling rule of projections.py:80-81 is global).  KL = candidates per rank:
-//   [boosted f64 x KL][column | bursting << 31  u32 x KL][winner word u32 x KL][needs-a-segment word u32 x KL]
-//   [n_dead u32][dead ids u32 x DEAD_CAP], padded to 16 bytes
-// (the active-cell word is not sent: it is all cells of a bursting column and the winner word otherwise)
-__host__ __device__ __forceinline__ size_t shard_record_bytes(int n_cand) {
-    size_t n = (size_t)n_cand * 20 + 4 + 4 * DEAD_CAP;
+// candidates -- a superset of its top-min(k, own columns), n of them, n <= CAP slots --, in ascending column order, each
+// with the cell words the column WOULD have if it became active (they only depend on the owner's previous predictions,
+// segment maxima and segment counts), and the global ids of own segments that fell below the matching threshold while
+// learning (the lowest-id-first recycling rule of projections.py:80-81 is global).  CAP = candidate slots per rank:
+//   [boosted f64 x CAP][column | bursting << 31  u32 x CAP][winner word u32 x CAP][needs-a-segment word u32 x CAP]
+//   [n_dead u32][dead ids u32 x DEAD_CAP][n u32], padded to 16 bytes
+// (the active-cell word is not sent: it is all cells of a bursting column and the winner word otherwise; the boosted
+// overlaps of the CAP - n unused slots are CAND_PAD, all bits set: the global select tells a candidate from a free slot by
+// the value it loads anyway)
+#define CAND_PAD (~0ull)
+__host__ __device__ __forceinline__ size_t shard_record_count_offset(int cap) { return (size_t)cap * 20 + 4 + 4 * DEAD_CAP; }
+__host__ __device__ __forceinline__ size_t shard_record_bytes(int cap) {
+    size_t n = shard_record_count_offset(cap) + 4;
     return (n + 15) / 16 * 16;
+}
+// candidate slots for a rank that must offer n_cand of n_local columns: room for the threshold bin of the windowed
+// histogram on top (128 steps per binade: a hundred-odd of 8 192 keys share the bin of the 1 311th)
+__host__ __device__ __forceinline__ int shard_cand_cap(int n_cand, int n_local) {
+    const int slack = n_cand / 4 > 64 ? n_cand / 4 : 64;
+    return n_cand + slack < n_local ? n_cand + slack : n_local;
 }
 
 // ---- finishing the select inside k_sp_emit ---------------------------------------------------
@@ -373,7 +383,7 @@ __host__ __device__ __forceinline__ size_t shard_record_bytes(int n_cand) {
 
 // pick the bucket that contains the krem-th largest key of a histogram held in LDS
 // (bins [0, nb)); all BS threads call; returns bucket and the keys above it
-template <int BS>
+template <int BS, bool LDS_ONLY = false>
 __device__ __forceinline__ void sel_pick(const uint32_t *h, int nb, uint32_t krem, uint32_t *s_wave,
                                          uint32_t *s_out /*[2]*/, uint32_t *bucket, uint32_t *above_out) {
     const int tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
@@ -387,7 +397,7 @@ __device__ __forceinline__ void sel_pick(const uint32_t *h, int nb, uint32_t kre
     const uint32_t pre = wave_incl_scan(cs);
     const uint32_t wtot = (uint32_t)__builtin_amdgcn_readlane((int)pre, 63);
     if (lane == 0) s_wave[wv] = wtot;
-    __syncthreads();
+    if (LDS_ONLY) lds_barrier(); else __syncthreads();
     uint32_t above = wtot - pre;
     for (int w = wv + 1; w < BS / 64; ++w) above += s_wave[w];
     if (above < krem && krem <= above + cs) {
@@ -397,7 +407,7 @@ __device__ __forceinline__ void sel_pick(const uint32_t *h, int nb, uint32_t kre
             above += hb;
         }
     }
-    __syncthreads();
+    if (LDS_ONLY) lds_barrier(); else __syncthreads();
     *bucket = s_out[0];
     *above_out = s_out[1];
 }
@@ -430,7 +440,7 @@ struct EmitShared {
     uint32_t predw[256];
     int col[256];
     uint32_t wave[4];
-    uint32_t gt, eq, out[2], flags, krem, r;
+    uint32_t gt, eq, out[4], flags, krem, r;
     int n, nraw, ne;
 };
 
@@ -474,6 +484,8 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
         u64 P;
         uint32_t krem;
         int lowbits = sel_shift(d.sel_passes - 1);              // key bits not resolved by launches
+        bool take_all = false;                                  // (a shard's candidates: the whole threshold bin fits the record)
+        uint32_t n_all = 0;
         if (wmode) {
             // The bin of the k-th key, and the keys above it: from the runs' sums first (64 of them, one wave, one read of the
             // copies), then from the 64 bins of the chosen run -- two dependent reads of a kilobyte each, no block-wide scan.
@@ -497,11 +509,13 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
                 const uint32_t incl_f = above_run + wave_incl_scan(f);
                 const u64 hit_f = __ballot(incl_f >= kk);
                 const int lane_f = hit_f ? __ffsll((long long)hit_f) - 1 : 63;
-                if (tid == lane_f) { s_out[0] = hit && hit_f ? (uint32_t)(run * 64 + 63 - lane_f) : 0u; s_out[1] = incl_f - f; }
+                if (tid == lane_f) { s_out[0] = hit && hit_f ? (uint32_t)(run * 64 + 63 - lane_f) : 0u; s_out[1] = incl_f - f; s_out[2] = f; }
             }
             __syncthreads();
-            const uint32_t bucket = s_out[0], above = s_out[1];
+            const uint32_t bucket = s_out[0], above = s_out[1], in_bin = s_out[2];
             __syncthreads();
+            take_all = local && d.cand_take_all && bucket >= 1u && bucket <= (WIN_COARSE << WIN_FINE) && above + in_bin <= (uint32_t)d.cand_cap;
+            n_all = above + in_bin;
             if (bucket >= 1u && bucket <= (WIN_COARSE << WIN_FINE)) {
                 const uint32_t fine = bucket - 1u;
                 P = ((u64)(d.ctr->sel_win[p] + (fine >> WIN_FINE)) << 52) | ((u64)(fine & ((1u << WIN_FINE) - 1u)) << WIN_LOWBITS);
@@ -517,6 +531,102 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
         }
         EMIT_STAMP(1);                               // (the launched part of the select is resolved)
         const u64 hiP = lowbits < 64 ? P >> lowbits : 0ull, hi = lowbits < 64 ? my_key >> lowbits : 0ull;
+        if (take_all) {
+            // A shard's candidates only have to CONTAIN its top-min(k, own columns): when the bins above the threshold bin and the
+            // bin itself fit the record's slots -- every block sees that in the histogram, so all decide alike -- every key of
+            // the bin goes in and nothing is left to resolve: no record exchange, no k-th key.  What the blocks still owe each
+            // other is a count (where in the record a block's candidates start), published first and read last: the cell words
+            // of the block's candidates are computed in between.
+            const bool sel = c < d.sel_hi && hi >= hiP;
+            uint32_t total;
+            const uint32_t ex = block_excl_scan<256, true>(sel ? 1u : 0u, s_wave, total);
+            const uint32_t tag2 = epoch | 0x800u;
+            if (tid == 0) __hip_atomic_store(&d.sel_blk[b], (tag2 << 20) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (sel) s_col[ex] = c;
+            lds_barrier();                       // (LDS only: not the published count's round trip, not the loads in flight)
+            EMIT_STAMP(2);
+            uint32_t *s_cw = h, *s_wn = h + 256, *s_un = h + 512;      // (the histogram's LDS is free on this path)
+            double *s_bo = (double *)(h + 768);
+            const int n_sel = (int)total;
+            {
+                const int has_distal = d.ctr->has_distal;
+                const uint32_t step = d.ctr->step[p];
+                constexpr int CPP = 4;
+                for (int i0 = 0; i0 < n_sel; i0 += 8 * CPP) {
+                    int a[CPP];
+                    bool ok[CPP];
+                    ColumnLoads l[CPP];
+                    double bo[CPP];
+#pragma unroll
+                    for (int u = 0; u < CPP; ++u) {
+                        const int i = i0 + u * 8 + (tid >> 5);
+                        ok[u] = i < n_sel;
+                        a[u] = ok[u] ? s_col[i] : d.c0;
+                        l[u] = tm_column_loads(d, p, ok[u], a[u], has_distal);
+                        bo[u] = d.boosted[p][a[u]];
+                    }
+#pragma unroll
+                    for (int u = 0; u < CPP; ++u) {
+                        const ColumnWords w = tm_column_compute(d, 1, ok[u], a[u], ok[u] ? s_predw[a[u] - cbase] : 0u, l[u], has_distal, step);
+                        const int i = i0 + u * 8 + (tid >> 5);
+                        if (ok[u] && (lane & 31) == 0) {
+                            s_bo[i] = bo[u];
+                            s_cw[i] = (uint32_t)a[u] | (w.burst ? 0x80000000u : 0u);
+                            s_wn[i] = w.winner;
+                            s_un[i] = w.unacc;
+                        }
+                    }
+                }
+            }
+            // everybody's counts (all of them, not just the earlier blocks': a block that has published has read the histogram,
+            // which is cleared below)
+            uint32_t before = 0;
+            for (int i = tid; i < nblk; i += 256) {
+                uint32_t v = 0;
+                int spins = 0;
+                do {
+                    v = __hip_atomic_load(&d.sel_blk[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((v >> 20) == tag2) break;
+                    __builtin_amdgcn_s_sleep(1);
+                } while (++spins < (1 << 22));
+                if ((v >> 20) != tag2) atomicOr(&d.ctr->error, 16);
+                if (i < b) before += v & 0xFFFFFu;
+            }
+            before = wave_sum(before);
+            if (lane == 0 && before) atomicAdd(&s_gt, before);
+            lds_barrier();
+            EMIT_STAMP(3);
+            const int first_pos = (int)s_gt;
+            {
+                const int cap = d.cand_cap;
+                double *r_boost = (double *)d.send;
+                uint32_t *r_col = (uint32_t *)(d.send + (size_t)cap * 8), *r_win = r_col + cap, *r_unacc = r_win + cap;
+                if (tid < n_sel && first_pos + tid < cap) {
+                    const int pos = first_pos + tid;
+                    r_boost[pos] = s_bo[tid];
+                    r_col[pos] = s_cw[tid];
+                    r_win[pos] = s_wn[tid];
+                    r_unacc[pos] = s_un[tid];
+                }
+                for (int i = (int)n_all + b * 256 + tid; i < cap; i += nblk * 256) ((u64 *)r_boost)[i] = CAND_PAD;
+                if (b == 0) {
+                    uint32_t *r_dead = r_unacc + cap;
+                    const int n = min(d.dead_list[0], DEAD_CAP);
+                    if (tid == 0) {
+                        r_dead[0] = (uint32_t)n;
+                        *(uint32_t *)(d.send + shard_record_count_offset(cap)) = n_all;
+                        // (the coming step's window around this bin; the k-th key itself is not known on this path)
+                        d.ctr->sel_win[p ^ 1] = min(win_base_for(P) + (uint32_t)d.win_offset, 4096u - WIN_COARSE);
+                    }
+                    for (int j = tid; j < n; j += 256) r_dead[1 + j] = (uint32_t)d.dead_list[1 + j];
+                }
+            }
+            if (d.sel_passes > 1)
+                for (int i = b * 256 + tid; i < HIST0_PAR; i += nblk * 256) d.hist0[(size_t)p * HIST0_PAR + i] = 0;
+            EMIT_STAMP(4);
+            EMIT_STAMP(5);
+            return;
+        }
         const bool c_gt = c < d.sel_hi && hi > hiP, c_cand = c < d.sel_hi && hi == hiP;
         // ---- this block's record
         {
@@ -525,7 +635,7 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
             u64 todo = __ballot(c_cand);
             while (todo) {                           // group equal bucket keys inside the wave
                 const int leader = __ffsll((long long)todo) - 1;
-                const u64 kl = ((u64)__shfl((uint32_t)(my_key >> 32), leader) << 32) | __shfl((uint32_t)my_key, leader);
+                const u64 kl = wave_read(my_key, leader);
                 const u64 same = __ballot(c_cand && my_key == kl) & todo;
                 if (lane == leader) {
                     const int slot = atomicAdd(&s_nraw, 1);
@@ -571,8 +681,8 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
             if (alive && pos >= 1 && pos < CAND_D)
                 __hip_atomic_store(rec + pos, etag | ((u64)cnt << 40) | (mine >> d.low_zero), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int l0 = ma ? __ffsll((long long)ma) - 1 : 0;      // the lane of pair 0
-            const u64 k0 = ((u64)__shfl((uint32_t)(mine >> 32), l0) << 32) | __shfl((uint32_t)mine, l0);
-            const uint32_t c0 = __shfl(cnt, l0);
+            const u64 k0 = wave_read(mine, l0);
+            const uint32_t c0 = wave_read(cnt, l0);
             if (tid == 0) {
                 const u64 pair0 = (ma && inline_ok) ? (((u64)(c0 & 0x1FFu) << 29) | (k0 >> d.low_zero)) : 0ull;
                 __hip_atomic_store(rec, etag | (overflow ? (1ull << 51) : 0ull) | ((u64)min(n_pairs, CAND_D) << 47) | ((u64)my_gt_hi << 38) | pair0,
@@ -616,7 +726,7 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
                 if (!mh) break;                       // (wave-uniform: np only shrinks with j)
                 int base = 0;
                 if (lane == __ffsll((long long)mh) - 1) base = atomicAdd(&s_ne, __popcll(mh));
-                base = __shfl(base, __ffsll((long long)mh) - 1);
+                base = wave_read(base, __ffsll((long long)mh) - 1);
                 if (has) {
                     const int slot = base + __popcll(mh & lanemask_lt());
                     if (slot < CAND_MAX) {
@@ -632,10 +742,7 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
         }
         // (the heaviest pair of all: for the many-way tie below -- settled here, before the barrier everybody needs anyway)
         if (__any(heaviest != 0)) {
-            for (int o = 32; o > 0; o >>= 1) {
-                const u64 other = ((u64)__shfl_xor((uint32_t)(heaviest >> 32), o) << 32) | __shfl_xor((uint32_t)heaviest, o);
-                heaviest = max(heaviest, other);
-            }
+            heaviest = wave_reduce64(heaviest, 0ull, [](u64 a, u64 b) { return a > b ? a : b; });
             if (lane == 0) atomicMax((unsigned long long *)&s_T, heaviest);
         }
         __syncthreads();
@@ -687,8 +794,8 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
                         if (mu) bu = atomicAdd(&sh->n_others, __popcll(mu));
                         if (md) bd = (int)atomicAdd(&s_mh[2], (uint32_t)__popcll(md));
                     }
-                    bu = __shfl(bu, 0);
-                    bd = __shfl(bd, 0);
+                    bu = wave_read(bu, 0);
+                    bd = wave_read(bd, 0);
                     if (up) {
                         const int pos = bu + __popcll(mu & lanemask_lt());
                         if (pos < CAND_OTHERS) { sh->ok[pos] = ke; sh->oc[pos] = ce; }
@@ -828,12 +935,12 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
         T = d.ctr->sel_prefix[p];
         r = d.ctr->sel_krem[p];
     }
-    __syncthreads();
+    lds_barrier();                                   // (LDS only: the histogram's clearing stores are not waited for)
     EMIT_STAMP(4);                                   // (the k-th key is known)
     uint32_t flag = 0;
     if (c < d.sel_hi) flag = (my_key > T) ? 1u : ((my_key == T) ? 0x10000u : 0u);
     uint32_t total;
-    const uint32_t ex = block_excl_scan<256>(flag, s_wave, total);
+    const uint32_t ex = block_excl_scan<256, true>(flag, s_wave, total);
     if (second_round || !fused) {
         uint32_t g = 0, e = 0;
         if (fused) {                                // tagged words, second round of this step
@@ -864,7 +971,7 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
         e = wave_sum(e);
         if (lane == 0) { atomicAdd(&s_gt, g); atomicAdd(&s_eq, e); }
     }
-    __syncthreads();
+    lds_barrier();
     const uint32_t gt_before = s_gt, eq_before = s_eq;
     const uint32_t g_run = gt_before + (ex & 0xFFFFu), e_run = eq_before + (ex >> 16);
     const int first_pos = (int)(gt_before + min(eq_before, r));
@@ -901,7 +1008,7 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
     const int n_sel = s_n;
     if (local) {                                   // this block's candidates into the exchange record
         double *r_boost = (double *)d.send;
-        uint32_t *r_col = (uint32_t *)(d.send + (size_t)d.n_cand * 8), *r_win = r_col + d.n_cand, *r_unacc = r_win + d.n_cand;
+        uint32_t *r_col = (uint32_t *)(d.send + (size_t)d.cand_cap * 8), *r_win = r_col + d.cand_cap, *r_unacc = r_win + d.cand_cap;
         // with the cell words each would have if it became active (networks.py:95-104: they only depend on the owner's previous
         // predictions, segment maxima and segment counts): one candidate per half-wave, four per half-wave and pass with all
         // their loads in flight together
@@ -933,10 +1040,15 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
                 }
             }
         }
+        for (int i = d.sel_k + b * 256 + tid; i < d.cand_cap; i += nblk * 256) ((u64 *)r_boost)[i] = CAND_PAD;      // (free slots)
         if (b == 0) {                              // and the segments that died while the previous step learned
-            uint32_t *r_dead = r_unacc + d.n_cand;
+            uint32_t *r_dead = r_unacc + d.cand_cap;
             const int n = min(d.dead_list[0], DEAD_CAP);
-            if (tid == 0) r_dead[0] = (uint32_t)n;
+            if (tid == 0) {
+                r_dead[0] = (uint32_t)n;
+                *(uint32_t *)(d.send + shard_record_count_offset(d.cand_cap)) = (uint32_t)d.sel_k;     // (this path cuts exactly)
+                if (fused && wmode) d.ctr->cand_exact += 1;
+            }
             for (int j = tid; j < n; j += 256) r_dead[1 + j] = (uint32_t)d.dead_list[1 + j];
         }
         return;
@@ -1056,15 +1168,22 @@ __global__ __launch_bounds__(RB) void k_shard_overlap(Dev d, const uint32_t *__r
 // The k-th largest of the keys a 1024-thread block holds in registers (bit j of vmask: kreg[j] is a key), and how many
 // of the keys equal to it are among the k largest.  First the windowed pass of the three-launch schedule (win_bin): one
 // histogram around `base` (the previous step's k-th key) -- 12-bit digits put thousands of similar keys into a handful
-// of bins, and same-address LDS atomics run one after the other --, counted tie-aware; a chosen bin of up to 256 keys
-// is ranked directly, a crowded one (ties) finished by 12-bit digit passes from the window's resolution on.  A k-th key
+// of bins, and same-address LDS atomics run one after the other --, counted tie-aware; a chosen bin of up to 1 024 keys
+// is ranked directly, a more crowded one (ties) finished by 12-bit digit passes from the window's resolution on.  A k-th key
 // outside the window leaves it all to the digit passes, which start below the keys' common prefix (same result;
 // *missed says so).  All threads call; h = SEL_BINS words of LDS.
-struct BlockSelLds { uint32_t *h, *s_wave, *s_out, *s_cnt; u64 *s_or, *s_and; };
+struct BlockSelLds { uint32_t *h, *s_wave, *s_out, *s_cnt; u64 *s_or, *s_and; unsigned long long *trace; };
+#ifdef BITHTM_SHARD_STAMPS                       // diagnostic build: device clock at the phases of block 0, d.trace[phase]
+#define SHARD_STAMP(i) do { if (d.trace && blockIdx.x == 0 && threadIdx.x == 0) d.trace[i] = wall_clock64(); } while (0)
+#define SEL_STAMP(i) do { if (L.trace && blockIdx.x == 0 && threadIdx.x == 0) L.trace[i] = wall_clock64(); } while (0)
+#else
+#define SHARD_STAMP(i) do { } while (0)
+#define SEL_STAMP(i) do { } while (0)
+#endif
 
 template <int KPT>
 __device__ __forceinline__ void block_select_regs(const u64 (&kreg)[KPT], uint32_t vmask, uint32_t k, uint32_t base, int low_zero,
-                                                  const BlockSelLds &L, u64 *T_out, uint32_t *r_out, bool *missed) {
+                                                  const BlockSelLds &L, u64 *T_out, uint32_t *r_out, bool *missed, bool h_zeroed = false) {
     const int tid = threadIdx.x, lane = lane_id();
     uint32_t *h = L.h;
     u64 P = 0;
@@ -1074,19 +1193,27 @@ __device__ __forceinline__ void block_select_regs(const u64 (&kreg)[KPT], uint32
     int top_start = 64, top0 = 64;
     bool outside = false;
     {
-        for (int i = tid; i < SEL_BINS; i += 1024) h[i] = 0;
-        if (tid == 0) { L.s_cnt[0] = 0; L.s_out[0] = 0; *L.s_or = 0; *L.s_and = ~0ull; }
-        __syncthreads();
+        if (!h_zeroed) {                           // (the caller may have done this while its keys were on their way)
+            for (int i = tid; i < SEL_BINS; i += 1024) h[i] = 0;
+            if (tid == 0) { L.s_cnt[0] = 0; L.s_out[0] = 0; *L.s_or = 0; *L.s_and = ~0ull; }
+            lds_barrier();
+        }
+        SEL_STAMP(8);
 #pragma unroll
-        for (int j = 0; j < KPT; ++j) hist_add_tie(h, win_bin(kreg[j], base), (vmask >> j) & 1u);
-        __syncthreads();
+        for (int j = 0; j < KPT; ++j) {              // (keys below the window are not counted: the pick counts from the top and, if
+            const uint32_t bin = win_bin(kreg[j], base);     // it gets that far, the k-th key is outside the window -- most keys of a
+            hist_add_tie(h, bin, ((vmask >> j) & 1u) && bin != 0u);      // sharded step's candidates are: same-CU LDS atomics are what this pass costs)
+        }
+        lds_barrier();
+        SEL_STAMP(9);
         uint32_t bucket, above;
-        sel_pick<1024>(h, WIN_BINS, krem, L.s_wave, L.s_out, &bucket, &above);
-        __syncthreads();
+        sel_pick<1024, true>(h, WIN_BINS, krem, L.s_wave, L.s_out, &bucket, &above);
+        lds_barrier();
+        SEL_STAMP(10);
         const bool inside = bucket >= 1u && bucket <= (WIN_COARSE << WIN_FINE);
         const uint32_t in_bin = inside ? h[bucket] : 0u;
-        __syncthreads();
-        if (inside && in_bin > 256u) {                 // a crowded bin: the digit passes below, from the window's resolution on
+        lds_barrier();
+        if (inside && in_bin > 1024u) {                // a crowded bin: the digit passes below, from the window's resolution on
             const uint32_t fine = bucket - 1u;
             P = ((u64)(base + (fine >> WIN_FINE)) << 52) | ((u64)(fine & ((1u << WIN_FINE) - 1u)) << WIN_LOWBITS);
             krem -= above;
@@ -1095,9 +1222,17 @@ __device__ __forceinline__ void block_select_regs(const u64 (&kreg)[KPT], uint32
             const uint32_t kb = krem - above;          // the kb-th largest of the bin's keys is the k-th overall
             u64 *list = (u64 *)h;                      // (the histogram is done with)
 #pragma unroll
-            for (int j = 0; j < KPT; ++j)
-                if (((vmask >> j) & 1u) && win_bin(kreg[j], base) == bucket) list[atomicAdd(&L.s_cnt[0], 1u)] = kreg[j];
-            __syncthreads();
+            for (int j = 0; j < KPT; ++j) {            // (one reservation per wave and pass: same-address LDS atomics run one after the other)
+                const bool hit = ((vmask >> j) & 1u) && win_bin(kreg[j], base) == bucket;
+                const u64 mh = __ballot(hit);
+                if (!mh) continue;
+                const int leader = __ffsll((long long)mh) - 1;
+                uint32_t at = 0;
+                if (lane == leader) at = atomicAdd(&L.s_cnt[0], (uint32_t)__popcll(mh));
+                at = wave_read(at, leader);
+                if (hit) list[at + __popcll(mh & lanemask_lt())] = kreg[j];
+            }
+            lds_barrier();
             for (uint32_t e = tid; e < in_bin; e += 1024) {
                 const u64 ke = list[e];
                 uint32_t ng = 0, nq = 0;
@@ -1108,11 +1243,11 @@ __device__ __forceinline__ void block_select_regs(const u64 (&kreg)[KPT], uint32
                 }
                 if (ng < kb && kb <= ng + nq) { *L.s_or = ke; L.s_out[1] = kb - ng; }      // (equal keys write the same pair)
             }
-            __syncthreads();
+            lds_barrier();
             T = *L.s_or;
             krem = L.s_out[1];
             done = true;
-            __syncthreads();
+            lds_barrier();
         } else {
             // the k-th key is outside the window: everything is left to the digit passes, which start below the keys' common
             // prefix (the bits that are the same in every key; only computed here, where they are needed)
@@ -1120,54 +1255,47 @@ __device__ __forceinline__ void block_select_regs(const u64 (&kreg)[KPT], uint32
 #pragma unroll
             for (int j = 0; j < KPT; ++j)
                 if ((vmask >> j) & 1u) { vo |= kreg[j]; va &= kreg[j]; }
-            for (int o = 32; o > 0; o >>= 1) {
-                vo |= ((u64)__shfl_xor((uint32_t)(vo >> 32), o) << 32) | __shfl_xor((uint32_t)vo, o);
-                va &= ((u64)__shfl_xor((uint32_t)(va >> 32), o) << 32) | __shfl_xor((uint32_t)va, o);
-            }
+            vo = wave_reduce64(vo, 0ull, [](u64 a, u64 b) { return a | b; });
+            va = wave_reduce64(va, ~0ull, [](u64 a, u64 b) { return a & b; });
             if (lane == 0) { atomicOr((unsigned long long *)L.s_or, vo); atomicAnd((unsigned long long *)L.s_and, va); }
-            __syncthreads();
+            lds_barrier();
             const u64 differ = *L.s_or ^ *L.s_and;
             top0 = differ ? 64 - __clzll((long long)differ) : 0;       // bits [top0, 64) are the same in every key
             P = top0 < 64 ? (*L.s_and >> top0) << top0 : 0ull;
             top_start = top0;
             outside = true;
-            __syncthreads();
+            lds_barrier();
         }
     }
     for (int top = top_start; !done && top > low_zero;) {
         const int bits = min(SEL_DIGIT, top - low_zero), shift = top - bits, nb = 1 << bits;
         for (int i = tid; i < nb; i += 1024) h[i] = 0;
-        __syncthreads();
+        lds_barrier();
 #pragma unroll
         for (int j = 0; j < KPT; ++j) {
             const u64 kk = kreg[j];
             hist_add_tie(h, (uint32_t)(kk >> shift) & (nb - 1), ((vmask >> j) & 1u) && (top >= 64 || ((kk ^ P) >> top) == 0));
         }
-        __syncthreads();
+        lds_barrier();
         uint32_t bucket, above;
-        sel_pick<1024>(h, nb, krem, L.s_wave, L.s_out, &bucket, &above);
+        sel_pick<1024, true>(h, nb, krem, L.s_wave, L.s_out, &bucket, &above);
         P |= (u64)bucket << shift;
         krem -= above;
         top = shift;
-        __syncthreads();
+        lds_barrier();
     }
     *T_out = done ? T : P;
     *r_out = krem;
     *missed = outside;
 }
 
-#ifdef BITHTM_SHARD_STAMPS                       // diagnostic build: device clock at the phases of block 0, d.trace[phase]
-#define SHARD_STAMP(i) do { if (d.trace && blockIdx.x == 0 && threadIdx.x == 0) d.trace[i] = wall_clock64(); } while (0)
-#else
-#define SHARD_STAMP(i) do { } while (0)
-#endif
 __global__ __launch_bounds__(1024) void k_shard_select(Dev d, const unsigned char *__restrict__ recv, int p) {
     __shared__ uint32_t h[SEL_BINS];
-    __shared__ uint32_t s_wave[16], s_out[2], s_cnt[2];
+    __shared__ uint32_t s_wave[16], s_out[2], s_cnt[2], s_rank[2];
     __shared__ u64 s_or, s_and;
     const int tid = threadIdx.x, lane = lane_id();
-    const int KL = d.n_cand, n_tot = d.world * KL;
-    const size_t rb = shard_record_bytes(KL);
+    const int KL = d.cand_cap, n_tot = d.world * KL;          // candidate SLOTS; rank r filled the first count_of(r) of its own
+    const size_t rb = shard_record_bytes(KL), cnt_off = shard_record_count_offset(KL);
     if ((int)blockIdx.x == d.world) {
         // one block beside the select (it used to be the tail of block 0, 2-3 us): every rank's death reports, all at once
         // (rank after rank, each with its dependent loads and atomics, this was 8 x 2 round trips): thread -> (rank, entry)
@@ -1192,34 +1320,63 @@ __global__ __launch_bounds__(1024) void k_shard_select(Dev d, const unsigned cha
         if (tid == 0) d.dead_list[0] = 0;          // reported; the coming learning role collects this step's
         return;
     }
+    auto count_of = [&](int r) -> int { return min((int)*(const uint32_t *)(recv + (size_t)r * rb + cnt_off), KL); };
     const u64 inv_kl = ((1ull << 32) + (u64)KL - 1) / (u64)KL;      // i / KL for i < 2^16-ish: one multiplication (64 bits: KL = 1 gives 2^32)
-    auto key_at = [&](int i) -> u64 {
+    auto key_at = [&](int i, bool *filled) -> u64 {      // the key in slot i and whether the slot holds a candidate (CAND_PAD: free)
         int r = (int)(((u64)(uint32_t)i * inv_kl) >> 32);
         if (r * KL > i) --r;
         const int j = i - r * KL;
-        return select_key(((const double *)(recv + (size_t)r * rb))[j]);
+        const u64 bits = ((const u64 *)(recv + (size_t)r * rb))[j];
+        *filled = bits != CAND_PAD;
+        return select_key_bits(bits);
     };
     // up to KPT keys per thread stay in registers over the passes (configs[3] 8-way: 10 488 candidates, 11 per thread);
     // beyond that they are read again, from L2
     SHARD_STAMP(0);
-    constexpr int KPT = 12;
+    constexpr int KPT = 13;
     const bool in_regs = n_tot <= KPT * 1024;
+    // everything this block will need that does not depend on the k-th key is asked for here, all at once: the window's base,
+    // the own rank's count and the words of its first 2 048 slots (own winners, below)
+    const uint32_t win_base = d.ctr->sel_win_global;
+    const int n_own = count_of((int)blockIdx.x);
+    const unsigned char *rec = recv + (size_t)blockIdx.x * rb;
+    const uint32_t *r_col = (const uint32_t *)(rec + (size_t)KL * 8), *r_win = r_col + KL, *r_unacc = r_win + KL;
+    u64 own_bits[2];
+    uint32_t own_cw[2], own_wn[2], own_un[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int j = min(2 * tid + u, KL - 1);
+        own_bits[u] = ((const u64 *)rec)[j];
+        own_cw[u] = r_col[j];
+        own_wn[u] = r_win[j];
+        own_un[u] = r_unacc[j];
+    }
     u64 kreg[KPT];
 #pragma unroll
     for (int j = 0; j < KPT; ++j) {                // (clamped and unconditional: a branch around a load makes the compiler wait for it)
-        const u64 kk = key_at(min(tid + j * 1024, n_tot - 1));
-        kreg[j] = (in_regs && tid + j * 1024 < n_tot) ? kk : 0ull;
+        const int i = min(tid + j * 1024, n_tot - 1);
+        int r = (int)(((u64)(uint32_t)i * inv_kl) >> 32);
+        if (r * KL > i) --r;
+        kreg[j] = ((const u64 *)(recv + (size_t)r * rb))[i - r * KL];          // (raw bits for now)
+    }
+    // while they travel: the histogram of the windowed pass, zeroed (its barrier does not wait for the loads)
+    for (int i = tid; i < SEL_BINS; i += 1024) h[i] = 0;
+    if (tid == 0) { s_cnt[0] = 0; s_out[0] = 0; s_or = 0; s_and = ~0ull; s_rank[0] = 0; s_rank[1] = 0; }
+    lds_barrier();
+    uint32_t vmask = 0;
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) {
+        const bool ok = in_regs && tid + j * 1024 < n_tot && kreg[j] != CAND_PAD;
+        kreg[j] = ok ? select_key_bits(kreg[j]) : 0ull;
+        vmask |= (ok ? 1u : 0u) << j;
     }
     u64 T;                                         // the k-th largest key; krem of the keys equal to it win
     uint32_t krem;
     bool missed = false;
     if (in_regs) {
-        uint32_t vmask = 0;
-#pragma unroll
-        for (int j = 0; j < KPT; ++j) vmask |= (tid + j * 1024 < n_tot ? 1u : 0u) << j;
-        const BlockSelLds L{h, s_wave, s_out, s_cnt, &s_or, &s_and};
+        const BlockSelLds L{h, s_wave, s_out, s_cnt, &s_or, &s_and, d.trace};
         SHARD_STAMP(1);                            // (keys loaded)
-        block_select_regs<KPT>(kreg, vmask, (uint32_t)d.k, d.ctr->sel_win_global, d.low_zero, L, &T, &krem, &missed);
+        block_select_regs<KPT>(kreg, vmask, (uint32_t)d.k, win_base, d.low_zero, L, &T, &krem, &missed, true);
     } else {
         // more candidates than the registers hold (configs[4]: 42 k): 12-bit digit passes over the records, from below the
         // keys' common prefix
@@ -1227,11 +1384,13 @@ __global__ __launch_bounds__(1024) void k_shard_select(Dev d, const unsigned cha
         __syncthreads();
         {
             u64 vo = 0, va = ~0ull;
-            for (int i = tid; i < n_tot; i += 1024) { const u64 kk = key_at(i); vo |= kk; va &= kk; }
-            for (int o = 32; o > 0; o >>= 1) {
-                vo |= ((u64)__shfl_xor((uint32_t)(vo >> 32), o) << 32) | __shfl_xor((uint32_t)vo, o);
-                va &= ((u64)__shfl_xor((uint32_t)(va >> 32), o) << 32) | __shfl_xor((uint32_t)va, o);
+            for (int i = tid; i < n_tot; i += 1024) {
+                bool filled;
+                const u64 kk = key_at(i, &filled);
+                if (filled) { vo |= kk; va &= kk; }
             }
+            vo = wave_reduce64(vo, 0ull, [](u64 a, u64 b) { return a | b; });
+            va = wave_reduce64(va, ~0ull, [](u64 a, u64 b) { return a & b; });
             if (lane == 0) { atomicOr((unsigned long long *)&s_or, vo); atomicAnd((unsigned long long *)&s_and, va); }
         }
         __syncthreads();
@@ -1244,9 +1403,11 @@ __global__ __launch_bounds__(1024) void k_shard_select(Dev d, const unsigned cha
             const int bits = min(SEL_DIGIT, top - d.low_zero), shift = top - bits, nb = 1 << bits;
             for (int i = tid; i < nb; i += 1024) h[i] = 0;
             __syncthreads();
-            for (int i = tid; i < n_tot; i += 1024) {
-                const u64 kk = key_at(i);
-                hist_add_tie(h, (uint32_t)(kk >> shift) & (nb - 1), top >= 64 || ((kk ^ P) >> top) == 0);
+            for (int i0 = 0; i0 < n_tot; i0 += 1024) {        // (whole waves: hist_add_tie is called by all lanes)
+                const int i = i0 + tid;
+                bool filled;
+                const u64 kk = key_at(min(i, n_tot - 1), &filled);
+                hist_add_tie(h, (uint32_t)(kk >> shift) & (nb - 1), i < n_tot && filled && (top >= 64 || ((kk ^ P) >> top) == 0));
             }
             __syncthreads();
             uint32_t bucket, above;
@@ -1260,64 +1421,76 @@ __global__ __launch_bounds__(1024) void k_shard_select(Dev d, const unsigned cha
     }
     SHARD_STAMP(2);                                // (k-th key known)
     const int b = blockIdx.x, lo = b * KL;
-    if (b == 0 && tid == 0) {
-        d.ctr->sel_win_global = min(win_base_for(T) + (uint32_t)d.win_offset, 4096u - WIN_COARSE);
-        if (missed) d.ctr->sel_fallbacks += 1;     // (telemetry: the window missed)
-    }
-    if (tid < 2) s_cnt[tid] = 0;
-    __syncthreads();
-    {   // winners among the candidates of the ranks before this one
+    {   // winners among the candidates of the ranks before this one (s_rank was zeroed at the top; the sums are read behind the
+        // barriers of the scan below)
         uint32_t g = 0, e = 0;
         if (in_regs) {
 #pragma unroll
             for (int j = 0; j < KPT; ++j) {
-                const bool before = tid + j * 1024 < lo;
+                const bool before = tid + j * 1024 < lo && ((vmask >> j) & 1u);
                 g += before && kreg[j] > T;
                 e += before && kreg[j] == T;
             }
         } else {
             for (int i = tid; i < lo; i += 1024) {
-                const u64 kk = key_at(i);
-                g += kk > T;
-                e += kk == T;
+                bool filled;
+                const u64 kk = key_at(i, &filled);
+                g += filled && kk > T;
+                e += filled && kk == T;
             }
         }
         g = wave_sum(g);
         e = wave_sum(e);
-        if (lane == 0) { atomicAdd(&s_cnt[0], g); atomicAdd(&s_cnt[1], e); }
+        if (lane == 0 && (g | e)) { atomicAdd(&s_rank[0], g); atomicAdd(&s_rank[1], e); }
     }
-    __syncthreads();
-    SHARD_STAMP(3);
-    uint32_t gt_run = s_cnt[0], eq_run = s_cnt[1];
-    const unsigned char *rec = recv + (size_t)b * rb;
-    const uint32_t *r_col = (const uint32_t *)(rec + (size_t)KL * 8), *r_win = r_col + KL, *r_unacc = r_win + KL;
-    for (int j0 = 0; j0 < KL; j0 += 1024) {
-        const int j = j0 + tid;
-        const u64 kk = j < KL ? key_at(lo + j) : 0;
-        // (the candidate's words with its key, not after the scan: one round trip per pass instead of two)
-        const uint32_t cw = j < KL ? r_col[j] : 0u, wn = j < KL ? r_win[j] : 0u, un = j < KL ? r_unacc[j] : 0u;
-        const uint32_t flag = j < KL ? ((kk > T) ? 1u : ((kk == T) ? 0x10000u : 0u)) : 0u;
+    // the own rank's winners, two neighbouring slots per thread and pass (one scan for 2 048 slots; the first pass's words
+    // have been here since the top of the kernel)
+    uint32_t gt_run = 0, eq_run = 0;
+    for (int j0 = 0; j0 < n_own; j0 += 2048) {
+        u64 bits[2];
+        uint32_t cw[2], wn[2], un[2], flag[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int j = j0 + 2 * tid + u;
+            if (j0 == 0) { bits[u] = own_bits[u]; cw[u] = own_cw[u]; wn[u] = own_wn[u]; un[u] = own_un[u]; }
+            else {
+                const int jc = min(j, KL - 1);
+                bits[u] = ((const u64 *)rec)[jc]; cw[u] = r_col[jc]; wn[u] = r_win[jc]; un[u] = r_unacc[jc];
+            }
+            const u64 kk = select_key_bits(bits[u]);
+            flag[u] = j < n_own ? ((kk > T) ? 1u : ((kk == T) ? 0x10000u : 0u)) : 0u;
+        }
         uint32_t total;
-        const uint32_t ex = block_excl_scan<1024>(flag, s_wave, total);
-        const uint32_t g = gt_run + (ex & 0xFFFFu), e = eq_run + (ex >> 16);
-        if ((flag & 1u) || ((flag >> 16) && e < krem)) {
-            const int pos = (int)(g + min(e, krem));
-            const int col = (int)(cw & 0x7FFFFFFFu);
-            const bool burst = cw >> 31;
-            const uint32_t act = burst ? cell_mask(d.K) : wn;                   // networks.py:115
-            d.active_cols[p][pos] = col;
-            atomicOr(&d.colbits[p][col >> 5], 1u << (col & 31));
-            d.act[p][col] = act;
-            d.win[p][col] = wn;
-            d.bursting[pos] = burst ? 1 : 0;
-            d.unacc_word[pos] = un;
-            d.winw_idx[pos] = wn;
-            d.actcnt[pos] = (uint8_t)__popc(act);
+        uint32_t ex = block_excl_scan<1024, true>(flag[0] + flag[1], s_wave, total);      // (LDS-only barriers: a later pass does not
+        if (j0 == 0) { gt_run = s_rank[0]; eq_run = s_rank[1]; }                          // wait for an earlier one's stores)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const uint32_t g = gt_run + (ex & 0xFFFFu), e = eq_run + (ex >> 16);
+            if ((flag[u] & 1u) || ((flag[u] >> 16) && e < krem)) {
+                const int pos = (int)(g + min(e, krem));
+                const int col = (int)(cw[u] & 0x7FFFFFFFu);
+                const bool burst = cw[u] >> 31;
+                const uint32_t act = burst ? cell_mask(d.K) : wn[u];                // networks.py:115
+                d.active_cols[p][pos] = col;
+                atomicOr(&d.colbits[p][col >> 5], 1u << (col & 31));
+                d.act[p][col] = act;
+                d.win[p][col] = wn[u];
+                d.bursting[pos] = burst ? 1 : 0;
+                d.unacc_word[pos] = un[u];
+                d.winw_idx[pos] = wn[u];
+                d.actcnt[pos] = (uint8_t)__popc(act);
+            }
+            ex += flag[u];
         }
         gt_run += total & 0xFFFFu;
         eq_run += total >> 16;
     }
+    SHARD_STAMP(3);
     SHARD_STAMP(4);                                // (own winners emitted)
+    if (b == 0 && tid == 0) {                      // (last: a store ahead of a barrier is waited for)
+        d.ctr->sel_win_global = min(win_base_global(T) + (uint32_t)d.win_offset, 4096u - WIN_COARSE);
+        if (missed) d.ctr->sel_fallbacks += 1;     // (telemetry: the window missed)
+    }
     SHARD_STAMP(5);
 }
 

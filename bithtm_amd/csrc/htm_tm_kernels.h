@@ -206,7 +206,7 @@ __device__ __forceinline__ void role_mid(const Dev &d, int p, int n_active, int 
                 if (n_l + n_p == 0) continue;
                 int base = 0;
                 if (lane_id() == 0) base = atomicAdd(&c->n_work[p], n_l + n_p);
-                base = __shfl(base, 0);
+                base = wave_read(base, 0);
                 if (learn) {
                     const int pos = base + __popcll(ml & lanemask_lt());
                     if (pos < d.work_cap) d.work[pos] = (uint32_t)seg; else atomicOr(&c->error, 4);
@@ -238,7 +238,7 @@ __device__ __forceinline__ void role_mid(const Dev &d, int p, int n_active, int 
             const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
             int base = 0;
             if (lane_id() == 63) base = atomicAdd(&c->n_work[p], (int)total);
-            int pos = __shfl(base, 63) + (int)(incl - cnt);
+            int pos = wave_read(base, 63) + (int)(incl - cnt);
             for (uint32_t rest = lmask; rest; rest &= rest - 1, ++pos) {
                 const uint32_t item = (uint32_t)(w * 32 + __ffs(rest) - 1);
                 if (pos < d.work_cap) d.work[pos] = item; else atomicOr(&c->error, 4);

@@ -103,6 +103,8 @@ typedef struct htm_info {
     int32_t work_items;                 /* last step: segments that learned or were punished */
     int32_t select_fallbacks;           /* steps so far whose top-k select overflowed the per-block records
                                            and took the exact in-kernel fallback (slower, same result) */
+    int32_t candidate_exact_steps;      /* column-sharded handles: steps so far whose LOCAL select cut its threshold bin exactly
+                                           instead of handing the whole bin over (slower, same result) */
 } htm_info;
 
 /* Device arrays readable with htm_read / writable with htm_write. Element type and count

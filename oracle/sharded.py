@@ -8,7 +8,11 @@ an id has fewer synapses than the matching threshold (`dead`, what projections.p
 
 One exchange per timestep (an all-gather of fixed-size per-rank records):
 
-    candidates[KL]   the rank's own top-min(k, own columns) columns by (boosted desc, column asc), in ascending
+    candidates[n]    a SUPERSET of the rank's own top-min(k, own columns) columns by (boosted desc, column asc) --
+                     exactly that set (offer="exact"), or together with every other own column whose boosted overlap
+                     shares the leading bits of the last one's (offer="bin": what the HIP engine's local select hands
+                     over when the whole threshold bin of its histogram fits the record's CAP slots; the global
+                     top-k does not care) --, in ascending
                      column order, each with its boosted overlap (f64), its bursting bit and the winner-cell and
                      needs-a-new-segment words the column WOULD have if it became active (computable before the
                      global top-k: they depend only on the rank's own previous predictions / segment maxima /
@@ -16,7 +20,7 @@ One exchange per timestep (an all-gather of fixed-size per-rank records):
     dead[]           ids of own segments that dropped below the matching threshold during the previous step's
                      learning (the lowest-id-first recycling rule, projections.py:80-81, is global)
 
-After the gather every rank performs the identical global top-k over the R x KL candidates and the identical
+After the gather every rank performs the identical global top-k over the candidates of all ranks and the identical
 segment-id allocation, so no further communication is needed and the R-way result equals the 1-way result bit for
 bit.  `all_gather` is injected: torch.distributed (gloo) in tests/test_sharded_gloo.py.
 """
@@ -38,15 +42,23 @@ def shard_range(rank, world, column_dim):
     return rank * per, (rank + 1) * per
 
 
+def cand_cap(n_cand, n_local):
+    """Candidate slots of a record (bithtm_amd/csrc/htm_sp_kernels.h: shard_cand_cap)."""
+    return min(n_local, n_cand + max(64, n_cand // 4))
+
+
 class ShardedHTMOracle:
     def __init__(self, rank, world, input_dim, column_dim, cell_dim, active_columns=None, seed=0,
-                 sp_params=None, tm_params=None, permanence=None):
+                 sp_params=None, tm_params=None, permanence=None, offer="exact"):
         if active_columns is None:
             active_columns = round(column_dim * 0.02)
         self.rank, self.world = rank, world
         self.input_dim, self.column_dim, self.cell_dim, self.k = input_dim, column_dim, cell_dim, active_columns
         self.c0, self.c1 = shard_range(rank, world, column_dim)
         self.n_cand = min(self.k, self.c1 - self.c0)
+        self.cap = cand_cap(self.n_cand, self.c1 - self.c0)
+        assert offer in ("exact", "bin")
+        self.offer = offer
         self.spp = sp_params or SPParams()
         self.d_sp = sp_derived(self.spp, column_dim, active_columns)
         assert permanence is not None and permanence.shape == (column_dim, input_dim)
@@ -76,6 +88,12 @@ class ShardedHTMOracle:
         overlaps = (connected & input_bits).sum(axis=1)
         boosted = exp_f32(self.d_sp.coef32 * self.duty).astype(np.float64) * overlaps
         cand = stable_topk(boosted, self.n_cand)           # own candidates, ascending (local) column
+        if self.offer == "bin" and len(cand):
+            # everything down to the leading bits (sign, exponent, 7 mantissa bits) of the weakest candidate, if it fits
+            lead = boosted.view(np.int64) >> 45
+            wide = np.flatnonzero(lead >= lead[cand].min())
+            if len(wide) <= self.cap:
+                cand = wide
         cols = cand + self.c0
         predicted = tm.prev_prediction[cols]
         bursting = ~predicted.any(axis=1)
@@ -227,38 +245,47 @@ class ShardedHTMOracle:
 DEAD_CAP = 256
 
 
-def record_nbytes(n_cand):
-    """[boosted f64 x KL][column | bursting << 31  u32 x KL][winner word u32 x KL][needs-a-segment word u32 x KL]
-    [n_dead u32][dead ids u32 x DEAD_CAP][pad to 16 bytes]"""
-    n = n_cand * (8 + 4 + 4 + 4) + 4 + 4 * DEAD_CAP
+def record_nbytes(cap):
+    """[boosted f64 x CAP][column | bursting << 31  u32 x CAP][winner word u32 x CAP][needs-a-segment word u32 x CAP]
+    [n_dead u32][dead ids u32 x DEAD_CAP][n u32: candidate slots in use][pad to 16 bytes]; the boosted overlaps of the
+    CAP - n free slots have all bits set"""
+    n = cap * (8 + 4 + 4 + 4) + 4 + 4 * DEAD_CAP + 4
     return (n + 15) // 16 * 16
 
 
-def pack_record(rec, cell_dim):
-    kl = len(rec.boosted)
-    buf = np.zeros(record_nbytes(kl), dtype=np.uint8)
+def pack_record(rec, cell_dim, cap=None):
+    n = len(rec.boosted)
+    cap = n if cap is None else cap
+    if n > cap:
+        raise OverflowError("more candidates than the exchange record has slots")
+    buf = np.zeros(record_nbytes(cap), dtype=np.uint8)
     weights = (np.uint32(1) << np.arange(cell_dim, dtype=np.uint32))
     o = 0
-    buf[o:o + 8 * kl] = rec.boosted.astype(np.float64).view(np.uint8); o += 8 * kl
+    buf[o:o + 8 * n] = rec.boosted.astype(np.float64).view(np.uint8)
+    buf[o + 8 * n:o + 8 * cap] = 0xFF               # free slots: all bits set (CAND_PAD), what the HIP global select keys on
+    o += 8 * cap
     colword = rec.col.astype(np.uint32) | (rec.bursting.astype(np.uint32) << np.uint32(31))
-    buf[o:o + 4 * kl] = colword.view(np.uint8); o += 4 * kl
+    buf[o:o + 4 * n] = colword.view(np.uint8); o += 4 * cap
     for mat in (rec.win, rec.unacc):
-        buf[o:o + 4 * kl] = (mat.astype(np.uint32) * weights).sum(axis=1).astype(np.uint32).view(np.uint8)
-        o += 4 * kl
+        buf[o:o + 4 * n] = (mat.astype(np.uint32) * weights).sum(axis=1).astype(np.uint32).view(np.uint8)
+        o += 4 * cap
     if len(rec.dead) > DEAD_CAP:
         raise OverflowError("more newly dead segments than the exchange record holds")
     buf[o:o + 4] = np.array([len(rec.dead)], dtype=np.uint32).view(np.uint8); o += 4
-    buf[o:o + 4 * len(rec.dead)] = rec.dead.astype(np.uint32).view(np.uint8)
+    buf[o:o + 4 * len(rec.dead)] = rec.dead.astype(np.uint32).view(np.uint8); o += 4 * DEAD_CAP
+    buf[o:o + 4] = np.array([n], dtype=np.uint32).view(np.uint8)
     return buf
 
 
-def unpack_record(buf, n_cand, cell_dim):
-    kl, o = n_cand, 0
-    boosted = buf[o:o + 8 * kl].view(np.float64).copy(); o += 8 * kl
-    colword = buf[o:o + 4 * kl].view(np.uint32); o += 4 * kl
+def unpack_record(buf, cap, cell_dim):
+    n = int(buf[cap * 20 + 4 + 4 * DEAD_CAP:][:4].view(np.uint32)[0])
+    assert np.all(buf[8 * n:8 * cap] == 0xFF), "free candidate slots must carry the pad value"
+    o = 0
+    boosted = buf[o:o + 8 * n].view(np.float64).copy(); o += 8 * cap
+    colword = buf[o:o + 4 * n].view(np.uint32); o += 4 * cap
     mats = []
     for _ in range(2):
-        words = buf[o:o + 4 * kl].view(np.uint32); o += 4 * kl
+        words = buf[o:o + 4 * n].view(np.uint32); o += 4 * cap
         mats.append(((words[:, None] >> np.arange(cell_dim, dtype=np.uint32)) & 1).astype(np.bool_))
     n_dead = int(buf[o:o + 4].view(np.uint32)[0]); o += 4
     dead = buf[o:o + 4 * n_dead].view(np.uint32).astype(np.int64)

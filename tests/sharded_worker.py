@@ -37,16 +37,20 @@ def main():
     std, mean = (spp.permanence_std, spp.permanence_mean) if spp else (0.1, 0.0)
     perm = np.random.randn(C, I) * std + mean
     full = HTMOracle(I, C, K, seed=seed, sp_params=spp, tm_params=tmp, permanence=perm)
-    part = ShardedHTMOracle(rank, world, I, C, K, seed=seed, sp_params=spp, tm_params=tmp, permanence=perm)
+    # odd ranks hand over whole threshold bins (variable candidate counts, as the HIP engine does when they fit), even ranks
+    # exactly their top-min(k, own columns): the global result must not care
+    part = ShardedHTMOracle(rank, world, I, C, K, seed=seed, sp_params=spp, tm_params=tmp, permanence=perm,
+                            offer="bin" if rank % 2 else "exact")
     c0, c1 = part.c0, part.c1
-    n_cand = part.n_cand
-    nbytes = record_nbytes(n_cand)
+    cap = part.cap
+    nbytes = record_nbytes(cap)
+    offered = 0
 
     def all_gather(rec):
-        send = torch.from_numpy(pack_record(rec, K))
+        send = torch.from_numpy(pack_record(rec, K, cap))
         recv = [torch.empty(nbytes, dtype=torch.uint8) for _ in range(world)]
         dist.all_gather(recv, send)
-        return [unpack_record(r.numpy(), n_cand, K) for r in recv]
+        return [unpack_record(r.numpy(), cap, K) for r in recv]
 
     rng = np.random.RandomState(seed + 1)
     bank = rng.rand(P, I) < density
@@ -59,6 +63,7 @@ def main():
         f_sp, f_tm = full.step(x, learning=learning)
         out, rec = part.step(x, all_gather, learning=learning)
         dead_total += len(part.dead_out)
+        offered += len(rec.col) - part.n_cand
 
         def eq(name, a, b):
             assert np.array_equal(np.asarray(a), np.asarray(b)), f"rank {rank} step {t}: {name}"
@@ -101,12 +106,14 @@ def main():
             eq("SP permanence (own)", part.permanence.view(np.int64), full.spatial_pooler.permanence[c0:c1].view(np.int64))
             eq("duty (own)", part.duty.view(np.int32), full.spatial_pooler.duty_cycle[c0:c1].view(np.int32))
     # the run must have exercised the cross-rank parts of the protocol
-    tot = torch.tensor([dead_total, int((f_tm.cell_prediction.any(axis=1)).sum())])
+    tot = torch.tensor([dead_total, int((f_tm.cell_prediction.any(axis=1)).sum()), offered])
     dist.all_reduce(tot)
     if rank == 0:
-        print(f"OK world={world} cfg={cfg} steps={steps} S={full.temporal_memory.S} dead_reported={int(tot[0])}")
+        print(f"OK world={world} cfg={cfg} steps={steps} S={full.temporal_memory.S} dead_reported={int(tot[0])} "
+              f"candidates_beyond_the_cut={int(tot[2])}")
         if cfg != "default":
             assert int(tot[0]) > 0, "stress run reported no dead segments: protocol path untested"
+        assert int(tot[2]) > 0, "no rank ever offered more than its exact cut: variable counts untested"
     dist.barrier()
     dist.destroy_process_group()
 

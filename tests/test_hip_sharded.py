@@ -100,6 +100,9 @@ def _run(world, I, C, K, P, density, noise, steps, jump, seed, spp=None, tmp=Non
                                       ora.spatial_pooler.permanence[c0:c1].view(np.int64)), f"{tag}: SP permanence (own)"
                 assert np.array_equal(eng.read_duty_cycle()[c0:c1].view(np.int32),
                                       ora.spatial_pooler.duty_cycle[c0:c1].view(np.int32)), f"{tag}: duty (own)"
+    exact = max(m.engine.info().candidate_exact_steps for m in group.members)
+    print(f"world {world}, {C} columns: local selects that cut their threshold bin exactly in {exact} of {steps} steps")
+    _run.exact_steps = exact
     return dead_seen
 
 
@@ -118,14 +121,18 @@ def test_two_shards_default_parameters():
     _run(2, I=256, C=2048, K=32, P=50, density=0.06, noise=0.01, steps=300, jump=0.0, seed=51)
 
 
-@pytest.mark.parametrize("env", [{"BITHTM_SHARD_WINDOW": "0"}, {"BITHTM_FUSE_TM": "0"}, {"BITHTM_SEL_WINDOW_OFFSET": "4000"}],
+@pytest.mark.parametrize("env", [{"BITHTM_SHARD_WINDOW": "0"}, {"BITHTM_FUSE_TM": "0"}, {"BITHTM_SEL_WINDOW_OFFSET": "4000"},
+                                 {"BITHTM_CAND_TAKE_ALL": "0"}],
                          ids=lambda e: ",".join(f"{k[7:]}={v}" for k, v in e.items()))
 def test_four_shards_with_the_other_select_and_launch_forms(env, monkeypatch):
     """The sharded step with two launched digits instead of the windowed histogram in the local select, with the
-    learning role and the scan as two launches, and with both windows (local and global) forced to miss every step."""
+    learning role and the scan as two launches, with both windows (local and global) forced to miss every step, and with a
+    local select that always cuts its threshold bin exactly (the record exchange) instead of handing the bin over."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     _run(4, I=200, C=1024, K=16, P=20, density=0.08, noise=0.01, steps=120, jump=0.02, seed=57)
+    if env.get("BITHTM_CAND_TAKE_ALL") == "0":
+        assert _run.exact_steps >= 118              # (every step but the first: that one has no window yet)
 
 
 def test_four_shards_stress_parameters_with_recycling():
@@ -146,6 +153,7 @@ def test_config3_65536_columns_eight_shards():
     """BASELINE.json configs[3]: 65 536 columns x 32 cells sharded 8-way (8 192 columns per shard),
     here with the 8 shards emulated on one GPU; every shard must agree with the unsharded oracle."""
     _run(8, I=1024, C=65536, K=32, P=12, density=0.02, noise=0.005, steps=60, jump=0.0, seed=0)
+    assert _run.exact_steps <= 30               # the whole-bin hand-over is the usual path at this size
 
 
 def test_random_sharded_configurations():

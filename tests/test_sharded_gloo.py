@@ -51,19 +51,23 @@ def test_four_ranks_stress():
 def test_wire_format_round_trip():
     import numpy as np
     from types import SimpleNamespace
-    from oracle.sharded import pack_record, unpack_record, record_nbytes, DEAD_CAP
+    from oracle.sharded import pack_record, unpack_record, record_nbytes, cand_cap, DEAD_CAP
     rng = np.random.RandomState(0)
     kl, K = 41, 12
     rec = SimpleNamespace(boosted=rng.rand(kl), col=np.sort(rng.choice(5000, kl, replace=False)).astype(np.int64),
                           bursting=rng.rand(kl) < 0.5, win=rng.rand(kl, K) < 0.2, unacc=rng.rand(kl, K) < 0.1,
                           dead=np.array([5, 77, 1234567], dtype=np.int64))
-    buf = pack_record(rec, K)
-    assert len(buf) == record_nbytes(kl) and len(buf) % 16 == 0
-    back = unpack_record(buf, kl, K)
-    for f in ("boosted", "col", "bursting", "win", "unacc", "dead"):
-        assert np.array_equal(getattr(back, f), getattr(rec, f)), f
+    for cap in (kl, kl + 23):                      # a full record, and one with free candidate slots
+        buf = pack_record(rec, K, cap)
+        assert len(buf) == record_nbytes(cap) and len(buf) % 16 == 0
+        back = unpack_record(buf, cap, K)
+        for f in ("boosted", "col", "bursting", "win", "unacc", "dead"):
+            assert np.array_equal(getattr(back, f), getattr(rec, f)), f
+    with pytest.raises(OverflowError):
+        pack_record(rec, K, kl - 1)
     rec.dead = np.arange(DEAD_CAP + 1)
     with pytest.raises(OverflowError):
         pack_record(rec, K)
     # 20 B per candidate; BASELINE.json configs[3] (65 536 columns, k = 1 311) sharded 8-way
-    assert record_nbytes(1311) <= 32 * 1024
+    # (+ a quarter more slots than the rank must offer: room for the threshold bin of its local select)
+    assert cand_cap(1311, 65536 // 8) == 1638 and record_nbytes(1638) <= 34 * 1024

@@ -6,8 +6,8 @@
 
 emit: every block of rank 0's candidates kernel (k_sp_emit, EMIT_LOCAL) stamps the device clock at 0 start, 1 windowed
 histogram resolved, 2 own record published, 3 everybody's records read, 4 k-th key known, 5 list written.
-select: block 0 of rank 0's k_shard_select at 0 start, 1 keys loaded, 2 k-th key known, 3 earlier ranks counted, 4 own
-winners emitted, 5 death reports applied.  The model is brought to bench.py's learned state unsharded and handed over."""
+select: block 0 of rank 0's k_shard_select at 0 start, 1 keys loaded (the histogram zeroed meanwhile), 2 k-th key known
+(8 / 9 / 10 inside: histogram ready, filled, bin picked), 3 own winners emitted, 5 end.  The model is brought to bench.py's learned state unsharded and handed over."""
 import os
 import sys
 
@@ -50,8 +50,10 @@ def main():
                   + "  ".join(f"{n} {np.median(ph[:, i]):.2f}/{ph[:, i].max():.2f}" for i, n in enumerate(names)))
         else:
             t = raw[:6].astype(np.float64) / 100.0
-            names = ["load keys", "k-th key", "earlier ranks", "own winners", "death reports"]
-            print(f"step {step}: " + "  ".join(f"{n} {v:.2f}" for n, v in zip(names, np.diff(t))) + f"  total {t[5] - t[0]:.2f} us")
+            names = ["load keys + zero the histogram", "k-th key", "earlier ranks + own winners", "-", "window for the next step"]
+            sub = raw[8:11].astype(np.float64) / 100.0           # inside "k-th key": histogram zeroed, filled, bin picked
+            print(f"step {step}: " + "  ".join(f"{n} {v:.2f}" for n, v in zip(names, np.diff(t))) + f"  total {t[5] - t[0]:.2f} us"
+                  + f"   [k-th key: zero {sub[0] - t[1]:.2f}  fill {sub[1] - sub[0]:.2f}  pick {sub[2] - sub[1]:.2f}  inside the bin {t[2] - sub[2]:.2f}]")
     info = eng.check_capacity()
     print(f"segments {info.segments}, rank 0 rows {info.local_segments}, select fallbacks {info.select_fallbacks} of {info.step_index} steps")
 
