@@ -19,6 +19,7 @@ typedef unsigned long long u64;
 #define RB 512                // threads per block of the role kernels (overlap, select, learn, scan)
 #define SCAN_SEGS 64          // segments per 256-thread block iteration of the segment scan
 #define DEAD_CAP 256          // newly dead segment ids one rank can report per exchange
+#define SHARD_HOT_KEYS 4      // hot-list keys per thread of the sharded step's global select (1024 threads: 4 096 between the ranks)
 #define CAND_CAP 256          // growth candidates staged per wave
 #define WIN_LDS 4096          // previous winner cells the learning role keeps in LDS (more are read from global memory)
 #define MAX_SLOTS 512
@@ -60,15 +61,10 @@ __host__ __device__ __forceinline__ uint32_t win_base_for(u64 kth_key) {
     return c > WIN_COARSE / 2 ? min(c - WIN_COARSE / 2, 4096u - WIN_COARSE) : 0u;
 }
 
-// The window of the column-sharded step's GLOBAL select (k_shard_select) starts 8 values of the top digit -- a factor of two:
-// the digit holds three mantissa bits -- below the previous step's k-th key (the k-th key of a new pattern is 1.5 times
-// lower at most), because there the keys below the window are not counted at all: of a step's 10-13 thousand candidates
-// (every rank's top-1 311) a tenth can win, and the histogram pass of one block is bound by its CU's LDS atomics.
-#define WIN_GLOBAL_BELOW 8
-__host__ __device__ __forceinline__ uint32_t win_base_global(u64 kth_key) {
-    const uint32_t c = (uint32_t)(kth_key >> 52);
-    return c > WIN_GLOBAL_BELOW ? min(c - WIN_GLOBAL_BELOW, 4096u - WIN_COARSE) : 0u;
-}
+// The window of the column-sharded step's GLOBAL select (k_shard_select), around the previous step's global k-th key: the
+// same shape as the local one.  Keys below it are not counted (the pick counts from the top; if it gets that far, the
+// digit passes take over).
+__host__ __device__ __forceinline__ uint32_t win_base_global(u64 kth_key) { return win_base_for(kth_key); }
 
 // radix-select digit p covers key bits [shift, shift + bits): 12 bits from the top, the last one 4
 __host__ __device__ __forceinline__ int sel_shift(int pass) { return pass < 5 ? 52 - SEL_DIGIT * pass : 0; }
@@ -96,6 +92,7 @@ struct Counters {
     int32_t sel_fallbacks;    // steps whose top-k select took the in-kernel fallback (telemetry)
     int32_t cand_exact;       // sharded: steps whose LOCAL select cut the threshold bin exactly (record exchange) instead of
                               // handing the whole bin over (telemetry)
+    int32_t hot_selects;      // sharded: steps whose GLOBAL select was settled among the ranks' hot lists (telemetry)
     uint32_t emit_epoch;      // bumped by every overlap launch: tags the records k_sp_emit's blocks exchange
     int32_t n_un;             // winners needing a new segment
     int32_t n_recycled, n_new, S_old;
@@ -120,6 +117,8 @@ struct Dev {
     int sel_lo, sel_hi, sel_k; // the select works on the keys of columns [sel_lo, sel_hi) and finds their sel_k largest
                               // (unsharded: all columns, k; a shard selects its own candidates: [c0, c1), min(k, c1 - c0))
     int Lcap, n_cand;         // sharded: local row capacity; candidates a rank must offer = sel_k = min(k, own columns)
+    int hot_budget, hot_target;   // ... entries of a rank's hot list the global select looks at; the list goes down to the bin of the
+                              // rank's hot_target-th largest key
     int cand_cap;             // ... and the candidate slots of its exchange record (>= n_cand: the local select may hand over the
                               // whole threshold bin instead of cutting it, see role_emit)
     double sp_thr, sp_don, sp_doff;
@@ -278,6 +277,26 @@ __device__ __forceinline__ int group8_sum_all(int v) {
 // loads that are not needed yet costs their round trip, about a microsecond.  Where the threads of a block only talk
 // through LDS, this is the barrier: LDS (and scalar) operations drained, then s_barrier.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// op over each half of the wave (32 lanes: the cells of one column), floats, the result in every lane of the half: the row
+// scan of wave_incl_scan, row 0's (2's) result broadcast into row 1 (3), then lanes 31 and 63 read out -- eight VALU
+// operations instead of five ds_bpermute round trips.
+template <typename Op>
+__device__ __forceinline__ float half_reduce(float v, float ident, Op op) {
+    const int id = __float_as_int(ident);
+#define BITHTM_DPPF(src, ctrl, rm, bm) __int_as_float(__builtin_amdgcn_update_dpp(id, __float_as_int(src), ctrl, rm, bm, false))
+    float t = v;
+    t = op(t, BITHTM_DPPF(v, 0x111, 0xf, 0xf));
+    t = op(t, BITHTM_DPPF(v, 0x112, 0xf, 0xf));
+    t = op(t, BITHTM_DPPF(v, 0x113, 0xf, 0xf));
+    t = op(t, BITHTM_DPPF(t, 0x114, 0xf, 0xe));
+    t = op(t, BITHTM_DPPF(t, 0x118, 0xf, 0xc));
+    t = op(t, BITHTM_DPPF(t, 0x142, 0xa, 0xf));
+#undef BITHTM_DPPF
+    const float lo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t), 31));
+    const float hi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t), 63));
+    return lane_id() < 32 ? lo : hi;
+}
 
 template <int BS, bool LDS_ONLY = false>
 __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *s_wave, uint32_t &total) {

@@ -295,8 +295,7 @@ __device__ __forceinline__ ColumnWords tm_column_compute(const Dev &d, int want_
     const float cm = l.cm;
     uint32_t winner = pw, unacc = 0;
     if (want_winner) {
-        float colmax = cm;
-        for (int o = 16; o > 0; o >>= 1) colmax = fmaxf(colmax, __shfl_xor(colmax, o));
+        const float colmax = half_reduce(cm, -3.0e38f, [](float x, float y) { return fmaxf(x, y); });
         const bool col_matching = has_distal && colmax >= (float)d.match_thr;      // networks.py:80
         const bool best = valid && has_distal && fabsf(cm - colmax) < d.eps;       // :81
         float jit = 3.0e38f;
@@ -304,8 +303,7 @@ __device__ __forceinline__ ColumnWords tm_column_compute(const Dev &d, int want_
             uint32_t base = htm_stream_base(d.seed, HTM_STREAM_LEAST_USED, step);
             jit = htm_jitter((float)l.segcount, htm_draw24(base, (uint32_t)(a * d.K + j), 0u));   // :86-87
         }
-        float mn = jit;
-        for (int o = 16; o > 0; o >>= 1) mn = fminf(mn, __shfl_xor(mn, o));
+        const float mn = half_reduce(jit, 3.0e38f, [](float x, float y) { return fminf(x, y); });
         const bool least = valid && fabsf(jit - mn) < d.eps;                       // :88
         const bool wbit = col_matching ? best : least;
         const u64 bw = __ballot(wbit);
@@ -347,14 +345,24 @@ __device__ __forceinline__ void tm_activate_column(const Dev &d, int p, int want
 // segment maxima and segment counts), and the global ids of own segments that fell below the matching threshold while
 // learning (the lowest-id-first recycling rule of projections.py:80-81 is global).  CAP = candidate slots per rank:
 //   [boosted f64 x CAP][column | bursting << 31  u32 x CAP][winner word u32 x CAP][needs-a-segment word u32 x CAP]
-//   [n_dead u32][dead ids u32 x DEAD_CAP][n u32], padded to 16 bytes
+//   [n_dead u32][dead ids u32 x DEAD_CAP][n u32][n_hot u32][hot floor: select key, u32 x 2], padded to 8 bytes
+//   [hot boosted f64 x CAP][hot slot u16 x CAP], padded to 16 bytes
 // (the active-cell word is not sent: it is all cells of a bursting column and the winner word otherwise; the boosted
 // overlaps of the CAP - n unused slots are CAND_PAD, all bits set: the global select tells a candidate from a free slot by
 // the value it loads anyway)
+// The hot list: the rank's best few candidates -- every own key from the histogram bin of its hot_target-th largest on;
+// the bin's lower edge is the list's floor --, their boosted overlaps once more, side by side, with their slots,
+// ascending too.  A tenth of a step's candidates can win.  The global select takes the k-th largest of the ranks' hot keys
+// (hot_target x ranks >= k); if that key is at or above every rank's floor, every candidate at or above it is in a hot list:
+// it is the k-th of all, and nothing else of the records is read (a few KB instead of 100: one block's loads are bound
+// by its CU).  n_hot = CAND_HOT_NONE: the rank has no hot list this step (its local select cut its threshold bin exactly, or
+// the list would not fit).
 #define CAND_PAD (~0ull)
+#define CAND_HOT_NONE 0xFFFFFFFFu
 __host__ __device__ __forceinline__ size_t shard_record_count_offset(int cap) { return (size_t)cap * 20 + 4 + 4 * DEAD_CAP; }
+__host__ __device__ __forceinline__ size_t shard_record_hot_offset(int cap) { return (shard_record_count_offset(cap) + 16 + 7) / 8 * 8; }
 __host__ __device__ __forceinline__ size_t shard_record_bytes(int cap) {
-    size_t n = shard_record_count_offset(cap) + 4;
+    size_t n = shard_record_hot_offset(cap) + (size_t)cap * 10;
     return (n + 15) / 16 * 16;
 }
 // candidate slots for a rank that must offer n_cand of n_local columns: room for the threshold bin of the windowed
@@ -440,7 +448,7 @@ struct EmitShared {
     uint32_t predw[256];
     int col[256];
     uint32_t wave[4];
-    uint32_t gt, eq, out[4], flags, krem, r;
+    uint32_t gt, eq, out[8], flags, krem, r;
     int n, nraw, ne;
 };
 
@@ -486,19 +494,23 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
         int lowbits = sel_shift(d.sel_passes - 1);              // key bits not resolved by launches
         bool take_all = false;                                  // (a shard's candidates: the whole threshold bin fits the record)
         uint32_t n_all = 0;
+        bool hot_ok = false;                                    // (... and the rank's best few fit its hot list)
+        u64 P_hot = 0;                                          // the lowest key a hot candidate can have
         if (wmode) {
             // The bin of the k-th key, and the keys above it: from the runs' sums first (64 of them, one wave, one read of the
             // copies), then from the 64 bins of the chosen run -- two dependent reads of a kilobyte each, no block-wide scan.
             // (Round 2 had every block fetch the copies whole, 64 KB, and scan 4 096 bins: 3.0-4.5 us at the head of the
             // select finish's chain.)
-            if (tid < 64) {
+            // (a shard's candidates: the second wave does the same for the hot_target-th key, the floor of the rank's hot list)
+            if (tid < 64 || (local && tid < 128)) {
                 const uint32_t *g0 = d.hist0 + (size_t)p * HIST0_PAR;
-                const int idx = 63 - tid;            // (from the top: the scan then gives "keys above")
+                const int idx = 63 - (tid & 63);     // (from the top: the scan then gives "keys above")
                 uint32_t v = 0;
 #pragma unroll
                 for (int r = 0; r < COARSE_REP; ++r) v += g0[HIST0_FINE + r * COARSE_STRIDE + idx];
                 uint32_t incl = wave_incl_scan(v);
-                const uint32_t kk = (uint32_t)d.sel_k;
+                const uint32_t kk = tid < 64 ? (uint32_t)d.sel_k : (uint32_t)d.hot_target;
+                uint32_t *s_out = sh->out + (tid < 64 ? 0 : 4);
                 const u64 hit = __ballot(incl >= kk);          // the first run (from the top) at which k keys have been seen
                 const int lane_r = hit ? __ffsll((long long)hit) - 1 : 63;
                 const int run = 63 - lane_r;
@@ -509,13 +521,20 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
                 const uint32_t incl_f = above_run + wave_incl_scan(f);
                 const u64 hit_f = __ballot(incl_f >= kk);
                 const int lane_f = hit_f ? __ffsll((long long)hit_f) - 1 : 63;
-                if (tid == lane_f) { s_out[0] = hit && hit_f ? (uint32_t)(run * 64 + 63 - lane_f) : 0u; s_out[1] = incl_f - f; s_out[2] = f; }
+                if ((tid & 63) == lane_f) { s_out[0] = hit && hit_f ? (uint32_t)(run * 64 + 63 - lane_f) : 0u; s_out[1] = incl_f - f; s_out[2] = f; }
             }
             __syncthreads();
             const uint32_t bucket = s_out[0], above = s_out[1], in_bin = s_out[2];
+            const uint32_t bucket_hot = s_out[4], n_hot_all = s_out[5] + s_out[6];
             __syncthreads();
             take_all = local && d.cand_take_all && bucket >= 1u && bucket <= (WIN_COARSE << WIN_FINE) && above + in_bin <= (uint32_t)d.cand_cap;
             n_all = above + in_bin;
+            // the hot list: the keys from the bin of the hot_target-th on (a bin of the window or the one above it), if they fit
+            hot_ok = take_all && bucket_hot >= bucket && n_hot_all <= (uint32_t)d.hot_budget && d.cand_cap <= 65536;
+            if (hot_ok) {
+                const uint32_t fine = bucket_hot - 1u;
+                P_hot = ((u64)(d.ctr->sel_win[p] + (fine >> WIN_FINE)) << 52) | ((u64)(fine & ((1u << WIN_FINE) - 1u)) << WIN_LOWBITS);
+            }
             if (bucket >= 1u && bucket <= (WIN_COARSE << WIN_FINE)) {
                 const uint32_t fine = bucket - 1u;
                 P = ((u64)(d.ctr->sel_win[p] + (fine >> WIN_FINE)) << 52) | ((u64)(fine & ((1u << WIN_FINE) - 1u)) << WIN_LOWBITS);
@@ -535,23 +554,27 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
             // A shard's candidates only have to CONTAIN its top-min(k, own columns): when the bins above the threshold bin and the
             // bin itself fit the record's slots -- every block sees that in the histogram, so all decide alike -- every key of
             // the bin goes in and nothing is left to resolve: no record exchange, no k-th key.  What the blocks still owe each
-            // other is a count (where in the record a block's candidates start), published first and read last: the cell words
-            // of the block's candidates are computed in between.
+            // other is a count (where in the record a block's candidates start, and where its hot ones do), published first and
+            // read last: the cell words of the block's candidates are computed in between.
             const bool sel = c < d.sel_hi && hi >= hiP;
+            const bool hot = sel && hot_ok && my_key >= P_hot;
             uint32_t total;
-            const uint32_t ex = block_excl_scan<256, true>(sel ? 1u : 0u, s_wave, total);
+            const uint32_t ex = block_excl_scan<256, true>((sel ? 1u : 0u) | (hot ? 0x10000u : 0u), s_wave, total);
+            const int n_sel = (int)(total & 0xFFFFu), n_hot_blk = (int)(total >> 16);
             const uint32_t tag2 = epoch | 0x800u;
-            if (tid == 0) __hip_atomic_store(&d.sel_blk[b], (tag2 << 20) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (sel) s_col[ex] = c;
-            lds_barrier();                       // (LDS only: not the published count's round trip, not the loads in flight)
-            EMIT_STAMP(2);
+            if (tid == 0)
+                __hip_atomic_store(&d.sel_blk[b], (tag2 << 20) | ((uint32_t)n_hot_blk << 10) | (uint32_t)n_sel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             uint32_t *s_cw = h, *s_wn = h + 256, *s_un = h + 512;      // (the histogram's LDS is free on this path)
             double *s_bo = (double *)(h + 768);
-            const int n_sel = (int)total;
+            int *s_hot = (int *)(h + 1280);
+            if (sel) s_col[ex & 0xFFFFu] = c;
+            if (hot) s_hot[ex >> 16] = (int)(ex & 0xFFFFu);
+            lds_barrier();                       // (LDS only: not the published count's round trip, not the loads in flight)
+            EMIT_STAMP(2);
             {
                 const int has_distal = d.ctr->has_distal;
                 const uint32_t step = d.ctr->step[p];
-                constexpr int CPP = 4;
+                constexpr int CPP = 8;           // (64 candidates per pass: a block has 40-50, all their loads in flight at once)
                 for (int i0 = 0; i0 < n_sel; i0 += 8 * CPP) {
                     int a[CPP];
                     bool ok[CPP];
@@ -579,8 +602,8 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
                 }
             }
             // everybody's counts (all of them, not just the earlier blocks': a block that has published has read the histogram,
-            // which is cleared below)
-            uint32_t before = 0;
+            // which is cleared below; and the hot lists' total decides where the padding starts)
+            uint32_t before = 0, before_hot = 0, all_hot = 0;
             for (int i = tid; i < nblk; i += 256) {
                 uint32_t v = 0;
                 int spins = 0;
@@ -590,17 +613,26 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
                     __builtin_amdgcn_s_sleep(1);
                 } while (++spins < (1 << 22));
                 if ((v >> 20) != tag2) atomicOr(&d.ctr->error, 16);
-                if (i < b) before += v & 0xFFFFFu;
+                if (i < b) { before += v & 0x3FFu; before_hot += (v >> 10) & 0x3FFu; }
+                all_hot += (v >> 10) & 0x3FFu;
             }
             before = wave_sum(before);
-            if (lane == 0 && before) atomicAdd(&s_gt, before);
+            before_hot = wave_sum(before_hot);
+            all_hot = wave_sum(all_hot);
+            if (lane == 0) {
+                if (before) atomicAdd(&s_gt, before);
+                if (before_hot) atomicAdd(&s_eq, before_hot);
+                if (all_hot) atomicAdd(&s_n, (int)all_hot);
+            }
             lds_barrier();
             EMIT_STAMP(3);
-            const int first_pos = (int)s_gt;
+            const int first_pos = (int)s_gt, first_hot = (int)s_eq, n_hot = s_n;
             {
                 const int cap = d.cand_cap;
                 double *r_boost = (double *)d.send;
                 uint32_t *r_col = (uint32_t *)(d.send + (size_t)cap * 8), *r_win = r_col + cap, *r_unacc = r_win + cap;
+                double *r_hot = (double *)(d.send + shard_record_hot_offset(cap));
+                uint16_t *r_hot_slot = (uint16_t *)(r_hot + cap);
                 if (tid < n_sel && first_pos + tid < cap) {
                     const int pos = first_pos + tid;
                     r_boost[pos] = s_bo[tid];
@@ -608,13 +640,23 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
                     r_win[pos] = s_wn[tid];
                     r_unacc[pos] = s_un[tid];
                 }
+                if (tid < n_hot_blk && first_hot + tid < cap) {
+                    const int li = s_hot[tid];
+                    r_hot[first_hot + tid] = s_bo[li];
+                    r_hot_slot[first_hot + tid] = (uint16_t)(first_pos + li);
+                }
                 for (int i = (int)n_all + b * 256 + tid; i < cap; i += nblk * 256) ((u64 *)r_boost)[i] = CAND_PAD;
+                for (int i = n_hot + b * 256 + tid; i < cap; i += nblk * 256) ((u64 *)r_hot)[i] = CAND_PAD;
                 if (b == 0) {
                     uint32_t *r_dead = r_unacc + cap;
                     const int n = min(d.dead_list[0], DEAD_CAP);
                     if (tid == 0) {
                         r_dead[0] = (uint32_t)n;
-                        *(uint32_t *)(d.send + shard_record_count_offset(cap)) = n_all;
+                        uint32_t *r_n = (uint32_t *)(d.send + shard_record_count_offset(cap));
+                        r_n[0] = n_all;
+                        r_n[1] = hot_ok ? (uint32_t)n_hot : CAND_HOT_NONE;
+                        r_n[2] = (uint32_t)P_hot;                                      // (the list's floor: every own key at or above it is in the list)
+                        r_n[3] = (uint32_t)(P_hot >> 32);
                         // (the coming step's window around this bin; the k-th key itself is not known on this path)
                         d.ctr->sel_win[p ^ 1] = min(win_base_for(P) + (uint32_t)d.win_offset, 4096u - WIN_COARSE);
                     }
@@ -1046,7 +1088,9 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
             const int n = min(d.dead_list[0], DEAD_CAP);
             if (tid == 0) {
                 r_dead[0] = (uint32_t)n;
-                *(uint32_t *)(d.send + shard_record_count_offset(d.cand_cap)) = (uint32_t)d.sel_k;     // (this path cuts exactly)
+                uint32_t *r_n = (uint32_t *)(d.send + shard_record_count_offset(d.cand_cap));
+                r_n[0] = (uint32_t)d.sel_k;         // (this path cuts exactly)
+                r_n[1] = CAND_HOT_NONE;             // (... and builds no hot list: the global select reads all candidates)
                 if (fused && wmode) d.ctr->cand_exact += 1;
             }
             for (int j = tid; j < n; j += 256) r_dead[1 + j] = (uint32_t)d.dead_list[1 + j];
@@ -1320,6 +1364,139 @@ __global__ __launch_bounds__(1024) void k_shard_select(Dev d, const unsigned cha
         if (tid == 0) d.dead_list[0] = 0;          // reported; the coming learning role collects this step's
         return;
     }
+    auto emit_winner = [&](int pos, uint32_t cw, uint32_t wn, uint32_t un) {
+        const int col = (int)(cw & 0x7FFFFFFFu);
+        const bool burst = cw >> 31;
+        const uint32_t act = burst ? cell_mask(d.K) : wn;                       // networks.py:115
+        d.active_cols[p][pos] = col;
+        atomicOr(&d.colbits[p][col >> 5], 1u << (col & 31));
+        d.act[p][col] = act;
+        d.win[p][col] = wn;
+        d.bursting[pos] = burst ? 1 : 0;
+        d.unacc_word[pos] = un;
+        d.winw_idx[pos] = wn;
+        d.actcnt[pos] = (uint8_t)__popc(act);
+    };
+    SHARD_STAMP(0);
+    {
+        // ---- the short way: the ranks' hot lists (see the record's layout).  Every rank's list within the budget, k keys
+        // between them and their k-th largest at or above every list's floor: it is the k-th largest of all candidates, and
+        // the winners are hot.  The block reads world x budget keys, its own rank's hot slots and, through them, the words of
+        // its own hot candidates -- a few KB -- and nothing of the candidates' arrays.
+        constexpr int KH = SHARD_HOT_KEYS;         // hot keys per thread
+        __shared__ uint32_t s_fast[2];
+        __shared__ u64 s_floor;
+        const int budget = d.hot_budget;
+        const size_t hot_off = shard_record_hot_offset(KL);
+        const uint32_t win_base = d.ctr->sel_win_global;
+        const int bq = blockIdx.x;
+        const unsigned char *rec = recv + (size_t)bq * rb;
+        const uint32_t *hdr = (const uint32_t *)(recv + (size_t)min(tid, d.world - 1) * rb + cnt_off);     // (threads < world use it)
+        const uint32_t nh = hdr[1];
+        const u64 floor_r = ((u64)hdr[3] << 32) | hdr[2];
+        const uint32_t n_own_raw = ((const uint32_t *)(rec + cnt_off))[1];
+        u64 hk[KH];
+        bool in_list[KH];
+#pragma unroll
+        for (int j = 0; j < KH; ++j) {
+            const int i = tid + j * 1024, r = i / budget, e = i - r * budget;
+            in_list[j] = r < d.world;
+            hk[j] = ((const u64 *)(recv + (size_t)min(r, d.world - 1) * rb + hot_off))[e];
+        }
+        u64 okey[2];
+        uint32_t oslot[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int e = min(2 * tid + u, KL - 1);
+            okey[u] = ((const u64 *)(rec + hot_off))[e];
+            oslot[u] = ((const uint16_t *)(rec + hot_off + (size_t)KL * 8))[e];
+        }
+        // while they travel: the histogram of the windowed pass, zeroed (its barrier does not wait for the loads)
+        for (int i = tid; i < SEL_BINS; i += 1024) h[i] = 0;
+        if (tid == 0) { s_cnt[0] = 0; s_out[0] = 0; s_or = 0; s_and = ~0ull; s_rank[0] = 0; s_rank[1] = 0; s_fast[0] = 0; s_fast[1] = 0; s_floor = 0; }
+        lds_barrier();
+        if (tid < d.world) {
+            if (nh == CAND_HOT_NONE || nh > (uint32_t)budget) atomicOr(&s_fast[0], 1u);
+            else { atomicAdd(&s_fast[1], nh); atomicMax((unsigned long long *)&s_floor, floor_r); }
+        }
+        // the own hot candidates' words, asked for as soon as their slots are here
+        const uint32_t *r_col = (const uint32_t *)(rec + (size_t)KL * 8), *r_win = r_col + KL, *r_unacc = r_win + KL;
+        uint32_t cw[2], wn[2], un[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int slot = min((int)oslot[u], KL - 1);
+            cw[u] = r_col[slot];
+            wn[u] = r_win[slot];
+            un[u] = r_unacc[slot];
+        }
+        lds_barrier();
+        if (s_fast[0] == 0 && s_fast[1] >= (uint32_t)d.k) {
+            const int n_own = (int)n_own_raw;          // (<= budget <= 2 048: one pass of two entries per thread)
+            uint32_t vmask = 0;
+#pragma unroll
+            for (int j = 0; j < KH; ++j) {
+                const bool ok = in_list[j] && hk[j] != CAND_PAD;
+                hk[j] = ok ? select_key_bits(hk[j]) : 0ull;
+                vmask |= (ok ? 1u : 0u) << j;
+            }
+            u64 T;
+            uint32_t krem;
+            bool missed = false;
+            const BlockSelLds L{h, s_wave, s_out, s_cnt, &s_or, &s_and, d.trace};
+            SHARD_STAMP(1);
+            block_select_regs<KH>(hk, vmask, (uint32_t)d.k, win_base, d.low_zero, L, &T, &krem, &missed, true);
+            SHARD_STAMP(2);
+            if (T >= s_floor) {                        // (else: a rank may hold a better candidate outside its list -- the long way)
+            {   // winners among the hot candidates of the ranks before this one
+                uint32_t g = 0, e = 0;
+#pragma unroll
+                for (int j = 0; j < KH; ++j) {
+                    const bool before = tid + j * 1024 < bq * budget && ((vmask >> j) & 1u);
+                    g += before && hk[j] > T;
+                    e += before && hk[j] == T;
+                }
+                g = wave_sum(g);
+                e = wave_sum(e);
+                if (lane == 0 && (g | e)) { atomicAdd(&s_rank[0], g); atomicAdd(&s_rank[1], e); }
+            }
+            uint32_t flag[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const u64 kk = select_key_bits(okey[u]);
+                flag[u] = 2 * tid + u < n_own ? ((kk > T) ? 1u : ((kk == T) ? 0x10000u : 0u)) : 0u;
+            }
+            uint32_t total;
+            uint32_t ex = block_excl_scan<1024, true>(flag[0] + flag[1], s_wave, total);
+            const uint32_t gt_run = s_rank[0], eq_run = s_rank[1];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const uint32_t g = gt_run + (ex & 0xFFFFu), e = eq_run + (ex >> 16);
+                if ((flag[u] & 1u) || ((flag[u] >> 16) && e < krem)) emit_winner((int)(g + min(e, krem)), cw[u], wn[u], un[u]);
+                ex += flag[u];
+            }
+            SHARD_STAMP(3);
+            if (bq == 0 && tid == 0) {
+                d.ctr->sel_win_global = min(win_base_global(T) + (uint32_t)d.win_offset, 4096u - WIN_COARSE);
+                if (missed) d.ctr->sel_fallbacks += 1;
+                d.ctr->hot_selects += 1;
+            }
+            SHARD_STAMP(5);
+            return;
+            }
+#ifdef BITHTM_SHARD_STAMPS
+            if (d.trace && bq == 0 && tid == 0) atomicAdd(&d.trace[20], 1ull);
+#endif
+            lds_barrier();                             // (everybody has read T's LDS words: the long way starts over)
+        }
+#ifdef BITHTM_SHARD_STAMPS                       // (why not: a rank without a hot list / over the budget / fewer than k hot keys)
+        if (d.trace && bq == 0 && tid < d.world) {
+            if (nh == CAND_HOT_NONE) atomicAdd(&d.trace[16], 1ull);
+            else if (nh > (uint32_t)budget) atomicAdd(&d.trace[17], 1ull);
+        }
+        if (d.trace && bq == 0 && tid == 0) { if (s_fast[0] == 0) atomicAdd(&d.trace[18], 1ull); d.trace[19] = s_fast[1]; }
+#endif
+    }
+    // ---- the long way: every candidate of every rank
     auto count_of = [&](int r) -> int { return min((int)*(const uint32_t *)(recv + (size_t)r * rb + cnt_off), KL); };
     const u64 inv_kl = ((1ull << 32) + (u64)KL - 1) / (u64)KL;      // i / KL for i < 2^16-ish: one multiplication (64 bits: KL = 1 gives 2^32)
     auto key_at = [&](int i, bool *filled) -> u64 {      // the key in slot i and whether the slot holds a candidate (CAND_PAD: free)
@@ -1330,9 +1507,8 @@ __global__ __launch_bounds__(1024) void k_shard_select(Dev d, const unsigned cha
         *filled = bits != CAND_PAD;
         return select_key_bits(bits);
     };
-    // up to KPT keys per thread stay in registers over the passes (configs[3] 8-way: 10 488 candidates, 11 per thread);
+    // up to KPT keys per thread stay in registers over the passes (configs[3] 8-way: 13 104 slots, 13 per thread);
     // beyond that they are read again, from L2
-    SHARD_STAMP(0);
     constexpr int KPT = 13;
     const bool in_regs = n_tot <= KPT * 1024;
     // everything this block will need that does not depend on the k-th key is asked for here, all at once: the window's base,
@@ -1466,20 +1642,7 @@ __global__ __launch_bounds__(1024) void k_shard_select(Dev d, const unsigned cha
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const uint32_t g = gt_run + (ex & 0xFFFFu), e = eq_run + (ex >> 16);
-            if ((flag[u] & 1u) || ((flag[u] >> 16) && e < krem)) {
-                const int pos = (int)(g + min(e, krem));
-                const int col = (int)(cw[u] & 0x7FFFFFFFu);
-                const bool burst = cw[u] >> 31;
-                const uint32_t act = burst ? cell_mask(d.K) : wn[u];                // networks.py:115
-                d.active_cols[p][pos] = col;
-                atomicOr(&d.colbits[p][col >> 5], 1u << (col & 31));
-                d.act[p][col] = act;
-                d.win[p][col] = wn[u];
-                d.bursting[pos] = burst ? 1 : 0;
-                d.unacc_word[pos] = un[u];
-                d.winw_idx[pos] = wn[u];
-                d.actcnt[pos] = (uint8_t)__popc(act);
-            }
+            if ((flag[u] & 1u) || ((flag[u] >> 16) && e < krem)) emit_winner((int)(g + min(e, krem)), cw[u], wn[u], un[u]);
             ex += flag[u];
         }
         gt_run += total & 0xFFFFu;

@@ -105,6 +105,9 @@ typedef struct htm_info {
                                            and took the exact in-kernel fallback (slower, same result) */
     int32_t candidate_exact_steps;      /* column-sharded handles: steps so far whose LOCAL select cut its threshold bin exactly
                                            instead of handing the whole bin over (slower, same result) */
+    int32_t hot_select_steps;           /* column-sharded handles: steps so far whose GLOBAL select was settled among the ranks'
+                                           hot lists (the candidates near the previous step's k-th key) without reading the
+                                           other candidates */
 } htm_info;
 
 /* Device arrays readable with htm_read / writable with htm_write. Element type and count

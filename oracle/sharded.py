@@ -66,6 +66,9 @@ class ShardedHTMOracle:
         self.duty = np.zeros(self.c1 - self.c0, dtype=np.float32)
         # the TM store is indexed by global id; a rank only ever touches the rows of segments it owns
         self.tm = TemporalMemoryOracle(column_dim, cell_dim, tm_params, seed)
+        self.hot_budget = min(self.cap, 4096 // world)    # entries of a rank's hot list the global select looks at
+        self.hot_target = max(1, min(self.n_cand, self.hot_budget // 2))
+        self.hot_selects = 0                              # steps whose global top-k was settled among the hot lists
         self.dead = np.zeros(0, dtype=np.bool_)           # replicated: id has fewer synapses than the matching threshold
         self.dead_out = np.zeros(0, dtype=np.int64)       # reported with the next exchange
 
@@ -88,12 +91,19 @@ class ShardedHTMOracle:
         overlaps = (connected & input_bits).sum(axis=1)
         boosted = exp_f32(self.d_sp.coef32 * self.duty).astype(np.float64) * overlaps
         cand = stable_topk(boosted, self.n_cand)           # own candidates, ascending (local) column
+        hot_slot, hot_floor = None, 0.0
         if self.offer == "bin" and len(cand):
             # everything down to the leading bits (sign, exponent, 7 mantissa bits) of the weakest candidate, if it fits
             lead = boosted.view(np.int64) >> 45
             wide = np.flatnonzero(lead >= lead[cand].min())
             if len(wide) <= self.cap:
                 cand = wide
+                # the hot list: the same cut at the hot_target-th largest key; its floor = the lowest value with those leading bits
+                lead_hot = lead[stable_topk(boosted, self.hot_target)].min()
+                hot = np.flatnonzero(lead >= lead_hot)
+                if len(hot) <= self.hot_budget and self.cap <= 65536:
+                    hot_slot = np.searchsorted(cand, hot)
+                    hot_floor = float(np.array([lead_hot << 45], dtype=np.int64).view(np.float64)[0])
         cols = cand + self.c0
         predicted = tm.prev_prediction[cols]
         bursting = ~predicted.any(axis=1)
@@ -114,8 +124,10 @@ class ShardedHTMOracle:
         least = np.abs(jittered - jittered.min(axis=1, keepdims=True)) < EPS32
         winner = predicted | (bursting[:, None] & np.where(column_matching[:, None], best, least))
         unacc = winner & ~has_match if tm.prev_distal is not None else np.zeros_like(winner)
+        # (a rank that cut its candidates exactly sends no hot list, hot_slot = None, as the HIP engine does)
         return SimpleNamespace(overlaps=overlaps, boosted_all=boosted, boosted=boosted[cand], col=cols.astype(np.int64),
-                               bursting=bursting, win=winner, unacc=unacc, dead=self.dead_out.copy())
+                               bursting=bursting, win=winner, unacc=unacc, dead=self.dead_out.copy(), hot_slot=hot_slot,
+                               hot_floor=hot_floor)
 
     # ---- phase B: identical global decisions + this rank's share of the work
     def finish_step(self, input_bits, records, learning=True):
@@ -129,6 +141,16 @@ class ShardedHTMOracle:
         burst_spec = np.concatenate([r.bursting for r in records])
         assert np.all(np.diff(col) > 0)
         chosen = stable_topk(boosted, self.k)                           # value desc, then candidate order = column asc
+        # the short way (what the HIP engine's global select does when it can): every rank sent a hot list, the lists hold k
+        # keys between them and the k-th largest of those is at or above every list's floor (every candidate at or above a
+        # rank's floor is in its list) -- then the top-k of the hot keys alone is the top-k of all
+        if all(r.hot_slot is not None for r in records) and sum(len(r.hot_slot) for r in records) >= self.k:
+            base = np.cumsum([0] + [len(r.boosted) for r in records[:-1]])
+            hot = np.concatenate([b + r.hot_slot for b, r in zip(base, records)])
+            top = stable_topk(boosted[hot], self.k)
+            if boosted[hot][top].min() >= max(r.hot_floor for r in records):
+                assert np.array_equal(hot[top], chosen), "hot lists select differently"
+                self.hot_selects += 1
         active = col[chosen]                                            # identical everywhere, ascending
         # deaths every rank reported (this one's own included): recyclable from now on
         self._ensure_dead(tm.S)
@@ -245,12 +267,20 @@ class ShardedHTMOracle:
 DEAD_CAP = 256
 
 
+HOT_NONE = 0xFFFFFFFF
+
+
+def _hot_offset(cap):
+    return (cap * 20 + 4 + 4 * DEAD_CAP + 16 + 7) // 8 * 8
+
+
 def record_nbytes(cap):
     """[boosted f64 x CAP][column | bursting << 31  u32 x CAP][winner word u32 x CAP][needs-a-segment word u32 x CAP]
-    [n_dead u32][dead ids u32 x DEAD_CAP][n u32: candidate slots in use][pad to 16 bytes]; the boosted overlaps of the
-    CAP - n free slots have all bits set"""
-    n = cap * (8 + 4 + 4 + 4) + 4 + 4 * DEAD_CAP + 4
-    return (n + 15) // 16 * 16
+    [n_dead u32][dead ids u32 x DEAD_CAP][n u32: candidate slots in use][n_hot u32][hot floor, 8 bytes: every own candidate at
+    or above it is in the hot list (here the float64; the HIP engine sends its select key)][pad to 8 bytes]
+    [hot boosted f64 x CAP][hot slot u16 x CAP][pad to 16 bytes]; the boosted overlaps of the CAP - n free slots and of the
+    CAP - n_hot free hot entries have all bits set; n_hot = HOT_NONE: no hot list"""
+    return (_hot_offset(cap) + cap * 10 + 15) // 16 * 16
 
 
 def pack_record(rec, cell_dim, cap=None):
@@ -273,12 +303,22 @@ def pack_record(rec, cell_dim, cap=None):
         raise OverflowError("more newly dead segments than the exchange record holds")
     buf[o:o + 4] = np.array([len(rec.dead)], dtype=np.uint32).view(np.uint8); o += 4
     buf[o:o + 4 * len(rec.dead)] = rec.dead.astype(np.uint32).view(np.uint8); o += 4 * DEAD_CAP
-    buf[o:o + 4] = np.array([n], dtype=np.uint32).view(np.uint8)
+    hot_slot = getattr(rec, "hot_slot", None)
+    n_hot = HOT_NONE if hot_slot is None or cap > 65536 else len(hot_slot)
+    buf[o:o + 8] = np.array([n, n_hot], dtype=np.uint32).view(np.uint8)
+    buf[o + 8:o + 16] = np.array([getattr(rec, "hot_floor", 0.0)], dtype=np.float64).view(np.uint8)
+    if n_hot != HOT_NONE:
+        o = _hot_offset(cap)
+        buf[o:o + 8 * n_hot] = rec.boosted[hot_slot].astype(np.float64).view(np.uint8)
+        buf[o + 8 * n_hot:o + 8 * cap] = 0xFF
+        o += 8 * cap
+        buf[o:o + 2 * n_hot] = np.asarray(hot_slot).astype(np.uint16).view(np.uint8)
     return buf
 
 
 def unpack_record(buf, cap, cell_dim):
-    n = int(buf[cap * 20 + 4 + 4 * DEAD_CAP:][:4].view(np.uint32)[0])
+    n, n_hot = (int(v) for v in buf[cap * 20 + 4 + 4 * DEAD_CAP:][:8].view(np.uint32))
+    hot_floor = float(buf[cap * 20 + 4 + 4 * DEAD_CAP + 8:][:8].view(np.float64)[0])
     assert np.all(buf[8 * n:8 * cap] == 0xFF), "free candidate slots must carry the pad value"
     o = 0
     boosted = buf[o:o + 8 * n].view(np.float64).copy(); o += 8 * cap
@@ -289,5 +329,12 @@ def unpack_record(buf, cap, cell_dim):
         mats.append(((words[:, None] >> np.arange(cell_dim, dtype=np.uint32)) & 1).astype(np.bool_))
     n_dead = int(buf[o:o + 4].view(np.uint32)[0]); o += 4
     dead = buf[o:o + 4 * n_dead].view(np.uint32).astype(np.int64)
+    hot_slot = None
+    if n_hot != HOT_NONE:
+        o = _hot_offset(cap)
+        assert np.all(buf[o + 8 * n_hot:o + 8 * cap] == 0xFF), "free hot entries must carry the pad value"
+        hot_slot = buf[o + 8 * cap:o + 8 * cap + 2 * n_hot].view(np.uint16).astype(np.int64)
+        assert np.array_equal(buf[o:o + 8 * n_hot].view(np.float64).view(np.int64), boosted[hot_slot].view(np.int64))
     return SimpleNamespace(boosted=boosted, col=(colword & np.uint32(0x7FFFFFFF)).astype(np.int64),
-                           bursting=(colword >> np.uint32(31)).astype(np.bool_), win=mats[0], unacc=mats[1], dead=dead)
+                           bursting=(colword >> np.uint32(31)).astype(np.bool_), win=mats[0], unacc=mats[1], dead=dead,
+                           hot_slot=hot_slot, hot_floor=hot_floor)

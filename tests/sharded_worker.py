@@ -37,10 +37,11 @@ def main():
     std, mean = (spp.permanence_std, spp.permanence_mean) if spp else (0.1, 0.0)
     perm = np.random.randn(C, I) * std + mean
     full = HTMOracle(I, C, K, seed=seed, sp_params=spp, tm_params=tmp, permanence=perm)
-    # odd ranks hand over whole threshold bins (variable candidate counts, as the HIP engine does when they fit), even ranks
-    # exactly their top-min(k, own columns): the global result must not care
+    # "stress": odd ranks hand over whole threshold bins (variable candidate counts, as the HIP engine does when they fit) with
+    # their hot lists, even ranks exactly their top-min(k, own columns) and no hot list: the global result must not care.
+    # "default": all ranks the former -- the global top-k is then settled among the hot lists wherever they hold k keys
     part = ShardedHTMOracle(rank, world, I, C, K, seed=seed, sp_params=spp, tm_params=tmp, permanence=perm,
-                            offer="bin" if rank % 2 else "exact")
+                            offer="bin" if (rank % 2 or cfg == "default") else "exact")
     c0, c1 = part.c0, part.c1
     cap = part.cap
     nbytes = record_nbytes(cap)
@@ -106,7 +107,7 @@ def main():
             eq("SP permanence (own)", part.permanence.view(np.int64), full.spatial_pooler.permanence[c0:c1].view(np.int64))
             eq("duty (own)", part.duty.view(np.int32), full.spatial_pooler.duty_cycle[c0:c1].view(np.int32))
     # the run must have exercised the cross-rank parts of the protocol
-    tot = torch.tensor([dead_total, int((f_tm.cell_prediction.any(axis=1)).sum()), offered])
+    tot = torch.tensor([dead_total, int((f_tm.cell_prediction.any(axis=1)).sum()), offered, part.hot_selects])
     dist.all_reduce(tot)
     if rank == 0:
         print(f"OK world={world} cfg={cfg} steps={steps} S={full.temporal_memory.S} dead_reported={int(tot[0])} "
@@ -114,6 +115,9 @@ def main():
         if cfg != "default":
             assert int(tot[0]) > 0, "stress run reported no dead segments: protocol path untested"
         assert int(tot[2]) > 0, "no rank ever offered more than its exact cut: variable counts untested"
+        if cfg == "default":
+            assert int(tot[3]) > world * steps // 2, "the hot lists hardly ever settled the global top-k: that path is untested"
+        print(f"global top-k settled among the hot lists in {int(tot[3]) // world} of {steps} steps")
     dist.barrier()
     dist.destroy_process_group()
 

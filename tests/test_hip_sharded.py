@@ -101,8 +101,10 @@ def _run(world, I, C, K, P, density, noise, steps, jump, seed, spp=None, tmp=Non
                 assert np.array_equal(eng.read_duty_cycle()[c0:c1].view(np.int32),
                                       ora.spatial_pooler.duty_cycle[c0:c1].view(np.int32)), f"{tag}: duty (own)"
     exact = max(m.engine.info().candidate_exact_steps for m in group.members)
-    print(f"world {world}, {C} columns: local selects that cut their threshold bin exactly in {exact} of {steps} steps")
-    _run.exact_steps = exact
+    hot = min(m.engine.info().hot_select_steps for m in group.members)
+    print(f"world {world}, {C} columns: local selects that cut their threshold bin exactly in {exact} of {steps} steps; "
+          f"global selects settled among the hot lists in {hot}")
+    _run.exact_steps, _run.hot_steps = exact, hot
     return dead_seen
 
 

@@ -56,13 +56,17 @@ def test_wire_format_round_trip():
     kl, K = 41, 12
     rec = SimpleNamespace(boosted=rng.rand(kl), col=np.sort(rng.choice(5000, kl, replace=False)).astype(np.int64),
                           bursting=rng.rand(kl) < 0.5, win=rng.rand(kl, K) < 0.2, unacc=rng.rand(kl, K) < 0.1,
-                          dead=np.array([5, 77, 1234567], dtype=np.int64))
+                          dead=np.array([5, 77, 1234567], dtype=np.int64), hot_slot=None, hot_floor=0.7)
     for cap in (kl, kl + 23):                      # a full record, and one with free candidate slots
-        buf = pack_record(rec, K, cap)
-        assert len(buf) == record_nbytes(cap) and len(buf) % 16 == 0
-        back = unpack_record(buf, cap, K)
-        for f in ("boosted", "col", "bursting", "win", "unacc", "dead"):
-            assert np.array_equal(getattr(back, f), getattr(rec, f)), f
+        for hot in (None, np.flatnonzero(rec.boosted > 0.7), np.arange(kl)):       # no hot list, some hot candidates, all
+            rec.hot_slot = hot
+            buf = pack_record(rec, K, cap)
+            assert len(buf) == record_nbytes(cap) and len(buf) % 16 == 0
+            back = unpack_record(buf, cap, K)
+            for f in ("boosted", "col", "bursting", "win", "unacc", "dead"):
+                assert np.array_equal(getattr(back, f), getattr(rec, f)), f
+            assert (back.hot_slot is None) == (hot is None) and (hot is None or np.array_equal(back.hot_slot, hot))
+            assert back.hot_floor == 0.7
     with pytest.raises(OverflowError):
         pack_record(rec, K, kl - 1)
     rec.dead = np.arange(DEAD_CAP + 1)
@@ -70,4 +74,5 @@ def test_wire_format_round_trip():
         pack_record(rec, K)
     # 20 B per candidate; BASELINE.json configs[3] (65 536 columns, k = 1 311) sharded 8-way
     # (+ a quarter more slots than the rank must offer: room for the threshold bin of its local select)
-    assert cand_cap(1311, 65536 // 8) == 1638 and record_nbytes(1638) <= 34 * 1024
+    # and 10 B for its place in the hot list
+    assert cand_cap(1311, 65536 // 8) == 1638 and record_nbytes(1638) <= 50 * 1024

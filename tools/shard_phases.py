@@ -54,6 +54,12 @@ def main():
             sub = raw[8:11].astype(np.float64) / 100.0           # inside "k-th key": histogram zeroed, filled, bin picked
             print(f"step {step}: " + "  ".join(f"{n} {v:.2f}" for n, v in zip(names, np.diff(t))) + f"  total {t[5] - t[0]:.2f} us"
                   + f"   [k-th key: zero {sub[0] - t[1]:.2f}  fill {sub[1] - sub[0]:.2f}  pick {sub[2] - sub[1]:.2f}  inside the bin {t[2] - sub[2]:.2f}]")
+    if what == "select":
+        group.run(200)
+        eng.sync()
+        raw = eng.trace_read().reshape(-1)
+        print(f"over ~270 steps, the long way was taken because: a rank had no hot list {int(raw[16])} (rank-steps), a hot list was over "
+              f"the budget {int(raw[17])} (rank-steps), the lists held fewer than k keys {int(raw[18])} (steps; last sum {int(raw[19])}), the k-th hot key was below a list's floor {int(raw[20])} (steps)")
     info = eng.check_capacity()
     print(f"segments {info.segments}, rank 0 rows {info.local_segments}, select fallbacks {info.select_fallbacks} of {info.step_index} steps")
 

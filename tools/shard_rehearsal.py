@@ -49,7 +49,7 @@ def main():
     print(json.dumps(dict(world=args.world, rank0_launch_us={n: round(v, 1) for n, v in prof.items()}, launches_per_step=len(steady),
                           rank0_kernels_us=round(sum(steady.values()), 1), all_ranks_wall_us_per_step=round(1e6 * wall, 1),
                           segments=info.segments, rank0_rows=info.local_segments, record_bytes=eng.shard_record_bytes(),
-                          select_fallbacks=info.select_fallbacks, local_selects_cut_exactly=info.candidate_exact_steps, steps=info.step_index)))
+                          select_fallbacks=info.select_fallbacks, local_selects_cut_exactly=info.candidate_exact_steps, global_selects_among_hot_lists=info.hot_select_steps, steps=info.step_index)))
 
 
 if __name__ == "__main__":
