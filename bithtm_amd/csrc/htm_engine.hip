@@ -69,6 +69,9 @@ struct htm_handle {
     bool emit_fused, emit_fused_open;     // the emit grid is resident at once in k_sp_emit / in k_open_emit (refreshed per call)
     bool emit_fits_lean;                  // ... and in k_learn_scan_emit
     int knob_lean, knob_fuse_tm, knob_shard_window, knob_scan_large, knob_step_window, knob_tail_rows;
+    int knob_defer_tail;                  // htm_step holds a step's last launch back for the next call's first (BITHTM_DEFER_TAIL)
+    bool tail_pending;                    // ... and one is held back now: the learning role and the scan of the step of parity tail_p
+    int tail_p;
     bool window_known;                    // a select has run on this handle since it was created / imported into: Counters::sel_win is meaningful      // environment knobs, read when the handle is created
     bool emit_fits, emit_fits_open;       // ... as far as this handle's own grids go (fixed at creation)
     int sel_passes_fused, sel_passes_full; // launched select digits with / without the in-kernel finish
@@ -281,31 +284,16 @@ static void enqueue_sp_back(htm_handle *h, const uint32_t *bank, int n_inputs, i
 // permanence update of this step rides along in the middle launch.
 // front_wmode >= 0 (column-sharded handles inside htm_shard_run): the overlap of the COMING step on the rank's own
 // columns rides in the last launch (wmode = front_wmode: windowed histogram or top digit)
-static void enqueue_tm(htm_handle *h, int n_active, int learning, int want_winner, int p,
-                       const uint32_t *bank, int n_inputs, bool sp_rows, int front_wmode = -1) {
+// the learning role and the scan: one launch (the learning waves scan their own rows), unless the pool is large (the
+// streaming scan kernels) or somebody is timing the roles one by one (unsharded handles under htm_profile)
+static bool tm_tail_fused(const htm_handle *h) {
+    return h->knob_fuse_tm && !(h->profile && h->world == 1) && !scan_pool_is_large(h) && scan_lds(h->d, 1) <= 64 * 1024;
+}
+
+// the learning role and the scan of the step of parity p, nothing beside them
+static void enqueue_tm_tail(htm_handle *h, int p) {
     Dev &d = h->d;
-    const int n_cls = learning ? kClassifyBlocks : 0;
-    // the learning role and the scan: one launch (the learning waves scan their own rows), unless the pool is large (the
-    // streaming scan kernels) or somebody is timing the roles one by one (unsharded handles under htm_profile)
-    const bool fuse = h->knob_fuse_tm && !(h->profile && h->world == 1) && !scan_pool_is_large(h) && scan_lds(d, 1) <= 64 * 1024;
-    int n_sp_rows = (sp_rows && learning && h->cfg.enable_sp) ? d.k : 0;
-    // an unsharded step's permanence rows ride in that launch (the middle launch is left with the Temporal Memory's chain);
-    // a shard's stay in the middle launch: the coming step's overlap, which reads them, may ride in the last one
-    const int n_tail_rows = (fuse && h->world == 1 && h->knob_tail_rows) ? n_sp_rows : 0;
-    if (n_tail_rows) n_sp_rows = 0;
-    const int n_duty = h->world > 1 ? (d.c1 - d.c0 + 255) / 256 : 0;      // (unsharded: the emit role updates the duty cycle)
-    LAUNCH(h, "tm_mid", k_mid_rows, 1 + n_cls + n_sp_rows + n_duty + h->zero_blocks, 256, d, p, n_active, want_winner, learning, n_cls, bank, n_inputs, n_sp_rows, 0, n_duty);
-    if (fuse && (front_wmode >= 0 || n_tail_rows)) {
-        const int epl = learn_epl(d), n_learn = h->lean_learn_blocks, n_scan = h->lean_scan_blocks, spec = scan_spec_blocks(h);
-        const size_t lds = std::max(std::max(learn_lds(epl, 256), scan_lds(d, 1)), (size_t)SEL_BINS * 4);
-        const int grid = n_learn + n_scan + (n_tail_rows ? n_tail_rows : h->lean_overlap_blocks);
-        const char *name = n_tail_rows ? "tm_learn+tm_scan+sp_learn" : "tm_learn+tm_scan+shard_overlap";
-#define LAUNCH_LST(E_) LAUNCH_ON(h, h->stream, lds, name, (k_learn_scan_tail<E_>), grid, 256, d, p, n_learn, n_scan, spec, bank, n_inputs, h->G, front_wmode, n_tail_rows)
-        switch (epl) { case 1: LAUNCH_LST(1); break; case 2: LAUNCH_LST(2); break; case 4: LAUNCH_LST(4); break; default: LAUNCH_LST(8); break; }
-#undef LAUNCH_LST
-        return;
-    }
-    if (fuse) {
+    if (tm_tail_fused(h)) {
         const int epl = learn_epl(d), n_learn = h->lean_learn_blocks, n_scan = h->lean_scan_blocks, spec = scan_spec_blocks(h);
         const size_t lds = std::max(learn_lds(epl, 256), scan_lds(d, 1));
         switch (epl) {
@@ -318,6 +306,42 @@ static void enqueue_tm(htm_handle *h, int n_active, int learning, int want_winne
         launch_learn(h, p);
         launch_scan(h, p, scan_lds(d, 1) <= 64 * 1024);
     }
+}
+
+// htm_step may hold a step's last launch back (the next call's first launch carries it beside its overlap): everything else
+// that touches the handle lets it go first
+static void flush_tail(htm_handle *h) {
+    if (!h->tail_pending) return;
+    h->tail_pending = false;
+    hipSetDevice(h->device);
+    enqueue_tm_tail(h, h->tail_p);
+}
+
+// defer_tail: the last launch is held back (htm_step: see flush_tail); the permanence rows then ride in the middle launch
+static void enqueue_tm(htm_handle *h, int n_active, int learning, int want_winner, int p,
+                       const uint32_t *bank, int n_inputs, bool sp_rows, int front_wmode = -1, bool defer_tail = false) {
+    Dev &d = h->d;
+    const int n_cls = learning ? kClassifyBlocks : 0;
+    const bool fuse = tm_tail_fused(h);
+    int n_sp_rows = (sp_rows && learning && h->cfg.enable_sp) ? d.k : 0;
+    // an unsharded step's permanence rows ride in that launch (the middle launch is left with the Temporal Memory's chain);
+    // a shard's stay in the middle launch: the coming step's overlap, which reads them, may ride in the last one
+    const int n_tail_rows = (fuse && h->world == 1 && h->knob_tail_rows && !defer_tail) ? n_sp_rows : 0;
+    if (n_tail_rows) n_sp_rows = 0;
+    const int n_duty = h->world > 1 ? (d.c1 - d.c0 + 255) / 256 : 0;      // (unsharded: the emit role updates the duty cycle)
+    LAUNCH(h, "tm_mid", k_mid_rows, 1 + n_cls + n_sp_rows + n_duty + h->zero_blocks, 256, d, p, n_active, want_winner, learning, n_cls, bank, n_inputs, n_sp_rows, 0, n_duty);
+    if (defer_tail) { h->tail_pending = true; h->tail_p = p; return; }
+    if (fuse && (front_wmode >= 0 || n_tail_rows)) {
+        const int epl = learn_epl(d), n_learn = h->lean_learn_blocks, n_scan = h->lean_scan_blocks, spec = scan_spec_blocks(h);
+        const size_t lds = std::max(std::max(learn_lds(epl, 256), scan_lds(d, 1)), (size_t)SEL_BINS * 4);
+        const int grid = n_learn + n_scan + (n_tail_rows ? n_tail_rows : h->lean_overlap_blocks);
+        const char *name = n_tail_rows ? "tm_learn+tm_scan+sp_learn" : "tm_learn+tm_scan+shard_overlap";
+#define LAUNCH_LST(E_) LAUNCH_ON(h, h->stream, lds, name, (k_learn_scan_tail<E_>), grid, 256, d, p, n_learn, n_scan, spec, bank, n_inputs, h->G, front_wmode, n_tail_rows)
+        switch (epl) { case 1: LAUNCH_LST(1); break; case 2: LAUNCH_LST(2); break; case 4: LAUNCH_LST(4); break; default: LAUNCH_LST(8); break; }
+#undef LAUNCH_LST
+        return;
+    }
+    enqueue_tm_tail(h, p);
     // (a large pool streams through kernels of its own: the front as a launch behind them)
     if (front_wmode >= 0)
         LAUNCH(h, "shard_overlap", k_shard_overlap, h->sp_blocks, RB, d, bank, n_inputs, h->G, p, front_wmode, 1);
@@ -670,6 +694,9 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
     h->knob_scan_large = getenv("BITHTM_SCAN_LARGE") ? atoi(getenv("BITHTM_SCAN_LARGE")) : -1;
     h->knob_step_window = getenv("BITHTM_STEP_WINDOW") ? atoi(getenv("BITHTM_STEP_WINDOW")) != 0 : 1;
     h->knob_tail_rows = getenv("BITHTM_TAIL_ROWS") ? atoi(getenv("BITHTM_TAIL_ROWS")) != 0 : 1;
+    h->knob_defer_tail = getenv("BITHTM_DEFER_TAIL") ? atoi(getenv("BITHTM_DEFER_TAIL")) != 0 : 1;
+    h->tail_pending = false;
+    h->tail_p = 0;
     h->lean_overlap_blocks = getenv("BITHTM_LEAN_OVERLAP") ? std::max(1, atoi(getenv("BITHTM_LEAN_OVERLAP"))) : h->sp_blocks * (RB / 256);
     h->lean_learn_blocks = getenv("BITHTM_LEAN_LEARN") ? std::max(1, atoi(getenv("BITHTM_LEAN_LEARN"))) : 512;
     h->lean_scan_blocks = getenv("BITHTM_LEAN_SCAN") ? std::max(1, atoi(getenv("BITHTM_LEAN_SCAN"))) : (h->scan_blocks > 512 ? std::max(256, (h->scan_blocks * 3 / 8 + 255) & ~255) : h->scan_blocks);
@@ -753,6 +780,7 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
 // potential < epsilon) then mean what they mean at 1e-8.  Kernels get it with their arguments: cached graphs are dropped.
 extern "C" int htm_set_epsilon(htm_handle *h, float epsilon) {
     if (!h) return HTM_ERR_ARGUMENT;
+    if (h) flush_tail(h);
     if (!(epsilon > 0.f) || epsilon > 1.f) { h->err = "htm_set_epsilon: need 0 < epsilon <= 1"; return HTM_ERR_ARGUMENT; }
     REJECT_WHEN_AHEAD(h);
     if (epsilon == h->d.eps) return HTM_OK;
@@ -772,6 +800,7 @@ extern "C" int htm_get_stream(htm_handle *h, void **stream) {
 
 extern "C" int htm_sync(htm_handle *h) {
     if (!h) return HTM_ERR_ARGUMENT;
+    if (h) flush_tail(h);
     HIPCHK(h, hipSetDevice(h->device));
     // a short run ends within a millisecond: poll for that long (a blocking wait is woken tens of microseconds late),
     // then block
@@ -797,6 +826,7 @@ static int check_rows(htm_handle *h, const void *rows, int row_begin, int row_co
 }
 
 extern "C" int htm_sp_set_permanence(htm_handle *h, const double *rows, int32_t row_begin, int32_t row_count) {
+    if (h) flush_tail(h);
     int rc = check_rows(h, rows, row_begin, row_count);
     if (rc) return rc;
     REJECT_WHEN_AHEAD(h);
@@ -813,6 +843,7 @@ extern "C" int htm_sp_set_permanence(htm_handle *h, const double *rows, int32_t 
 }
 
 extern "C" int htm_sp_get_permanence(htm_handle *h, double *rows, int32_t row_begin, int32_t row_count) {
+    if (h) flush_tail(h);
     int rc = check_rows(h, rows, row_begin, row_count);
     if (rc) return rc;
     REJECT_WHEN_AHEAD(h);
@@ -856,14 +887,46 @@ extern "C" int htm_step(htm_handle *h, const uint32_t *packed_input, int32_t lea
     int rc = close_open_phases(h);
     if (rc) return rc;
     if (h->d.W > ARG_INPUT_WORDS) {                 // (an input too wide for the launch's arguments: staged by a copy)
+        flush_tail(h);
         rc = stage_input(h, packed_input);
         if (rc) return rc;
     }
+    // Three launches per step for a caller that steps and steps: the learning role and the scan of a step need nothing of the
+    // NEXT input and nothing the next step's overlap touches -- they are held back and ride beside that overlap (the
+    // permanence rows, which the overlap does read, in the middle launch instead).  Any other call lets them go first.
+    Dev &d = h->d;
+    if (h->knob_defer_tail && d.W <= ARG_INPUT_WORDS && tm_tail_fused(h) && !h->profile) {
+        const int p = (int)(h->step_host & 1), wmode = step_wmode(h);
+        if (h->tail_pending) {
+            PackedInputArg in;
+            memset(&in, 0, sizeof(in));
+            memcpy(in.w, packed_input, (size_t)((d.I + 31) / 32) * 4);
+            const int epl = learn_epl(d), n_learn = h->lean_learn_blocks, n_scan = h->lean_scan_blocks, spec = scan_spec_blocks(h);
+            const size_t lds = std::max(std::max(learn_lds(epl, 256), scan_lds(d, 1)), (size_t)(SEL_BINS + ARG_INPUT_WORDS) * 4);
+            const int grid = n_learn + n_scan + h->lean_overlap_blocks;
+            h->tail_pending = false;
+#define LAUNCH_LSF(E_) LAUNCH_ON(h, h->stream, lds, "tm_learn+tm_scan+sp_overlap", (k_learn_scan_front<E_>), grid, 256, d, h->tail_p, n_learn, n_scan, spec, in, h->G, p, wmode)
+            switch (epl) { case 1: LAUNCH_LSF(1); break; case 2: LAUNCH_LSF(2); break; case 4: LAUNCH_LSF(4); break; default: LAUNCH_LSF(8); break; }
+#undef LAUNCH_LSF
+            if (!wmode)
+                for (int pass = 1; pass < d.sel_passes; ++pass) LAUNCH(h, "sp_select", k_sel_pass, h->sel_blocks, RB, d, pass, p);
+        } else {
+            enqueue_sp_front(h, d.input_stage, 1, p, wmode, packed_input);
+        }
+        enqueue_sp_back(h, d.input_stage, 1, p, 1, EMIT_ALL, false, wmode);
+        enqueue_tm(h, d.k, learning ? 1 : 0, 1, p, d.input_stage, 1, true, -1, true);
+        h->step_host += 1;
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { h->err = std::string("kernel launch: ") + hipGetErrorString(e); return HTM_ERR_HIP; }
+        return HTM_OK;
+    }
+    flush_tail(h);
     return enqueue_step(h, h->d.input_stage, 1, learning ? 1 : 0, StepPlan{false, false, false}, packed_input);
 }
 
 extern "C" int htm_sp_step(htm_handle *h, const uint32_t *packed_input, int32_t learning) {
     if (!h || !packed_input) return HTM_ERR_ARGUMENT;
+    if (h) flush_tail(h);
     REJECT_WHEN_AHEAD(h);
     if (!h->cfg.enable_sp) { h->err = "handle has no Spatial Pooler"; return HTM_ERR_STATE; }
     // a handle that also owns a Temporal Memory steps both layers together: an SP-only step would skip the SP
@@ -886,6 +949,7 @@ extern "C" int htm_sp_step(htm_handle *h, const uint32_t *packed_input, int32_t 
 // (bithtm_amd/networks.py) interleaves these with the `process` / `update` methods of the user's objects.
 extern "C" int htm_sp_phase(htm_handle *h, int32_t phase, const void *data, int64_t count) {
     if (!h) return HTM_ERR_ARGUMENT;
+    if (h) flush_tail(h);
     REJECT_WHEN_AHEAD(h);
     if (!h->cfg.enable_sp) { h->err = "handle has no Spatial Pooler"; return HTM_ERR_STATE; }
     if (h->world > 1) { h->err = "htm_sp_phase: not available on a column-sharded handle"; return HTM_ERR_STATE; }
@@ -967,6 +1031,7 @@ extern "C" int htm_sp_phase(htm_handle *h, int32_t phase, const void *data, int6
 
 extern "C" int htm_tm_step(htm_handle *h, const int32_t *active_column, int32_t n, int32_t learning, int32_t return_winner_cell) {
     if (!h || (!active_column && n > 0)) return HTM_ERR_ARGUMENT;
+    if (h) flush_tail(h);
     REJECT_WHEN_AHEAD(h);
     if (!h->cfg.enable_tm) { h->err = "handle has no Temporal Memory"; return HTM_ERR_STATE; }
     Dev &d = h->d;
@@ -999,6 +1064,7 @@ extern "C" int htm_tm_step(htm_handle *h, const int32_t *active_column, int32_t 
 extern "C" int htm_tm_update(htm_handle *h, const int32_t *columns, const uint32_t *winner_words, const uint32_t *unaccounted_words,
                              int32_t n, const uint32_t *punish_words) {
     if (!h || (n > 0 && (!columns || !winner_words || !unaccounted_words))) return HTM_ERR_ARGUMENT;
+    if (h) flush_tail(h);
     REJECT_WHEN_AHEAD(h);
     if (!h->cfg.enable_tm) { h->err = "handle has no Temporal Memory"; return HTM_ERR_STATE; }
     if (h->world > 1) { h->err = "htm_tm_update: not available on a column-sharded handle"; return HTM_ERR_STATE; }
@@ -1050,6 +1116,7 @@ extern "C" int htm_tm_update(htm_handle *h, const int32_t *columns, const uint32
 // closes the timestep.  The State is read with htm_read (MATCH_*, SEG_POTENTIAL, CELL_MAX_JITTER, CELL_PREDICTION).
 extern "C" int htm_tm_scan(htm_handle *h, const uint32_t *active_words) {
     if (!h || !active_words) return HTM_ERR_ARGUMENT;
+    if (h) flush_tail(h);
     REJECT_WHEN_AHEAD(h);
     if (!h->cfg.enable_tm) { h->err = "handle has no Temporal Memory"; return HTM_ERR_STATE; }
     if (h->world > 1) { h->err = "htm_tm_scan: not available on a column-sharded handle"; return HTM_ERR_STATE; }
@@ -1079,6 +1146,7 @@ extern "C" int htm_tm_scan(htm_handle *h, const uint32_t *active_words) {
 // htm_run, or (dry) only the capture + instantiation of every hipGraph that htm_run call would replay
 static int run_or_prepare(htm_handle *h, const uint32_t *device_inputs, int32_t n_inputs, int32_t n_steps, int32_t learning,
                           int32_t use_graph, bool dry) {
+    if (h) flush_tail(h);
     if (!h || !device_inputs || n_inputs < 1 || n_steps < 0) return HTM_ERR_ARGUMENT;
     if (!h->cfg.enable_sp || !h->cfg.enable_tm) { h->err = "htm_run needs a handle with SP and TM"; return HTM_ERR_STATE; }
     if (h->world > 1) { h->err = "sharded handle: use htm_shard_begin / htm_shard_finish"; return HTM_ERR_STATE; }
@@ -1639,6 +1707,7 @@ extern "C" int htm_shard_group_run(htm_handle *const *handles, int32_t n, const 
 extern "C" int htm_populate(htm_handle *h, int64_t cell_begin, int64_t cell_end, int32_t segments_per_cell, int32_t synapses,
                             double perm_lo, double perm_hi, uint32_t seed) {
     if (!h) return HTM_ERR_ARGUMENT;
+    if (h) flush_tail(h);
     if (!h->cfg.enable_tm) { h->err = "handle has no Temporal Memory"; return HTM_ERR_STATE; }
     Dev &d = h->d;
     const int64_t N = (int64_t)d.C * d.K;
@@ -1694,6 +1763,7 @@ static int read_counters(htm_handle *h, Counters *out) {
 
 extern "C" int htm_get_info(htm_handle *h, htm_info *out) {
     if (!h || !out) return HTM_ERR_ARGUMENT;
+    if (h) flush_tail(h);
     Counters c;
     int rc = read_counters(h, &c);
     if (rc) return rc;
@@ -1737,6 +1807,7 @@ static inline int flat_enc(int flat, int K) { return (flat / K) * 32 + (flat % K
 
 extern "C" int64_t htm_read(htm_handle *h, int32_t field, void *dst, int64_t count) {
     if (!h || !dst) return HTM_ERR_ARGUMENT;
+    if (h) flush_tail(h);
     Counters c;
     int rc = read_counters(h, &c);
     if (rc) return rc;
@@ -1858,6 +1929,7 @@ extern "C" int64_t htm_read(htm_handle *h, int32_t field, void *dst, int64_t cou
 // not matching.
 extern "C" int64_t htm_read_rows(htm_handle *h, int32_t field, int64_t row_begin, int64_t row_count, void *dst, int64_t count) {
     if (!h || !dst || row_begin < 0 || row_count < 0) return HTM_ERR_ARGUMENT;
+    if (h) flush_tail(h);
     if (!h->cfg.enable_tm) { h->err = "htm_read_rows: handle has no Temporal Memory"; return HTM_ERR_STATE; }
     Counters c;
     int rc = read_counters(h, &c);
@@ -1927,6 +1999,7 @@ extern "C" int64_t htm_read_rows(htm_handle *h, int32_t field, int64_t row_begin
 
 extern "C" int htm_write(htm_handle *h, int32_t field, const void *src, int64_t count) {
     if (!h || (!src && count > 0) || count < 0) return HTM_ERR_ARGUMENT;
+    if (h) flush_tail(h);
     REJECT_WHEN_AHEAD(h);
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1988,6 +2061,7 @@ extern "C" int htm_write(htm_handle *h, int32_t field, const void *src, int64_t 
 
 extern "C" int htm_import_begin(htm_handle *h, int64_t step_index) {
     if (!h || (step_index < 0 && step_index != HTM_IMPORT_PREV_STATE)) return HTM_ERR_ARGUMENT;
+    if (h) flush_tail(h);
     REJECT_WHEN_AHEAD(h);
     if (h->world > 1 && step_index == HTM_IMPORT_PREV_STATE) { h->err = "prev_state adoption is not available on a column-sharded handle"; return HTM_ERR_STATE; }
     if (h->shard_open) { h->err = "htm_import_begin: a step opened with htm_shard_begin is not finished"; return HTM_ERR_STATE; }
@@ -2012,6 +2086,7 @@ __global__ __launch_bounds__(256) void k_tm_winner_bits(Dev d, int q, int n) {
 extern "C" int htm_import_commit(htm_handle *h, int32_t segments, int32_t matching_segments, int32_t winner_cells,
                                  int32_t has_distal_state, int32_t has_winner_cells) {
     if (!h) return HTM_ERR_ARGUMENT;
+    if (h) flush_tail(h);
     Dev &d = h->d;
     const bool keep = h->import_keep;              // TemporalMemory.process(prev_state=X): the previous step's State only
     h->import_keep = false;
@@ -2146,12 +2221,14 @@ extern "C" int htm_import_commit(htm_handle *h, int32_t segments, int32_t matchi
 
 extern "C" int htm_profile(htm_handle *h, int32_t enable) {
     if (!h) return HTM_ERR_ARGUMENT;
+    if (h) flush_tail(h);
     h->profile = enable != 0;
     return HTM_OK;
 }
 
 extern "C" int64_t htm_trace_read(htm_handle *h, uint64_t *dst, int64_t count) {
     if (!h || !dst) return HTM_ERR_ARGUMENT;
+    if (h) flush_tail(h);
     if (!h->d.trace) { h->err = "htm_trace_read: handle was not created with BITHTM_TRACE=1"; return HTM_ERR_STATE; }
     const int64_t n = (int64_t)8 * 4096 * 2;
     if (count < n) { h->err = "htm_trace_read: buffer too small"; return HTM_ERR_ARGUMENT; }
@@ -2163,6 +2240,7 @@ extern "C" int64_t htm_trace_read(htm_handle *h, uint64_t *dst, int64_t count) {
 
 extern "C" int htm_profile_read(htm_handle *h, int32_t max_kernels, const char **names, double *total_ms, int64_t *launches) {
     if (!h) return HTM_ERR_ARGUMENT;
+    if (h) flush_tail(h);
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     for (size_t i = 0; i < h->prof_names.size(); ++i) {

@@ -237,4 +237,31 @@ __global__ __launch_bounds__(256, 6) void k_learn_scan_tail(Dev d, int p, int n_
     else role_overlap<256>(d, bank, n_inputs, G, p, p ^ 1, 1, b, (int)gridDim.x - n_learn_blocks - n_scan_blocks, (uint32_t *)dyn_lds, wmode);
 }
 
+// A host-fed step's first launch when the PREVIOUS step's last one was held back (htm_step, one input per call): that
+// step's learning role and scan beside this step's overlap.  The overlap needs the previous step's permanence rows -- they
+// rode in its middle launch -- and nothing of the Temporal Memory; the input comes with the launch's arguments.
+template <int EPL>
+__global__ __launch_bounds__(256, 6) void k_learn_scan_front(Dev d, int p_prev, int n_learn_blocks, int n_scan_blocks, int n_spec,
+                                                             PackedInputArg in, int G, int p, int wmode) {
+    int b = blockIdx.x;
+    if (b < n_learn_blocks) {
+        role_learn<EPL, 256, true>(d, p_prev, b, n_learn_blocks, (LearnShared<EPL, 256> *)dyn_lds);
+        return;
+    }
+    b -= n_learn_blocks;
+    if (b < n_scan_blocks) {
+        role_scan<256, true, false, false>(d, p_prev, b, n_scan_blocks, n_spec, (uint32_t *)dyn_lds);
+        return;
+    }
+    b -= n_scan_blocks;
+    uint32_t *h = (uint32_t *)dyn_lds, *s_in = h + SEL_BINS;       // (SEL_BINS * 4 is a multiple of 16: the row loads are 16 bytes)
+    if (threadIdx.x < ARG_INPUT_WORDS) {
+        const uint32_t v = (int)threadIdx.x < d.W ? in.w[threadIdx.x] : 0u;
+        s_in[threadIdx.x] = v;
+        if (b == 0 && (int)threadIdx.x < d.W) d.input_stage[threadIdx.x] = v;
+    }
+    __syncthreads();
+    role_overlap<256>(d, s_in, 1, G, p, p, 0, b, (int)gridDim.x - n_learn_blocks - n_scan_blocks, h, wmode);
+}
+
 #endif

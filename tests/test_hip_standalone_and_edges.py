@@ -259,12 +259,22 @@ def test_batched_run_equals_step_by_step():
     rng = np.random.RandomState(11)
     bank = rng.rand(30, 200) < 0.08
     outs = []
-    for mode in ("graph", "eager", "graph-nopipe", "mixed", "chunks", "chunks-eager", "continuing", "continuing-eager", "process"):
+    for mode in ("graph", "eager", "graph-nopipe", "mixed", "chunks", "chunks-eager", "continuing", "continuing-eager", "process",
+                 "process-read", "process-plain"):
         np.random.seed(12)
+        os.environ["BITHTM_DEFER_TAIL"] = "0" if mode == "process-plain" else "1"
         htm = B.HierarchicalTemporalMemory(200, 2048, 16)
-        if mode == "process":
-            for t in range(95):
+        os.environ.pop("BITHTM_DEFER_TAIL")
+        if mode in ("process", "process-plain"):   # a caller that steps and steps: each step's last launch rides in the next call's first
+            for t in range(95):                    # ("plain": four launches per call, nothing held back)
                 htm.process(bank[t % 30])
+        elif mode == "process-read":               # ... and one that reads something every few steps (the held-back launch is let go)
+            for t in range(95):
+                sp_state, tm_state = htm.process(bank[t % 30])
+                if t % 3 == 0:
+                    assert tm_state.cell_prediction.shape == (2048, 16)
+                if t % 7 == 0:
+                    htm.engine.info()
         elif mode == "mixed":                      # batched runs, host-fed steps and another bank object in turn
             htm.run(bank, 40)
             for t in range(40, 47):
