@@ -2,8 +2,8 @@
 
 Each rank owns a contiguous block of mini-columns (their Spatial Pooler rows, their cells and the
 distal segments of those cells, in rows of its own) and runs its own engine handle; the only exchange is an
-all-gather of one fixed-size record per rank and step -- the rank's top-k candidate columns with their cell
-words, 20 bytes each (DESIGN.md "Multi-GPU"; the protocol is pinned by oracle/sharded.py and
+all-gather of one fixed-size record per rank and step -- the rank's candidate columns (a superset of its top-k)
+with their cell words and a short list of its best ones, 30 bytes per slot (DESIGN.md "Multi-GPU"; the protocol is pinned by oracle/sharded.py and
 tests/test_sharded_gloo.py).  torch is used for what it is here for: device
 buffers, the current stream, and torch.distributed (backend "nccl" = RCCL over xGMI).
 """

@@ -45,14 +45,16 @@ def main():
         if what == "emit":
             t = raw[: nb * 8].reshape(nb, 8)[:, :6].astype(np.float64) / 100.0
             ph = np.diff(t, axis=1)
-            names = ["resolve histogram", "own record", "read all records", "k-th key", "list + record"]
+            # (the usual path hands the whole threshold bin over; in brackets what the phase is when the bin is cut exactly)
+            names = ["resolve histogram", "scan + count published [own record]", "cell words + the others' counts [read all records]",
+                     "record written [k-th key]", "- [list + record]"]
             print(f"step {step}: blocks end {(t[:, 5] - t[:, 0].min()).min():.2f}..{(t[:, 5] - t[:, 0].min()).max():.2f} us; "
                   + "  ".join(f"{n} {np.median(ph[:, i]):.2f}/{ph[:, i].max():.2f}" for i, n in enumerate(names)))
         else:
-            t = raw[:6].astype(np.float64) / 100.0
-            names = ["load keys + zero the histogram", "k-th key", "earlier ranks + own winners", "-", "window for the next step"]
+            t = raw[[0, 1, 2, 3, 5]].astype(np.float64) / 100.0
+            names = ["load keys + zero the histogram", "k-th key", "earlier ranks + own winners", "window for the next step"]
             sub = raw[8:11].astype(np.float64) / 100.0           # inside "k-th key": histogram zeroed, filled, bin picked
-            print(f"step {step}: " + "  ".join(f"{n} {v:.2f}" for n, v in zip(names, np.diff(t))) + f"  total {t[5] - t[0]:.2f} us"
+            print(f"step {step}: " + "  ".join(f"{n} {v:.2f}" for n, v in zip(names, np.diff(t))) + f"  total {t[4] - t[0]:.2f} us"
                   + f"   [k-th key: zero {sub[0] - t[1]:.2f}  fill {sub[1] - sub[0]:.2f}  pick {sub[2] - sub[1]:.2f}  inside the bin {t[2] - sub[2]:.2f}]")
     if what == "select":
         group.run(200)
