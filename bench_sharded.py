@@ -1,6 +1,7 @@
 """bench.py --gpus N (N > 1): the same workload column-sharded over N MI355X, one process per GPU
-(launched by torch.distributed.run), one RCCL all-gather per timestep -- each rank's top-k candidate columns with
-their cell words, 20 bytes each (27 KB per rank at 8-way) -- issued from inside the library on the engine's stream:
+(launched by torch.distributed.run), one RCCL all-gather per timestep -- each rank's candidate columns (a superset of its
+top-k) with their cell words and the short list of its best ones, 30 bytes per slot (50 KB per rank at 8-way) -- issued from
+inside the library on the engine's stream:
 `htm_shard_run` runs the whole timed region as ONE C call, whole timesteps (the collective included) replayed as
 hipGraphs.  Strong scaling: the model (65 536 columns x 32 cells) is fixed, each rank owns column_dim / N columns,
 their cells and their cells' segments.
@@ -33,13 +34,16 @@ def shard_launch_bytes(w, world, k, rows, syn, n_work, n_match):
     C, I = w["column_dim"], w["input_dim"]
     cl, kl, W = C // world, min(k, C // world), ((I + 127) // 128) * 4
     overlap = cl * W * 4 + W * 4 + cl * 4 + cl * 20
+    blocks = (cl + 255) // 256
+    hot = max(1, min(kl, 4096 // world // 2))       # entries of a rank's hot list (its floor is the bin of its hot-th key)
     return {
         "shard_overlap": overlap,
-        # local select finish: histogram copies, own keys, records; the candidates' cell words (32 x (maximum + count) each); the
-        # record; the zeroing of the step's dense words
-        "shard_candidates": 4 * 4096 * 4 + cl * 8 + 2 * 128 * ((cl + 255) // 256) + kl * (4 + 32 * 8) + 20 * kl + 12 * C,
-        # every rank's candidates (keys, then the winners' words) + the winners' dense words
-        "shard_select": 8 * world * kl + 12 * world * kl + 20 * k,
+        # local select: the threshold bin from the run sums and one run's bins (two waves per block), own keys, the blocks'
+        # counts; the candidates' cell words (32 x (maximum + count) each); the record (at least the kl candidates the rank
+        # must offer, 20 B each, + its hot list, 10 B each); the zeroing of the step's dense words
+        "shard_candidates": blocks * 2 * (16 * 64 + 4 * 64) * 4 + cl * 8 + 8 * blocks + kl * (4 + 32 * 8) + 20 * kl + 10 * hot + 12 * C,
+        # the short way: every rank's hot keys, the own rank's hot slots and their words, the winners' dense words
+        "shard_select": 8 * world * hot + (2 + 12) * hot + 20 * k,
         "tm_mid": 13 * k + 8 * rows + 12 * n_match + (2 * 8 * I + W * 4) * k // world + 8 * cl,
         "tm_learn+tm_scan+shard_overlap": int(16 * syn / max(rows, 1) * n_work) + 4 * rows + 4 * syn + 8 * rows + overlap,
         "tm_learn+tm_scan": int(16 * syn / max(rows, 1) * n_work) + 4 * rows + 4 * syn + 8 * rows,

@@ -579,7 +579,7 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
     d.sel_lo = d.c0; d.sel_hi = d.c1;
     d.sel_k = d.n_cand = std::min(d.k, d.c1 - d.c0);
     d.cand_cap = shard_cand_cap(d.n_cand, d.c1 - d.c0);
-    d.hot_budget = std::min(d.cand_cap, (SHARD_HOT_KEYS * 1024) / std::max(world, 1));
+    d.hot_budget = std::max(1, std::min(d.cand_cap, (SHARD_HOT_KEYS * 1024) / std::max(world, 1)));
     d.hot_target = std::max(1, std::min(d.sel_k, d.hot_budget / 2));
     d.sp_thr = cfg->sp_permanence_threshold; d.sp_don = cfg->sp_delta_on; d.sp_doff = cfg->sp_delta_off;
     d.coef = cfg->boost_coefficient; d.mom = cfg->duty_momentum; d.dinc = cfg->duty_increment;
