@@ -6,7 +6,7 @@ Used where the timestep is orchestrated on the host because a plug-in object liv
 
 import numpy as np
 
-STREAM_LEAST_USED = 1
+STREAM_LEAST_USED, STREAM_GROWTH, STREAM_SEGMENT_JITTER = 1, 2, 3
 
 _M1, _M2 = np.uint32(0x7FEB352D), np.uint32(0x846CA68B)
 

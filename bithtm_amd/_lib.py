@@ -73,6 +73,7 @@ EXPORTS = {
     "htm_shard_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "htm_shard_group_run": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "htm_rccl_selftest": (C.c_int, [C.c_int32]),
+    "htm_keyed_draws": (C.c_int, [C.c_uint32, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "htm_shard_group_step": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.POINTER(C.c_void_p), C.c_int32, C.c_void_p, C.c_int32]),
     "htm_populate": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_uint32]),
     "htm_sync": (C.c_int, [C.c_void_p]),

@@ -1385,6 +1385,13 @@ extern "C" int htm_shard_unique_id(void *out128) {
     return HTM_OK;
 }
 
+extern "C" int htm_keyed_draws(uint32_t seed, int32_t stream, uint32_t step, const uint32_t *a, const uint32_t *b, int64_t n, double *out) {
+    if (stream < 1 || stream > 5 || n < 0 || (n && (!a || !out))) return HTM_ERR_ARGUMENT;
+    const uint32_t base = htm_stream_base(seed, (uint32_t)stream, step);
+    for (int64_t i = 0; i < n; ++i) out[i] = (double)htm_draw24(base, a[i], b ? b[i] : 0u) * (1.0 / 16777216.0);
+    return HTM_OK;
+}
+
 // RCCL round trip at world size 1 on `device`: load the library, create a communicator, all-gather a buffer on a
 // stream, compare, destroy.  What a one-GPU box can verify of the in-library exchange (the symbols, the by-value
 // unique id, the call on a non-default stream); returns 0 or a negative status (htm_last_error(NULL)).

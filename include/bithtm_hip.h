@@ -287,6 +287,16 @@ int htm_shard_group_run(htm_handle *const *handles, int32_t n, const uint32_t *c
  * take.  0: both work; 1: the collective works but is not capturable on this runtime; negative: failure. */
 int htm_rccl_selftest(int32_t device);
 
+/* The keyed random draws of the engine (bithtm_amd/csrc/htm_rng.h), computed on the host: out[i] =
+ * the number in [0, 1) -- a multiple of 2^-24 -- that the step `step` of a handle created with `seed` uses for
+ *   stream 1  the least-used-cell jitter of flat cell a[i]                                     (networks.py:87)
+ *   stream 2  the growth priority of presynaptic cell b[i] for segment a[i]                    (projections.py:120)
+ *   stream 3  the jitter of matching segment a[i]                                              (projections.py:235)
+ * (b may be NULL: all zeros).  This is the direction in which the reference and the engine are made to agree draw for
+ * draw: the reference consumes THESE numbers where it would call np.random.rand (INTEGRATION.md section 5 shows the patch);
+ * the engine cannot take MT19937's instead -- their shapes depend on data the step has not produced yet when it starts. */
+int htm_keyed_draws(uint32_t seed, int32_t stream, uint32_t step, const uint32_t *a, const uint32_t *b, int64_t n, double *out);
+
 /* All the shards of one model inside ONE process on one device: handles[r] = rank r of n = shard_world, created on
  * the same stream; the all-gather becomes n x n device copies.  For tests and single-GPU rehearsals of the sharded
  * path.  device_inputs[r] = rank r's copy of the input bank (or NULL and one host input, as for htm_step). */

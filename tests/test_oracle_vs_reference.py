@@ -47,3 +47,21 @@ def test_lockstep_learning_off_and_jumps(ref):
                                        density=0.1, noise=0.02, steps=200, store_every=25, jump=0.2,
                                        learning_schedule=lambda t: (t % 17) != 3)
     assert stats["segments"] > 500
+
+
+def test_the_products_bridge_makes_the_reference_agree(ref, monkeypatch):
+    """bithtm_amd.reference_bridge.keyed_rand -- what INTEGRATION.md hands to a maintainer of the reference -- in place of the
+    test infrastructure's own patch: the unmodified reference, drawing the engine's keyed numbers through it, stays in
+    lock-step with the oracle (and so with the engine, which the GPU tests pin to the oracle)."""
+    import numpy as np
+    import refdiff
+    from bithtm_amd.reference_bridge import keyed_rand, keyed_draws
+    from oracle.keyed_rng import draw_unit
+    monkeypatch.setattr(refdiff, "keyed_rand", keyed_rand)
+    stats, _, _ = refdiff.run_lockstep(ref, seed=35, input_dim=160, column_dim=1024, cell_dim=8, patterns=20,
+                                       density=0.1, noise=0.02, steps=120, store_every=20, jump=0.1)
+    assert stats["segments"] > 300
+    # ... and the C entry behind it gives the oracle's numbers
+    a, b = np.arange(500, dtype=np.uint32) * 7919, np.arange(500, dtype=np.uint32)[::-1].copy()
+    for stream in (1, 2, 3):
+        assert np.array_equal(keyed_draws(35, stream, 99, a, b if stream == 2 else None), draw_unit(35, stream, 99, a, b if stream == 2 else 0))
