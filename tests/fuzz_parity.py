@@ -1,6 +1,6 @@
 """Manual GPU fuzz (not collected by pytest): random small configurations, the HIP path against the
-oracle in lock-step through process(), then batched pipelined runs against the oracle's final
-state.  Every draw is seeded; a failure prints the configuration that reproduces it.
+oracle in lock-step through process(), then batched pipelined runs and host-fed steps with nothing read in between
+against the oracle's final state.  Every draw is seeded; a failure prints the configuration that reproduces it.
 
     python tests/fuzz_parity.py [--configs 40] [--seed 0]
 """
@@ -62,6 +62,20 @@ def run_one(cfg, seed):
             o_sp, _ = ora.step(bank[t % cfg["P"]])
             t += 1
         htm.run(bank, n, use_graph=graph)
+    assert np.array_equal(htm.engine.read_sp_fields()["active_column"], o_sp.active_column)
+    compare_store_with_oracle(t - 1, ora, htm)
+    # (c) host-fed steps with nothing read in between (each step's last launch rides in the next call's first), learning
+    # toggled, then one more batched run straight behind them
+    for i in range(23):
+        x = bank[t % cfg["P"]] ^ (rng.rand(I) < cfg["noise"])
+        learning = (i % 7) != 3
+        o_sp, o_tm = ora.step(x, learning=learning)
+        htm.process(x, learning=learning)
+        t += 1
+    for _ in range(3):
+        o_sp, o_tm = ora.step(bank[t % cfg["P"]])
+        t += 1
+    htm.run(bank, 3)
     assert np.array_equal(htm.engine.read_sp_fields()["active_column"], o_sp.active_column)
     compare_store_with_oracle(t - 1, ora, htm)
     htm.engine.check_capacity()
