@@ -31,6 +31,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# (this pool's driver supports dmabuf IPC only: RCCL across processes fails with `hipIpcGetMemHandle: invalid argument` without
+# it.  The launcher exports it; keep it when somebody runs the line by hand.)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 WORKLOAD = dict(input_dim=1024, column_dim=65536, cell_dim=32, patterns=50, density=0.02, noise=0.005,
                 noisy_copies=20, segment_slots=128)
