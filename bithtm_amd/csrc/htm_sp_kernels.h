@@ -29,90 +29,157 @@ __global__ __launch_bounds__(256) void k_sp_build_mask(Dev d, int row_begin, int
 // Roles are written against (blk, nblk) instead of blockIdx / gridDim so that two independent
 // roles can share one launch (pipelined schedule: step t's TM work beside step t+1's SP work).
 // sp = parity buffer of the SP step being computed; step_offset = that step minus the current one.
+// diagnostic build (-DBITHTM_OVERLAP_STAMPS, handle created under BITHTM_TRACE=1): device clock at the phases of every
+// overlap block of the three-launch schedule, d.trace[3 * 8192 + block * 8 + phase] (tools/overlap_phases.py)
+#ifdef BITHTM_OVERLAP_STAMPS
+#define OV_STAMP(i) do { if (d.trace && wmode && threadIdx.x == 0 && blk < 512) d.trace[(size_t)3 * 8192 + (size_t)blk * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define OV_STAMP(i) do { } while (0)
+#endif
 template <int BS>
 // wmode: the histogram of the windowed select (win_bin) instead of the top key digit
 __device__ __forceinline__ void role_overlap(const Dev &d, const uint32_t *__restrict__ bank, int n_inputs, int G,
                                              int p, int sp, int step_offset, int blk, int nblk, uint32_t *h, int wmode = 0) {
     const int gtid = blk * BS + threadIdx.x;
     const int nthreads = nblk * BS;
-    const bool do_hist = true;
     uint32_t *ghist = d.hist + sp * SEL_MAX_PASSES * SEL_BINS;
+    OV_STAMP(0);
     if (gtid == 0) d.ctr->emit_epoch += 1;          // a new generation of k_sp_emit records
-    if (do_hist) {
-        for (int i = gtid; i < (d.sel_passes - 1) * SEL_BINS; i += nthreads) ghist[SEL_BINS + i] = 0;
-        for (int i = threadIdx.x; i < SEL_BINS; i += BS) h[i] = 0;
-        if (gtid == 0) {
-            d.ctr->sel_pass_prefix[sp][0] = 0;
-            d.ctr->sel_pass_krem[sp][0] = (uint32_t)d.sel_k;
-        }
-        lds_barrier();                             // (LDS only: the zeroing stores above are for later launches -- the rows' loads
-    }                                              // below do not wait for them)
-    const uint32_t wbase = wmode ? d.ctr->sel_win[sp] : 0u;
-    static_assert(WIN_BINS <= SEL_BINS - SEL_COARSE, "the runs' sums live behind the window's bins in the LDS histogram");
-    uint32_t *hc = h + SEL_BINS - SEL_COARSE;       // (window mode only)
     const uint4 *in4 = (const uint4 *)(bank + (size_t)((d.ctr->step[p] + (uint32_t)step_offset) % (uint32_t)n_inputs) * d.W);
     const uint4 *mask4 = (const uint4 *)d.mask;
     const int lane = lane_id();
     const int rpw = 64 / G, sub = lane / G, l = lane % G;
     const int wave = gtid >> 6, nwaves = nthreads >> 6;
     constexpr int U = 4;                           // row groups in flight per wave
-    for (int row0 = d.c0 + wave * rpw * U; row0 < d.c1; row0 += nwaves * rpw * U) {
+    // With 8 lanes to a row (inputs of up to 1 024 bits: G == 8) a wave's 32 rows are finished by 32 of its lanes, one row
+    // each -- lane l < 4 of group `sub` takes row group u = l: the group's sum is in all of its lanes --, not by the rows'
+    // first lanes four times over (the exponential, the key and its bin were a microsecond of a wave's instructions that way).
+    const bool spread = G == 8;
+    const int first_row0 = d.c0 + wave * rpw * U;
+    // the first rows' masks and duty cycles are asked for before anything else: the LDS histogram is zeroed while they travel
+    uint4 m_first[U];
+    float dty_first[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int row = first_row0 + u * rpw + sub;
+        m_first[u] = (row < d.c1 && l < d.W4) ? mask4[(size_t)row * d.W4 + l] : make_uint4(0, 0, 0, 0);
+        dty_first[u] = 0.f;
+    }
+    if (spread) {
+        const int row = first_row0 + (l & 3) * rpw + sub;
+        dty_first[0] = (l < U && row < d.c1) ? d.duty[row] : 0.f;
+    } else {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int row = first_row0 + u * rpw + sub;
+            dty_first[u] = (l == 0 && row < d.c1) ? d.duty[row] : 0.f;
+        }
+    }
+    for (int i = gtid; i < (d.sel_passes - 1) * SEL_BINS; i += nthreads) ghist[SEL_BINS + i] = 0;
+    for (int i = threadIdx.x; i < SEL_BINS; i += BS) h[i] = 0;
+    if (gtid == 0) {
+        d.ctr->sel_pass_prefix[sp][0] = 0;
+        d.ctr->sel_pass_krem[sp][0] = (uint32_t)d.sel_k;
+    }
+    const uint32_t wbase = wmode ? d.ctr->sel_win[sp] : 0u;
+    lds_barrier();                                 // (LDS only: the zeroing stores above are for later launches, the loads stay in flight)
+    OV_STAMP(1);
+    static_assert(WIN_BINS <= SEL_BINS - SEL_COARSE, "the runs' sums live behind the window's bins in the LDS histogram");
+    uint32_t *hc = h + SEL_BINS - SEL_COARSE;       // (window mode only)
+    // one row's share of the step: overlap (projections.py:18-21), boosted overlap (regularizations.py:15-17), key, bin
+    auto finish_row = [&](bool owner, int row, int cn, float duty) {
+        u64 key = 0;
+        if (owner) {
+            d.overlap[sp][row] = cn;
+            const float f = htm_exp_f32(d.coef * duty);                // float32 product, documented exp
+            const double bo = (double)f * (double)cn;                  // exact (24-bit x <= 16-bit)
+            d.boosted[sp][row] = bo;
+            key = select_key(bo);
+            d.key[sp][row] = key;
+        }
+        // (plain LDS atomics: hist_add's loop over the distinct digits, a dependent shuffle + ballot + atomic each, cost
+        // 0.3 us per call here)
+        // (the windowed histogram leaves out the bin below the window, where most columns are: the select counts from the
+        // top and never gets there -- if it would, the k-th key is outside the window and the exact fallback takes over)
+        const uint32_t bin = wmode ? win_bin(key, wbase) : (uint32_t)(key >> sel_shift(0));
+        if (owner && (!wmode || bin != 0u)) {
+            atomicAdd(&h[bin], 1u);
+            if (wmode) atomicAdd(&hc[bin >> 6], 1u);
+        }
+    };
+    for (int row0 = first_row0; row0 < d.c1; row0 += nwaves * rpw * U) {
+        const bool first = row0 == first_row0;
         int cnt[U];
         float dty[U];                              // fetched with the mask rows, not after the reduction
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             cnt[u] = 0;
-            const int row = row0 + u * rpw + sub;
-            dty[u] = (l == 0 && row < d.c1) ? d.duty[row] : 0.f;
+            dty[u] = dty_first[u];
+        }
+        if (!first) {
+            if (spread) {
+                const int row = row0 + (l & 3) * rpw + sub;
+                dty[0] = (l < U && row < d.c1) ? d.duty[row] : 0.f;
+            } else {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int row = row0 + u * rpw + sub;
+                    dty[u] = (l == 0 && row < d.c1) ? d.duty[row] : 0.f;
+                }
+            }
         }
         for (int j = l; j < d.W4; j += G) {
             uint4 m[U];                            // the mask rows first: they do not wait for the step counter
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int row = row0 + u * rpw + sub;
-                m[u] = row < d.c1 ? mask4[(size_t)row * d.W4 + j] : make_uint4(0, 0, 0, 0);
+                m[u] = (first && j == l) ? m_first[u] : (row < d.c1 ? mask4[(size_t)row * d.W4 + j] : make_uint4(0, 0, 0, 0));
             }
             const uint4 x = in4[j];
 #pragma unroll
             for (int u = 0; u < U; ++u)
                 cnt[u] += __popc(m[u].x & x.x) + __popc(m[u].y & x.y) + __popc(m[u].z & x.z) + __popc(m[u].w & x.w);
         }
+        OV_STAMP(2);
+        if (spread) {
+            int mine = 0;
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            int cn = cnt[u];
-            if (G == 8) cn = group8_sum_first(cn);                     // (only the row's first lane uses the sum)
-            else for (int o = G >> 1; o > 0; o >>= 1) cn += __shfl_xor(cn, o);
-            const int row = row0 + u * rpw + sub;
-            const bool owner = l == 0 && row < d.c1;
-            u64 key = 0;
-            if (owner) {
-                d.overlap[sp][row] = cn;
-                const float f = htm_exp_f32(d.coef * dty[u]);          // float32 product, documented exp
-                const double bo = (double)f * (double)cn;              // exact (24-bit x <= 16-bit)
-                d.boosted[sp][row] = bo;
-                key = select_key(bo);
-                d.key[sp][row] = key;
+            for (int u = 0; u < U; ++u) {
+                const int cn = group8_sum_all(cnt[u]);
+                if (l == u) mine = cn;
             }
-            // (plain LDS atomics: only the 64 / G row owners of the wave take part, and hist_add's loop over the
-            // distinct digits, a dependent shuffle + ballot + atomic each, cost 0.3 us per call here)
-            // (the windowed histogram leaves out the bin below the window, where most columns are: the select counts from the
-            // top and never gets there -- if it would, the k-th key is outside the window and the exact fallback takes over)
-            const uint32_t bin = wmode ? win_bin(key, wbase) : (uint32_t)(key >> sel_shift(0));
-            if (do_hist && owner && (!wmode || bin != 0u)) {
-                atomicAdd(&h[bin], 1u);
-                if (wmode) atomicAdd(&hc[bin >> 6], 1u);
+            const int row = row0 + (l & 3) * rpw + sub;
+            finish_row(l < U && row < d.c1, row, mine, dty[0]);
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                int cn = cnt[u];
+                for (int o = G >> 1; o > 0; o >>= 1) cn += __shfl_xor(cn, o);
+                const int row = row0 + u * rpw + sub;
+                finish_row(l == 0 && row < d.c1, row, cn, dty[u]);
             }
         }
     }
-    if (!do_hist) return;
+    OV_STAMP(3);
     lds_barrier();                                 // (LDS only: the flush does not wait for the stores of the keys)
+    OV_STAMP(4);
     uint32_t *g0 = d.hist0 + (size_t)sp * HIST0_PAR + (size_t)(blk & (HIST_REP - 1)) * SEL_BINS;
     uint32_t *gc = d.hist0 + (size_t)sp * HIST0_PAR + HIST0_FINE + (size_t)(blk & (COARSE_REP - 1)) * COARSE_STRIDE;
     const int n_fine = wmode ? SEL_BINS - SEL_COARSE : SEL_BINS;
-    for (int i = threadIdx.x; i < n_fine; i += BS)
-        if (h[i]) atomicAdd(&g0[i], h[i]);
+    {   // (the block's bins first, all of them at once, then the atomics of those that hold anything: one LDS round trip)
+        constexpr int PER = SEL_BINS / BS;
+        uint32_t v[PER];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) v[k] = h[threadIdx.x + k * BS];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int i = threadIdx.x + k * BS;
+            if (v[k] && i < n_fine) atomicAdd(&g0[i], v[k]);
+        }
+    }
     // the runs' sums were counted beside the bins (in the words of the LDS histogram the window never uses: bins >= WIN_BINS)
     if (wmode && threadIdx.x < SEL_COARSE && hc[threadIdx.x]) atomicAdd(&gc[threadIdx.x], hc[threadIdx.x]);
+    OV_STAMP(5);
 }
 
 __global__ __launch_bounds__(RB) void k_sp_overlap(Dev d, const uint32_t *__restrict__ bank, int n_inputs, int G, int p, int sp, int step_offset, int wmode) {
