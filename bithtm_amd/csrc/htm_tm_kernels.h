@@ -125,24 +125,37 @@ __device__ __forceinline__ void shard_bind(const Dev &d, int p, int gid, int cel
 // row's connected mask, by TPR threads (t = 0..TPR-1): two float64 per lane (16-byte accesses); a
 // wave covers 128 consecutive elements = four mask words, assembled from the ballots of its even
 // and odd elements
+// diagnostic build (-DBITHTM_ROWS_STAMPS, handle created under BITHTM_TRACE=1): device clock at the phases of the first 1 024
+// row blocks, d.trace[7 * 8192 + row index * 8 + phase] (tools/rows_phases.py)
+#ifdef BITHTM_ROWS_STAMPS
+#define ROW_STAMP(i) do { if (d.trace && t == 0 && ri < 1024) d.trace[(size_t)7 * 8192 + (size_t)ri * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define ROW_STAMP(i) do { } while (0)
+#endif
 template <int TPR>
 // p: parity of the step the rows belong to; ahead = 1 when that step's index is not published yet
 // (the row update runs beside the previous step's scan): it is step[p ^ 1] + 1 then
 __device__ __forceinline__ void role_sp_row(const Dev &d, int p, const uint32_t *__restrict__ bank, int n_inputs, int ahead, int ri, int t) {
+    ROW_STAMP(0);
     const uint32_t step = ahead ? d.ctr->step[p ^ 1] + 1u : d.ctr->step[p];
     const uint32_t *in = bank + (size_t)(step % (uint32_t)n_inputs) * d.W;
     const int row = d.active_cols[p][ri];
     if (row < d.c0 || row >= d.c1) return;          // another rank's column
+    ROW_STAMP(1);
     double *prow = d.perm + (size_t)row * d.Ipad;
     uint32_t *mrow = d.mask + (size_t)row * d.W;
     for (int i0 = 0; i0 < d.Ipad; i0 += 2 * TPR) {
         const int e0 = i0 + 2 * t;                   // Ipad is a multiple of 128: e0 + 1 < Ipad whenever e0 < Ipad
         bool c0 = false, c1 = false;
         if (e0 < d.Ipad) {
+            // (one pass at a time on purpose: with the second pass's loads in flight beside the first's the first pass waits
+            // 2.9 us instead of 1.8 and the launch is a microsecond longer -- 1 311 scattered 8-KB rows read at 3-3.7 TB/s
+            // whatever is asked at once: tools/rows_phases.py)
             double2 v = *(double2 *)(prow + e0);
             const uint32_t bits = in[e0 >> 5] >> (e0 & 31);
             if (e0 < d.I) { v.x = v.x + ((bits & 1u) ? d.sp_don : d.sp_doff); c0 = v.x >= d.sp_thr; }
             if (e0 + 1 < d.I) { v.y = v.y + ((bits & 2u) ? d.sp_don : d.sp_doff); c1 = v.y >= d.sp_thr; }
+            if (i0 == 0) ROW_STAMP(2); else ROW_STAMP(4);       // (the pass's values are here)
             {   // 16-byte write-through store (sc0 sc1): nothing of the rows stays dirty in L2 for the kernel-end release
                 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
                 union { double2 d2; u32x4 u4; } cvt;
@@ -158,6 +171,7 @@ __device__ __forceinline__ void role_sp_row(const Dev &d, int p, const uint32_t 
             mw[0] = spread32((uint32_t)b0) | (spread32((uint32_t)b1) << 1);
             mw[1] = spread32((uint32_t)(b0 >> 32)) | (spread32((uint32_t)(b1 >> 32)) << 1);
         }
+        if (i0 == 0) ROW_STAMP(3); else ROW_STAMP(5);
     }
 }
 
