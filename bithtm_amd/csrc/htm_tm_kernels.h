@@ -511,9 +511,10 @@ __device__ __forceinline__ void role_learn(const Dev &d, int p, int blk, int nbl
 #pragma unroll
         for (int jj = 0; jj < EPL; ++jj) {
             const int idx = jj * 64 + lane;
-            ps_all[jj] = 0;
-            pm_all[jj] = 0.f;
-            if (idx < n) { ps_all[jj] = prow[idx] & SYN_CELL; pm_all[jj] = mrow[idx]; }
+            // (unconditional: under `idx < n` the row's loads would wait for the synapse count, one more round trip on the
+            // item's chain; slots past the count hold a free slot's -1 / -1.0 and are masked by `valid` below)
+            ps_all[jj] = idx < d.E ? prow[idx] & SYN_CELL : 0;
+            pm_all[jj] = idx < d.E ? mrow[idx] : 0.f;
         }
 #pragma unroll
         for (int jj = 0; jj < EPL; ++jj) {
