@@ -84,5 +84,7 @@ find $OUT -name "*kernel_trace.csv" -delete
 cd $GRAFT_REPO_ROOT
 BITHTM_EXTRA_FLAGS=-DBITHTM_EMIT_STAMPS python -m bithtm_amd.build --force > /dev/null 2>&1 && { timeout -k 10 200 python tools/emit_phases.py > $OUT/emit_phases.txt 2>&1; timeout -k 10 200 python tools/shard_phases.py emit > $OUT/shard_phases.txt 2>&1; }
 BITHTM_EXTRA_FLAGS=-DBITHTM_SHARD_STAMPS python -m bithtm_amd.build --force > /dev/null 2>&1 && timeout -k 10 200 python tools/shard_phases.py select >> $OUT/shard_phases.txt 2>&1
+BITHTM_EXTRA_FLAGS=-DBITHTM_OVERLAP_STAMPS python -m bithtm_amd.build --force > /dev/null 2>&1 && timeout -k 10 200 python tools/overlap_phases.py > $OUT/overlap_phases.txt 2>&1
+BITHTM_EXTRA_FLAGS=-DBITHTM_ROWS_STAMPS python -m bithtm_amd.build --force > /dev/null 2>&1 && timeout -k 10 200 python tools/rows_phases.py > $OUT/rows_phases.txt 2>&1
 python -m bithtm_amd.build --force > /dev/null 2>&1
 ls -R $OUT | head -80
