@@ -45,7 +45,10 @@ __device__ __forceinline__ void role_overlap(const Dev &d, const uint32_t *__res
     uint32_t *ghist = d.hist + sp * SEL_MAX_PASSES * SEL_BINS;
     OV_STAMP(0);
     if (gtid == 0) d.ctr->emit_epoch += 1;          // a new generation of k_sp_emit records
-    const uint4 *in4 = (const uint4 *)(bank + (size_t)((d.ctr->step[p] + (uint32_t)step_offset) % (uint32_t)n_inputs) * d.W);
+    // (a bank of one row -- the host-fed step's input, the row the three-launch schedule stages ahead -- is read where it is:
+    // its loads do not wait for the step counter)
+    const uint4 *in4 = (const uint4 *)bank;
+    if (n_inputs > 1) in4 = (const uint4 *)(bank + (size_t)((d.ctr->step[p] + (uint32_t)step_offset) % (uint32_t)n_inputs) * d.W);
     const uint4 *mask4 = (const uint4 *)d.mask;
     const int lane = lane_id();
     const int rpw = 64 / G, sub = lane / G, l = lane % G;
