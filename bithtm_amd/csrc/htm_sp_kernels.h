@@ -436,9 +436,13 @@ __host__ __device__ __forceinline__ size_t shard_record_bytes(int cap) {
     return (n + 15) / 16 * 16;
 }
 // candidate slots for a rank that must offer n_cand of n_local columns: room for the threshold bin of the windowed
-// histogram on top (128 steps per binade: a hundred-odd of 8 192 keys share the bin of the 1 311th)
+// histogram on top.  The fewer own columns stand behind a candidate, the closer the rank's cut lies to the ties of a learned
+// pattern's columns and the fuller its bin: a quarter more slots where a rank offers less than an eighth of its columns
+// (8 shards of 65 536 columns: 13 steps of 1 000 cut exactly all the same), half as many again otherwise (2 shards: 93 with
+// a quarter)
 __host__ __device__ __forceinline__ int shard_cand_cap(int n_cand, int n_local) {
-    const int slack = n_cand / 4 > 64 ? n_cand / 4 : 64;
+    const int part = (long long)n_cand * 8 > n_local ? n_cand / 4 : n_cand / 2;
+    const int slack = part > 64 ? part : 64;
     return n_cand + slack < n_local ? n_cand + slack : n_local;
 }
 

@@ -44,7 +44,7 @@ def shard_range(rank, world, column_dim):
 
 def cand_cap(n_cand, n_local):
     """Candidate slots of a record (bithtm_amd/csrc/htm_sp_kernels.h: shard_cand_cap)."""
-    return min(n_local, n_cand + max(64, n_cand // 4))
+    return min(n_local, n_cand + max(64, n_cand // 4 if n_cand * 8 > n_local else n_cand // 2))
 
 
 class ShardedHTMOracle:

@@ -76,3 +76,4 @@ def test_wire_format_round_trip():
     # (+ a quarter more slots than the rank must offer: room for the threshold bin of its local select)
     # and 10 B for its place in the hot list
     assert cand_cap(1311, 65536 // 8) == 1638 and record_nbytes(1638) <= 50 * 1024
+    assert cand_cap(1311, 65536 // 2) == 1966       # (below 8 shards: half as many again)

@@ -56,7 +56,7 @@ BITHTM_LEAN=0 timeout -k 10 300 python bench.py --no-cpu-baseline --no-stress > 
 timeout -k 10 200 python bench.py --no-cpu-baseline --no-stress --pretrain 0 --steps 250 --warmup 0 --reps 1 > $OUT/bench_cold_250.json 2> $OUT/bench_cold_250.log; echo "bench (cold) exit=$?"
 timeout -k 10 200 python tools/pcie_rate.py > $OUT/pcie_rate.txt 2>&1
 timeout -k 10 200 python tools/hostfed_profile.py >> $OUT/pcie_rate.txt 2>&1
-for w in 2 8; do timeout -k 10 200 python tools/shard_rehearsal.py --world $w; done > $OUT/shard_rehearsal.jsonl 2>&1
+for w in 2 4 8; do timeout -k 10 200 python tools/shard_rehearsal.py --world $w; done > $OUT/shard_rehearsal.jsonl 2>&1
 # bench.py --gpus 2 as two processes on this one GPU, records staged through the host over gloo (the multi-process flow of
 # bench_sharded.py; the RCCL path needs one GPU per rank)
 BITHTM_DIST_BACKEND=gloo BITHTM_SINGLE_DEVICE=1 timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 2 --steps 20 --warmup 5 > $OUT/bench_2ranks_one_gpu_gloo.json 2> $OUT/bench_2ranks_one_gpu_gloo.log; echo "2-rank rehearsal exit=$?"
