@@ -436,10 +436,10 @@ __host__ __device__ __forceinline__ size_t shard_record_bytes(int cap) {
     return (n + 15) / 16 * 16;
 }
 // candidate slots for a rank that must offer n_cand of n_local columns: room for the threshold bin of the windowed
-// histogram on top.  The fewer own columns stand behind a candidate, the closer the rank's cut lies to the ties of a learned
-// pattern's columns and the fuller its bin: a quarter more slots where a rank offers less than an eighth of its columns
-// (8 shards of 65 536 columns: 13 steps of 1 000 cut exactly all the same), half as many again otherwise (2 shards: 93 with
-// a quarter)
+// histogram on top.  The smaller the share of its columns a rank offers, the closer its cut lies to the ties of a learned
+// pattern's columns and the fuller its bin: a quarter more slots where a rank offers more than an eighth of its columns
+// (8 shards of 65 536 columns, 1 311 of 8 192: 13 steps of 1 000 cut exactly all the same), half as many again where it
+// offers less (2 shards, 1 311 of 32 768: 93 steps with a quarter, 18 with a half)
 __host__ __device__ __forceinline__ int shard_cand_cap(int n_cand, int n_local) {
     const int part = (long long)n_cand * 8 > n_local ? n_cand / 4 : n_cand / 2;
     const int slack = part > 64 ? part : 64;
