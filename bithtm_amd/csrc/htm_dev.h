@@ -111,7 +111,7 @@ struct Counters {
 };
 
 struct Dev {
-    int I, W, W4, Ipad, C, K, k, E, Scap, work_cap, sel_passes, colwords, low_zero, cand_d, cand_pairwise, cand_others, cand_speculate, cand_take_all;
+    int I, W, W4, Ipad, C, K, k, E, Scap, work_cap, sel_passes, colwords, low_zero, cand_d, cand_pairwise, cand_others, cand_speculate, cand_take_all, poll_delay;
     int win_offset;           // test knob: added to the select window's base (a window that misses: the fallback every step)
     int world, c0, c1;        // this rank owns columns [c0, c1) (world == 1: everything)
     int sel_lo, sel_hi, sel_k; // the select works on the keys of columns [sel_lo, sel_hi) and finds their sel_k largest

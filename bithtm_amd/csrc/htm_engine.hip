@@ -761,6 +761,7 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
         d.win_offset = getenv("BITHTM_SEL_WINDOW_OFFSET") ? std::max(0, atoi(getenv("BITHTM_SEL_WINDOW_OFFSET"))) : 0;
         d.cand_speculate = getenv("BITHTM_CAND_SPECULATE") ? atoi(getenv("BITHTM_CAND_SPECULATE")) != 0 : 1;     // (test knob: 0 = always the general path)
         d.cand_take_all = getenv("BITHTM_CAND_TAKE_ALL") ? atoi(getenv("BITHTM_CAND_TAKE_ALL")) != 0 : 1;      // (test knob: 0 = a shard's local select always cuts exactly)
+        d.poll_delay = getenv("BITHTM_POLL_DELAY") ? std::max(0, std::min(64, atoi(getenv("BITHTM_POLL_DELAY")))) : 7;     // (the select finish's first look at the other blocks' records: x 256 clocks after its own)
         d.cand_others = CAND_OTHERS;
         if (const char *e = getenv("BITHTM_CAND_OTHERS")) d.cand_others = std::max(0, std::min(CAND_OTHERS, atoi(e)));
     }

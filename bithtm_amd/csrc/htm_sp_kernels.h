@@ -809,6 +809,12 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
         EMIT_STAMP(2);                               // (own record published)
         // ---- everybody's records: the head granule is polled alone (one lane-load per spin keeps the
         // polling traffic low); further pairs, if any, are fetched in one batch; each granule validates itself
+        // Not yet: a look that comes before the last blocks have published costs a whole round trip -- and 65 536 such loads (256
+        // blocks x 256 records) in the way of the roles that share the launch: with the first look 0.8 us later the learning role
+        // and the scan run beside less of that, and the third launch's median goes from 8.9 to 8.0 us (BITHTM_POLL_DELAY, in
+        // units of 4 x 64 clocks: 4 = 0.45 us ... 8 = 0.9 us all within a percent; 0 and 16 both 4 % slower).
+        if (nblk >= 32)
+            for (int i = 0; i < d.poll_delay; ++i) __builtin_amdgcn_s_sleep(4);
         uint32_t gthi_before = 0;
         u64 heaviest = 0;                            // multiplicity:12 | unresolved key bits:40 of the heaviest pair this thread has read
         for (int rb = tid; rb < nblk; rb += 256) {
