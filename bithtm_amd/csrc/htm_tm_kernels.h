@@ -688,6 +688,9 @@ __device__ __forceinline__ void role_learn(const Dev &d, int p, int blk, int nbl
             d.seg_jit[seg] = jit;
             atomicOr(&d.match_bits[p][seg >> 5], 1u << (seg & 31));
         }
+        // The new count clears SEG_BUSY: from then on the scan of this launch may take the row -- so the row must be there
+        // first (every store of this wave acknowledged), not just issued first.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) {
             d.seg_nsyn[seg] = n_total;
             // recyclable segments (fewer synapses than the matching threshold, projections.py:80) per 1024 ids.
