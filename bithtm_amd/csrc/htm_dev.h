@@ -271,6 +271,11 @@ __device__ __forceinline__ int group8_sum_all(int v) {
     return v;
 }
 
+// A 4-byte store that goes through to memory (sc0 sc1), for data another XCD's waves may read within the same launch: a
+// plain store stays in the writer's L2 until the line is evicted or the kernel ends.
+__device__ __forceinline__ void store_through(int *p, int v) { asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void store_through(float *p, float v) { asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); }
+
 // A block barrier that orders LDS traffic only.  __syncthreads() is a workgroup-scope release + barrier + acquire: the
 // release waits for EVERY outstanding vector-memory operation of the wave -- gfx9's vmcnt counts loads, stores and atomics
 // alike --, so a barrier behind a global store (a published record, a cleared histogram, a winner's words) or behind

@@ -531,8 +531,9 @@ __device__ __forceinline__ void role_learn(const Dev &d, int p, int blk, int nbl
             const u64 mk = __ballot(keep);
             if (keep) {
                 const int pos = n_keep + __popcll(mk & lanemask_lt());
-                prow[pos] = ps | (connected ? (int)SYN_CONNECTED : 0);     // the scan's `permanence >= threshold`, kept with the id
-                mrow[pos] = p32;
+                // (written through: the scan waves of this launch that take the row once its flag is gone may sit on another XCD)
+                store_through(&prow[pos], ps | (connected ? (int)SYN_CONNECTED : 0));     // the scan's `permanence >= threshold`, kept with the id
+                store_through(&mrow[pos], p32);
                 s_keep[wv][pos] = ps;
             }
             n_keep += __popcll(mk);
@@ -657,8 +658,8 @@ __device__ __forceinline__ void role_learn(const Dev &d, int p, int blk, int nbl
                             const int slot = n_keep + rank[j];
                             if (slot < d.E) {
                                 const int wc = winner_at((int)(uint32_t)key[j]);
-                                prow[slot] = wc | (d.perm_init >= d.perm_thr ? (int)SYN_CONNECTED : 0);
-                                mrow[slot] = d.perm_init;                               // :149,158
+                                store_through(&prow[slot], wc | (d.perm_init >= d.perm_thr ? (int)SYN_CONNECTED : 0));
+                                store_through(&mrow[slot], d.perm_init);                // :149,158
                                 a_now = SELF && ((act_cur[wc >> 5] >> (wc & 31)) & 1u);
                             } else {
                                 atomicOr(&c->error, 2);
@@ -692,7 +693,7 @@ __device__ __forceinline__ void role_learn(const Dev &d, int p, int blk, int nbl
         // first (every store of this wave acknowledged), not just issued first.
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) {
-            d.seg_nsyn[seg] = n_total;
+            store_through(&d.seg_nsyn[seg], n_total);
             // recyclable segments (fewer synapses than the matching threshold, projections.py:80) per 1024 ids.
             // Sharded: a death is reported with the next exchange and every rank, this one included, applies it
             // then; what becomes of a row bound this step every rank knew when it was bound (shard_bind).
