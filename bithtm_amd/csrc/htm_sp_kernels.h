@@ -462,6 +462,7 @@ __host__ __device__ __forceinline__ int shard_cand_cap(int n_cand, int n_local) 
 #define CAND_MAX 1024         // bucket entries a block can merge
 #define CAND_OTHERS 160         // ... after folding the copies of one key, if at most this many others remain (<= 256: one per thread)
 #define CAND_PAIRWISE 160      // ... by comparing all pairs; above that, by radix refinement in LDS
+#define ZOOM_BINS 1024         // more pairs than CAND_PAIRWISE: the sub-bin of the k-th key first (the next 10 key bits), then its pairs only
 
 // pick the bucket that contains the krem-th largest key of a histogram held in LDS
 // (bins [0, nb)); all BS threads call; returns bucket and the keys above it
@@ -546,10 +547,11 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
     u64 *s_ek = (u64 *)h;                           // [CAND_MAX] keys
     uint16_t *s_ec = sh->ec, *s_eb = sh->eb;        // [CAND_MAX] multiplicities (12 bits), publishing block
     uint32_t *s_mh = sh->mh;
-    static_assert(2 * CAND_MAX <= SEL_BINS, "bucket keys must fit the histogram");
+    uint32_t *s_zh = h + 2 * CAND_MAX;              // [ZOOM_BINS] the pairs' multiplicities by sub-bin, behind the merged keys
+    static_assert(2 * CAND_MAX + ZOOM_BINS <= SEL_BINS, "bucket keys and their sub-bins must fit the histogram");
     const int tid = threadIdx.x, lane = lane_id();
     EMIT_STAMP(0);
-    if (tid == 0) { s_gt = 0; s_eq = 0; s_n = 0; s_nraw = 0; s_ne = 0; s_flags = 0; s_T = 0; }
+    if (tid == 0) { s_gt = 0; s_eq = 0; s_n = 0; s_nraw = 0; s_ne = 0; s_flags = 0; s_T = 0; sh->n_others = 0; }
     const int cbase = d.sel_lo + b * 256, c = cbase + tid;      // the select covers columns [sel_lo, sel_hi)
     const bool local = mode & EMIT_LOCAL;
     // independent of everything below: in flight while the select state is resolved
@@ -562,6 +564,8 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
     uint32_t r;                                     // how many of the keys == T are selected
     bool second_round = false;                      // per-block counts still to be exchanged
     const uint32_t epoch = (d.ctr->emit_epoch & 0x3FFu) + 1u;           // 1..1024, changes with every overlap launch
+    if (fused && wmode)                             // (the sub-bin counts of a crowded bin, below: zeroed while the window's sums are on their way)
+        for (int i = tid; i < ZOOM_BINS; i += 256) s_zh[i] = 0;
     if (fused) {
         u64 P;
         uint32_t krem;
@@ -744,6 +748,8 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
             return;
         }
         const bool c_gt = c < d.sel_hi && hi > hiP, c_cand = c < d.sel_hi && hi == hiP;
+        if (!wmode)
+            for (int i = tid; i < ZOOM_BINS; i += 256) s_zh[i] = 0;  // (the resolved histogram's LDS is free from here on)
         // ---- this block's record
         {
             const u64 mg = __ballot(c_gt);
@@ -817,6 +823,9 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
             for (int i = 0; i < d.poll_delay; ++i) __builtin_amdgcn_s_sleep(4);
         uint32_t gthi_before = 0;
         u64 heaviest = 0;                            // multiplicity:12 | unresolved key bits:40 of the heaviest pair this thread has read
+        // (... and every pair's multiplicity into the histogram of the next ZB key bits: for a crowded bin, below)
+        const int sigbits = lowbits - d.low_zero;                      // unresolved key bits that can be set (<= 40 unless a record says overflow)
+        const int ZB = sigbits >= 10 ? 10 : (sigbits > 0 ? sigbits : 0), zsh = sigbits > ZB ? sigbits - ZB : 0;
         for (int rb = tid; rb < nblk; rb += 256) {
             const u64 *rr = (const u64 *)(d.sel_rec + (size_t)rb * 32);
             u64 g[CAND_D];
@@ -839,25 +848,28 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
             }
             if (rb < b) gthi_before += (uint32_t)((g[0] >> 38) & 0x1FFu);
             if ((g[0] >> 51) & 1ull) atomicOr(&s_flags, 1u);
-            // the pairs into the merged list: one reservation per wave and pair index (a reservation per lane is a same-address
-            // LDS atomic served lane by lane: 400-570 of them in a crowded bin, microseconds)
-#pragma unroll
-            for (int j = 0; j < CAND_D; ++j) {
-                const bool has = j < np;
-                const u64 mh = __ballot(has);
-                if (!mh) break;                       // (wave-uniform: np only shrinks with j)
+            // the pairs into the merged list: ONE reservation per wave for all its records' pairs (a reservation per lane is a
+            // same-address LDS atomic served lane by lane, one per wave and pair index a chain of up to 9 returning atomics in a
+            // crowded bin: 400-570 pairs, microseconds either way)
+            // (the lanes here are the wave's first n -- tid < nblk in the last round --: the scan's sources are lower lanes, and
+            // the total is the last of them's)
+            const uint32_t incl = wave_incl_scan((uint32_t)np);
+            const uint32_t wtot = wave_read(incl, 63 - __clzll((long long)__ballot(true)));
+            if (wtot) {                               // (wave-uniform)
                 int base = 0;
-                if (lane == __ffsll((long long)mh) - 1) base = atomicAdd(&s_ne, __popcll(mh));
-                base = wave_read(base, __ffsll((long long)mh) - 1);
-                if (has) {
-                    const int slot = base + __popcll(mh & lanemask_lt());
-                    if (slot < CAND_MAX) {
+                if (lane == 0) base = atomicAdd(&s_ne, (int)wtot);
+                const int slot0 = wave_read(base, 0) + (int)(incl - (uint32_t)np);
+#pragma unroll
+                for (int j = 0; j < CAND_D; ++j) {
+                    if (!__ballot(j < np)) break;
+                    if (j < np && slot0 + j < CAND_MAX) {
                         const u64 low40 = j == 0 ? g[0] & 0x1FFFFFFFull : g[j] & 0xFFFFFFFFFFull;
                         const u64 cnt = j == 0 ? (g[0] >> 29) & 0x1FFu : (g[j] >> 40) & 0xFFFu;
-                        s_ek[slot] = (lowbits < 64 ? hiP << lowbits : 0ull) | (low40 << d.low_zero);
-                        s_ec[slot] = (uint16_t)cnt;
-                        s_eb[slot] = (uint16_t)rb;
+                        s_ek[slot0 + j] = (lowbits < 64 ? hiP << lowbits : 0ull) | (low40 << d.low_zero);
+                        s_ec[slot0 + j] = (uint16_t)cnt;
+                        s_eb[slot0 + j] = (uint16_t)rb;
                         heaviest = max(heaviest, (cnt << 40) | low40);
+                        atomicAdd(&s_zh[(uint32_t)(low40 >> zsh) & (ZOOM_BINS - 1)], (uint32_t)cnt);
                     }
                 }
             }
@@ -868,16 +880,71 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
             if (lane == 0) atomicMax((unsigned long long *)&s_T, heaviest);
         }
         __syncthreads();
-        const int ne = s_ne;
+        int ne = s_ne;
         EMIT_STAMP(3);                               // (everybody's records read)
 #ifdef BITHTM_EMIT_STAMPS
         if (d.trace && wmode && tid == 0 && b < 1024) d.trace[(size_t)b * 8 + 7] = (unsigned long long)ne | ((unsigned long long)s_nraw << 32);
         if (d.trace && wmode && b == 0 && ne > 160)      // the merged entries themselves, behind the emit blocks' rows
             for (int e = tid; e < min(ne, 1024); e += 256) d.trace[(size_t)256 * 8 + e] = ((s_ek[e] & lowmask) >> d.low_zero) | ((unsigned long long)s_ec[e] << 32) | ((unsigned long long)s_eb[e] << 48);
 #endif
+        bool settled = false;                        // (the k-th key is known already: the sub-bin held one key)
+        if (!(s_flags & 1u) && ne <= CAND_MAX && ne > d.cand_pairwise && ZB > 0) {
+            // A crowded bin -- a learned pattern's thousand columns behind ONE key and a few dozen stragglers a part in 10^5 off
+            // it, 400-570 (key, block) pairs -- is not ranked whole: the sub-bin of the k-th key is picked from the histogram of
+            // the next ZB key bits, and only THAT sub-bin's pairs stay on the list (one key, nearly always: the fold below settles
+            // it in its first pass); the pairs above it are winners outright.
+            uint32_t zF, above_f;
+            sel_pick<256, true>(s_zh, 1 << ZB, krem, s_wave, s_out, &zF, &above_f);
+            krem -= above_f;
+            constexpr int EPT = CAND_MAX / 256;
+            u64 ek[EPT];
+            uint32_t ecb[EPT];
+#pragma unroll
+            for (int u = 0; u < EPT; ++u) {
+                const int e = tid + 256 * u;
+                ek[u] = e < ne ? s_ek[e] : 0ull;
+                ecb[u] = e < ne ? (uint32_t)s_ec[e] | ((uint32_t)s_eb[e] << 16) : 0u;
+            }
+            if (tid == 0) { s_ne = 0; s_T = 0; s_prefix = 0; }
+            lds_barrier();
+            heaviest = 0;
+            u64 and_or = 0;                          // ~(and of the kept keys' low words) : or of them -- one key kept <=> the halves are complements
+#pragma unroll
+            for (int u = 0; u < EPT; ++u) {
+                const bool valid = tid + 256 * u < ne;
+                if (!__ballot(valid)) break;
+                const u64 low40 = (ek[u] & lowmask) >> d.low_zero;
+                const uint32_t sub = (uint32_t)(low40 >> zsh) & (ZOOM_BINS - 1), cnt = ecb[u] & 0xFFFFu;
+                const bool keep = valid && sub == zF;
+                if (valid && sub > zF && (int)(ecb[u] >> 16) < b) gthi_before += cnt;
+                const u64 mk = __ballot(keep);
+                if (!mk) continue;
+                int base = 0;
+                if (lane == __ffsll((long long)mk) - 1) base = atomicAdd(&s_ne, __popcll(mk));
+                base = wave_read(base, __ffsll((long long)mk) - 1);
+                if (keep) {
+                    const int slot = base + __popcll(mk & lanemask_lt());
+                    s_ek[slot] = ek[u];
+                    s_ec[slot] = (uint16_t)cnt;
+                    s_eb[slot] = (uint16_t)(ecb[u] >> 16);
+                    heaviest = max(heaviest, ((u64)cnt << 40) | low40);
+                    and_or |= ((u64)~(uint32_t)low40 << 32) | (u64)(uint32_t)low40;
+                }
+            }
+            if (__any(heaviest != 0)) {
+                heaviest = wave_reduce64(heaviest, 0ull, [](u64 a, u64 b) { return a > b ? a : b; });
+                and_or = wave_reduce64(and_or, 0ull, [](u64 a, u64 b) { return a | b; });
+                if (lane == 0) { atomicMax((unsigned long long *)&s_T, heaviest); atomicOr((unsigned long long *)&s_prefix, and_or); }
+            }
+            lds_barrier();
+            ne = s_ne;
+            // (the kept keys agree above their low 32 bits -- the bin's prefix and the sub-bin, zsh <= 30 bits below it)
+            if (ne > 0 && (uint32_t)s_prefix == ~(uint32_t)(s_prefix >> 32)) { T = s_ek[0]; r = krem; settled = true; }
+        }
         if (!(s_flags & 1u) && ne <= CAND_MAX) {
-            bool folded = false;
-            if (ne <= d.cand_pairwise) {                // the krem-th largest of the merged bucket: all pairs
+            bool folded = settled;
+            if (settled) {                              // (nothing left to rank)
+            } else if (ne <= d.cand_pairwise) {         // the krem-th largest of the merged bucket: all pairs
                 for (int e = tid; e < ne; e += 256) {
                     const u64 ke = s_ek[e];
                     uint32_t ng = 0, nq = 0;

@@ -29,6 +29,22 @@ def test_library_exports_every_declared_symbol(lib):
     assert lib.htm_abi_version() == _lib.ABI_VERSION == 3
 
 
+def test_the_three_launches_keep_their_register_budget():
+    """k_learn_scan_emit is three roles in one launch, all resident at once at 6 waves per SIMD: 80 VGPRs and NO scratch.
+    One spilled register costs every role of the launch microseconds (measured: 32 bytes of scratch per lane, the scan's
+    last block 7.8 -> 10.5 us, 37 -> 32.5 k timesteps/s).  The compiler's own report of the build."""
+    from bithtm_amd.build import kernel_resources
+    res = kernel_resources()
+    if res is None:
+        pytest.skip("the library in the tree was not built here")
+    timed = {k: v for k, v in res.items() if re.search(r"k_learn_scan_emitILi\dELi6E", k)}
+    assert len(timed) == 8, sorted(res)
+    for name, r in {**timed, **{k: v for k, v in res.items() if re.search(r"k_act_rows|k_mid_overlap|k_learn_scan_(tail|front)", k)}}.items():
+        assert r["scratch_bytes_per_lane"] == 0, (name, r)
+    for name, r in timed.items():
+        assert r["vgprs"] <= 80 and r["occupancy"] >= 6, (name, r)
+
+
 def test_create_rejects_bad_config_without_touching_a_gpu(lib):
     import ctypes as C
     from bithtm_amd import _lib
