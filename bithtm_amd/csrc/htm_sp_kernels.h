@@ -551,7 +551,7 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
     static_assert(2 * CAND_MAX + ZOOM_BINS <= SEL_BINS, "bucket keys and their sub-bins must fit the histogram");
     const int tid = threadIdx.x, lane = lane_id();
     EMIT_STAMP(0);
-    if (tid == 0) { s_gt = 0; s_eq = 0; s_n = 0; s_nraw = 0; s_ne = 0; s_flags = 0; s_T = 0; sh->n_others = 0; }
+    if (tid == 0) { s_gt = 0; s_eq = 0; s_n = 0; s_nraw = 0; s_ne = 0; s_flags = 0; s_T = 0; }
     const int cbase = d.sel_lo + b * 256, c = cbase + tid;      // the select covers columns [sel_lo, sel_hi)
     const bool local = mode & EMIT_LOCAL;
     // independent of everything below: in flight while the select state is resolved
@@ -893,9 +893,7 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
             // it, 400-570 (key, block) pairs -- is not ranked whole: the sub-bin of the k-th key is picked from the histogram of
             // the next ZB key bits, and only THAT sub-bin's pairs stay on the list (one key, nearly always: the fold below settles
             // it in its first pass); the pairs above it are winners outright.
-            uint32_t zF, above_f;
-            sel_pick<256, true>(s_zh, 1 << ZB, krem, s_wave, s_out, &zF, &above_f);
-            krem -= above_f;
+            // (two barrier stages, not five: the entries go into registers first, the first wave picks alone)
             constexpr int EPT = CAND_MAX / 256;
             u64 ek[EPT];
             uint32_t ecb[EPT];
@@ -905,8 +903,27 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
                 ek[u] = e < ne ? s_ek[e] : 0ull;
                 ecb[u] = e < ne ? (uint32_t)s_ec[e] | ((uint32_t)s_eb[e] << 16) : 0u;
             }
-            if (tid == 0) { s_ne = 0; s_T = 0; s_prefix = 0; }
+            if (tid < 64) {                          // lane l: sub-bins (nb - 16 (l + 1), nb - 16 l], from the top
+                const int top = (1 << ZB) - 1 - (ZOOM_BINS / 64) * lane;
+                uint32_t cs = 0;
+#pragma unroll
+                for (int j = 0; j < ZOOM_BINS / 64; ++j) cs += top - j >= 0 ? s_zh[top - j] : 0u;
+                const uint32_t incl = wave_incl_scan(cs);
+                const u64 hit = __ballot(incl >= krem);
+                if (hit && lane == __ffsll((long long)hit) - 1) {
+                    uint32_t above = incl - cs;
+                    for (int j = 0; j < ZOOM_BINS / 64; ++j) {
+                        const uint32_t hb = top - j >= 0 ? s_zh[top - j] : 0u;
+                        if (above + hb >= krem) { s_out[0] = (uint32_t)(top - j); s_out[1] = above; break; }
+                        above += hb;
+                    }
+                }
+                // (the kept pairs are counted in s_nraw: a wave that has not read s_ne yet may still be behind the barrier above)
+                if (tid == 0) { s_nraw = 0; s_T = 0; s_prefix = 0; }
+            }
             lds_barrier();
+            const uint32_t zF = s_out[0];
+            krem -= s_out[1];
             heaviest = 0;
             u64 and_or = 0;                          // ~(and of the kept keys' low words) : or of them -- one key kept <=> the halves are complements
 #pragma unroll
@@ -920,7 +937,7 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
                 const u64 mk = __ballot(keep);
                 if (!mk) continue;
                 int base = 0;
-                if (lane == __ffsll((long long)mk) - 1) base = atomicAdd(&s_ne, __popcll(mk));
+                if (lane == __ffsll((long long)mk) - 1) base = atomicAdd(&s_nraw, __popcll(mk));
                 base = wave_read(base, __ffsll((long long)mk) - 1);
                 if (keep) {
                     const int slot = base + __popcll(mk & lanemask_lt());
@@ -937,7 +954,7 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
                 if (lane == 0) { atomicMax((unsigned long long *)&s_T, heaviest); atomicOr((unsigned long long *)&s_prefix, and_or); }
             }
             lds_barrier();
-            ne = s_ne;
+            ne = s_nraw;
             // (the kept keys agree above their low 32 bits -- the bin's prefix and the sub-bin, zsh <= 30 bits below it)
             if (ne > 0 && (uint32_t)s_prefix == ~(uint32_t)(s_prefix >> 32)) { T = s_ek[0]; r = krem; settled = true; }
         }
