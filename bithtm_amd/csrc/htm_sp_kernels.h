@@ -903,55 +903,58 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
                 ek[u] = e < ne ? s_ek[e] : 0ull;
                 ecb[u] = e < ne ? (uint32_t)s_ec[e] | ((uint32_t)s_eb[e] << 16) : 0u;
             }
-            if (tid < 64) {                          // lane l: sub-bins (nb - 16 (l + 1), nb - 16 l], from the top
-                const int top = (1 << ZB) - 1 - (ZOOM_BINS / 64) * lane;
+            if (tid < 64) {                          // lane l: sub-bins (nb - 16 (l + 1), nb - 16 l] from the top, then lane j: the j-th of
+                constexpr int PER = ZOOM_BINS / 64;  // the chosen sixteen -- two reads, two scans, no walk along dependent reads
+                const int top = (1 << ZB) - 1 - PER * lane;
                 uint32_t cs = 0;
 #pragma unroll
-                for (int j = 0; j < ZOOM_BINS / 64; ++j) cs += top - j >= 0 ? s_zh[top - j] : 0u;
+                for (int j = 0; j < PER; ++j) cs += top - j >= 0 ? s_zh[top - j] : 0u;
                 const uint32_t incl = wave_incl_scan(cs);
                 const u64 hit = __ballot(incl >= krem);
-                if (hit && lane == __ffsll((long long)hit) - 1) {
-                    uint32_t above = incl - cs;
-                    for (int j = 0; j < ZOOM_BINS / 64; ++j) {
-                        const uint32_t hb = top - j >= 0 ? s_zh[top - j] : 0u;
-                        if (above + hb >= krem) { s_out[0] = (uint32_t)(top - j); s_out[1] = above; break; }
-                        above += hb;
-                    }
-                }
+                const int hl = hit ? __ffsll((long long)hit) - 1 : 0;
+                const uint32_t above_g = wave_read(incl - cs, hl);
+                const int bin = (1 << ZB) - 1 - PER * hl - lane;
+                const uint32_t f = lane < PER && bin >= 0 ? s_zh[bin] : 0u;
+                const uint32_t incl_f = above_g + wave_incl_scan(f);
+                const u64 hit_f = __ballot(lane < PER && incl_f >= krem);
+                if (hit_f && lane == __ffsll((long long)hit_f) - 1) { s_out[0] = (uint32_t)bin; s_out[1] = incl_f - f; }
                 // (the kept pairs are counted in s_nraw: a wave that has not read s_ne yet may still be behind the barrier above)
-                if (tid == 0) { s_nraw = 0; s_T = 0; s_prefix = 0; }
+                if (tid == 0) { s_nraw = 0; s_prefix = 0; }
             }
             lds_barrier();
             const uint32_t zF = s_out[0];
             krem -= s_out[1];
-            heaviest = 0;
             u64 and_or = 0;                          // ~(and of the kept keys' low words) : or of them -- one key kept <=> the halves are complements
+            u64 mk[EPT];
+            int n_keep = 0;
 #pragma unroll
             for (int u = 0; u < EPT; ++u) {
                 const bool valid = tid + 256 * u < ne;
-                if (!__ballot(valid)) break;
                 const u64 low40 = (ek[u] & lowmask) >> d.low_zero;
-                const uint32_t sub = (uint32_t)(low40 >> zsh) & (ZOOM_BINS - 1), cnt = ecb[u] & 0xFFFFu;
-                const bool keep = valid && sub == zF;
-                if (valid && sub > zF && (int)(ecb[u] >> 16) < b) gthi_before += cnt;
-                const u64 mk = __ballot(keep);
-                if (!mk) continue;
-                int base = 0;
-                if (lane == __ffsll((long long)mk) - 1) base = atomicAdd(&s_nraw, __popcll(mk));
-                base = wave_read(base, __ffsll((long long)mk) - 1);
-                if (keep) {
-                    const int slot = base + __popcll(mk & lanemask_lt());
-                    s_ek[slot] = ek[u];
-                    s_ec[slot] = (uint16_t)cnt;
-                    s_eb[slot] = (uint16_t)(ecb[u] >> 16);
-                    heaviest = max(heaviest, ((u64)cnt << 40) | low40);
-                    and_or |= ((u64)~(uint32_t)low40 << 32) | (u64)(uint32_t)low40;
-                }
+                const uint32_t sub = (uint32_t)(low40 >> zsh) & (ZOOM_BINS - 1);
+                if (valid && sub > zF && (int)(ecb[u] >> 16) < b) gthi_before += ecb[u] & 0xFFFFu;
+                mk[u] = __ballot(valid && sub == zF);
+                n_keep += __popcll(mk[u]);
             }
-            if (__any(heaviest != 0)) {
-                heaviest = wave_reduce64(heaviest, 0ull, [](u64 a, u64 b) { return a > b ? a : b; });
+            if (n_keep) {                            // (wave-uniform; one reservation for all the wave keeps)
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&s_nraw, n_keep);
+                int slot = wave_read(base, 0);
+#pragma unroll
+                for (int u = 0; u < EPT; ++u) {
+                    if ((mk[u] >> lane) & 1ull) {
+                        const int at = slot + __popcll(mk[u] & lanemask_lt());
+                        const u64 low40 = (ek[u] & lowmask) >> d.low_zero;
+                        s_ek[at] = ek[u];
+                        s_ec[at] = (uint16_t)(ecb[u] & 0xFFFFu);
+                        s_eb[at] = (uint16_t)(ecb[u] >> 16);
+                        if (at == 0) s_T = ((u64)(ecb[u] & 0xFFFFu) << 40) | low40;      // (the fold's first guess, should more than one key be left)
+                        and_or |= ((u64)~(uint32_t)low40 << 32) | (u64)(uint32_t)low40;
+                    }
+                    slot += __popcll(mk[u]);
+                }
                 and_or = wave_reduce64(and_or, 0ull, [](u64 a, u64 b) { return a | b; });
-                if (lane == 0) { atomicMax((unsigned long long *)&s_T, heaviest); atomicOr((unsigned long long *)&s_prefix, and_or); }
+                if (lane == 0) atomicOr((unsigned long long *)&s_prefix, and_or);
             }
             lds_barrier();
             ne = s_nraw;
