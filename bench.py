@@ -395,7 +395,7 @@ def run_single(args):
     steps_per_s = float(np.median(rates))
     log(f"[bench] {reps} x {args.steps} timed steps: median {steps_per_s:.0f} timesteps/s "
         f"(min {min(rates):.0f}, max {max(rates):.0f}); S={info.segments}; "
-        f"select fallbacks so far: {info.select_fallbacks} of {info.step_index} steps")
+        f"select fallbacks so far: {info.select_fallbacks} of {info.step_index} steps, crowded bins cut to a sub-bin: {info.select_zoom_steps}")
 
     # per-launch device time (HIP events on the engine's stream) of the TIMED schedule, then of the same
     # workload with one role per launch; both eager (events cannot be read out of a graph replay)

@@ -35,6 +35,7 @@ class HtmInfo(C.Structure):
         ("has_winner_cells", C.c_int32), ("capacity_error", C.c_int32), ("words_per_row", C.c_int32),
         ("new_segment_requests", C.c_int32), ("recycled_segments", C.c_int32), ("appended_segments", C.c_int32),
         ("work_items", C.c_int32), ("select_fallbacks", C.c_int32), ("candidate_exact_steps", C.c_int32), ("hot_select_steps", C.c_int32),
+        ("select_zoom_steps", C.c_int32),
     ]
 
 

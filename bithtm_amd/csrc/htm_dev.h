@@ -93,6 +93,7 @@ struct Counters {
     int32_t cand_exact;       // sharded: steps whose LOCAL select cut the threshold bin exactly (record exchange) instead of
                               // handing the whole bin over (telemetry)
     int32_t hot_selects;      // sharded: steps whose GLOBAL select was settled among the ranks' hot lists (telemetry)
+    int32_t sel_zooms;        // steps whose select finish cut a crowded threshold bin to the k-th key's sub-bin (telemetry)
     uint32_t emit_epoch;      // bumped by every overlap launch: tags the records k_sp_emit's blocks exchange
     int32_t n_un;             // winners needing a new segment
     int32_t n_recycled, n_new, S_old;
@@ -111,7 +112,7 @@ struct Counters {
 };
 
 struct Dev {
-    int I, W, W4, Ipad, C, K, k, E, Scap, work_cap, sel_passes, colwords, low_zero, cand_d, cand_pairwise, cand_others, cand_speculate, cand_take_all, poll_delay;
+    int I, W, W4, Ipad, C, K, k, E, Scap, work_cap, sel_passes, colwords, low_zero, cand_d, cand_pairwise, cand_others, cand_speculate, cand_take_all, cand_zoom, poll_delay;
     int win_offset;           // test knob: added to the select window's base (a window that misses: the fallback every step)
     int world, c0, c1;        // this rank owns columns [c0, c1) (world == 1: everything)
     int sel_lo, sel_hi, sel_k; // the select works on the keys of columns [sel_lo, sel_hi) and finds their sel_k largest

@@ -759,6 +759,7 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
         d.cand_pairwise = CAND_PAIRWISE;
         if (const char *e = getenv("BITHTM_CAND_PAIRWISE")) d.cand_pairwise = std::max(0, atoi(e));     // test knobs
         d.win_offset = getenv("BITHTM_SEL_WINDOW_OFFSET") ? std::max(0, atoi(getenv("BITHTM_SEL_WINDOW_OFFSET"))) : 0;
+        d.cand_zoom = getenv("BITHTM_CAND_ZOOM") ? atoi(getenv("BITHTM_CAND_ZOOM")) : -1;      // (test knob: the pairs above which a merge is cut to a sub-bin; -1 = more pairs than blocks by a quarter)
         d.cand_speculate = getenv("BITHTM_CAND_SPECULATE") ? atoi(getenv("BITHTM_CAND_SPECULATE")) != 0 : 1;     // (test knob: 0 = always the general path)
         d.cand_take_all = getenv("BITHTM_CAND_TAKE_ALL") ? atoi(getenv("BITHTM_CAND_TAKE_ALL")) != 0 : 1;      // (test knob: 0 = a shard's local select always cuts exactly)
         d.poll_delay = getenv("BITHTM_POLL_DELAY") ? std::max(0, std::min(64, atoi(getenv("BITHTM_POLL_DELAY")))) : 7;     // (the select finish's first look at the other blocks' records: x 256 clocks after its own)
@@ -1799,6 +1800,7 @@ extern "C" int htm_get_info(htm_handle *h, htm_info *out) {
     out->select_fallbacks = c.sel_fallbacks;
     out->candidate_exact_steps = c.cand_exact;
     out->hot_select_steps = c.hot_selects;
+    out->select_zoom_steps = c.sel_zooms;
     if (c.error) {
         h->err = std::string("capacity exhausted:") + ((c.error & 1) ? " segment pool (segment_capacity)" : "") +
                  ((c.error & 2) ? " synapse slots (segment_slots)" : "") + ((c.error & 4) ? " work list / growth staging" : "") +

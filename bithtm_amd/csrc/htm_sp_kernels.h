@@ -564,8 +564,8 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
     uint32_t r;                                     // how many of the keys == T are selected
     bool second_round = false;                      // per-block counts still to be exchanged
     const uint32_t epoch = (d.ctr->emit_epoch & 0x3FFu) + 1u;           // 1..1024, changes with every overlap launch
-    if (fused && wmode)                             // (the sub-bin counts of a crowded bin, below: zeroed while the window's sums are on their way)
-        for (int i = tid; i < ZOOM_BINS; i += 256) s_zh[i] = 0;
+    if (fused && wmode && tid >= 64)                // (the sub-bin counts of a crowded bin, below: zeroed by the waves that wait while
+        for (int i = tid - 64; i < ZOOM_BINS; i += 192) s_zh[i] = 0;      // the first one resolves the window's sums)
     if (fused) {
         u64 P;
         uint32_t krem;
@@ -769,16 +769,16 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
         __syncthreads();
         const int nraw = min(s_nraw, CAND_RAW);
         const uint32_t my_gt_hi = s_gt;
-        int first = -1;                              // merge duplicates that came from different waves
-        uint32_t my_cnt = 0;
-        if (nraw > 1) {                              // (uniform in the block; most blocks have at most one bucket key)
-            if (tid < nraw) {
-                my_cnt = s_bc[tid];
-                for (first = 0; s_bk[first] != s_bk[tid]; ++first) {}
+        int first = -1;                              // merge duplicates that came from different waves: the first wave alone, its
+        if (tid < 64 && nraw > 1) {                  // lanes holding a raw key each (no walk along dependent LDS reads, no block barrier)
+            const u64 k = lane < nraw ? s_bk[lane] : 0ull;
+            const uint32_t cn = lane < nraw ? s_bc[lane] : 0u;
+            for (int j = 0; j < nraw; ++j) {         // (uniform)
+                const u64 kj = wave_read(k, j);
+                if (first < 0 && lane < nraw && kj == k) first = j;
             }
-            __syncthreads();
-            if (tid < nraw && first != tid) atomicAdd(&s_bc[first], my_cnt);
-            __syncthreads();
+            if (lane < nraw && first != lane) atomicAdd(&s_bc[first], cn);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (read again below, by this wave)
         } else if (tid < nraw) {
             first = tid;
         }
@@ -888,7 +888,9 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
             for (int e = tid; e < min(ne, 1024); e += 256) d.trace[(size_t)256 * 8 + e] = ((s_ek[e] & lowmask) >> d.low_zero) | ((unsigned long long)s_ec[e] << 32) | ((unsigned long long)s_eb[e] << 48);
 #endif
         bool settled = false;                        // (the k-th key is known already: the sub-bin held one key)
-        if (!(s_flags & 1u) && ne <= CAND_MAX && ne > d.cand_pairwise && ZB > 0) {
+        // (Only where blocks hold SEVERAL keys each -- more pairs than blocks by a quarter --: a many-way tie alone, one pair per
+        // block, is settled by the fold's first pass a microsecond sooner than by the two stages here; measured both ways.)
+        if (!(s_flags & 1u) && ne <= CAND_MAX && ne > d.cand_pairwise && ne > (d.cand_zoom >= 0 ? d.cand_zoom : nblk + (nblk >> 2)) && ZB > 0) {
             // A crowded bin -- a learned pattern's thousand columns behind ONE key and a few dozen stragglers a part in 10^5 off
             // it, 400-570 (key, block) pairs -- is not ranked whole: the sub-bin of the k-th key is picked from the histogram of
             // the next ZB key bits, and only THAT sub-bin's pairs stay on the list (one key, nearly always: the fold below settles
@@ -919,7 +921,7 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
                 const u64 hit_f = __ballot(lane < PER && incl_f >= krem);
                 if (hit_f && lane == __ffsll((long long)hit_f) - 1) { s_out[0] = (uint32_t)bin; s_out[1] = incl_f - f; }
                 // (the kept pairs are counted in s_nraw: a wave that has not read s_ne yet may still be behind the barrier above)
-                if (tid == 0) { s_nraw = 0; s_prefix = 0; }
+                if (tid == 0) { s_nraw = 0; s_prefix = 0; if (b == 0) d.ctr->sel_zooms += 1; }
             }
             lds_barrier();
             const uint32_t zF = s_out[0];

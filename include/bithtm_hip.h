@@ -108,6 +108,8 @@ typedef struct htm_info {
     int32_t hot_select_steps;           /* column-sharded handles: steps so far whose GLOBAL select was settled among the ranks'
                                            hot lists (the candidates near the previous step's k-th key) without reading the
                                            other candidates */
+    int32_t select_zoom_steps;          /* steps so far whose top-k select found its threshold bin crowded (blocks holding several
+                                           distinct keys each) and cut it to the k-th key's sub-bin before ranking it */
 } htm_info;
 
 /* Device arrays readable with htm_read / writable with htm_write. Element type and count

@@ -162,6 +162,7 @@ def test_full_size_timed_path_equals_from_scratch_oracle(full_size_oracle, use_g
     eng = htm.engine
     info = eng.check_capacity()
     assert info.step_index == n and info.select_fallbacks == 0
+    print(f"threshold bins cut to the k-th key's sub-bin: {info.select_zoom_steps} of {n} steps")
     sp_state = type(htm.spatial_pooler).State(eng, eng.steps)
     tm_state = htm.temporal_memory.last_state
     got = step_outputs(sp_state, tm_state, K)

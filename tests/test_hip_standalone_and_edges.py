@@ -313,6 +313,7 @@ def test_batched_run_equals_step_by_step():
                                  {"BITHTM_CAND_PAIRWISE": "0", "BITHTM_CAND_OTHERS": "0"}, {"BITHTM_CAND_PAIRWISE": "0", "BITHTM_CAND_OTHERS": "4"},
                                  {"BITHTM_CAND_PAIRWISE": "0", "BITHTM_CAND_OTHERS": "0", "BITHTM_CAND_SPECULATE": "0"},
                                  {"BITHTM_CAND_PAIRWISE": "0", "BITHTM_CAND_OTHERS": "4", "BITHTM_CAND_SPECULATE": "0"},
+                                 {"BITHTM_CAND_PAIRWISE": "0", "BITHTM_CAND_ZOOM": "0"}, {"BITHTM_CAND_PAIRWISE": "2", "BITHTM_CAND_ZOOM": "3", "BITHTM_CAND_OTHERS": "0"},
                                  {"BITHTM_LEAN_SCAN": "1", "BITHTM_LEAN_LEARN": "1"}, {"BITHTM_LEAN_SCAN": "3", "BITHTM_LEAN_LEARN": "2", "BITHTM_LEAN_OVERLAP": "3"},
                                  {"BITHTM_FUSE_TM": "0"}],
                          ids=lambda e: ",".join(f"{k[7:]}={v}" for k, v in e.items()) or "default")
@@ -320,8 +321,9 @@ def test_pipelined_schedules_and_select_paths_equal_step_by_step(env, monkeypatc
     """htm.run in its pipelined schedules -- three launches per step (the learning role scanning its own rows beside the
     scan, the one-pass windowed select) and the four-launch one -- against process(), with the select forced down every
     path: a window that always misses (exact fallback each step), records that overflow (slots 0 / 1), the tie merge
-    (pairwise 0; others 0 = radix refinement only; SPECULATE 0 = without the shortcut "the k-th key is the heaviest key"), and
-    grids of a few blocks (every wave loops)."""
+    (pairwise 0; others 0 = radix refinement only; SPECULATE 0 = without the shortcut "the k-th key is the heaviest key"), the
+    cut to the k-th key's sub-bin that a crowded bin gets before it is ranked (ZOOM 0: every merge; 3: some), and grids of a
+    few blocks (every wave loops)."""
     import bithtm_amd as B
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -342,6 +344,8 @@ def test_pipelined_schedules_and_select_paths_equal_step_by_step(env, monkeypatc
         info = htm.engine.check_capacity()
         if mode == "graph" and "BITHTM_SEL_WINDOW_OFFSET" in env:
             assert info.select_fallbacks >= 100          # (the knob did what it is for)
+        if mode == "graph" and "BITHTM_CAND_ZOOM" in env:
+            assert info.select_zoom_steps >= (100 if env["BITHTM_CAND_ZOOM"] == "0" else 10), info.select_zoom_steps
         st = htm.engine.read_store()
         d = htm.engine.read_distal()
         outs.append((htm.engine.read_sp_fields()["active_column"], st["seg_cell"], st["seg_nsyn"], st["presyn"], st["perm"],
@@ -454,19 +458,23 @@ def test_batched_run_with_learning_switched_off_and_on():
             assert np.array_equal(a, b)
 
 
-@pytest.mark.parametrize("digits,slots,pairwise,others,spec", [("2", "8", "160", "128", "1"), ("3", "8", "160", "128", "1"), ("2", "0", "160", "128", "1"),
-                                                               ("2", "1", "160", "128", "1"), ("2", "8", "0", "128", "1"), ("2", "8", "0", "4", "1"), ("2", "8", "0", "0", "1"),
-                                                               ("2", "8", "0", "128", "0"), ("2", "8", "0", "4", "0"), ("2", "8", "0", "0", "0")])
-def test_select_is_exact_on_the_record_path_and_on_the_fallback(digits, slots, pairwise, others, spec, monkeypatch):
+@pytest.mark.parametrize("digits,slots,pairwise,others,spec,zoom", [("2", "8", "160", "128", "1", "-1"), ("3", "8", "160", "128", "1", "-1"), ("2", "0", "160", "128", "1", "-1"),
+                                                                    ("2", "1", "160", "128", "1", "-1"), ("2", "8", "0", "128", "1", "-1"), ("2", "8", "0", "4", "1", "-1"), ("2", "8", "0", "0", "1", "-1"),
+                                                                    ("2", "8", "0", "128", "0", "-1"), ("2", "8", "0", "4", "0", "-1"), ("2", "8", "0", "0", "0", "-1"),
+                                                                    ("2", "8", "0", "128", "1", "0"), ("3", "8", "0", "0", "0", "0"), ("2", "8", "1", "0", "1", "2"), ("2", "8", "2", "128", "0", "4")])
+def test_select_is_exact_on_the_record_path_and_on_the_fallback(digits, slots, pairwise, others, spec, zoom, monkeypatch):
     """k_sp_emit finishes the top-k select from per-block bucket records.  slots=0 makes every block
     with a bucket key overflow its record, so the exact in-kernel fallback runs every step; slots=1
     mixes both paths; 3 launched digits is the variant with smaller buckets; pairwise=0 merges the
     records on every step the way a many-way tie is merged (the copies of one key folded into one
     entry, then all pairs if fewer than `others` other entries remain, else radix refinement:
-    others=4 mixes both, others=0 is radix only; spec=0: without the shortcut that tries the heaviest key first)."""
+    others=4 mixes both, others=0 is radix only; spec=0: without the shortcut that tries the heaviest key first);
+    zoom >= 0: a merge of more pairs than that is first cut to the sub-bin of the k-th key (what a crowded bin of the
+    full-size model gets: more pairs than blocks by a quarter)."""
     import bithtm_amd as B
     from oracle import HTMOracle
     monkeypatch.setenv("BITHTM_SEL_LAUNCH_DIGITS", digits)
+    monkeypatch.setenv("BITHTM_CAND_ZOOM", zoom)
     monkeypatch.setenv("BITHTM_CAND_D", slots)
     monkeypatch.setenv("BITHTM_CAND_PAIRWISE", pairwise)
     monkeypatch.setenv("BITHTM_CAND_OTHERS", others)
@@ -482,7 +490,9 @@ def test_select_is_exact_on_the_record_path_and_on_the_fallback(digits, slots, p
         os_, om = ora.step(x)
         assert np.array_equal(s.active_column, os_.active_column), (digits, slots, pairwise, others, t)
         assert np.array_equal(m.cell_prediction, om.cell_prediction), (digits, slots, pairwise, others, t)
-    htm.engine.check_capacity()
+    info = htm.engine.check_capacity()
+    print(f"digits {digits} slots {slots} pairwise {pairwise} others {others} spec {spec} zoom {zoom}: fallbacks {info.select_fallbacks}, sub-bin cuts {info.select_zoom_steps}")
+    assert zoom == "-1" or info.select_zoom_steps >= 10, info.select_zoom_steps
 
 
 def test_example_harness_prints_the_reference_report_format():

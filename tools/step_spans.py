@@ -16,7 +16,7 @@ os.environ["BITHTM_TRACE"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 
-WARMUP = 1500
+WARMUP = int(os.environ.get("BITHTM_SPANS_WARMUP", 1500))      # (the state: bench.py times at 8 604 steps by default, 979 at the driver's arguments)
 
 
 def main():
