@@ -893,8 +893,8 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
         if (!(s_flags & 1u) && ne <= CAND_MAX && ne > d.cand_pairwise && ne > (d.cand_zoom >= 0 ? d.cand_zoom : nblk + (nblk >> 2)) && ZB > 0) {
             // A crowded bin -- a learned pattern's thousand columns behind ONE key and a few dozen stragglers a part in 10^5 off
             // it, 400-570 (key, block) pairs -- is not ranked whole: the sub-bin of the k-th key is picked from the histogram of
-            // the next ZB key bits, and only THAT sub-bin's pairs stay on the list (one key, nearly always: the fold below settles
-            // it in its first pass); the pairs above it are winners outright.
+            // the next ZB key bits, and only THAT sub-bin's pairs stay on the list (one key, nearly always: then it IS the k-th
+            // key and nothing is ranked; otherwise the stages below run on the short list); the pairs above it are winners outright.
             // (two barrier stages, not five: the entries go into registers first, the first wave picks alone)
             constexpr int EPT = CAND_MAX / 256;
             u64 ek[EPT];
