@@ -37,7 +37,12 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 WORKLOAD = dict(input_dim=1024, column_dim=65536, cell_dim=32, patterns=50, density=0.02, noise=0.005,
                 noisy_copies=20, segment_slots=128)
+# The same shape with a larger learned pool ("40 % of roofline and 10^4 steps/s coincide only if ... the
+# segment pool is larger (S*E*8 ~ 300 MB, e.g. P ~ 350 patterns)"): 350 patterns, 10 passes of untimed pre-training.  The
+# `large_pool` leg of the line; the headline stays P = 50.
+LARGE_POOL = dict(WORKLOAD, patterns=350, noisy_copies=4, segment_capacity=1 << 20)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+PMC_FILES = ("r04_pmc_summary.json", "r03_pmc_summary.json")      # recorded PMC passes, newest first
 
 
 def log(*a):
@@ -67,20 +72,33 @@ def build_htm(w, perm, device, column_range=None):
     proximal.permanence_threshold, proximal.permanence_increment, proximal.permanence_decrement = 0.0, 0.03, 0.015
     proximal._engine, proximal._permanence = None, perm
     sp = B.SpatialPooler(I, C, k, proximal_projection=proximal)
-    tm = B.TemporalMemory(C, K, distal_projection=B.PredictiveProjection(C * K, segment_slots=w["segment_slots"]), seed=0,
+    tm = B.TemporalMemory(C, K, distal_projection=B.PredictiveProjection(C * K, segment_slots=w["segment_slots"],
+                                                                         segment_capacity=w.get("segment_capacity")), seed=0,
                           device=device)
     return B.HierarchicalTemporalMemory(I, C, K, active_columns=k, spatial_pooler=sp, temporal_memory=tm, device=device)
 
 
 # the launches of the pipelined schedules (htm_pipeline.h) and the roles each holds: three per timestep (the default) ...
-LEAN_KERNEL = {"tm_activate+sp_learn": "k_act_rows", "tm_mid+sp_overlap": "k_mid_overlap", "tm_learn+tm_scan+sp_emit": "k_learn_scan_emit"}
+# (the last launch's name says which form of the scan it holds: small pools are scanned by blocks that are all resident at
+# once, pools of more than ~295 k segments by the streaming form -- htm_engine.hip: scan_pool_is_large)
+LEAN_KERNEL = {"tm_activate+sp_learn": "k_act_rows", "tm_mid+sp_overlap": "k_mid_overlap", "tm_learn+tm_scan+sp_emit": "k_learn_scan_emit",
+               "tm_learn+tm_scan_large+sp_emit": "k_learn_scan_emit"}
 LEAN_ROLES = {"tm_activate+sp_learn": ("tm_activate", "sp_rows", "tm_clear"), "tm_mid+sp_overlap": ("tm_mid", "sp_overlap"),
-              "tm_learn+tm_scan+sp_emit": ("tm_learn", "tm_scan", "sp_emit")}
+              "tm_learn+tm_scan+sp_emit": ("tm_learn", "tm_scan", "sp_emit"), "tm_learn+tm_scan_large+sp_emit": ("tm_learn", "tm_scan", "sp_emit")}
 # ... or four (BITHTM_LEAN=0)
 LAUNCH_KERNEL = {"tm_activate+sp_emit": "k_open_emit", "tm_mid+sp_learn": "k_mid_rows",
-                 "tm_learn+sp_overlap": "k_learn_overlap", "tm_scan+sp_select": "k_scan_sel"}
+                 "tm_learn+sp_overlap": "k_learn_overlap", "tm_scan+sp_select": "k_scan_sel", "tm_scan_large+sp_select": "k_scan_sel"}
 LAUNCH_ROLES = {"tm_activate+sp_emit": ("tm_activate", "sp_emit"), "tm_mid+sp_learn": ("tm_mid", "sp_rows"),
-                "tm_learn+sp_overlap": ("tm_learn", "sp_overlap"), "tm_scan+sp_select": ("tm_scan", "sp_select", "tm_clear")}
+                "tm_learn+sp_overlap": ("tm_learn", "sp_overlap"), "tm_scan+sp_select": ("tm_scan", "sp_select", "tm_clear"),
+                "tm_scan_large+sp_select": ("tm_scan", "sp_select", "tm_clear")}
+
+
+def launches_seen(prof, table):
+    """The launches of a pipelined schedule among the profiled names: every launch of `table` that ran (the last launch has two
+    names, one per form of the scan -- a run that crosses the threshold shows both), or None if a launch of the schedule is missing."""
+    ran = {n: prof[n] for n in table if prof.get(n, (0, 0))[1]}
+    kernels = {table[n] for n in table}
+    return ran if {table[n] for n in ran} == kernels else None
 
 
 def role_bytes(w, k, seg_nsyn, n_work, n_match):
@@ -113,7 +131,7 @@ def role_bytes(w, k, seg_nsyn, n_work, n_match):
     }
 
 
-def recorded_traffic(kernel, files=("r03_pmc_summary.json",), sum_nsyn=None):
+def recorded_traffic(kernel, files=PMC_FILES, sum_nsyn=None, section=None):
     """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r03_pmc_summary.json: rocprofv3 --pmc
     FETCH_SIZE and --pmc WRITE_SIZE in separate runs of this same command and schedule; KB units; FETCH_SIZE doubled as
     MI355X_MICROARCH.md section HBM prescribes for gfx950).  PMC counters cannot be read from inside this process, so this is a
@@ -123,6 +141,8 @@ def recorded_traffic(kernel, files=("r03_pmc_summary.json",), sum_nsyn=None):
         path = os.path.join(ROOT, "profiles", name)
         try:
             d = json.load(open(path))
+            if section:                             # (a leg of the line recorded beside the headline: its own counters and state)
+                d = d[section]
             key = next(k for k in d["FETCH_SIZE"] if kernel in k)          # template kernels: "void k_scan_sel<true, 6>"
             f = d["FETCH_SIZE"][key]["mean_last150_KB"]
             wr = d["WRITE_SIZE"][key]["mean_last150_KB"]
@@ -136,7 +156,7 @@ def recorded_traffic(kernel, files=("r03_pmc_summary.json",), sum_nsyn=None):
     return dict(traffic=None)
 
 
-def cpu_baseline(w, htm, noisy, bank, start_step, sample_steps, run):
+def cpu_baseline(w, htm, noisy, bank, start_step, sample_steps, run, chunk_plan=(5, 20, 5)):
     """Time the NumPy oracle on this host from the GPU's learned state (a port of the
     reference's CPU path: dense float64 `>=` + `&` + sum overlap, NumPy segment scan) -- and then let it check the
     bench's own call pattern at the full size: the GPU runs the same timesteps the way the timed region made its calls
@@ -158,16 +178,19 @@ def cpu_baseline(w, htm, noisy, bank, start_step, sample_steps, run):
                sample=f"{sample_steps} timesteps of the NumPy oracle from the GPU's learned state "
                       f"(S={ora.temporal_memory.S} segments), single-threaded NumPy")
     try:
-        out.update(check_against_oracle(w, htm, noisy, bank, ora, states, run))
+        out.update(check_against_oracle(w, htm, noisy, bank, ora, states, run, chunk_plan))
     except AssertionError as e:
         log(f"[bench] PARITY FAILURE against the oracle: {e}")
         out.update(parity=f"FAILED: {e}")
     return out
 
 
-def check_against_oracle(w, htm, noisy, bank, ora, states, run):
+def check_against_oracle(w, htm, noisy, bank, ora, states, run, chunk_plan=(5, 20, 5)):
     """The GPU's next len(states) timesteps, called as the timed region calls (run = its use_graph / pipeline flags),
-    against the oracle's: Temporal Memory outputs at every chunk boundary, everything at the end."""
+    against the oracle's: Temporal Memory outputs at every chunk boundary, everything at the end.  The chunks: `chunk_plan`
+    ([5 warm-up, 20 timed] as the driver's arguments make them, ...) and then the rest in one call -- long enough, with the
+    default sample, to replay hipGraphs where the timed region does (htm_run launches calls of fewer than 64 steps eagerly):
+    what each chunk did is asked of the library (htm_run_plan) and reported."""
     from bithtm_amd import _lib as L
     from bithtm_amd.engine import bool_to_words
     eng = htm.engine
@@ -175,16 +198,18 @@ def check_against_oracle(w, htm, noisy, bank, ora, states, run):
     n_bank = noisy.shape[0]
     n = len(states)
     cont = bool(run["pipeline"])
-    chunks, left = [], n                              # [5 warm-up, 20 timed] as the driver's arguments make them, then the rest
-    for c in (5, 20, 5):
+    chunks, left = [], n
+    for c in chunk_plan:
         if left > c:
             chunks.append(c)
             left -= c
     chunks.append(left)
-    done = 0
+    done, modes = 0, []
     for i, c in enumerate(chunks):
         last = i == len(chunks) - 1
         flags = dict(run, continuing=cont and not last)
+        plan = eng.run_plan(c, **flags)
+        modes.append(("graph" if plan["hip_graph"] else "eager") + ("+large-pool scan" if plan["scan_large"] else ""))
         eng.prepare(bank, n_bank, c, **flags)
         eng.run(bank, n_bank, c, **flags)
         done += c
@@ -225,10 +250,11 @@ def check_against_oracle(w, htm, noisy, bank, ora, states, run):
     assert np.array_equal(np.where(a_ps >= 0, a_pm, 0), np.where(b_ps >= 0, b_pm, 0)), "permanence bits of the segment store"
     assert np.array_equal(eng.read_duty_cycle().view(np.int32), osp.duty_cycle.view(np.int32)), "duty cycle"
     assert np.array_equal(eng.get_permanence().view(np.int64), osp.permanence.view(np.int64)), "Spatial Pooler permanences"
-    log(f"[bench] parity: {n} timesteps in chunks of {chunks} (streamed calls, prepared graphs) equal the oracle's at every chunk "
+    called = ", ".join(f"{c} ({m})" for c, m in zip(chunks, modes))
+    log(f"[bench] parity: {n} timesteps in chunks of {called} (streamed calls, prepared graphs) equal the oracle's at every chunk "
         f"boundary; whole state equal at the end (S={S})")
-    return dict(parity="ok", parity_checked=f"{n} timesteps called as the timed region calls them (chunks {chunks}, HTM_RUN_CONTINUE={cont}, "
-                                            f"htm_prepare, hip_graph={bool(run['use_graph'])}): TM outputs at every chunk boundary, SP outputs and the whole "
+    return dict(parity="ok", parity_checked=f"{n} timesteps called as the timed region calls them (chunks of {called}; HTM_RUN_CONTINUE={cont}, "
+                                            f"htm_prepare): TM outputs at every chunk boundary, SP outputs and the whole "
                                             f"state (segment store, permanence bits, duty cycle) at the end, bit for bit")
 
 
@@ -345,11 +371,10 @@ def stress_leg(steps=8, warmup=3, check=True):
     return out
 
 
-def run_single(args):
-    w = dict(WORKLOAD)
-    if args.columns:
-        w["column_dim"] = args.columns
-    device = int(os.environ.get("LOCAL_RANK", "0"))
+def measure(w, args, device, label, reps, cpu_steps, chunk_plan, pmc_section=None):
+    """One workload through the bench protocol: untimed pre-training to the learned state, R repetitions of [W warm-up
+    steps, exactly K timed steps] called as a streaming caller calls, per-launch HIP-event times of the timed schedule,
+    the roofline object, and (cpu_steps > 0) the oracle timed from the same state + the parity check of the call pattern."""
     t_setup = time.perf_counter()
     noisy, perm = make_inputs(w)
     htm = build_htm(w, perm, device)
@@ -361,25 +386,27 @@ def run_single(args):
     # rocprofv3 crashes inside hipGraph replay on this image: under the profiler, launch eagerly
     under_profiler = "ROCP_TOOL_LIBRARIES" in os.environ
     if under_profiler and not args.no_graph:
-        log("[bench] rocprofv3 detected: hipGraph replay switched off (eager launches of the same schedule)")
+        log(f"[bench] {label}: rocprofv3 detected: hipGraph replay switched off (eager launches of the same schedule)")
     use_graph = not args.no_graph and not under_profiler
     pipeline = not args.no_pipeline
     run = dict(learning=True, use_graph=use_graph, pipeline=pipeline)
     # Untimed setup: bring the model to the learned state the metric is quoted on (warm-up of
     # at least 10 passes over the pattern bank; predictions appear after four).  The W warm-up steps of the
-    # command line come on top of it, before every timed repetition.
+    # command line come on top of it, before every timed repetition.  (In calls of one pass: the library sees the pool's
+    # size between calls and switches the scan to its streaming form when the pool has outgrown the resident one.)
     pretrain = args.pretrain if args.pretrain >= 0 else 10 * w["patterns"]
-    eng.run(bank, n_bank, pretrain, **run)
-    eng.sync()
+    for a in range(0, pretrain, w["patterns"]):
+        eng.run(bank, n_bank, min(w["patterns"], pretrain - a), **run)
+        eng.sync()
     eng.check_capacity()
-    log(f"[bench] setup {time.perf_counter() - t_setup:.1f}s incl. {pretrain} untimed pre-training steps; "
+    log(f"[bench] {label}: setup {time.perf_counter() - t_setup:.1f}s incl. {pretrain} untimed pre-training steps; "
         f"S={eng.info().segments} segments")
     # R repetitions of [W warm-up steps, exactly K timed steps]; `value` is the median repetition
     # The calls are made the way a caller streaming its input in chunks makes them (HTM_RUN_CONTINUE, include/bithtm_hip.h):
     # the Spatial Pooler's look-ahead is kept across the call boundaries, so a timed region of K steps holds exactly K
     # Temporal Memory steps and K Spatial Pooler steps of the steady state, not a cold start plus a drain.
-    reps = args.reps if args.reps > 0 else max(3, min(15, -(-4000 // max(args.steps, 1))))
     stream = dict(run, continuing=pipeline and args.warmup > 0)
+    plan = eng.run_plan(args.steps, **stream)          # what the timed call does: asked of the library, not assumed
     rates = []
     for r in range(reps):
         eng.run(bank, n_bank, args.warmup, **stream)
@@ -393,7 +420,8 @@ def run_single(args):
     eng.sync()
     info = eng.check_capacity()
     steps_per_s = float(np.median(rates))
-    log(f"[bench] {reps} x {args.steps} timed steps: median {steps_per_s:.0f} timesteps/s "
+    log(f"[bench] {label}: {reps} x {args.steps} timed steps ({'hipGraph replay' if plan['hip_graph'] else 'eager launches'}"
+        f"{', large-pool scan' if plan['scan_large'] else ''}): median {steps_per_s:.0f} timesteps/s "
         f"(min {min(rates):.0f}, max {max(rates):.0f}); S={info.segments}; "
         f"select fallbacks so far: {info.select_fallbacks} of {info.step_index} steps, crowded bins cut to a sub-bin: {info.select_zoom_steps}")
 
@@ -410,24 +438,21 @@ def run_single(args):
     store = eng.read_store()
     rb = role_bytes(w, k, store["seg_nsyn"], info.work_items, info.matching_segments)
     role_us = {n: 1e3 * ms / cnt for n, (ms, cnt) in prof_roles.items() if cnt}
-    log("[bench] one role per launch, average launch (us): " +
+    log(f"[bench] {label}: one role per launch, average launch (us): " +
         ", ".join(f"{n}={v:.1f}" for n, v in sorted(role_us.items(), key=lambda kv: -kv[1])))
-    if pipeline and all(prof_timed.get(n, (0, 0))[1] for n in LEAN_ROLES):
-        launch_us = {n: 1e3 * prof_timed[n][0] / max(prof_timed[n][1], 1) for n in LEAN_ROLES}
-        launch_bytes = {n: sum(rb[r] for r in roles) for n, roles in LEAN_ROLES.items()}
-        kernel_of = LEAN_KERNEL
-    elif pipeline and all(prof_timed.get(n, (0, 0))[1] for n in LAUNCH_ROLES):
-        launch_us = {n: 1e3 * prof_timed[n][0] / max(prof_timed[n][1], 1) for n in LAUNCH_ROLES}
-        launch_bytes = {n: sum(rb[r] for r in roles) for n, roles in LAUNCH_ROLES.items()}
-        kernel_of = LAUNCH_KERNEL
+    lean, four = launches_seen(prof_timed, LEAN_KERNEL), launches_seen(prof_timed, LAUNCH_KERNEL)
+    if pipeline and (lean or four):
+        ran, roles_of, kernel_of = (lean, LEAN_ROLES, LEAN_KERNEL) if lean else (four, LAUNCH_ROLES, LAUNCH_KERNEL)
+        launch_us = {n: 1e3 * ms / cnt for n, (ms, cnt) in ran.items()}
+        launch_bytes = {n: sum(rb[r] for r in roles_of[n]) for n in ran}
     else:                                             # --no-pipeline (or a grid too large to pipeline): the roles ARE the launches
         per_role = {"sp_overlap": ("sp_overlap",), "sp_select": ("sp_select",), "sp_emit": ("sp_emit", "tm_activate", "tm_clear"),
-                    "tm_mid": ("tm_mid", "sp_rows"), "tm_learn": ("tm_learn",), "tm_scan": ("tm_scan",)}
+                    "tm_mid": ("tm_mid", "sp_rows"), "tm_learn": ("tm_learn",), "tm_scan": ("tm_scan",), "tm_scan_large": ("tm_scan",)}
         launch_us = {n: v for n, v in role_us.items() if n in per_role}
         launch_bytes = {n: sum(rb[r] for r in per_role[n]) for n in launch_us}
         kernel_of = {"sp_overlap": "k_sp_overlap", "sp_select": "k_sel_pass", "sp_emit": "k_sp_emit", "tm_mid": "k_mid_rows",
-                     "tm_learn": "k_tm_learn", "tm_scan": "k_tm_scan"}
-    log("[bench] launches of the timed schedule (us): " + ", ".join(f"{n}={v:.1f}" for n, v in launch_us.items()) +
+                     "tm_learn": "k_tm_learn", "tm_scan": "k_tm_scan", "tm_scan_large": "k_tm_scan"}
+    log(f"[bench] {label}: launches of the timed schedule (us): " + ", ".join(f"{n}={v:.1f}" for n, v in launch_us.items()) +
         f"; sum {sum(launch_us.values()):.1f} of {1e6 / steps_per_s:.1f} us per step")
     dominant = max(launch_us, key=lambda n: launch_us[n])
     achieved = launch_bytes[dominant] / (launch_us[dominant] * 1e-6) / 1e9
@@ -435,30 +460,85 @@ def run_single(args):
     roofline = dict(bound="hbm", kernel=f"{kernel_of[dominant]} ({dominant})", achieved=round(achieved, 1), peak=HBM_PEAK_GBS,
                     unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
                     bytes_per_launch=int(launch_bytes[dominant]), avg_launch_us=round(launch_us[dominant], 2),
+                    # which clock `avg_launch_us` is: the begin / end timestamps hipExtLaunchKernelGGL stamps on the engine's
+                    # stream, eager launches of the timed schedule, measured in this run (rocprofv3's per-dispatch duration of
+                    # the same kernel, from a run of its own, is in profiles/: about a microsecond above)
+                    clock="hip_events",
                     whole_step_bytes=whole, whole_step_frac=round(whole * steps_per_s / 1e9 / HBM_PEAK_GBS, 4),
                     launches={n: dict(kernel=kernel_of[n], us=round(launch_us[n], 2), bytes=int(launch_bytes[n]),
                                       frac=round(launch_bytes[n] / (launch_us[n] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4))
                               for n in launch_us})
     sum_nsyn = int(store["seg_nsyn"].astype(np.int64).sum())
-    roofline.update(recorded_traffic(kernel_of[dominant], sum_nsyn=sum_nsyn))
+    roofline.update(recorded_traffic(kernel_of[dominant], sum_nsyn=sum_nsyn, section=pmc_section))
     roofline["state"] = dict(step_index=int(info.step_index), segments=int(info.segments), sum_nsyn=sum_nsyn)
+    try:                                               # rocprofv3's duration of the same kernel, where a pass of this command was kept
+        rec = json.load(open(os.path.join(ROOT, "profiles", "r04_pipelined_kernel_us.json")))
+        rec = rec[pmc_section] if pmc_section else rec
+        key = next(k2 for k2 in rec if kernel_of[dominant] in k2 and "mean_last300_us" in rec[k2])
+        roofline["rocprofv3_us"] = round(rec[key]["mean_last300_us"], 2)
+        roofline["rocprofv3_source"] = "profiles/r04_pipelined_kernel_us.json (mean of the last 300 launches, a run of its own)"
+    except Exception:
+        pass
 
     cpu = None
-    if not args.no_cpu_baseline:
-        cpu = cpu_baseline(w, htm, noisy, bank, int(eng.info().step_index), args.cpu_steps, run)
-        log(f"[bench] cpu baseline: {cpu['value']:.2f} timesteps/s; parity {cpu.get('parity')}")
-    step_index, segments = int(info.step_index), int(info.segments)
+    if cpu_steps > 0:
+        cpu = cpu_baseline(w, htm, noisy, bank, int(eng.info().step_index), cpu_steps, run, chunk_plan)
+        log(f"[bench] {label}: cpu baseline: {cpu['value']:.2f} timesteps/s; parity {cpu.get('parity')}")
+    return dict(steps_per_s=steps_per_s, rates=rates, roofline=roofline, cpu=cpu, role_us=role_us, role_bytes=rb, k=k,
+                pretrain=pretrain, segments=int(info.segments), launches_per_step=len({kernel_of[n] for n in launch_us}),
+                plan=plan, streamed=bool(stream["continuing"]), pipeline=pipeline)
+
+
+def large_pool_leg(args, device):
+    """The headline shape with a larger learned pool (LARGE_POOL: 350 patterns instead of 50, S ~ 0.65 M segments): where
+    SURVEY section 8(d) says the two halves of the target -- >= 10^4 timesteps/s and >= 40 % of the HBM roofline -- can
+    coincide on 65 536 x 32.  Same protocol as the headline (untimed pre-training of 10 passes, R x [W, K], the oracle's
+    parity check of the call pattern, per-launch HIP events, recorded PMC traffic)."""
+    w = dict(LARGE_POOL)
+    m = measure(w, args, device, "large_pool", reps=max(3, min(7, -(-2000 // max(args.steps, 1)))),
+                cpu_steps=0 if args.no_cpu_baseline else args.large_cpu_steps, chunk_plan=(5,), pmc_section="large_pool")
+    rf = m["roofline"]
+    out = dict(workload=f"65536 columns x 32 cells, SP + TM learning on, {w['patterns']} patterns (headline: {WORKLOAD['patterns']}): "
+                        f"a learned pool of {m['segments']} segments",
+               value=round(m["steps_per_s"], 1), unit="timesteps/s", ms_per_step=round(1e3 / m["steps_per_s"], 5),
+               steps=args.steps, warmup=args.warmup, repetitions=[round(r, 1) for r in m["rates"]],
+               patterns=w["patterns"], pretrain_steps=m["pretrain"], segments=m["segments"], hip_graph=m["plan"]["hip_graph"],
+               scan_form="large-pool (streaming)" if m["plan"]["scan_large"] else "small-pool (resident)",
+               launches_per_step=m["launches_per_step"], whole_step_frac=rf["whole_step_frac"], roofline=rf)
+    if m["cpu"] is not None:
+        out.update(parity=m["cpu"].get("parity"), parity_checked=m["cpu"].get("parity_checked"),
+                   cpu_baseline={k2: m["cpu"][k2] for k2 in ("value", "unit", "cores", "kind", "sample")})
+    return out
+
+
+def run_single(args):
+    w = dict(WORKLOAD)
+    if args.columns:
+        w["column_dim"] = args.columns
+    device = int(os.environ.get("LOCAL_RANK", "0"))
+    import gc
+    if args.large_pool_only:
+        return large_pool_leg(args, device)
+    reps = args.reps if args.reps > 0 else max(3, min(15, -(-4000 // max(args.steps, 1))))
+    m = measure(w, args, device, "headline", reps, 0 if args.no_cpu_baseline else args.cpu_steps, (5, 20, 5))
+    gc.collect()                                        # (the legs need the device to themselves: memory, and CU slots -- DESIGN.md)
+    large = None
+    if not args.no_large_pool and not args.columns:
+        try:
+            large = large_pool_leg(args, device)
+        except Exception as e:                          # a report beside the headline: never a reason to lose the line
+            log(f"[bench] large_pool leg failed: {e!r}")
+            large = dict(error=repr(e))
+        gc.collect()
     stress = None
     if not args.no_stress and not args.columns:
-        del eng, htm, bank, store                       # the leg needs the device to itself (memory, and CU slots: see DESIGN.md)
-        import gc
-        gc.collect()
         try:
             stress = stress_leg(check=not args.no_cpu_baseline)
-        except Exception as e:                          # a report beside the headline: never a reason to lose the line
+        except Exception as e:
             log(f"[bench] configs[4] leg failed: {e!r}")
             stress = dict(error=repr(e))
 
+    steps_per_s, k = m["steps_per_s"], m["k"]
     return dict(
         metric="HTM timesteps/sec (SP + TM, learning on), 65536 cols x 32 cells", value=round(steps_per_s, 1),
         unit="timesteps/s", n_gpus=1, steps=args.steps, warmup=args.warmup, ms_per_step=round(1e3 / steps_per_s, 5),
@@ -467,12 +547,14 @@ def run_single(args):
         config=dict(workload="configs[2]: 65536 columns x 32 cells, SP + TM learning on, 1 MI355X",
                     input_dim=w["input_dim"], column_dim=w["column_dim"], cell_dim=w["cell_dim"], active_columns=k,
                     patterns=w["patterns"], input_density=w["density"], flip_noise=w["noise"],
-                    pretrain_steps=pretrain, segments=segments, segment_slots=w["segment_slots"],
-                    hip_graph=use_graph, pipelined=pipeline, launches_per_step=len(launch_us), repetitions=reps, streamed_calls=bool(stream["continuing"])),
-        repetitions=[round(r, 1) for r in rates],
-        roofline=roofline, cpu_baseline=cpu, stress=stress,
-        role_us_one_per_launch={n: round(v, 2) for n, v in role_us.items()},
-        role_bytes={n: int(v) for n, v in rb.items()})
+                    pretrain_steps=m["pretrain"], segments=m["segments"], segment_slots=w["segment_slots"],
+                    # what the TIMED call did (htm_run_plan): calls of fewer than 64 steps launch eagerly whatever was asked
+                    hip_graph=m["plan"]["hip_graph"], hip_graph_requested=not args.no_graph, pipelined=m["plan"]["pipelined"],
+                    launches_per_step=m["launches_per_step"], repetitions=reps, streamed_calls=m["streamed"]),
+        repetitions=[round(r, 1) for r in m["rates"]],
+        roofline=m["roofline"], cpu_baseline=m["cpu"], large_pool=large, stress=stress,
+        role_us_one_per_launch={n: round(v, 2) for n, v in m["role_us"].items()},
+        role_bytes={n: int(v) for n, v in m["role_bytes"].items()})
 
 
 def main():
@@ -483,7 +565,10 @@ def main():
     ap.add_argument("--columns", type=int, default=0, help="override column_dim (debugging)")
     ap.add_argument("--pretrain", type=int, default=-1, help="untimed pre-training steps (default: 10 passes over the pattern bank)")
     ap.add_argument("--reps", type=int, default=0, help="timed repetitions (default: enough for about 4000 timed steps, 3..15)")
-    ap.add_argument("--cpu-steps", type=int, default=40)
+    ap.add_argument("--cpu-steps", type=int, default=100, help="timesteps of the NumPy oracle timed for cpu_baseline (and checked against the GPU)")
+    ap.add_argument("--large-cpu-steps", type=int, default=69, help="... of the large_pool leg's parity check")
+    ap.add_argument("--no-large-pool", action="store_true", help="skip the large_pool leg (the headline shape with 350 patterns)")
+    ap.add_argument("--large-pool-only", action="store_true", help="run only the large_pool leg and print its object (profiling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stress", action="store_true", help="skip the configs[4] leg (one rank's pre-populated shard)")
     ap.add_argument("--stress-only", action="store_true", help="run only the configs[4] leg and print its object (profiling)")

@@ -6,7 +6,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libbithtm_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class HtmConfig(C.Structure):
@@ -44,6 +44,7 @@ F_ACTIVE_COLUMN, F_OVERLAPS, F_BOOSTED, F_DUTY_CYCLE, F_CELL_ACTIVATION, F_CELL_
 F_WINNER_WORDS, F_BURSTING, F_WINNER_CELL, F_SEG_CELL, F_SEG_NSYN, F_SEG_PRESYN, F_SEG_PERM = 7, 8, 9, 10, 11, 12, 13
 F_SEGCOUNT, F_SEG_POTENTIAL, F_MATCH_SEGMENT, F_MATCH_INFO, F_MATCH_JITTER, F_CELL_MAX_JITTER = 14, 15, 16, 17, 18, 19
 F_SEG_GID = 20
+PLAN_GRAPH, PLAN_PIPELINED, PLAN_LEAN, PLAN_SCAN_LARGE = 1, 2, 4, 8
 SP_OVERLAP, SP_BOOST, SP_SELECT, SP_ACTIVE, SP_LEARN, SP_DUTY, SP_COMMIT = 1, 2, 3, 4, 5, 6, 7
 
 EXPORTS = {
@@ -62,6 +63,7 @@ EXPORTS = {
     "htm_tm_scan": (C.c_int, [C.c_void_p, C.c_void_p]),
     "htm_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "htm_prepare": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "htm_run_plan": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "htm_bank_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]),
     "htm_shard_record_bytes": (C.c_int64, [C.c_void_p]),
     "htm_shard_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),

@@ -69,6 +69,7 @@ struct htm_handle {
     bool emit_fused, emit_fused_open;     // the emit grid is resident at once in k_sp_emit / in k_open_emit (refreshed per call)
     bool emit_fits_lean;                  // ... and in k_learn_scan_emit
     int knob_lean, knob_fuse_tm, knob_shard_window, knob_scan_large, knob_step_window, knob_tail_rows;
+    int scan_large_above;                 // segments above which the scan takes its streaming (large-pool) form (BITHTM_SCAN_LARGE_ABOVE)
     int knob_defer_tail;                  // htm_step holds a step's last launch back for the next call's first (BITHTM_DEFER_TAIL)
     bool tail_pending;                    // ... and one is held back now: the learning role and the scan of the step of parity tail_p
     int tail_p;
@@ -223,7 +224,7 @@ static int scan_spec_blocks(const htm_handle *h) { return std::min(h->seg_hint /
 // more segments than three rounds of resident blocks: the scan is bandwidth-bound (see k_tm_scan)
 static bool scan_pool_is_large(const htm_handle *h) {
     if (h->knob_scan_large >= 0) return h->knob_scan_large != 0;      // (BITHTM_SCAN_LARGE: tuning knob)
-    return h->seg_hint > 3 * 1536 * SCAN_SEGS;
+    return h->seg_hint > h->scan_large_above;
 }
 
 static void launch_scan(htm_handle *h, int p, int use_lds) {
@@ -382,7 +383,9 @@ static void enqueue_lean(htm_handle *h, int p, int learning, const uint32_t *ban
     const size_t lds = std::max(std::max(learn_lds(epl, 256), lean_scan_lds(d)), sizeof(EmitShared));
     const int n_learn = h->lean_learn_blocks, n_scan = h->lean_scan_blocks;
     const int grid = n_emit + n_learn + n_scan;
-#define LAUNCH_LSE(EPL_, MINW_, TAB_) LAUNCH_ON(h, h->stream, lds, "tm_learn+tm_scan+sp_emit", (k_learn_scan_emit<EPL_, MINW_, TAB_>), grid, 256, d, p, n_emit, n_learn, n_scan, spec)
+    // (the launch's name says which form of the scan it holds: htm_profile_read is how tests and bench.py tell)
+    const char *lse_name = scan_pool_is_large(h) ? "tm_learn+tm_scan_large+sp_emit" : "tm_learn+tm_scan+sp_emit";
+#define LAUNCH_LSE(EPL_, MINW_, TAB_) LAUNCH_ON(h, h->stream, lds, lse_name, (k_learn_scan_emit<EPL_, MINW_, TAB_>), grid, 256, d, p, n_emit, n_learn, n_scan, spec)
     if (scan_pool_is_large(h)) {
         switch (epl) { case 1: LAUNCH_LSE(1, 4, false); break; case 2: LAUNCH_LSE(2, 4, false); break; case 4: LAUNCH_LSE(4, 4, false); break; default: LAUNCH_LSE(8, 4, false); break; }
     } else if (lean_tab(d)) {
@@ -419,8 +422,8 @@ static void enqueue_pipelined(htm_handle *h, int p, int learning, const uint32_t
     const int grid = h->scan_blocks + n_sel + n_clear;
     const int spec = scan_spec_blocks(h);
     if (scan_pool_is_large(h)) {
-        if (use_lds) LAUNCH_ON(h, h->stream, lds, "tm_scan+sp_select", (k_scan_sel<true, 1>), grid, 256, d, p, n_sel, n_clear, p, spec);
-        else LAUNCH_ON(h, h->stream, lds, "tm_scan+sp_select", (k_scan_sel<false, 1>), grid, 256, d, p, n_sel, n_clear, p, spec);
+        if (use_lds) LAUNCH_ON(h, h->stream, lds, "tm_scan_large+sp_select", (k_scan_sel<true, 1>), grid, 256, d, p, n_sel, n_clear, p, spec);
+        else LAUNCH_ON(h, h->stream, lds, "tm_scan_large+sp_select", (k_scan_sel<false, 1>), grid, 256, d, p, n_sel, n_clear, p, spec);
     } else {
         if (use_lds) LAUNCH_ON(h, h->stream, lds, "tm_scan+sp_select", (k_scan_sel<true, 6>), grid, 256, d, p, n_sel, n_clear, p, spec);
         else LAUNCH_ON(h, h->stream, lds, "tm_scan+sp_select", (k_scan_sel<false, 6>), grid, 256, d, p, n_sel, n_clear, p, spec);
@@ -692,6 +695,8 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
     h->knob_fuse_tm = getenv("BITHTM_FUSE_TM") ? atoi(getenv("BITHTM_FUSE_TM")) != 0 : 1;
     h->knob_shard_window = getenv("BITHTM_SHARD_WINDOW") ? atoi(getenv("BITHTM_SHARD_WINDOW")) != 0 : 1;
     h->knob_scan_large = getenv("BITHTM_SCAN_LARGE") ? atoi(getenv("BITHTM_SCAN_LARGE")) : -1;
+    // (test knob: a small model crosses the threshold in the middle of a run, as the headline shape does with more patterns)
+    h->scan_large_above = getenv("BITHTM_SCAN_LARGE_ABOVE") ? std::max(0, atoi(getenv("BITHTM_SCAN_LARGE_ABOVE"))) : 3 * 1536 * SCAN_SEGS;
     h->knob_step_window = getenv("BITHTM_STEP_WINDOW") ? atoi(getenv("BITHTM_STEP_WINDOW")) != 0 : 1;
     h->knob_tail_rows = getenv("BITHTM_TAIL_ROWS") ? atoi(getenv("BITHTM_TAIL_ROWS")) != 0 : 1;
     h->knob_defer_tail = getenv("BITHTM_DEFER_TAIL") ? atoi(getenv("BITHTM_DEFER_TAIL")) != 0 : 1;
@@ -1091,13 +1096,21 @@ extern "C" int htm_tm_update(htm_handle *h, const int32_t *columns, const uint32
     uint32_t *d_ww = nullptr, *d_uw = nullptr, *d_pun = nullptr;
     auto release = [&]() { if (d_cols) hipFree(d_cols); if (d_ww) hipFree(d_ww); if (d_uw) hipFree(d_uw); if (d_pun) hipFree(d_pun); };
     const size_t nb = (size_t)std::max(n, 1) * 4;
+    // punish_words == NULL: every cell of a column that is not listed (networks.py:107-108,111).  The mask is built here: the
+    // middle launch's own default reads the step's active words, which this entry point does not write (htm_tm_scan does, later)
+    std::vector<uint32_t> default_pun;
+    if (!punish_words) {
+        default_pun.assign((size_t)d.C, d.K >= 32 ? 0xFFFFFFFFu : ((1u << d.K) - 1u));
+        for (int i = 0; i < n; ++i) default_pun[(size_t)cols[(size_t)i]] = 0u;
+        punish_words = default_pun.data();
+    }
     if (hipMalloc((void **)&d_cols, nb) != hipSuccess || hipMalloc((void **)&d_ww, nb) != hipSuccess || hipMalloc((void **)&d_uw, nb) != hipSuccess ||
-        (punish_words && hipMalloc((void **)&d_pun, (size_t)d.C * 4) != hipSuccess)) { release(); h->err = "htm_tm_update: hipMalloc failed"; return HTM_ERR_HIP; }
+        hipMalloc((void **)&d_pun, (size_t)d.C * 4) != hipSuccess) { release(); h->err = "htm_tm_update: hipMalloc failed"; return HTM_ERR_HIP; }
     bool ok = true;
     if (n) ok = hipMemcpyAsync(d_cols, cols.data(), nb, hipMemcpyHostToDevice, h->stream) == hipSuccess &&
                 hipMemcpyAsync(d_ww, ww.data(), nb, hipMemcpyHostToDevice, h->stream) == hipSuccess &&
                 hipMemcpyAsync(d_uw, uw.data(), nb, hipMemcpyHostToDevice, h->stream) == hipSuccess;
-    if (ok && punish_words) ok = hipMemcpyAsync(d_pun, punish_words, (size_t)d.C * 4, hipMemcpyHostToDevice, h->stream) == hipSuccess;
+    if (ok) ok = hipMemcpyAsync(d_pun, punish_words, (size_t)d.C * 4, hipMemcpyHostToDevice, h->stream) == hipSuccess;
     if (!ok) { release(); h->err = "htm_tm_update: hipMemcpy failed"; return HTM_ERR_HIP; }
     hipLaunchKernelGGL(k_tm_ext_winners, dim3(std::min((d.C + 255) / 256, 1024)), dim3(256), 0, h->stream, d, p, d_cols, d_ww, d_uw, n, 0);
     if (n) hipLaunchKernelGGL(k_tm_ext_winners, dim3((n + 255) / 256), dim3(256), 0, h->stream, d, p, d_cols, d_ww, d_uw, n, 1);
@@ -1260,6 +1273,17 @@ extern "C" int htm_run(htm_handle *h, const uint32_t *device_inputs, int32_t n_i
 
 extern "C" int htm_prepare(htm_handle *h, const uint32_t *device_inputs, int32_t n_inputs, int32_t n_steps, int32_t learning, int32_t use_graph) {
     return run_or_prepare(h, device_inputs, n_inputs, n_steps, learning, use_graph, true);
+}
+
+extern "C" int htm_run_plan(htm_handle *h, int32_t n_steps, int32_t use_graph) {
+    if (!h || n_steps < 0) return HTM_ERR_ARGUMENT;
+    if (!h->cfg.enable_sp || !h->cfg.enable_tm || h->world > 1) { h->err = "htm_run_plan: htm_run needs an unsharded handle with SP and TM"; return HTM_ERR_STATE; }
+    refresh_exchange_mode(h);
+    if (h->seg_pinned) { const int seen = *(volatile int *)h->seg_pinned; h->seg_hint = std::max(h->seg_hint, seen); }
+    const bool graph = (use_graph & 1) && !h->profile && n_steps >= h->eager_below;
+    const bool pipeline = !(use_graph & 2) && can_pipeline(h) && n_steps > 1;
+    return (graph ? HTM_PLAN_GRAPH : 0) | (pipeline ? HTM_PLAN_PIPELINED : 0) | (pipeline && can_lean(h) ? HTM_PLAN_LEAN : 0) |
+           (scan_pool_is_large(h) ? HTM_PLAN_SCAN_LARGE : 0);
 }
 
 static int read_counters(htm_handle *h, Counters *out);

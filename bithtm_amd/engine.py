@@ -288,6 +288,13 @@ class Engine:
         self._check(self.lib.htm_prepare(self.h, C.c_void_p(device_bank), int(n_inputs), int(n_steps), int(bool(learning)),
                                          flags), "htm_prepare")
 
+    def run_plan(self, n_steps, use_graph=True, pipeline=True, continuing=False, **_):
+        """What a run() with these arguments would do now (htm_run_plan): dict(hip_graph, pipelined, lean, scan_large)."""
+        flags = (1 if use_graph else 0) | (0 if pipeline else 2) | (4 if continuing else 0)
+        bits = self._check(self.lib.htm_run_plan(self.h, int(n_steps), flags), "htm_run_plan")
+        return dict(hip_graph=bool(bits & L.PLAN_GRAPH), pipelined=bool(bits & L.PLAN_PIPELINED), lean=bool(bits & L.PLAN_LEAN),
+                    scan_large=bool(bits & L.PLAN_SCAN_LARGE))
+
     # ---- column-sharded stepping (shard_world > 1): begin -> all-gather by the caller -> finish
     def shard_record_bytes(self):
         return int(self._check(self.lib.htm_shard_record_bytes(self.h), "htm_shard_record_bytes"))

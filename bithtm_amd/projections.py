@@ -268,4 +268,7 @@ class PredictiveProjection:
         from .engine import bool_to_words
         ww, uw = bool_to_words(learn_mask.reshape(C, K)), bool_to_words(need.reshape(C, K))
         cols = np.flatnonzero(ww)
-        eng.tm_update(cols, ww[cols], uw[cols], bool_to_words(self._padded(np.asarray(output_punishment, dtype=np.bool_)).reshape(C, K)))
+        # output_punishment=None: the mask TemporalMemory builds (networks.py:107-108,111) -- every cell of a column without a
+        # learning cell -- is built by the library (htm_tm_update's punish_words == NULL)
+        eng.tm_update(cols, ww[cols], uw[cols], None if output_punishment is None else
+                      bool_to_words(self._padded(np.asarray(output_punishment, dtype=np.bool_)).reshape(C, K)))

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define BITHTM_ABI_VERSION 3
+#define BITHTM_ABI_VERSION 4
 
 typedef struct htm_handle htm_handle;
 
@@ -238,6 +238,20 @@ int htm_run(htm_handle *h, const uint32_t *device_inputs, int32_t n_inputs, int3
  * time a launch pattern is met).  Latency-sensitive callers invoke it once after their warm-up. */
 int htm_prepare(htm_handle *h, const uint32_t *device_inputs, int32_t n_inputs, int32_t n_steps,
                 int32_t learning, int32_t use_graph);
+
+/* What an htm_run / htm_prepare call with these arguments would do if it came now (nothing is enqueued): a caller that
+ * reports how it ran (bench.py's `config.hip_graph`) asks instead of assuming.  Bits of the result:
+ *   HTM_PLAN_GRAPH      the steady-state steps replay hipGraphs (use_graph bit 0 AND n_steps at or above the eager limit,
+ *                       64 unless BITHTM_EAGER_BELOW says otherwise, AND no htm_profile collection in progress)
+ *   HTM_PLAN_PIPELINED  the Spatial Pooler works ahead of the Temporal Memory (heterogeneous launches)
+ *   HTM_PLAN_LEAN       ... in the three-launch schedule (else four launches per step)
+ *   HTM_PLAN_SCAN_LARGE the segment scan runs in its streaming (large-pool) form
+ * Negative: an error status. */
+#define HTM_PLAN_GRAPH 1
+#define HTM_PLAN_PIPELINED 2
+#define HTM_PLAN_LEAN 4
+#define HTM_PLAN_SCAN_LARGE 8
+int htm_run_plan(htm_handle *h, int32_t n_steps, int32_t use_graph);
 
 /* Convenience for callers without their own device allocator: copy n_inputs packed inputs
  * (ceil(input_dim/32) host words each, as for htm_step) into a handle-owned device bank laid out

@@ -38,5 +38,8 @@ def golden_dir():
 @pytest.fixture(autouse=True)
 def _graphs_for_short_runs_too(monkeypatch):
     """htm_run launches calls of fewer than 64 steps eagerly whatever use_graph says (BITHTM_EAGER_BELOW, read when a
-    handle is created).  The tests ask for graphs to exercise every capture plan with short runs: switch the policy off."""
+    handle is created).  The tests ask for graphs to exercise every capture plan with short runs: switch the policy off --
+    by default.  The batched-run tests set the variable themselves and run under the library's own policy as well
+    (test_batched_run_equals_step_by_step, test_pipelined_schedules_and_select_paths_equal_step_by_step,
+    test_random_call_patterns_equal_step_by_step: `EAGER_BELOW=64`), and the full-size tests make calls on both sides of it."""
     monkeypatch.setenv("BITHTM_EAGER_BELOW", "0")

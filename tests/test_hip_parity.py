@@ -245,3 +245,115 @@ def test_emit_grid_too_large_for_the_pipelined_launch_falls_back():
     assert np.array_equal(htm.engine.read_sp_fields()["active_column"], o_sp.active_column)
     compare_store_with_oracle(steps - 1, ora, htm)
     htm.engine.check_capacity()
+
+
+@pytest.fixture(scope="module")
+def large_pool_oracle():
+    """The NumPy oracle stepped 260 times FROM THE SEED at 65 536 x 32 with bench.py's LARGE_POOL input stream (350
+    patterns): everything bursts, 1 311 new segments per step -- 340 k segments, past the 294 912 above which the scan
+    takes its streaming form (htm_engine.hip: scan_pool_is_large)."""
+    import bench
+    from oracle import HTMOracle
+    w = dict(bench.LARGE_POOL)
+    noisy, perm = bench.make_inputs(w)
+    ora = HTMOracle(w["input_dim"], w["column_dim"], w["cell_dim"], seed=0, permanence=perm)
+    n = 260
+    for t in range(n):
+        o_sp, o_tm = ora.step(noisy[t % len(noisy)])
+    assert ora.temporal_memory.S > 320000
+    return dict(w=w, noisy=noisy, ora=ora, o_sp=o_sp, o_tm=o_tm, n=n)
+
+
+@pytest.mark.parametrize("lean", [True, False], ids=["three-launches", "four-launches"])
+def test_full_size_pool_outgrows_the_resident_scan_in_mid_run(large_pool_oracle, lean, monkeypatch):
+    """The headline shape fed 350 patterns instead of 50: the pool crosses the large-pool threshold in the middle of a
+    stream of htm.run calls (graph keys change, the last launch becomes k_learn_scan_emit<E, 4, false>: the streaming scan
+    beside the learning role and the select finish -- or k_scan_sel<*, 1> in the four-launch schedule).  From scratch
+    against the from-scratch oracle: last step's outputs, every potential, the per-cell maxima, the whole state."""
+    import bench
+    from hip_impl import compare_store_with_oracle, step_outputs
+    if not lean:
+        monkeypatch.setenv("BITHTM_LEAN", "0")
+    f = large_pool_oracle
+    w, noisy, ora, n = f["w"], f["noisy"], f["ora"], f["n"]
+    K = w["cell_dim"]
+    _, perm = bench.make_inputs(w)
+    htm = bench.build_htm(w, perm, 0)
+    del perm
+    eng = htm.engine
+    bank = eng.upload_bank(noisy)
+    plans = []
+    for chunk, graph in ((120, True), (70, True), (40, True), (24, False)):       # S = 157 k, 249 k, 301 k (> 294 912), 333 k
+        plans.append(eng.run_plan(chunk, use_graph=graph, continuing=True))
+        eng.run(bank, len(noisy), chunk, use_graph=graph, continuing=True)
+        eng.sync()                                   # (the call's last copy -- the segment count -- has landed: the next call sees it)
+    assert [p["scan_large"] for p in plans] == [False, False, False, True] and all(p["lean"] == lean for p in plans), plans
+    eng.profile(True)                                # the launches of the last steps, by name (eager under the profile)
+    eng.run(bank, len(noisy), 6, continuing=False)
+    names = set(eng.profile_read())
+    eng.profile(False)
+    assert ("tm_learn+tm_scan_large+sp_emit" if lean else "tm_scan_large+sp_select") in names, names
+    assert not ({"tm_learn+tm_scan+sp_emit", "tm_scan+sp_select", "tm_scan"} & names), names
+    info = eng.check_capacity()
+    assert info.step_index == n and info.segments == ora.temporal_memory.S
+    sp_state = type(htm.spatial_pooler).State(eng, eng.steps)
+    tm_state = htm.temporal_memory.last_state
+    got = step_outputs(sp_state, tm_state, K)
+    o_sp, o_tm = f["o_sp"], f["o_tm"]
+    od = o_tm.distal_state
+    want = dict(active_column=o_sp.active_column, overlaps=o_sp.overlaps, boosted=o_sp.boosted_overlaps,
+                bursting=o_tm.active_column_bursting[:, 0],
+                act_bits=np.packbits(o_tm.cell_activation.reshape(-1), bitorder="little"),
+                pred_bits=np.packbits(o_tm.cell_prediction.reshape(-1), bitorder="little"),
+                winner=o_tm.winner_cell[0] * K + o_tm.winner_cell[1], matching=od.matching_segment,
+                match_pot=od.segment_potential[od.matching_segment], match_act=od.matching_segment_activation,
+                match_active=od.matching_segment_active, S=len(od.segment_potential))
+    for key in gr.FIELDS:
+        a, b = np.asarray(got[key]), np.asarray(want[key])
+        if key == "boosted":
+            a, b = a.view(np.int64), b.view(np.int64)
+        assert a.shape == b.shape and np.array_equal(a, b), f"{key} after {n} steps"
+    d = tm_state.distal_state
+    assert np.array_equal(d.segment_potential, od.segment_potential)
+    assert np.array_equal(d.max_jittered_potential.view(np.int32), od.max_jittered_potential.view(np.int32))
+    compare_store_with_oracle(n - 1, ora, htm)
+
+
+def test_full_size_large_learned_pool_against_the_oracle():
+    """bench.py's `large_pool` leg as a test: 65 536 x 32 with 350 patterns brought to the learned state on the GPU (10 passes,
+    S ~ 0.65 M segments: every step of the timed schedule runs the streaming scan beside the learning role and the select
+    finish), the whole state handed to the oracle, and then the bench's own parity check -- the next timesteps called as the
+    timed region calls them (streamed chunks, prepared graphs; one chunk long enough to replay hipGraphs), every Temporal
+    Memory output at the chunk boundaries, the Spatial Pooler's outputs and the whole state at the end."""
+    import bench
+    from oracle import HTMOracle
+    w = dict(bench.LARGE_POOL)
+    noisy, perm = bench.make_inputs(w)
+    htm = bench.build_htm(w, perm, 0)
+    del perm
+    eng = htm.engine
+    bank = eng.upload_bank(noisy)
+    n_bank = len(noisy)
+    run = dict(learning=True, use_graph=True, pipeline=True)
+    for _ in range(10):
+        eng.run(bank, n_bank, w["patterns"], **run)
+        eng.sync()
+    info = eng.check_capacity()
+    assert info.segments > 400000 and info.select_fallbacks == 0, (info.segments, info.select_fallbacks)
+    assert eng.run_plan(100, **run) == dict(hip_graph=True, pipelined=True, lean=True, scan_large=True)
+    # size-independent properties of the learned state
+    st = eng.read_store()
+    C, K = w["column_dim"], w["cell_dim"]
+    assert np.array_equal(np.bincount(st["seg_cell"], minlength=C * K), st["segcount"])
+    valid = st["presyn"] >= 0
+    assert np.array_equal(valid.sum(axis=1), st["seg_nsyn"]) and np.all(valid[:, :-1] >= valid[:, 1:])
+    del st, valid
+    ora = HTMOracle(w["input_dim"], C, K, seed=0, permanence=eng.get_permanence())
+    ora.spatial_pooler.duty_cycle = eng.read_duty_cycle().copy()
+    ora.temporal_memory.import_state(eng.export_tm_state())
+    start = int(eng.info().step_index)
+    states = [ora.step(noisy[(start + t) % n_bank]) for t in range(70)]
+    out = bench.check_against_oracle(w, htm, noisy, bank, ora, states, run, chunk_plan=(5,))
+    assert out["parity"] == "ok" and "65 (graph+large-pool scan)" in out["parity_checked"], out
+    # the learning curve: after ten passes the sequence is predicted (few bursting columns)
+    assert states[-1][1].active_column_bursting.mean() < 0.2

@@ -271,16 +271,21 @@ def test_temporal_memory_with_a_host_side_distal_projection():
     assert np.array_equal(proj.o.seg_nsyn[:proj.o.S], ora.seg_nsyn[:ora.S]) and proj.o.S == ora.S > 100
 
 
-def test_predictive_projection_methods_on_their_own_drive_the_device():
+@pytest.mark.parametrize("default_mask", [False, True], ids=["mask-from-caller", "mask-built-by-the-library"])
+def test_predictive_projection_methods_on_their_own_drive_the_device(default_mask):
     """PredictiveProjection.process / .update / .get_jittered_potential_info (projections.py:229-293) called on their own: a
     subclass of the device's projection is not the fused kind, so TemporalMemory orchestrates on the host and every call
-    lands on the device through htm_tm_update / htm_tm_scan -- learning, allocation, recycling, scan -- against the oracle."""
+    lands on the device through htm_tm_update / htm_tm_scan -- learning, allocation, recycling, scan -- against the oracle.
+    default_mask: htm_tm_update's punish_words == NULL ("every cell of a column not listed", include/bithtm_hip.h) in place
+    of the mask TemporalMemory builds (networks.py:107-108,111) -- the same cells, since every active column has a learning
+    cell."""
     import bithtm_amd as B
     from types import SimpleNamespace
     from oracle import TMParams, TemporalMemoryOracle, canonical_synapses
 
     class MyProjection(B.PredictiveProjection):
-        pass
+        def update(self, prev_state, input_activation, learning_output, output_punishment, *a, **kw):
+            return super().update(prev_state, input_activation, learning_output, None if default_mask else output_punishment, *a, **kw)
 
     C, K, k, seed = 1024, 16, 21, 91
     tmp = TMParams(segment_activation_threshold=9, segment_matching_threshold=7, segment_sampling_synapses=18, permanence_punishment=0.15,

@@ -250,12 +250,16 @@ def test_bad_arguments_fail_loudly():
         tm.process(SimpleNamespace(active_column=np.array([1, 2])), epsilon=0.0)     # (0, 1] only
 
 
-def test_batched_run_equals_step_by_step():
+@pytest.mark.parametrize("eager_below", ["0", "64", "18"], ids=["graphs-for-every-call", "default-call-policy", "eager-below-18"])
+def test_batched_run_equals_step_by_step(eager_below, monkeypatch):
     """htm.run (device-resident bank, hipGraph replay, the Spatial Pooler working ahead of the Temporal
     Memory) == the same inputs through process().  The run lengths exercise every launch plan: single
     steps, the two shortened steps at the end of a run, the eager cold start, single-step graphs and
-    the 16-step steady-state graph with its remainders."""
+    the 16-step steady-state graph with its remainders.  Under three call policies: graphs for every call that asks for them
+    (what conftest.py sets for the suite), the library's default (calls of fewer than 64 steps launch eagerly whatever they
+    ask: what the driver's bench command runs), and a limit in the middle of this test's run lengths."""
     import bithtm_amd as B
+    monkeypatch.setenv("BITHTM_EAGER_BELOW", eager_below)
     rng = np.random.RandomState(11)
     bank = rng.rand(30, 200) < 0.08
     outs = []
@@ -315,7 +319,13 @@ def test_batched_run_equals_step_by_step():
                                  {"BITHTM_CAND_PAIRWISE": "0", "BITHTM_CAND_OTHERS": "4", "BITHTM_CAND_SPECULATE": "0"},
                                  {"BITHTM_CAND_PAIRWISE": "0", "BITHTM_CAND_ZOOM": "0"}, {"BITHTM_CAND_PAIRWISE": "2", "BITHTM_CAND_ZOOM": "3", "BITHTM_CAND_OTHERS": "0"},
                                  {"BITHTM_LEAN_SCAN": "1", "BITHTM_LEAN_LEARN": "1"}, {"BITHTM_LEAN_SCAN": "3", "BITHTM_LEAN_LEARN": "2", "BITHTM_LEAN_OVERLAP": "3"},
-                                 {"BITHTM_FUSE_TM": "0"}],
+                                 {"BITHTM_FUSE_TM": "0"},
+                                 # the streaming (large-pool) scan beside the learning role and the select finish (k_learn_scan_emit<E, 4, false>),
+                                 # and in the four-launch schedule (k_scan_sel<*, 1>); ..._ABOVE: the pool outgrows the threshold in mid-run
+                                 {"BITHTM_SCAN_LARGE": "1"}, {"BITHTM_SCAN_LARGE": "1", "BITHTM_LEAN": "0"}, {"BITHTM_SCAN_LARGE": "1", "BITHTM_LEAN_SCAN": "2", "BITHTM_LEAN_LEARN": "2"},
+                                 {"BITHTM_SCAN_LARGE_ABOVE": "1500"}, {"BITHTM_SCAN_LARGE_ABOVE": "1500", "BITHTM_LEAN": "0"},
+                                 # the library's default call policy (conftest.py asks for graphs whatever the call's length)
+                                 {"BITHTM_EAGER_BELOW": "64"}, {"BITHTM_EAGER_BELOW": "64", "BITHTM_LEAN": "0"}],
                          ids=lambda e: ",".join(f"{k[7:]}={v}" for k, v in e.items()) or "default")
 def test_pipelined_schedules_and_select_paths_equal_step_by_step(env, monkeypatch):
     """htm.run in its pipelined schedules -- three launches per step (the learning role scanning its own rows beside the
@@ -356,11 +366,17 @@ def test_pipelined_schedules_and_select_paths_equal_step_by_step(env, monkeypatc
             assert np.array_equal(a, b)
 
 
-def test_random_call_patterns_equal_step_by_step():
+@pytest.mark.parametrize("env", [{}, {"BITHTM_SCAN_LARGE": "1"}, {"BITHTM_SCAN_LARGE_ABOVE": "600"}, {"BITHTM_EAGER_BELOW": "64"}],
+                         ids=lambda e: ",".join(f"{k[7:]}={v}" for k, v in e.items()) or "default")
+def test_random_call_patterns_equal_step_by_step(env, monkeypatch):
     """Seeded random sequences of htm.run (graph / eager, continuing or not, learning on or off, run lengths on either
     side of the 16-step graphs), host-fed process() steps in between, on random small shapes -- against a twin that only
-    ever calls process().  (A longer sweep: BITHTM_CALL_FUZZ_SEQUENCES.)"""
+    ever calls process().  (A longer sweep: BITHTM_CALL_FUZZ_SEQUENCES.)  Also with the large-pool form of the scan in every
+    launch that holds one, and with a threshold the pools cross somewhere inside the sequence (the twin is created under the
+    default policy)."""
     import bithtm_amd as B
+    for key, v in env.items():
+        monkeypatch.setenv(key, v)
 
     def digest(htm):
         st, d = htm.engine.read_store(), htm.engine.read_distal()
@@ -376,7 +392,11 @@ def test_random_call_patterns_equal_step_by_step():
         np.random.seed(seed)
         a = B.HierarchicalTemporalMemory(I, C, K)
         np.random.seed(seed)
-        b = B.HierarchicalTemporalMemory(I, C, K)
+        with monkeypatch.context() as m:               # (the knobs are read when a handle is created)
+            for key in env:
+                if key != "BITHTM_EAGER_BELOW":
+                    m.delenv(key)
+            b = B.HierarchicalTemporalMemory(I, C, K)
         t, ahead = 0, False
         for _ in range(int(rng.randint(4, 12))):
             kind = "run" if ahead else str(rng.choice(["run", "run", "run", "process", "nolearn"]))

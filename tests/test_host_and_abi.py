@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol(lib):
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.htm_abi_version() == _lib.ABI_VERSION == 3
+    assert lib.htm_abi_version() == _lib.ABI_VERSION == 4
 
 
 def test_the_three_launches_keep_their_register_budget():
