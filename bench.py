@@ -40,7 +40,7 @@ WORKLOAD = dict(input_dim=1024, column_dim=65536, cell_dim=32, patterns=50, dens
 # The same shape with a larger learned pool ("40 % of roofline and 10^4 steps/s coincide only if ... the
 # segment pool is larger (S*E*8 ~ 300 MB, e.g. P ~ 350 patterns)"): 350 patterns, 10 passes of untimed pre-training.  The
 # `large_pool` leg of the line; the headline stays P = 50.
-LARGE_POOL = dict(WORKLOAD, patterns=350, noisy_copies=4, segment_capacity=1 << 20)
+LARGE_POOL = dict(WORKLOAD, patterns=350, noisy_copies=4, segment_capacity=2 << 20)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 PMC_FILES = ("r04_pmc_summary.json", "r03_pmc_summary.json")      # recorded PMC passes, newest first
 

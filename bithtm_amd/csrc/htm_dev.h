@@ -114,6 +114,7 @@ struct Counters {
 struct Dev {
     int I, W, W4, Ipad, C, K, k, E, Scap, work_cap, sel_passes, colwords, low_zero, cand_d, cand_pairwise, cand_others, cand_speculate, cand_take_all, cand_zoom, poll_delay;
     int win_offset;           // test knob: added to the select window's base (a window that misses: the fallback every step)
+    int cls_rows_max;         // test knob: pools of more rows than this classify by 32-row words (role_mid); -1 = the default, 8 rows per thread of the launch
     int world, c0, c1;        // this rank owns columns [c0, c1) (world == 1: everything)
     int sel_lo, sel_hi, sel_k; // the select works on the keys of columns [sel_lo, sel_hi) and finds their sel_k largest
                               // (unsharded: all columns, k; a shard selects its own candidates: [c0, c1), min(k, c1 - c0))

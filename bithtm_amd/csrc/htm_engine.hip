@@ -70,6 +70,10 @@ struct htm_handle {
     bool emit_fits_lean;                  // ... and in k_learn_scan_emit
     int knob_lean, knob_fuse_tm, knob_shard_window, knob_scan_large, knob_step_window, knob_tail_rows;
     int scan_large_above;                 // segments above which the scan takes its streaming (large-pool) form (BITHTM_SCAN_LARGE_ABOVE)
+    int scan_dyn_rounds;                  // ... the rounds of every 8 a wave of each class takes a group in (three bits each, minus one)
+    int knob_scan_dyn;                    // ... hands its groups out on demand, every block of the launch joining in (BITHTM_SCAN_DYN)
+    int lean_resident_large;              // blocks of the large-pool k_learn_scan_emit that are resident at once
+    int knob_large_tab;                   // the three-launch schedule's streaming scan looks cells up in the LDS tables (BITHTM_LARGE_TAB)
     int knob_defer_tail;                  // htm_step holds a step's last launch back for the next call's first (BITHTM_DEFER_TAIL)
     bool tail_pending;                    // ... and one is held back now: the learning role and the scan of the step of parity tail_p
     int tail_p;
@@ -78,7 +82,7 @@ struct htm_handle {
     int sel_passes_fused, sel_passes_full; // launched select digits with / without the in-kernel finish
     int seg_hint;                         // a lower bound of the segment count (see scan_spec_blocks)
     int *seg_pinned;                      // pinned word the end of each htm_run copies the count into
-    int sp_blocks, sel_blocks, c256_blocks, s1024_blocks, scan_blocks, zero_blocks, lean_learn_blocks, lean_scan_blocks, lean_overlap_blocks, cus;
+    int sp_blocks, sel_blocks, c256_blocks, s1024_blocks, scan_blocks, zero_blocks, lean_learn_blocks, lean_learn_blocks_large, lean_scan_blocks, lean_scan_blocks_large, lean_overlap_blocks, cus;
     const uint32_t *ahead_bank;           // htm_run ended with HTM_RUN_CONTINUE on this bank: the SP has done the next step
     int ahead_n_inputs, ahead_learning;   //   and the front of the one after it
     bool ahead_lean;                      //   ... in the three-launch schedule (else the four-launch one)
@@ -379,15 +383,29 @@ static void enqueue_lean(htm_handle *h, int p, int learning, const uint32_t *ban
     const int n_cls = learning ? kClassifyBlocks : 0, n_ov = plan.next_sp ? h->lean_overlap_blocks : 0;
     LAUNCH_ON(h, h->stream, (size_t)SEL_BINS * 4, "tm_mid+sp_overlap", k_mid_overlap, 1 + n_cls + n_ov + h->zero_blocks, 256, d, p, d.k, 1, learning, n_cls,
               bank, n_inputs, h->G, n_ov);
-    const int epl = learn_epl(d), n_emit = plan.next_sp ? h->c256_blocks : 0, spec = scan_spec_blocks(h);
+    const int epl = learn_epl(d), n_emit = plan.next_sp ? h->c256_blocks : 0;
     const size_t lds = std::max(std::max(learn_lds(epl, 256), lean_scan_lds(d)), sizeof(EmitShared));
-    const int n_learn = h->lean_learn_blocks, n_scan = h->lean_scan_blocks;
+    // (a large pool streams: more scan blocks than are resident at once -- as the select finish's and the learning role's blocks
+    // leave, the dispatcher fills their slots with scan blocks; 768 resident-at-once blocks left the launch 13 % longer)
+    // DYN (the default for a large pool): the grid is what is resident at once and every block ends up scanning (role_scan); the
+    // kernel is told by the sign of its n_scan argument, and `spec` carries the joining blocks' share (rounds in every 8).  More
+    // learning blocks than a small pool gets: a wave per work item (a large learned pool has ~2 800 a step), so that no block
+    // joins late because its waves had second items.
+    const bool large = scan_pool_is_large(h), dyn = large && h->knob_scan_dyn > 0;
+    const int n_learn = dyn ? std::min(h->lean_learn_blocks_large, 2047) : h->lean_learn_blocks;
+    int n_scan = large ? h->lean_scan_blocks_large : h->lean_scan_blocks;
+    if (dyn) n_scan = std::max(64, std::min(1023, h->lean_resident_large - n_emit - n_learn));
     const int grid = n_emit + n_learn + n_scan;
+    if (large && !dyn) n_scan = -n_scan;
+    const int spec = dyn ? h->scan_dyn_rounds : scan_spec_blocks(h);
     // (the launch's name says which form of the scan it holds: htm_profile_read is how tests and bench.py tell)
     const char *lse_name = scan_pool_is_large(h) ? "tm_learn+tm_scan_large+sp_emit" : "tm_learn+tm_scan+sp_emit";
 #define LAUNCH_LSE(EPL_, MINW_, TAB_) LAUNCH_ON(h, h->stream, lds, lse_name, (k_learn_scan_emit<EPL_, MINW_, TAB_>), grid, 256, d, p, n_emit, n_learn, n_scan, spec)
     if (scan_pool_is_large(h)) {
-        switch (epl) { case 1: LAUNCH_LSE(1, 4, false); break; case 2: LAUNCH_LSE(2, 4, false); break; case 4: LAUNCH_LSE(4, 4, false); break; default: LAUNCH_LSE(8, 4, false); break; }
+        // (the streaming form; with the LDS tables of the step's select finish and activation where they fit: its cell-word
+        // lookups are then LDS reads, not a dependent gather per chunk)
+        if (lean_tab(d) && h->knob_large_tab) { switch (epl) { case 1: LAUNCH_LSE(1, 4, true); break; case 2: LAUNCH_LSE(2, 4, true); break; case 4: LAUNCH_LSE(4, 4, true); break; default: LAUNCH_LSE(8, 4, true); break; } }
+        else switch (epl) { case 1: LAUNCH_LSE(1, 4, false); break; case 2: LAUNCH_LSE(2, 4, false); break; case 4: LAUNCH_LSE(4, 4, false); break; default: LAUNCH_LSE(8, 4, false); break; }
     } else if (lean_tab(d)) {
         switch (epl) { case 1: LAUNCH_LSE(1, 6, true); break; case 2: LAUNCH_LSE(2, 6, true); break; case 4: LAUNCH_LSE(4, 6, true); break; default: LAUNCH_LSE(8, 6, true); break; }
     } else {
@@ -699,12 +717,29 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
     h->scan_large_above = getenv("BITHTM_SCAN_LARGE_ABOVE") ? std::max(0, atoi(getenv("BITHTM_SCAN_LARGE_ABOVE"))) : 3 * 1536 * SCAN_SEGS;
     h->knob_step_window = getenv("BITHTM_STEP_WINDOW") ? atoi(getenv("BITHTM_STEP_WINDOW")) != 0 : 1;
     h->knob_tail_rows = getenv("BITHTM_TAIL_ROWS") ? atoi(getenv("BITHTM_TAIL_ROWS")) != 0 : 1;
+    // (0: scan blocks with fixed shares, nothing joining; else every block of the launch joins the scan -- and how many rounds each class takes
+    // of every 8: "scan,finish,learn", e.g. 6,8,7; one number: 0 = off)
+    h->knob_scan_dyn = 1;
+    {
+        int r[3] = {8, 8, 8};                     // (equal shares: measured against 6,8,7 / 5,8,6 / 7,8,7 ... all within a microsecond -- the launch is bound by what
+                                                 // the chip issues and fetches in total, and whoever is left runs faster once the others are done)
+        if (const char *e = getenv("BITHTM_SCAN_DYN")) {
+            if (sscanf(e, "%d,%d,%d", &r[0], &r[1], &r[2]) < 3) { h->knob_scan_dyn = atoi(e) != 0; r[0] = r[1] = r[2] = 8; }
+        }
+        for (int &x : r) x = std::max(1, std::min(8, x));
+        h->scan_dyn_rounds = (r[0] - 1) | (r[1] - 1) << 3 | (r[2] - 1) << 6;
+    }
+    // (off by default: measured on a learned pool of 1.6 M segments the tables made the launch 3 % longer -- 91 registers against 76,
+    // a block per CU fewer -- and the streaming form hides the gathers' round trip behind its prefetch anyway)
+    h->knob_large_tab = getenv("BITHTM_LARGE_TAB") ? atoi(getenv("BITHTM_LARGE_TAB")) != 0 : 0;
     h->knob_defer_tail = getenv("BITHTM_DEFER_TAIL") ? atoi(getenv("BITHTM_DEFER_TAIL")) != 0 : 1;
     h->tail_pending = false;
     h->tail_p = 0;
     h->lean_overlap_blocks = getenv("BITHTM_LEAN_OVERLAP") ? std::max(1, atoi(getenv("BITHTM_LEAN_OVERLAP"))) : h->sp_blocks * (RB / 256);
     h->lean_learn_blocks = getenv("BITHTM_LEAN_LEARN") ? std::max(1, atoi(getenv("BITHTM_LEAN_LEARN"))) : 512;
+    h->lean_learn_blocks_large = getenv("BITHTM_LEAN_LEARN_LARGE") ? std::max(1, atoi(getenv("BITHTM_LEAN_LEARN_LARGE"))) : getenv("BITHTM_LEAN_LEARN") ? h->lean_learn_blocks : 768;
     h->lean_scan_blocks = getenv("BITHTM_LEAN_SCAN") ? std::max(1, atoi(getenv("BITHTM_LEAN_SCAN"))) : (h->scan_blocks > 512 ? std::max(256, (h->scan_blocks * 3 / 8 + 255) & ~255) : h->scan_blocks);
+    h->lean_scan_blocks_large = getenv("BITHTM_LEAN_SCAN_LARGE") ? std::max(1, atoi(getenv("BITHTM_LEAN_SCAN_LARGE"))) : getenv("BITHTM_LEAN_SCAN") ? h->lean_scan_blocks : h->scan_blocks;
     {
         hipDeviceProp_t prop;
         h->cus = hipGetDeviceProperties(&prop, h->device) == hipSuccess ? prop.multiProcessorCount : 256;
@@ -737,22 +772,26 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
                 // (asked of every instantiation enqueue_lean may launch for this handle -- LDS tables or not, small-pool or
                 // large-pool scan: they differ in launch bounds and registers -- and the smallest answer counts)
                 int per_cu_lean = 1 << 30;
+                h->lean_resident_large = 1 << 30;
                 const size_t lean_lds = std::max(std::max(learn_lds(learn_epl(d), 256), lean_scan_lds(d)), sizeof(EmitShared));
                 const int epl = learn_epl(d);
-#define LSE_VARIANTS(E_) {(const void *)k_learn_scan_emit<E_, 6, true>, (const void *)k_learn_scan_emit<E_, 6, false>, (const void *)k_learn_scan_emit<E_, 4, false>}
-                const void *kerns[4][3] = {LSE_VARIANTS(1), LSE_VARIANTS(2), LSE_VARIANTS(4), LSE_VARIANTS(8)};
+#define LSE_VARIANTS(E_) {(const void *)k_learn_scan_emit<E_, 6, true>, (const void *)k_learn_scan_emit<E_, 4, true>, (const void *)k_learn_scan_emit<E_, 6, false>, (const void *)k_learn_scan_emit<E_, 4, false>}
+                const void *kerns[4][4] = {LSE_VARIANTS(1), LSE_VARIANTS(2), LSE_VARIANTS(4), LSE_VARIANTS(8)};
 #undef LSE_VARIANTS
                 bool asked = cfg->enable_tm && h->emit_fits && lean_lds <= 64 * 1024;
-                for (int v = 0; asked && v < 3; ++v) {
-                    if (v == 0 && !lean_tab(d)) continue;           // (never launched without the tables)
+                for (int v = 0; asked && v < 4; ++v) {
+                    if (v < 2 && !lean_tab(d)) continue;            // (never launched without the tables)
                     int per_cu = 0;
                     asked = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kerns[epl == 1 ? 0 : epl == 2 ? 1 : epl == 4 ? 2 : 3][v], 256, lean_lds) == hipSuccess;
                     per_cu_lean = std::min(per_cu_lean, per_cu);
+                    if (asked && v == ((lean_tab(d) && h->knob_large_tab) ? 1 : 3)) h->lean_resident_large = per_cu * cus;      // (the large-pool form this handle launches)
                 }
                 h->emit_fits_lean = asked && c256 <= std::min(1024, per_cu_lean * cus);
+                if (h->lean_resident_large == (1 << 30)) h->lean_resident_large = 4 * cus;
             } else {
                 (void)hipGetLastError();
                 h->emit_fits = h->emit_fits_open = h->emit_fits_lean = false;
+                h->lean_resident_large = 1024;
             }
         }
         h->sel_passes_full = d.sel_passes;
@@ -763,6 +802,7 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
         if (const char *e = getenv("BITHTM_CAND_D")) d.cand_d = std::max(0, std::min(CAND_D, atoi(e)));
         d.cand_pairwise = CAND_PAIRWISE;
         if (const char *e = getenv("BITHTM_CAND_PAIRWISE")) d.cand_pairwise = std::max(0, atoi(e));     // test knobs
+        d.cls_rows_max = getenv("BITHTM_CLASSIFY_WORDS_ABOVE") ? std::max(0, atoi(getenv("BITHTM_CLASSIFY_WORDS_ABOVE"))) : -1;
         d.win_offset = getenv("BITHTM_SEL_WINDOW_OFFSET") ? std::max(0, atoi(getenv("BITHTM_SEL_WINDOW_OFFSET"))) : 0;
         d.cand_zoom = getenv("BITHTM_CAND_ZOOM") ? atoi(getenv("BITHTM_CAND_ZOOM")) : -1;      // (test knob: the pairs above which a merge is cut to a sub-bin; -1 = more pairs than blocks by a quarter)
         d.cand_speculate = getenv("BITHTM_CAND_SPECULATE") ? atoi(getenv("BITHTM_CAND_SPECULATE")) != 0 : 1;     // (test knob: 0 = always the general path)

@@ -197,21 +197,36 @@ __global__ __launch_bounds__(256) void k_mid_overlap(Dev d, int p, int n_active,
 // TAB: the scan looks active cells up in the LDS tables of the step's select finish and activation (role_scan) -- the
 // three-launch schedule, whose every step has them; the launch without emit blocks (enqueue_tm: stand-alone Temporal
 // Memory, shards) reads the cell words from memory
+// MINW < 6: the large-pool form: the scan streams, the grid is what is resident at once, and a block whose select finish or
+// learning items are done JOINS the scan (role_scan, DYN) instead of leaving its slot to a scan block that would have to be
+// dispatched and stage the bitmap first.  n_scan_blocks < 0: scan blocks with fixed shares and nothing joining, as before
+// (BITHTM_SCAN_DYN=0); else n_spec = the three classes' rounds in every 8 (role_scan).
 template <int EPL, int MINW, bool TAB = false>
 __global__ __launch_bounds__(256, MINW) void k_learn_scan_emit(Dev d, int p, int n_emit_blocks, int n_learn_blocks, int n_scan_blocks, int n_spec) {
     TraceScope ts(d, 2 + 4 * p);
+    constexpr bool LARGE = MINW < 6;
+    const bool dyn = LARGE && n_scan_blocks > 0;
+    if (n_scan_blocks < 0) n_scan_blocks = -n_scan_blocks;
+    const int join_arg = n_emit_blocks | (n_learn_blocks << 11) | (n_spec << 22);      // (dyn: n_spec = the classes' rounds, see role_scan)
     int b = blockIdx.x;
     if (b < n_emit_blocks) {
         role_emit(d, p ^ 1, 1, 1, 0, b, n_emit_blocks, (EmitShared *)dyn_lds, 1);
+        if (LARGE) { if (dyn) role_scan<256, true, LARGE, TAB, LARGE>(d, p, -1 - b, n_scan_blocks, join_arg, (uint32_t *)dyn_lds); }
         return;
     }
     b -= n_emit_blocks;
     if (b < n_learn_blocks) {
         role_learn<EPL, 256, true>(d, p, b, n_learn_blocks, (LearnShared<EPL, 256> *)dyn_lds);
+        if (LARGE) { if (dyn) role_scan<256, true, LARGE, TAB, LARGE>(d, p, -1 - (n_emit_blocks + b), n_scan_blocks, join_arg, (uint32_t *)dyn_lds); }
         return;
     }
     b -= n_learn_blocks;
-    role_scan<256, true, MINW < 6, TAB>(d, p, b, n_scan_blocks, n_spec, (uint32_t *)dyn_lds);      // (MINW < 6: the large-pool form)
+    if (LARGE) {
+        if (dyn) role_scan<256, true, LARGE, TAB, LARGE>(d, p, b, n_scan_blocks, join_arg, (uint32_t *)dyn_lds);
+        else role_scan<256, true, LARGE, TAB, false>(d, p, b, n_scan_blocks, n_spec, (uint32_t *)dyn_lds);
+    } else {
+        role_scan<256, true, false, TAB>(d, p, b, n_scan_blocks, n_spec, (uint32_t *)dyn_lds);
+    }
 }
 
 // The last launch of a step run role by role (enqueue_tm): the learning role, the scan, and a streaming role behind them --

@@ -207,7 +207,7 @@ __device__ __forceinline__ void role_mid(const Dev &d, int p, int n_active, int 
             learn = is_winner && ((info >> 31) || (unpred && best));                     // :268
             punish = d.punish ? (d.punish[col] >> cb) & 1u : d.act[p][col] == 0;         // :269
         };
-        if (n <= 8 * n_cls * BS) {
+        if (n <= (d.cls_rows_max >= 0 ? d.cls_rows_max : 8 * n_cls * BS)) {
             // small pools: one row per thread, so that the rows of a word -- segments created together match together --
             // are classified side by side, not one after the other
             for (int i0 = (blk - 1) * BS; i0 < n; i0 += n_cls * BS) {
@@ -232,34 +232,63 @@ __device__ __forceinline__ void role_mid(const Dev &d, int p, int n_active, int 
             }
             return;
         }
-        // large pools: a thread takes a 32-row word of match bits (coalesced; almost all are zero) and walks its set bits
+        // Large pools: the match bits are read a 32-row word per thread (almost all of them zero) -- but the rows of a word are
+        // NOT walked by the thread that read it: segments created together match together, a learned pattern's ~1 300 of them
+        // are 40 consecutive words with nearly every bit set, and a thread walking one chained 64 dependent round trips
+        // (38 us for this launch on a learned pool of 1.5 M segments).  Consecutive words go to different BLOCKS, a block
+        // lists its few non-zero words in LDS, and the listed words are classified 32 rows by 32 lanes, eight words per
+        // pass, exactly as the small-pool form does.  Which block: the 32 words of a 128-byte line go to 32 different
+        // blocks of ONE residue mod 8 -- blocks are dealt round-robin to the 8 XCDs, so a line is fetched into one L2, not
+        // eight (a pool of 134 M rows has 17 MB of match bits).  With u = the index of a word among those of the lines
+        // L = x mod 8: block 8 * (u mod G8) + x takes it as its (u / G8)-th word.
+        __shared__ int s_words[BS];
+        __shared__ uint32_t s_bits[BS];
+        __shared__ int s_nwords;
         const int nwords = (n + 31) >> 5;
-        for (int w0 = (blk - 1) * BS; w0 < nwords; w0 += n_cls * BS) {
-            const int w = w0 + (int)threadIdx.x;
-            const uint32_t word = w < nwords ? d.match_bits[q][w] : 0u;
-            uint32_t lmask = 0, pmask = 0;
-            for (uint32_t rest = word; rest; rest &= rest - 1) {
-                const int bit = __ffs(rest) - 1;
-                bool learn, punish;
-                classify(w * 32 + bit, learn, punish);
-                lmask |= (learn ? 1u : 0u) << bit;
-                pmask |= (punish ? 1u : 0u) << bit;
-                if (learn || punish) d.seg_nsyn[w * 32 + bit] |= (int)SEG_BUSY;
+        const bool by_xcd = n_cls % 8 == 0 && n_cls >= 256;
+        const int G8 = by_xcd ? n_cls / 8 : 1, x = (blk - 1) & 7, g = (blk - 1) >> 3;
+        const int per_class = ((nwords + 255) >> 8) * 32;          // words of one residue class (rounded up to whole lines)
+        const int n_turns = by_xcd ? (per_class + G8 - 1) / G8 : (nwords + n_cls - 1) / n_cls;
+        for (int t0 = 0; t0 < n_turns; t0 += BS) {
+            if (threadIdx.x == 0) s_nwords = 0;
+            __syncthreads();
+            const int T = t0 + (int)threadIdx.x;
+            int w;
+            if (by_xcd) {
+                const int u = T * G8 + g;
+                w = ((x + 8 * (u >> 5)) << 5) + (u & 31);
+            } else {
+                w = (blk - 1) + n_cls * T;
             }
-            const uint32_t cnt = (uint32_t)(__popc(lmask) + __popc(pmask));
-            if (!__any(cnt != 0)) continue;
-            const uint32_t incl = wave_incl_scan(cnt);
-            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-            int base = 0;
-            if (lane_id() == 63) base = atomicAdd(&c->n_work[p], (int)total);
-            int pos = wave_read(base, 63) + (int)(incl - cnt);
-            for (uint32_t rest = lmask; rest; rest &= rest - 1, ++pos) {
-                const uint32_t item = (uint32_t)(w * 32 + __ffs(rest) - 1);
-                if (pos < d.work_cap) d.work[pos] = item; else atomicOr(&c->error, 4);
+            const uint32_t word = (T < n_turns && w < nwords) ? d.match_bits[q][w] : 0u;
+            if (word) {
+                const int slot = atomicAdd(&s_nwords, 1);
+                s_words[slot] = w;
+                s_bits[slot] = word;
             }
-            for (uint32_t rest = pmask; rest; rest &= rest - 1, ++pos) {
-                const uint32_t item = (uint32_t)(w * 32 + __ffs(rest) - 1) | 0x80000000u;
-                if (pos < d.work_cap) d.work[pos] = item; else atomicOr(&c->error, 4);
+            __syncthreads();
+            const int listed = s_nwords;
+            for (int i0 = 0; i0 < listed; i0 += BS / 32) {
+                const int i = i0 + ((int)threadIdx.x >> 5);
+                const bool on = i < listed && ((s_bits[min(i, BS - 1)] >> (threadIdx.x & 31)) & 1u);
+                const int seg = on ? s_words[i] * 32 + (int)(threadIdx.x & 31) : 0;
+                bool learn = false, punish = false;
+                if (on) classify(seg, learn, punish);
+                if (learn || punish) d.seg_nsyn[seg] |= (int)SEG_BUSY;
+                const u64 ml = __ballot(learn), mp = __ballot(punish);
+                const int n_l = __popcll(ml), n_p = __popcll(mp);
+                if (n_l + n_p == 0) continue;
+                int base = 0;
+                if (lane_id() == 0) base = atomicAdd(&c->n_work[p], n_l + n_p);
+                base = wave_read(base, 0);
+                if (learn) {
+                    const int pos = base + __popcll(ml & lanemask_lt());
+                    if (pos < d.work_cap) d.work[pos] = (uint32_t)seg; else atomicOr(&c->error, 4);
+                }
+                if (punish) {
+                    const int pos = base + n_l + __popcll(mp & lanemask_lt());
+                    if (pos < d.work_cap) d.work[pos] = (uint32_t)seg | 0x80000000u; else atomicOr(&c->error, 4);
+                }
             }
         }
         return;
@@ -467,9 +496,42 @@ __device__ __forceinline__ void role_learn(const Dev &d, int p, int blk, int nbl
         } else if (n <= 8 * nblk * BS) {           // small pools: one row per thread (matching rows cluster in words)
             for (int i = blk * BS + threadIdx.x; i < n; i += nblk * BS)
                 if ((d.match_bits[p ^ 1][i >> 5] >> (i & 31)) & 1u) d.cellmax[p ^ 1][d.seg_cell[i]] = 0u;
-        } else {                                   // large pools: one 32-row word per thread, almost all of them zero
-            for (int w = blk * BS + threadIdx.x; w < (n + 31) >> 5; w += nblk * BS)
-                for (uint32_t rest = d.match_bits[p ^ 1][w]; rest; rest &= rest - 1) d.cellmax[p ^ 1][d.seg_cell[w * 32 + __ffs(rest) - 1]] = 0u;
+        } else {
+            // large pools: one 32-row word per lane, almost all of them zero -- and a non-zero word's rows cleared by 32 lanes at
+            // once, two words per pass (matching rows cluster: a lane walking the 32 set bits of its own word chained 32 round
+            // trips -- each owner-cell load behind the previous store -- and the role's items started 15 us late).  Which
+            // words a wave takes: as in role_mid's classification -- consecutive words to different waves, the words of a
+            // 128-byte line to waves of blocks of one residue mod 8 (one XCD's L2 fetches the line).
+            const int nwords = (n + 31) >> 5, lane = lane_id();
+            constexpr int WPB = BS / 64;
+            const bool by_xcd = nblk % 8 == 0 && (nblk / 8) * WPB >= 32;
+            const int G8 = by_xcd ? (nblk / 8) * WPB : 1, x = blk & 7, g = (blk >> 3) * WPB + ((int)threadIdx.x >> 6);
+            const int n_units = nblk * WPB, unit = blk * WPB + ((int)threadIdx.x >> 6);
+            const int per_class = ((nwords + 255) >> 8) * 32;
+            const int n_turns = by_xcd ? (per_class + G8 - 1) / G8 : (nwords + n_units - 1) / n_units;
+            for (int t0 = 0; t0 < n_turns; t0 += 64) {
+                const int T = t0 + lane;
+                int w;
+                if (by_xcd) {
+                    const int u = T * G8 + g;
+                    w = ((x + 8 * (u >> 5)) << 5) + (u & 31);
+                } else {
+                    w = unit + n_units * T;
+                }
+                const uint32_t word = (T < n_turns && w < nwords) ? d.match_bits[p ^ 1][w] : 0u;
+                for (u64 nz = __ballot(word != 0); nz;) {
+                    const int l0 = __ffsll((long long)nz) - 1;
+                    nz &= nz - 1;
+                    const int l1 = nz ? __ffsll((long long)nz) - 1 : l0;
+                    const bool two = nz != 0;
+                    nz &= nz - 1;
+                    const uint32_t wa = wave_read(word, l0), wb = two ? wave_read(word, l1) : 0u;
+                    const int ia = wave_read(w, l0), ib = wave_read(w, l1);
+                    const uint32_t mine = lane < 32 ? wa : wb;
+                    const int row = (lane < 32 ? ia : ib) * 32 + (lane & 31);
+                    if ((mine >> (lane & 31)) & 1u) d.cellmax[p ^ 1][d.seg_cell[row]] = 0u;
+                }
+            }
         }
     }
     const int wv = threadIdx.x >> 6, lane = lane_id();
@@ -961,10 +1023,41 @@ __device__ __forceinline__ void chunk_count_tab(const ScanTabs &tb, const uint32
 
 // LDS: from word 4: column bitmap [colwords] (words 0..3 unused)
 // TAB (small pools under the LDS bitmap, three-launch schedule): + rank [colwords] u16, active words [k + 8]
-template <int BS, bool use_lds, bool LARGE, bool TAB = false>
+// DYN (the streaming form inside the three-launch schedule's last launch): EVERY block of that launch scans.  The launch's other
+// blocks -- the select finish, the learning role -- are done after 7 to 16 us of its ~50; with scan blocks only, the ones
+// dispatched into their slots end that much later than the rest, or, with more blocks than slots, in a second round that
+// leaves the chip half empty (2 048 blocks over 1 280 slots: the last block ended 13 us after the chip had begun to
+// drain).  Here the grid is what is resident at once and a block whose other role is done JOINS the scan (blk < 0; a barrier
+// first: its LDS is still in use by slower waves of the other role).  The groups of 16 segments are dealt in rounds: in
+// every round a wave takes one group, and a wave of class c (scan / select finish / learning role) takes part in rounds[c] of
+// every 8 rounds.  The shares are not the times the classes spend scanning: the SIMDs issue oldest wave first, and the scan
+// is bound by what it issues (eight LDS lookups and ~50 VALU operations per lane and chunk) -- measured with equal shares, a
+// wave of the select finish's blocks (dispatched first) took 1.5 us per group, one of the learning role's 1.9, one of the scan
+// blocks (dispatched last) 2.6.  (Handing the groups out on demand instead -- one
+// returning atomic per wave and group, on 64 counters a page apart -- made the launch five times LONGER: the chip completes
+// about 300 such atomics per microsecond, whatever their addresses; measured.)
+struct ScanRounds {
+    int n[3], rounds[3], cls, idx;                 // waves and rounds-of-8 per class (0 scan, 1 select finish, 2 learning role); this wave's class and index in it
+    __device__ __forceinline__ int group(int r) const {
+        const int q = r >> 3, m = r & 7;
+        int g = q * (rounds[0] * n[0] + rounds[1] * n[1] + rounds[2] * n[2]) + idx;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) g += min(m, rounds[c]) * n[c] + ((c < cls && m < rounds[c]) ? n[c] : 0);
+        return g;
+    }
+    __device__ __forceinline__ int first() const { return 0; }
+    __device__ __forceinline__ int next(int r) const {
+        ++r;
+        return (r & 7) >= rounds[cls] ? (r | 7) + 1 : r;
+    }
+};
+
+template <int BS, bool use_lds, bool LARGE, bool TAB = false, bool DYN = false>
 __device__ __forceinline__ void role_scan(const Dev &d, int p, int blk, int nblk, int n_spec, uint32_t *lds) {
     static_assert(BS % 64 == 0, "whole waves of 16 segments");
-    static_assert(!TAB || (use_lds && !LARGE), "the tables go with the LDS bitmap of the small-pool form");
+    static_assert(!TAB || use_lds, "the tables go with the LDS bitmap");
+    static_assert(!DYN || LARGE, "on-demand groups belong to the streaming form");
+    if (DYN && blk < 0) __syncthreads();
     constexpr int U = 2;                           // segments in flight per lane group
     uint32_t *s_colbits = lds + 4;
     const int rank_q = (d.colwords * 2 + 15) / 16, actw_q = (d.k + 8 + 3) / 4;      // 16-byte units of the two tables
@@ -991,8 +1084,16 @@ __device__ __forceinline__ void role_scan(const Dev &d, int p, int blk, int nblk
     // of the launch (8.2 us against 4.6 for the others); one per CU is not.
     constexpr int WPB = BS / 64;
     const int sg = LARGE ? 1 : (nblk % 256 == 0 ? 256 : nblk);
-    const int gw = LARGE ? wave : wave * sg;                                          // this wave's group within the block's
-    const int g_first = LARGE ? blk * WPB : (blk / sg) * (sg * WPB) + blk % sg;      // the block's first group
+    const int gw = DYN ? 0 : LARGE ? wave : wave * sg;                                // this wave's group within the block's
+    // (DYN: nblk = scan blocks of the launch; n_spec = its select-finish blocks | learning blocks << 11 | the three classes' rounds of
+    // every 8, minus one, three bits each from bit 22; a joiner's blk = -1 - its index among the joiners, the select finish's first)
+    const int n_jemit = n_spec & 0x7FF, n_jlearn = (n_spec >> 11) & 0x7FF, jblk = -1 - blk;
+    const int my_cls = blk >= 0 ? 0 : jblk < n_jemit ? 1 : 2;
+    const ScanRounds rounds{{nblk * WPB, n_jemit * WPB, n_jlearn * WPB},
+                            {((n_spec >> 22) & 7) + 1, ((n_spec >> 25) & 7) + 1, ((n_spec >> 28) & 7) + 1}, my_cls,
+                            (blk >= 0 ? blk : my_cls == 1 ? jblk : jblk - n_jemit) * WPB + wave};
+    int round = 0;
+    const int g_first = DYN ? rounds.group(0) : LARGE ? blk * WPB : (blk / sg) * (sg * WPB) + blk % sg;      // the block's first group (DYN: the wave's)
     const int gstride = nblk * WPB;
     // round trip 1 of an iteration: synapse count, owner cell and the first chunk of each row, all unconditional
     // (rows are clamped to the pool and masked once the row count is known)
@@ -1010,8 +1111,8 @@ __device__ __forceinline__ void role_scan(const Dev &d, int p, int blk, int nblk
     };
     // In the first n_spec blocks (the ones that had segments when the host last saw the segment count)
     // the loads of the first batch do not wait for the count: one dependent round trip less.
-    const bool speculative = g_first * 16 < n_spec * SCAN_SEGS;
-    if (!speculative && g_first * 16 >= S) return;
+    const bool speculative = !DYN && g_first * 16 < n_spec * SCAN_SEGS;
+    if (!DYN && !speculative && g_first * 16 >= S) return;       // (DYN: a wave without a group still meets the block's barrier)
     bool first_iter = true;
     (void)first_iter;
 #ifdef BITHTM_SCAN_STAMPS
@@ -1068,16 +1169,18 @@ __device__ __forceinline__ void role_scan(const Dev &d, int p, int blk, int nblk
         ChunkHitsAll g1;
         const bool any_hit = __any(m1 != 0);
         g1.m = 0; g1.aw[0] = g1.aw[1] = 0;
-        if (LARGE) h1 = chunk_read(act, e1, m1);
+        if (LARGE && !TAB) h1 = chunk_read(act, e1, m1);
         else if (!TAB && any_hit) g1 = chunk_read_all<2>(act, e1, m1);
         // large pools: the next iteration's rows are requested now, behind this iteration's cell-word reads (loads
         // return in issue order: requested earlier they would be waited for with those reads)
-        const int b_next = b + gstride;
+        if (DYN) round = rounds.next(round);
+        const int b_next = DYN ? rounds.group(round) : b + gstride;
         const int cell_cur[U] = {cur.cell[0], cur.cell[1]};
         // (unconditional -- past the last batch the clamped ids fetch a row nobody uses: a branch around the loads
         // would make the compiler wait for them with everything else)
         Batch nxt = cur;
         if (LARGE) nxt = fetch(b_next);
+
         const bool any_long = __any(n[0] > 32 || n[1] > 32);         // (a row that long which can still match: few waves have one)
         const uint32_t e2[8] = {(uint32_t)ps2[0].x, (uint32_t)ps2[0].y, (uint32_t)ps2[0].z, (uint32_t)ps2[0].w,
                                 (uint32_t)ps2[1].x, (uint32_t)ps2[1].y, (uint32_t)ps2[1].z, (uint32_t)ps2[1].w};
@@ -1102,13 +1205,13 @@ __device__ __forceinline__ void role_scan(const Dev &d, int p, int blk, int nblk
         // trips per further chunk when they were read and looked up one after the other): two chunks per pass, their
         // four row loads in flight together, then their cell-word reads
         // (the large-pool kernels take one chunk per pass: the second pair of rows in registers costs them a wave per SIMD)
-        for (int c = 2; __any(n[0] > c * 32 || n[1] > c * 32); c += LARGE ? 1 : 2) {
+        for (int c = 2; __any(n[0] > c * 32 || n[1] > c * 32); c += (LARGE && !TAB) ? 1 : 2) {
             int4 pa[U], pb[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int *prow = d.presyn + (size_t)seg[u] * d.E + l * 4;
                 pa[u] = n[u] > c * 32 ? *(const int4 *)(prow + c * 32) : make_int4(0, 0, 0, 0);
-                if (!LARGE) pb[u] = n[u] > (c + 1) * 32 ? *(const int4 *)(prow + (c + 1) * 32) : make_int4(0, 0, 0, 0);
+                if (!LARGE || TAB) pb[u] = n[u] > (c + 1) * 32 ? *(const int4 *)(prow + (c + 1) * 32) : make_int4(0, 0, 0, 0);
             }
             const uint32_t ea[8] = {(uint32_t)pa[0].x, (uint32_t)pa[0].y, (uint32_t)pa[0].z, (uint32_t)pa[0].w,
                                     (uint32_t)pa[1].x, (uint32_t)pa[1].y, (uint32_t)pa[1].z, (uint32_t)pa[1].w};
@@ -1179,6 +1282,7 @@ __device__ __forceinline__ void role_scan(const Dev &d, int p, int blk, int nblk
         }
         SCAN_STAMP(5);
         first_iter = false;
+        if (DYN) b = b_next - gstride;                // (the loop adds the stride back)
         if (b_next * 16 >= S) break;
         cur = LARGE ? nxt : fetch(b_next);
 #ifdef BITHTM_SCAN_STAMPS

@@ -339,7 +339,7 @@ def test_full_size_large_learned_pool_against_the_oracle():
         eng.run(bank, n_bank, w["patterns"], **run)
         eng.sync()
     info = eng.check_capacity()
-    assert info.segments > 400000 and info.select_fallbacks == 0, (info.segments, info.select_fallbacks)
+    assert info.segments > 1000000 and info.select_fallbacks == 0, (info.segments, info.select_fallbacks)
     assert eng.run_plan(100, **run) == dict(hip_graph=True, pipelined=True, lean=True, scan_large=True)
     # size-independent properties of the learned state
     st = eng.read_store()

@@ -324,6 +324,11 @@ def test_batched_run_equals_step_by_step(eager_below, monkeypatch):
                                  # and in the four-launch schedule (k_scan_sel<*, 1>); ..._ABOVE: the pool outgrows the threshold in mid-run
                                  {"BITHTM_SCAN_LARGE": "1"}, {"BITHTM_SCAN_LARGE": "1", "BITHTM_LEAN": "0"}, {"BITHTM_SCAN_LARGE": "1", "BITHTM_LEAN_SCAN": "2", "BITHTM_LEAN_LEARN": "2"},
                                  {"BITHTM_SCAN_LARGE_ABOVE": "1500"}, {"BITHTM_SCAN_LARGE_ABOVE": "1500", "BITHTM_LEAN": "0"},
+                                 # ... with fixed shares instead of groups handed out on demand; with the LDS tables
+                                 {"BITHTM_SCAN_LARGE": "1", "BITHTM_SCAN_DYN": "0"}, {"BITHTM_SCAN_LARGE": "1", "BITHTM_LARGE_TAB": "1"},
+                                 {"BITHTM_SCAN_LARGE": "1", "BITHTM_LARGE_TAB": "1", "BITHTM_SCAN_DYN": "0", "BITHTM_LEAN_SCAN": "3"},
+                                 # the large-pool form of the learn / punish classification (32-row words listed per block)
+                                 {"BITHTM_CLASSIFY_WORDS_ABOVE": "0"}, {"BITHTM_CLASSIFY_WORDS_ABOVE": "0", "BITHTM_SCAN_LARGE": "1"},
                                  # the library's default call policy (conftest.py asks for graphs whatever the call's length)
                                  {"BITHTM_EAGER_BELOW": "64"}, {"BITHTM_EAGER_BELOW": "64", "BITHTM_LEAN": "0"}],
                          ids=lambda e: ",".join(f"{k[7:]}={v}" for k, v in e.items()) or "default")

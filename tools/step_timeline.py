@@ -29,7 +29,7 @@ def roles(launch, k, C):
     """(first block, last block + 1, name) of the roles of each launch, as bench's handle lays them out."""
     c256, cls = (C + 255) // 256, 96
     if LEAN_ON:                                      # the three-launch schedule (htm_pipeline.h); block counts as htm_create sets them
-        n_act, n_learn = (k * 32 + 255) // 256, int(os.environ.get("BITHTM_LEAN_LEARN", 512))
+        n_act, n_learn = (k * 32 + 255) // 256, int(os.environ.get("BITHTM_LEAN_LEARN", 768 if os.environ.get("TIMELINE_WORKLOAD") == "large" else 512))
         n_ov = int(os.environ.get("BITHTM_LEAN_OVERLAP", 512))
         if launch == 0:
             return ((0, n_act, "tm_activate"), (n_act, n_act + k, "sp rows"), (n_act + k, n_act + k + c256, "sp duty"), (n_act + k + c256, 4096, "clear"))
@@ -50,12 +50,15 @@ def roles(launch, k, C):
 
 def main():
     args = argparse.Namespace(steps=STEPS, warmup=WARMUP)
-    w = dict(bench.WORKLOAD)
+    # (TIMELINE_WORKLOAD=large: bench.py's large_pool leg -- 350 patterns; give TIMELINE_WARMUP=3500 for its learned state)
+    w = dict(bench.LARGE_POOL if os.environ.get("TIMELINE_WORKLOAD") == "large" else bench.WORKLOAD)
     noisy, perm = bench.make_inputs(w)
     htm = bench.build_htm(w, perm, 0)
     eng = htm.engine
     bank = eng.upload_bank(noisy)
     eng.run(bank, noisy.shape[0], args.warmup, learning=True)
+    eng.sync()                                       # (the pool's size has reached the host: the traced call picks the scan's form by it)
+    print(f"segments: {eng.info().segments}; the traced call: {eng.run_plan(args.steps)}")
     # (TIMELINE_LEARNING=0: the traced steps run with learning off -- what the learning role's writes cost the others)
     eng.run(bank, noisy.shape[0], args.steps, learning=os.environ.get("TIMELINE_LEARNING", "1") != "0", use_graph=True, pipeline=True)
     eng.sync()
