@@ -307,7 +307,12 @@ def check_stress_sample(eng, s, rows0, k, ranges=48, rows_per_range=256):
         n_rows += rows_per_range
         n_match += int(matching.sum())
     log(f"[bench] configs[4] leg: self-check of {n_rows} sampled rows ok ({n_match} of them matching)")
-    return dict(checked=True, check=f"{n_rows} rows in {ranges} ranges over rank 0's pool: presynaptic cells, permanence bits and owner cells equal the "
+    # (a uniformly random pool matches nothing under the default thresholds -- SURVEY section 8d: a pure scan stress -- so of
+    # the scan's verdict only "no match word where the potential is below the threshold" is seen here; what a MATCHING row's
+    # word holds is pinned at this shape by tests/test_hip_populate.py, thresholds lowered until 3 % of the rows match)
+    return dict(checked=True if n_match else "partial: rows, potentials and the non-matching verdicts (no sampled row matches under the default "
+                                             "thresholds); matching rows of this kernel at this shape: tests/test_hip_populate.py",
+                check=f"{n_rows} rows in {ranges} ranges over rank 0's pool: presynaptic cells, permanence bits and owner cells equal the "
                                     f"keyed generator's for those ids; potentials and the scan's match words equal the host's count against the "
                                     f"last step's active cells ({n_match} matching)")
 

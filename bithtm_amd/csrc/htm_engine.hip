@@ -60,7 +60,9 @@ struct htm_handle {
     bool shard_open;
     bool shard_graph_ok;                  // htm_shard_comm_init's preflight: this communicator's all-gather replays correctly from a captured hipGraph
     int shard_front_wmode;                // htm_shard_run: the histogram form of the overlap computed ahead for the coming step
-    std::map<std::tuple<int, int, const void *, int>, hipGraphExec_t> shard_graphs;      // (on rank 0's handle for a group in one process)
+    // keyed by the exact launch parameters: (parity | learning | front flags | span, ranks, n_inputs, per rank: scan blocks known to have
+    // segments, scan form, exchange mode) and the bank -- (on rank 0's handle for a group in one process)
+    std::map<std::pair<std::vector<int>, const void *>, hipGraphExec_t> shard_graphs;
     void *rccl_comm;                      // ncclComm_t of htm_shard_comm_init (the exchange of htm_shard_step)
     unsigned char *shard_send, *shard_recv;   // ... and its device buffers
     int G;                                // lanes per SP row
@@ -1535,9 +1537,11 @@ extern "C" int htm_shard_comm_init(htm_handle *h, const void *unique_id128) {
         };
         HIPCHK(h, hipMemsetAsync(h->shard_send, h->rank + 1, rb, h->stream));
         HIPCHK(h, hipMemsetAsync(h->shard_recv, 0, rb * (size_t)h->world, h->stream));
+        // (a rank whose first gather fails still issues the second: its peers are on their way into theirs and would wait for
+        // it for ever; the failure is reported after both)
         int nrc = g_rccl.all_gather(h->shard_send, h->shard_recv, rb, 0, comm, h->stream);
-        if (nrc != 0 || !check()) { h->err = "htm_shard_comm_init: the all-gather over this communicator does not deliver the ranks' records"; return HTM_ERR_HIP; }
-        bool ok = h->stream != nullptr && hipMemsetAsync(h->shard_recv, 0, rb * (size_t)h->world, h->stream) == hipSuccess &&
+        const bool first_ok = nrc == 0 && check();
+        bool ok = first_ok && h->stream != nullptr && hipMemsetAsync(h->shard_recv, 0, rb * (size_t)h->world, h->stream) == hipSuccess &&
                   hipStreamSynchronize(h->stream) == hipSuccess;      // (the default stream cannot be captured)
         hipGraph_t graph_obj = nullptr;
         hipGraphExec_t exec = nullptr;
@@ -1558,6 +1562,7 @@ extern "C" int htm_shard_comm_init(htm_handle *h, const void *unique_id128) {
         HIPCHK(h, hipMemsetAsync(h->shard_send, 0, rb, h->stream));
         HIPCHK(h, hipMemsetAsync(h->shard_recv, 0, rb * (size_t)h->world, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (!first_ok) { h->err = "htm_shard_comm_init: the all-gather over this communicator does not deliver the ranks' records"; return HTM_ERR_HIP; }
     }
     return HTM_OK;
 }
@@ -1716,10 +1721,12 @@ static int shard_run(htm_handle *const *hs, int n, const uint32_t *const *banks,
             t += span;
             continue;
         }
-        int flags = (int)(h0->step_host & 1) | learning << 1 | (fd ? 4 : 0) | (fn ? 8 : 0) | span << 4;
-        for (int r = 0; r < n; ++r)           // what the launches of a rank depend on besides its arguments
-            flags ^= (int)((scan_spec_blocks(hs[r]) * 2654435761u + (scan_pool_is_large(hs[r]) ? 97u : 0u) + (hs[r]->emit_fused ? 193u : 0u)) << 10) * (r + 1);
-        auto key = std::make_tuple(flags, n, (const void *)banks[0], n_inputs);
+        std::vector<int> params{(int)(h0->step_host & 1) | learning << 1 | (fd ? 4 : 0) | (fn ? 8 : 0) | span << 4, n, n_inputs};
+        for (int r = 0; r < n; ++r) {         // what the launches of a rank depend on besides its arguments
+            params.push_back(scan_spec_blocks(hs[r]));
+            params.push_back((scan_pool_is_large(hs[r]) ? 1 : 0) | (hs[r]->emit_fused ? 2 : 0));
+        }
+        auto key = std::make_pair(params, (const void *)banks[0]);
         auto it = h0->shard_graphs.find(key);
         if (it == h0->shard_graphs.end()) {
             std::vector<long long> saved((size_t)n);

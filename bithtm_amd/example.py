@@ -4,6 +4,7 @@ the three counters: :55-57), so that its output can be compared line by line.
 
     python -m bithtm_amd.example --epochs 8
     python -m bithtm_amd.example --epochs 8 --batched   # one C-ABI call per epoch, hipGraph replay
+    python -m bithtm_amd.example --epochs 8 --use_reference_implementation   # example.py:30,36-37 (needs the user's `bithtm`)
 """
 
 import argparse
@@ -30,6 +31,9 @@ def parse(argv):
     ap = argparse.ArgumentParser(description=__doc__.splitlines()[0])
     for name, kind, default in FLAGS:
         ap.add_argument("--" + name, type=kind, default=default)
+    ap.add_argument("--use_reference_implementation", action="store_true",
+                    help="the reference's flag (example.py:30): swap the Temporal Memory for the textbook one of the user's own "
+                         "`bithtm.reference_implementations` (example.py:7-12, 36-37); the Spatial Pooler stays on the device")
     ap.add_argument("--seed", type=int, default=0, help="seed of the Temporal Memory's keyed random draws")
     ap.add_argument("--batched", action="store_true",
                     help="run each epoch with HierarchicalTemporalMemory.run (no per-step read-back) and "
@@ -85,7 +89,19 @@ def run_batched(htm, bank, opts, out):
 def main(argv=None, out=sys.stdout):
     opts = parse(argv)
     bank = np.random.rand(opts.input_patterns, opts.input_dim) < opts.input_density
-    htm = HierarchicalTemporalMemory(opts.input_dim, opts.column_dim, opts.cell_dim, seed=opts.seed)
+    if opts.use_reference_implementation:
+        # example.py:7-12: the same network with `temporal_memory=` the textbook implementation -- the user's package, imported
+        # at the user's request (this package ships no copy of it and no CPU path of its own)
+        if opts.batched:
+            raise SystemExit("--batched runs the fused device step; --use_reference_implementation steps a host-side Temporal Memory")
+        try:
+            from bithtm.reference_implementations import TemporalMemory as ReferenceTemporalMemory
+        except ImportError as e:
+            raise SystemExit(f"--use_reference_implementation needs the reference's `bithtm` package on PYTHONPATH ({e})")
+        htm = HierarchicalTemporalMemory(opts.input_dim, opts.column_dim, opts.cell_dim,
+                                         temporal_memory=ReferenceTemporalMemory(opts.column_dim, opts.cell_dim))
+    else:
+        htm = HierarchicalTemporalMemory(opts.input_dim, opts.column_dim, opts.cell_dim, seed=opts.seed)
     began = time.time()
     (run_batched if opts.batched else run_stepwise)(htm, bank, opts, out)
     print(f"{time.time() - began} seconds.", file=out)

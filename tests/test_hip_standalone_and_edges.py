@@ -538,6 +538,45 @@ def test_example_harness_prints_the_reference_report_format():
     assert "timesteps/s" in out.getvalue()
 
 
+def test_example_harness_swaps_in_the_users_reference_temporal_memory(monkeypatch):
+    """--use_reference_implementation (example.py:30,36-37): the Temporal Memory of the user's own `bithtm.reference_implementations`
+    in the `temporal_memory=` slot, the Spatial Pooler on the device.  The reference does not travel to the GPU box: a stand-in
+    module with the textbook class's surface (constructor, process, last_state) takes its place here, backed by the oracle --
+    so the report must equal the device's own, line for line."""
+    import io
+    import sys
+    import types
+    from bithtm_amd import example
+    from oracle import TemporalMemoryOracle
+
+    class TextbookTM:
+        def __init__(self, column_dim, cell_dim):
+            self.o = TemporalMemoryOracle(column_dim, cell_dim, seed=0)
+            self.last_state = types.SimpleNamespace(cell_prediction=np.zeros((column_dim, cell_dim), dtype=bool))
+
+        def process(self, sp_state, prev_state=None, learning=True):
+            self.last_state = self.o.step(np.sort(np.asarray(sp_state.active_column)), learning=learning)
+            return self.last_state
+
+    pkg, mod = types.ModuleType("bithtm"), types.ModuleType("bithtm.reference_implementations")
+    mod.TemporalMemory = TextbookTM
+    pkg.reference_implementations = mod
+    monkeypatch.setitem(sys.modules, "bithtm", pkg)
+    monkeypatch.setitem(sys.modules, "bithtm.reference_implementations", mod)
+    args = ["--epochs", "6", "--input_patterns", "12", "--input_dim", "200", "--column_dim", "1024", "--cell_dim", "8"]
+    outs = []
+    for extra in ([], ["--use_reference_implementation"]):
+        np.random.seed(3)
+        out = io.StringIO()
+        example.main(args + extra, out=out)
+        outs.append(out.getvalue().strip().splitlines()[:-1])
+    assert len(outs[0]) == 6 * 12 and outs[0] == outs[1]
+    monkeypatch.delitem(sys.modules, "bithtm.reference_implementations")
+    monkeypatch.delitem(sys.modules, "bithtm")
+    with pytest.raises(SystemExit, match="PYTHONPATH"):
+        example.main(args + ["--use_reference_implementation"], out=io.StringIO())
+
+
 def test_checkpoint_and_resume(tmp_path):
     """save() after 90 steps, then a fresh object load()s and continues exactly like the original."""
     import bithtm_amd as B
