@@ -115,6 +115,9 @@ struct Dev {
     int I, W, W4, Ipad, C, K, k, E, Scap, work_cap, sel_passes, colwords, low_zero, cand_d, cand_pairwise, cand_others, cand_speculate, cand_take_all, cand_zoom, poll_delay;
     int win_offset;           // test knob: added to the select window's base (a window that misses: the fallback every step)
     int cls_rows_max;         // test knob: pools of more rows than this classify by 32-row words (role_mid); -1 = the default, 8 rows per thread of the launch
+    int LK, KP, WPC;          // cells per column, padded: KP = 32 (cell_dim <= 32) or 64 cell slots, LK = log2(KP), WPC = KP / 32 words per
+                              // column.  A cell is enc = column * KP + cell; the dense cell words (act, pred, win) are indexed by
+                              // enc >> 5 = column * WPC + (cell >> 5), the per-cell arrays by enc
     int world, c0, c1;        // this rank owns columns [c0, c1) (world == 1: everything)
     int sel_lo, sel_hi, sel_k; // the select works on the keys of columns [sel_lo, sel_hi) and finds their sel_k largest
                               // (unsharded: all columns, k; a shard selects its own candidates: [c0, c1), min(k, c1 - c0))
@@ -146,26 +149,28 @@ struct Dev {
                               // list while step t's scan still reads its own)
     uint32_t *input_stage;    // [W] host-fed input
     // Temporal Memory
-    uint32_t *act[2];         // [C] active-cell words, parity double buffer
-    uint32_t *pred[2];        // [C] predicted-cell words
-    uint32_t *win[2];         // [C] winner-cell words
+    uint32_t *act[2];         // [C * WPC] active-cell words, parity double buffer
+    uint32_t *pred[2];        // [C * WPC] predicted-cell words
+    uint32_t *win[2];         // [C * WPC] winner-cell words
     uint32_t *colbits[2];     // [ceil(C/64)*2] bitmap of the step's active columns
-    int *winners[2];          // [k*32] winner cells (enc), ascending
+    int *winners[2];          // [k * KP] winner cells (enc), ascending
     uint8_t *bursting;        // [k]
-    uint32_t *winw_idx;       // [k] winner word of the idx-th active column (same as win[active_cols[idx]])
-    uint8_t *actcnt;          // [k] popc(active word) of the idx-th active column
-    uint32_t *act_list;       // [k] active word of the idx-th active column (same as act[p][active_cols[p][idx]])
+    // per word slot s = idx * WPC + h of the step's active columns (idx-th of the ascending list, its h-th word):
+    int *actw_id;             // [k * WPC] the word's index in the dense arrays: active_cols[idx] * WPC + h
+    uint32_t *winw_idx;       // [k * WPC] winner word (same as win[actw_id[s]])
+    uint8_t *actcnt;          // [k * WPC] popc(active word)
+    uint32_t *act_list;       // [k * WPC] active word (same as act[p][actw_id[s]])
     uint16_t *col_rank[2];    // [colwords] active columns below each 32-column word of colbits[p] (written by the select's finish)
-    uint32_t *unacc_word;     // [k]
-    int *unacc_list;          // [k*32] winners without a matching segment, ascending
+    uint32_t *unacc_word;     // [k * WPC]
+    int *unacc_list;          // [k * KP] winners without a matching segment, ascending
     int *seg_cell;            // [Scap] owning cell (enc)
     int *seg_nsyn;            // [Scap] valid synapses; rows are packed: slots [0, nsyn) are valid
     int *presyn;              // [Scap][E] presynaptic cell (enc)
     float *sperm;             // [Scap][E] float32 permanence
-    int *segcount;            // [C*32] segments per cell
+    int *segcount;            // [C * KP] segments per cell
     // results of the scan of step t live in buffer t & 1: step t + 1 reads them (activation, classification) while its
     // own scan, which may share a launch with its learning role, accumulates into the other one
-    uint32_t *cellmax[2];     // [C*32] float bits of max jittered potential per cell (0 = none); entries are cleared by the
+    uint32_t *cellmax[2];     // [C * KP] float bits of max jittered potential per cell (0 = none); entries are cleared by the
                               // learning role of the step after the scan that set them
     uint32_t *match_bits[2];  // [ceil(Scap/32)] segment is matching (projections.py:247); zeroed by the middle launch of the
                               // step whose scan (and learning role) then set bits with atomicOr
@@ -379,6 +384,10 @@ __device__ __forceinline__ u64 spread32(uint32_t v) {
 }
 
 __device__ __forceinline__ uint32_t cell_mask(int K) { return K >= 32 ? 0xFFFFFFFFu : ((1u << K) - 1u); }
-__device__ __forceinline__ uint32_t enc_to_flat(int enc, int K) { return (uint32_t)((enc >> 5) * K + (enc & 31)); }
+__device__ __forceinline__ u64 cell_mask64(int K) { return K >= 64 ? ~0ull : ((1ull << K) - 1ull); }
+// the valid cells of the h-th word of a column
+__device__ __forceinline__ uint32_t cell_mask_word(int K, int h) { return cell_mask(K - 32 * h); }
+// the reference's flat cell id (column * cell_dim + cell) of an encoded cell (column * KP + cell)
+__device__ __forceinline__ uint32_t enc_to_flat(const Dev &d, int enc) { return (uint32_t)((enc >> d.LK) * d.K + (enc & (d.KP - 1))); }
 
 #endif

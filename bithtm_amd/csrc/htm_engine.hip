@@ -9,7 +9,8 @@
 // reference checkout) under the deterministic policies of DESIGN.md.  Compile with
 // -ffp-contract=off: several kernels must round exactly like the NumPy expressions they replace.
 //
-// Internal cell encoding: enc = column * 32 + cell ("one 32-bit word per column" bitmaps);
+// Internal cell encoding: enc = column * KP + cell, KP = 32 cell slots per column (one 32-bit word per column in the dense
+// bitmaps) or 64 for cell_dim above 32 (two words);
 // the ABI converts to / from the reference's flat id column * cell_dim + cell.
 
 #include <hip/hip_runtime.h>
@@ -72,7 +73,6 @@ struct htm_handle {
     bool emit_fits_lean;                  // ... and in k_learn_scan_emit
     int knob_lean, knob_fuse_tm, knob_shard_window, knob_scan_large, knob_step_window, knob_tail_rows;
     int scan_large_above;                 // segments above which the scan takes its streaming (large-pool) form (BITHTM_SCAN_LARGE_ABOVE)
-    int scan_dyn_rounds;                  // ... the rounds of every 8 a wave of each class takes a group in (three bits each, minus one)
     int knob_scan_dyn;                    // ... hands its groups out on demand, every block of the launch joining in (BITHTM_SCAN_DYN)
     int lean_resident_large;              // blocks of the large-pool k_learn_scan_emit that are resident at once
     int knob_large_tab;                   // the three-launch schedule's streaming scan looks cells up in the LDS tables (BITHTM_LARGE_TAB)
@@ -202,10 +202,10 @@ static size_t scan_lds(const Dev &d, int use_lds) { return 16 + (use_lds ? (size
 // ... with the rank of every bitmap word and the active words of the step's active columns behind the bitmap (the
 // three-launch schedule's scan looks the cells of active columns up in LDS: role_scan, TAB)
 static size_t scan_lds_tab(const Dev &d) {
-    return 16 + (size_t)((d.colwords + 3) & ~3) * 4 + (size_t)((d.colwords * 2 + 15) / 16) * 16 + (size_t)((d.k + 8 + 3) / 4) * 16;
+    return 16 + (size_t)((d.colwords + 3) & ~3) * 4 + (size_t)((d.colwords * 2 + 15) / 16) * 16 + (size_t)((d.k * d.WPC + 8 + 3) / 4) * 16;
 }
 // ... which needs them to fit (and the ranks 16 bits); otherwise the schedule's scan reads the cell words from memory
-static bool lean_tab(const Dev &d) { return scan_lds_tab(d) <= 64 * 1024 && d.k < 65536; }
+static bool lean_tab(const Dev &d) { return scan_lds_tab(d) <= 64 * 1024 && d.k * d.WPC < 65536; }
 static size_t lean_scan_lds(const Dev &d) { return lean_tab(d) ? scan_lds_tab(d) : scan_lds(d, 1); }
 static const int kClassifyBlocks = 384;           // x 256 segments per pass of the learn / punish classification
 static const int kLearnBlocks = 256;               // x RB/64 waves: one wave per learning / punished segment
@@ -380,8 +380,8 @@ static bool can_lean(const htm_handle *h) {
 // the next step's winners beside this step's Temporal Memory.
 static void enqueue_lean(htm_handle *h, int p, int learning, const uint32_t *bank, int n_inputs, StepPlan plan) {
     Dev &d = h->d;
-    const int n_act = (d.k * 32 + 255) / 256, n_rows = learning ? d.k : 0;
-    LAUNCH(h, "tm_activate+sp_learn", k_act_rows, n_act + n_rows + 2 * h->c256_blocks, 256, d, p, d.k, n_act, bank, n_inputs, n_rows, h->c256_blocks);
+    const int n_act = (d.k * d.KP + 255) / 256, n_rows = learning ? d.k : 0;
+    LAUNCH(h, "tm_activate+sp_learn", k_act_rows, n_act + n_rows + (1 + d.WPC) * h->c256_blocks, 256, d, p, d.k, n_act, bank, n_inputs, n_rows, h->c256_blocks);
     const int n_cls = learning ? kClassifyBlocks : 0, n_ov = plan.next_sp ? h->lean_overlap_blocks : 0;
     LAUNCH_ON(h, h->stream, (size_t)SEL_BINS * 4, "tm_mid+sp_overlap", k_mid_overlap, 1 + n_cls + n_ov + h->zero_blocks, 256, d, p, d.k, 1, learning, n_cls,
               bank, n_inputs, h->G, n_ov);
@@ -390,16 +390,16 @@ static void enqueue_lean(htm_handle *h, int p, int learning, const uint32_t *ban
     // (a large pool streams: more scan blocks than are resident at once -- as the select finish's and the learning role's blocks
     // leave, the dispatcher fills their slots with scan blocks; 768 resident-at-once blocks left the launch 13 % longer)
     // DYN (the default for a large pool): the grid is what is resident at once and every block ends up scanning (role_scan); the
-    // kernel is told by the sign of its n_scan argument, and `spec` carries the joining blocks' share (rounds in every 8).  More
+    // kernel is told by the sign of its n_scan argument.  More
     // learning blocks than a small pool gets: a wave per work item (a large learned pool has ~2 800 a step), so that no block
     // joins late because its waves had second items.
     const bool large = scan_pool_is_large(h), dyn = large && h->knob_scan_dyn > 0;
-    const int n_learn = dyn ? std::min(h->lean_learn_blocks_large, 2047) : h->lean_learn_blocks;
+    const int n_learn = dyn ? h->lean_learn_blocks_large : h->lean_learn_blocks;
     int n_scan = large ? h->lean_scan_blocks_large : h->lean_scan_blocks;
-    if (dyn) n_scan = std::max(64, std::min(1023, h->lean_resident_large - n_emit - n_learn));
+    if (dyn) n_scan = std::max(64, h->lean_resident_large - n_emit - n_learn);
     const int grid = n_emit + n_learn + n_scan;
     if (large && !dyn) n_scan = -n_scan;
-    const int spec = dyn ? h->scan_dyn_rounds : scan_spec_blocks(h);
+    const int spec = dyn ? 0 : scan_spec_blocks(h);
     // (the launch's name says which form of the scan it holds: htm_profile_read is how tests and bench.py tell)
     const char *lse_name = scan_pool_is_large(h) ? "tm_learn+tm_scan_large+sp_emit" : "tm_learn+tm_scan+sp_emit";
 #define LAUNCH_LSE(EPL_, MINW_, TAB_) LAUNCH_ON(h, h->stream, lds, lse_name, (k_learn_scan_emit<EPL_, MINW_, TAB_>), grid, 256, d, p, n_emit, n_learn, n_scan, spec)
@@ -422,7 +422,7 @@ static void enqueue_pipelined(htm_handle *h, int p, int learning, const uint32_t
     Dev &d = h->d;
     const int n_cls = learning ? kClassifyBlocks : 0;
     const int n_emit = plan.next_sp ? h->c256_blocks : 0;
-    LAUNCH_ON(h, h->stream, sizeof(EmitShared), "tm_activate+sp_emit", k_open_emit, n_emit + (d.k * 32 + 255) / 256, 256, d, p, n_emit, d.k);
+    LAUNCH_ON(h, h->stream, sizeof(EmitShared), "tm_activate+sp_emit", k_open_emit, n_emit + (d.k * d.KP + 255) / 256, 256, d, p, n_emit, d.k);
     const int n_rows = (plan.next_sp && learning) ? d.k : 0, n_duty = plan.next_sp ? h->c256_blocks : 0;
     LAUNCH(h, "tm_mid+sp_learn", k_mid_rows, 1 + n_cls + n_rows + n_duty + h->zero_blocks, 256, d, p, d.k, 1, learning, n_cls, bank, n_inputs, n_rows, 1, n_duty);
     {
@@ -526,7 +526,7 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
         return fail_create(nullptr, "htm_create: need 1 <= active_columns <= column_dim", HTM_ERR_ARGUMENT);
     if (cfg->enable_sp && cfg->input_dim < 1) return fail_create(nullptr, "htm_create: input_dim < 1", HTM_ERR_ARGUMENT);
     if (cfg->enable_tm) {
-        if (cfg->cell_dim < 1 || cfg->cell_dim > 32) return fail_create(nullptr, "htm_create: cell_dim must be in 1..32", HTM_ERR_ARGUMENT);
+        if (cfg->cell_dim < 1 || cfg->cell_dim > 64) return fail_create(nullptr, "htm_create: cell_dim must be in 1..64", HTM_ERR_ARGUMENT);
         if (cfg->segment_slots < 64 || cfg->segment_slots > MAX_SLOTS || cfg->segment_slots % 64)
             return fail_create(nullptr, "htm_create: segment_slots must be a multiple of 64 in 64..512", HTM_ERR_ARGUMENT);
         if (cfg->segment_capacity < 1) return fail_create(nullptr, "htm_create: segment_capacity < 1", HTM_ERR_ARGUMENT);
@@ -534,12 +534,13 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
             return fail_create(nullptr, "htm_create: segment_sampling_synapses must be in 1..64", HTM_ERR_ARGUMENT);
         if (cfg->segment_activation_threshold < cfg->segment_matching_threshold)      // projections.py:211
             return fail_create(nullptr, "htm_create: activation threshold < matching threshold", HTM_ERR_ARGUMENT);
-        if ((long long)cfg->column_dim * 32 > 0x7FFFFFFFLL) return fail_create(nullptr, "htm_create: column_dim too large", HTM_ERR_ARGUMENT);
+        if ((long long)cfg->column_dim * (cfg->cell_dim > 32 ? 64 : 32) > 0x7FFFFFFFLL) return fail_create(nullptr, "htm_create: column_dim too large", HTM_ERR_ARGUMENT);
     }
     if (!cfg->enable_sp && !cfg->enable_tm) return fail_create(nullptr, "htm_create: nothing enabled", HTM_ERR_ARGUMENT);
     const int world = cfg->shard_world > 1 ? cfg->shard_world : 1;
     if (world > 1) {
         if (!cfg->enable_sp || !cfg->enable_tm) return fail_create(nullptr, "htm_create: a sharded handle needs SP and TM", HTM_ERR_ARGUMENT);
+        if (cfg->cell_dim > 32) return fail_create(nullptr, "htm_create: a sharded handle takes cell_dim up to 32 (the exchange record carries one 32-bit word per column)", HTM_ERR_ARGUMENT);
         if (world > 64) return fail_create(nullptr, "htm_create: at most 64 shards", HTM_ERR_ARGUMENT);
         if (cfg->shard_rank < 0 || cfg->shard_rank >= world) return fail_create(nullptr, "htm_create: shard_rank out of range", HTM_ERR_ARGUMENT);
         if (cfg->column_dim % (world * 64)) return fail_create(nullptr, "htm_create: column_dim must be a multiple of 64 * shard_world", HTM_ERR_ARGUMENT);
@@ -589,6 +590,9 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
     d.c0 = h->rank * (d.C / world);
     d.c1 = d.c0 + d.C / world;
     d.K = cfg->enable_tm ? cfg->cell_dim : 0;
+    d.KP = d.K > 32 ? 64 : 32;
+    d.LK = d.K > 32 ? 6 : 5;
+    d.WPC = d.KP / 32;
     d.k = cfg->active_columns;
     d.E = cfg->enable_tm ? cfg->segment_slots : 64;
     d.Scap = cfg->enable_tm ? cfg->segment_capacity : 0;
@@ -597,7 +601,7 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
         const long long dflt = std::min<long long>(d.Scap, 2LL * d.Scap / world + 1024);
         d.Lcap = cfg->segment_capacity_local > 0 ? std::min(cfg->segment_capacity_local, cfg->segment_capacity) : (int)dflt;
     }
-    d.work_cap = d.Lcap + d.k * 32;
+    d.work_cap = d.Lcap + d.k * d.KP;
     // the select: all columns and their k largest; a shard selects its own candidates for the exchange
     d.sel_lo = d.c0; d.sel_hi = d.c1;
     d.sel_k = d.n_cand = std::min(d.k, d.c1 - d.c0);
@@ -637,33 +641,35 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
     }
     if (cfg->enable_tm) {
         const size_t S = d.Lcap, E = d.E, G = d.Scap;        // local rows (= ids on an unsharded handle), slots, segment ids
+        const size_t KP = d.KP, WPC = d.WPC;
         for (int q = 0; q < 2; ++q) {
-            rc |= dalloc(h, &d.act[q], C);
-            rc |= dalloc(h, &d.pred[q], C);
-            rc |= dalloc(h, &d.winners[q], k * 32);
+            rc |= dalloc(h, &d.act[q], C * WPC);
+            rc |= dalloc(h, &d.pred[q], C * WPC);
+            rc |= dalloc(h, &d.winners[q], k * KP);
         }
-        rc |= dalloc(h, &d.win[0], C);
-        rc |= dalloc(h, &d.win[1], C);
+        rc |= dalloc(h, &d.win[0], C * WPC);
+        rc |= dalloc(h, &d.win[1], C * WPC);
         d.colwords = (int)((C + 63) / 64) * 2;
         // (the emit blocks write the bitmap words of whole 256-column blocks)
         const size_t colwords_padded = (size_t)((C + 255) / 256) * 8;
         rc |= dalloc(h, &d.colbits[0], colwords_padded);
         rc |= dalloc(h, &d.colbits[1], colwords_padded);
         rc |= dalloc(h, &d.bursting, k);
-        rc |= dalloc(h, &d.winw_idx, k + 8);
-        rc |= dalloc(h, &d.actcnt, k + 8);
-        rc |= dalloc(h, &d.act_list, k + 16);         // (staged into LDS in 16-byte units)
+        rc |= dalloc(h, &d.actw_id, k * WPC + 8);
+        rc |= dalloc(h, &d.winw_idx, k * WPC + 8);
+        rc |= dalloc(h, &d.actcnt, k * WPC + 8);
+        rc |= dalloc(h, &d.act_list, k * WPC + 16);   // (staged into LDS in 16-byte units)
         rc |= dalloc(h, &d.col_rank[0], colwords_padded);
         rc |= dalloc(h, &d.col_rank[1], colwords_padded);
-        rc |= dalloc(h, &d.unacc_word, k + 8);
-        rc |= dalloc(h, &d.unacc_list, k * 32);
+        rc |= dalloc(h, &d.unacc_word, k * WPC + 8);
+        rc |= dalloc(h, &d.unacc_list, k * KP);
         rc |= dalloc(h, &d.seg_cell, S);
         rc |= dalloc(h, &d.seg_nsyn, S);
         rc |= dalloc(h, &d.presyn, S * E);
         rc |= dalloc(h, &d.sperm, S * E);
-        rc |= dalloc(h, &d.segcount, C * 32);
+        rc |= dalloc(h, &d.segcount, C * KP);
         for (int q = 0; q < 2; ++q) {
-            rc |= dalloc(h, &d.cellmax[q], C * 32);
+            rc |= dalloc(h, &d.cellmax[q], C * KP);
             rc |= dalloc(h, &d.match_bits[q], (S + 255) / 256 * 8);
         }
         rc |= dalloc(h, &d.seg_info, S);
@@ -671,7 +677,7 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
         rc |= dalloc(h, &d.work, (size_t)d.work_cap);
         rc |= dalloc(h, &d.recyc_cnt, (G + 1023) / 1024);
         rc |= dalloc(h, &d.recyc_cnt2, ((G + 1023) / 1024 + 1023) / 1024 + 1);
-        rc |= dalloc(h, &d.recyc_need, 2 * k * 32);
+        rc |= dalloc(h, &d.recyc_need, 2 * k * KP);
         rc |= dalloc(h, &d.dead_list, (size_t)1 + DEAD_CAP);
         if (world > 1) {
             rc |= dalloc(h, &d.seg_gid, S);
@@ -719,18 +725,8 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
     h->scan_large_above = getenv("BITHTM_SCAN_LARGE_ABOVE") ? std::max(0, atoi(getenv("BITHTM_SCAN_LARGE_ABOVE"))) : 3 * 1536 * SCAN_SEGS;
     h->knob_step_window = getenv("BITHTM_STEP_WINDOW") ? atoi(getenv("BITHTM_STEP_WINDOW")) != 0 : 1;
     h->knob_tail_rows = getenv("BITHTM_TAIL_ROWS") ? atoi(getenv("BITHTM_TAIL_ROWS")) != 0 : 1;
-    // (0: scan blocks with fixed shares, nothing joining; else every block of the launch joins the scan -- and how many rounds each class takes
-    // of every 8: "scan,finish,learn", e.g. 6,8,7; one number: 0 = off)
-    h->knob_scan_dyn = 1;
-    {
-        int r[3] = {8, 8, 8};                     // (equal shares: measured against 6,8,7 / 5,8,6 / 7,8,7 ... all within a microsecond -- the launch is bound by what
-                                                 // the chip issues and fetches in total, and whoever is left runs faster once the others are done)
-        if (const char *e = getenv("BITHTM_SCAN_DYN")) {
-            if (sscanf(e, "%d,%d,%d", &r[0], &r[1], &r[2]) < 3) { h->knob_scan_dyn = atoi(e) != 0; r[0] = r[1] = r[2] = 8; }
-        }
-        for (int &x : r) x = std::max(1, std::min(8, x));
-        h->scan_dyn_rounds = (r[0] - 1) | (r[1] - 1) << 3 | (r[2] - 1) << 6;
-    }
+    // (0: scan blocks with fixed shares, nothing joining; else every block of the launch joins the scan)
+    h->knob_scan_dyn = getenv("BITHTM_SCAN_DYN") ? atoi(getenv("BITHTM_SCAN_DYN")) != 0 : 1;
     // (off by default: measured on a learned pool of 1.6 M segments the tables made the launch 3 % longer -- 91 registers against 76,
     // a block per CU fewer -- and the streaming form hides the gathers' round trip behind its prefetch anyway)
     h->knob_large_tab = getenv("BITHTM_LARGE_TAB") ? atoi(getenv("BITHTM_LARGE_TAB")) != 0 : 0;
@@ -769,7 +765,7 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
                 const int cus = prop.multiProcessorCount;
                 h->emit_fits = c256 <= std::min(1024, per_cu_emit * cus);
                 // the pipelined launch puts the activation blocks of the current step behind the emit blocks
-                h->emit_fits_open = h->emit_fits && c256 + (d.k * 32 + 255) / 256 <= std::min(1024, per_cu_open * cus);
+                h->emit_fits_open = h->emit_fits && c256 + (d.k * d.KP + 255) / 256 <= std::min(1024, per_cu_open * cus);
                 // the three-launch schedule: the emit blocks come first in the grid of the learn + scan + emit kernel
                 // (asked of every instantiation enqueue_lean may launch for this handle -- LDS tables or not, small-pool or
                 // large-pool scan: they differ in launch bounds and registers -- and the smallest answer counts)
@@ -1095,7 +1091,7 @@ extern "C" int htm_tm_step(htm_handle *h, const int32_t *active_column, int32_t 
     const int p = (int)(h->step_host & 1);
     const int want = (learning || return_winner_cell) ? 1 : 0;
     LAUNCH(h, "tm_load_active", k_tm_load_active, std::min((d.C + 255) / 256, 1024), 256, d, p, h->d_cols_stage, n);
-    LAUNCH(h, "tm_activate", k_tm_activate, std::max(1, (n * 32 + 255) / 256), 256, d, p, n, want);
+    LAUNCH(h, "tm_activate", k_tm_activate, std::max(1, (n * d.KP + 255) / 256), 256, d, p, n, want);
     enqueue_tm(h, n, learning ? 1 : 0, want, p, nullptr, 1, false);
     h->step_host += 1;
     h->phase_open = false;
@@ -1124,12 +1120,15 @@ extern "C" int htm_tm_update(htm_handle *h, const int32_t *columns, const uint32
     for (int i = 0; i < n; ++i) order[(size_t)i] = i;
     std::sort(order.begin(), order.end(), [&](int a, int b) { return columns[a] < columns[b]; });
     std::vector<int> cols((size_t)n);
-    std::vector<uint32_t> ww((size_t)n), uw((size_t)n);
+    const int WPC = d.WPC;                          // (the words: WPC per listed column)
+    std::vector<uint32_t> ww((size_t)n * WPC), uw((size_t)n * WPC);
     for (int i = 0; i < n; ++i) {
         const int o = order[(size_t)i];
         cols[(size_t)i] = columns[o];
-        ww[(size_t)i] = winner_words[o];
-        uw[(size_t)i] = unaccounted_words[o] & winner_words[o];
+        for (int hw = 0; hw < WPC; ++hw) {
+            ww[(size_t)i * WPC + hw] = winner_words[(size_t)o * WPC + hw];
+            uw[(size_t)i * WPC + hw] = unaccounted_words[(size_t)o * WPC + hw] & winner_words[(size_t)o * WPC + hw];
+        }
         if (cols[(size_t)i] < 0 || cols[(size_t)i] >= d.C || (i && cols[(size_t)i] == cols[(size_t)i - 1])) { h->err = "htm_tm_update: bad column list"; return HTM_ERR_ARGUMENT; }
     }
     HIPCHK(h, hipSetDevice(h->device));
@@ -1137,25 +1136,30 @@ extern "C" int htm_tm_update(htm_handle *h, const int32_t *columns, const uint32
     int *d_cols = nullptr;
     uint32_t *d_ww = nullptr, *d_uw = nullptr, *d_pun = nullptr;
     auto release = [&]() { if (d_cols) hipFree(d_cols); if (d_ww) hipFree(d_ww); if (d_uw) hipFree(d_uw); if (d_pun) hipFree(d_pun); };
-    const size_t nb = (size_t)std::max(n, 1) * 4;
+    const size_t nb = (size_t)std::max(n, 1) * 4, nbw = nb * WPC, pun_bytes = (size_t)d.C * WPC * 4;
     // punish_words == NULL: every cell of a column that is not listed (networks.py:107-108,111).  The mask is built here: the
     // middle launch's own default reads the step's active words, which this entry point does not write (htm_tm_scan does, later)
     std::vector<uint32_t> default_pun;
     if (!punish_words) {
-        default_pun.assign((size_t)d.C, d.K >= 32 ? 0xFFFFFFFFu : ((1u << d.K) - 1u));
-        for (int i = 0; i < n; ++i) default_pun[(size_t)cols[(size_t)i]] = 0u;
+        default_pun.resize((size_t)d.C * WPC);
+        for (size_t w = 0; w < default_pun.size(); ++w) {
+            const int cells = d.K - 32 * (int)(w % WPC);
+            default_pun[w] = cells >= 32 ? 0xFFFFFFFFu : ((1u << cells) - 1u);
+        }
+        for (int i = 0; i < n; ++i)
+            for (int hw = 0; hw < WPC; ++hw) default_pun[(size_t)cols[(size_t)i] * WPC + hw] = 0u;
         punish_words = default_pun.data();
     }
-    if (hipMalloc((void **)&d_cols, nb) != hipSuccess || hipMalloc((void **)&d_ww, nb) != hipSuccess || hipMalloc((void **)&d_uw, nb) != hipSuccess ||
-        hipMalloc((void **)&d_pun, (size_t)d.C * 4) != hipSuccess) { release(); h->err = "htm_tm_update: hipMalloc failed"; return HTM_ERR_HIP; }
+    if (hipMalloc((void **)&d_cols, nb) != hipSuccess || hipMalloc((void **)&d_ww, nbw) != hipSuccess || hipMalloc((void **)&d_uw, nbw) != hipSuccess ||
+        hipMalloc((void **)&d_pun, pun_bytes) != hipSuccess) { release(); h->err = "htm_tm_update: hipMalloc failed"; return HTM_ERR_HIP; }
     bool ok = true;
     if (n) ok = hipMemcpyAsync(d_cols, cols.data(), nb, hipMemcpyHostToDevice, h->stream) == hipSuccess &&
-                hipMemcpyAsync(d_ww, ww.data(), nb, hipMemcpyHostToDevice, h->stream) == hipSuccess &&
-                hipMemcpyAsync(d_uw, uw.data(), nb, hipMemcpyHostToDevice, h->stream) == hipSuccess;
-    if (ok) ok = hipMemcpyAsync(d_pun, punish_words, (size_t)d.C * 4, hipMemcpyHostToDevice, h->stream) == hipSuccess;
+                hipMemcpyAsync(d_ww, ww.data(), nbw, hipMemcpyHostToDevice, h->stream) == hipSuccess &&
+                hipMemcpyAsync(d_uw, uw.data(), nbw, hipMemcpyHostToDevice, h->stream) == hipSuccess;
+    if (ok) ok = hipMemcpyAsync(d_pun, punish_words, pun_bytes, hipMemcpyHostToDevice, h->stream) == hipSuccess;
     if (!ok) { release(); h->err = "htm_tm_update: hipMemcpy failed"; return HTM_ERR_HIP; }
     hipLaunchKernelGGL(k_tm_ext_winners, dim3(std::min((d.C + 255) / 256, 1024)), dim3(256), 0, h->stream, d, p, d_cols, d_ww, d_uw, n, 0);
-    if (n) hipLaunchKernelGGL(k_tm_ext_winners, dim3((n + 255) / 256), dim3(256), 0, h->stream, d, p, d_cols, d_ww, d_uw, n, 1);
+    if (n) hipLaunchKernelGGL(k_tm_ext_winners, dim3((n * WPC + 255) / 256), dim3(256), 0, h->stream, d, p, d_cols, d_ww, d_uw, n, 1);
     d.punish = d_pun;                               // (kernels take Dev by value: set for the middle launch only)
     LAUNCH(h, "tm_mid", k_mid_rows, 1 + kClassifyBlocks + h->zero_blocks, 256, d, p, n, 1, 1, kClassifyBlocks, nullptr, 1, 0, 0, 0);
     d.punish = nullptr;
@@ -1181,12 +1185,12 @@ extern "C" int htm_tm_scan(htm_handle *h, const uint32_t *active_words) {
     HIPCHK(h, hipSetDevice(h->device));
     const int p = (int)(h->step_host & 1);
     uint32_t *d_act = nullptr;
-    if (hipMalloc((void **)&d_act, (size_t)d.C * 4) != hipSuccess) { h->err = "htm_tm_scan: hipMalloc failed"; return HTM_ERR_HIP; }
-    bool ok = hipMemcpyAsync(d_act, active_words, (size_t)d.C * 4, hipMemcpyHostToDevice, h->stream) == hipSuccess;
+    if (hipMalloc((void **)&d_act, (size_t)d.C * d.WPC * 4) != hipSuccess) { h->err = "htm_tm_scan: hipMalloc failed"; return HTM_ERR_HIP; }
+    bool ok = hipMemcpyAsync(d_act, active_words, (size_t)d.C * d.WPC * 4, hipMemcpyHostToDevice, h->stream) == hipSuccess;
     // clean accumulators: the scan sets match bits, per-cell maxima and prediction bits with atomics (in a whole timestep the
     // middle launch and the learning role of the step before leave them clean)
     ok = ok && hipMemsetAsync(d.match_bits[p], 0, (size_t)(d.Lcap + 255) / 256 * 8 * 4, h->stream) == hipSuccess &&
-         hipMemsetAsync(d.cellmax[p], 0, (size_t)d.C * 32 * 4, h->stream) == hipSuccess &&
+         hipMemsetAsync(d.cellmax[p], 0, (size_t)d.C * d.KP * 4, h->stream) == hipSuccess &&
          hipMemsetAsync(&d.ctr->n_active_cells, 0, sizeof(int), h->stream) == hipSuccess;
     if (!ok) { hipFree(d_act); h->err = "htm_tm_scan: staging failed"; return HTM_ERR_HIP; }
     hipLaunchKernelGGL(k_tm_ext_active, dim3(std::min((d.C + 255) / 256, 1024)), dim3(256), 0, h->stream, d, p, d_act);
@@ -1882,9 +1886,10 @@ extern "C" int htm_get_info(htm_handle *h, htm_info *out) {
     return HTM_OK;
 }
 
-// conversions between the internal cell encoding (col*32+cell) and the ABI's flat ids
-static inline int enc_flat(int enc, int K) { return (enc >> 5) * K + (enc & 31); }
-static inline int flat_enc(int flat, int K) { return (flat / K) * 32 + (flat % K); }
+// conversions between the internal cell encoding (col * KP + cell: 32 cell slots per column, 64 for cell_dim above 32) and the
+// ABI's flat ids
+static inline int enc_flat(int enc, int K) { return K > 32 ? (enc >> 6) * K + (enc & 63) : (enc >> 5) * K + (enc & 31); }
+static inline int flat_enc(int flat, int K) { return (flat / K) * (K > 32 ? 64 : 32) + (flat % K); }
 
 extern "C" int64_t htm_read(htm_handle *h, int32_t field, void *dst, int64_t count) {
     if (!h || !dst) return HTM_ERR_ARGUMENT;
@@ -1896,7 +1901,7 @@ extern "C" int64_t htm_read(htm_handle *h, int32_t field, void *dst, int64_t cou
     const int q = (int)((h->step_host + 1) & 1);
     const int qs = h->phase_open ? (int)(h->step_host & 1) : q;      // Spatial Pooler fields while a step is run phase by phase
     const bool sp = h->cfg.enable_sp, tm = h->cfg.enable_tm;
-    const int64_t C = d.C, K = d.K, S = h->world > 1 ? c.L : c.S, E = d.E;      // S: rows of the per-segment fields
+    const int64_t C = d.C, K = d.K, S = h->world > 1 ? c.L : c.S, E = d.E, CW = (int64_t)d.C * d.WPC, KP = d.KP;      // S: rows of the per-segment fields; CW: cell words
     auto need = [&](bool ok, int64_t n) -> int64_t {
         if (!ok) { h->err = "htm_read: field not available on this handle"; return HTM_ERR_STATE; }
         if (count < n) { h->err = "htm_read: buffer too small"; return HTM_ERR_ARGUMENT; }
@@ -1912,9 +1917,9 @@ extern "C" int64_t htm_read(htm_handle *h, int32_t field, void *dst, int64_t cou
         case HTM_F_OVERLAPS: REJECT_WHEN_AHEAD(h); if ((n = need(sp, C)) < 0) return n; return copy(d.overlap[qs], n, 4);
         case HTM_F_BOOSTED: REJECT_WHEN_AHEAD(h); if ((n = need(sp, C)) < 0) return n; return copy(d.boosted[qs], n, 8);
         case HTM_F_DUTY_CYCLE: REJECT_WHEN_AHEAD(h); if ((n = need(sp, C)) < 0) return n; return copy(d.duty, n, 4);
-        case HTM_F_CELL_ACTIVATION: if ((n = need(tm, C)) < 0) return n; return copy(d.act[q], n, 4);
-        case HTM_F_CELL_PREDICTION: if ((n = need(tm, C)) < 0) return n; return copy(d.pred[q], n, 4);
-        case HTM_F_WINNER_WORDS: if ((n = need(tm, C)) < 0) return n; return copy(d.win[q], n, 4);
+        case HTM_F_CELL_ACTIVATION: if ((n = need(tm, CW)) < 0) return n; return copy(d.act[q], n, 4);
+        case HTM_F_CELL_PREDICTION: if ((n = need(tm, CW)) < 0) return n; return copy(d.pred[q], n, 4);
+        case HTM_F_WINNER_WORDS: if ((n = need(tm, CW)) < 0) return n; return copy(d.win[q], n, 4);
         case HTM_F_BURSTING: if ((n = need(tm, d.k)) < 0) return n; return copy(d.bursting, n, 1);
         case HTM_F_SEG_NSYN: if ((n = need(tm, S)) < 0) return n; return copy(d.seg_nsyn, n, 4);
         case HTM_F_SEG_POTENTIAL:
@@ -1987,12 +1992,12 @@ extern "C" int64_t htm_read(htm_handle *h, int32_t field, void *dst, int64_t cou
         case HTM_F_SEGCOUNT:
         case HTM_F_CELL_MAX_JITTER: {
             if ((n = need(tm, C * K)) < 0) return n;
-            std::vector<uint32_t> tmp((size_t)C * 32);
+            std::vector<uint32_t> tmp((size_t)C * KP);
             const void *src = field == HTM_F_SEGCOUNT ? (const void *)d.segcount : (const void *)d.cellmax[q];
             if (hipMemcpy(tmp.data(), src, tmp.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) { h->err = "htm_read: hipMemcpy failed"; return HTM_ERR_HIP; }
             uint32_t *v = (uint32_t *)dst;
             for (int64_t col = 0; col < C; ++col)
-                for (int64_t j = 0; j < K; ++j) v[col * K + j] = tmp[(size_t)col * 32 + j];
+                for (int64_t j = 0; j < K; ++j) v[col * K + j] = tmp[(size_t)col * KP + j];
             return n;
         }
         case HTM_F_SEG_GID: {
@@ -2110,8 +2115,8 @@ extern "C" int htm_write(htm_handle *h, int32_t field, const void *src, int64_t 
     }
     switch (field) {
         case HTM_F_DUTY_CYCLE: return put(d.duty, src, count, 4, C);
-        case HTM_F_CELL_ACTIVATION: return put(d.act[q], src, count, 4, C);
-        case HTM_F_CELL_PREDICTION: return put(d.pred[q], src, count, 4, C);
+        case HTM_F_CELL_ACTIVATION: return put(d.act[q], src, count, 4, C * d.WPC);
+        case HTM_F_CELL_PREDICTION: return put(d.pred[q], src, count, 4, C * d.WPC);
         case HTM_F_SEG_NSYN: return put(d.seg_nsyn, src, count, 4, d.Scap);
         case HTM_F_SEG_POTENTIAL: h->imp_pot.assign((const int *)src, (const int *)src + count); return HTM_OK;
         case HTM_F_MATCH_SEGMENT: h->imp_match_seg.assign((const int *)src, (const int *)src + count); return HTM_OK;
@@ -2123,17 +2128,17 @@ extern "C" int htm_write(htm_handle *h, int32_t field, const void *src, int64_t 
         case HTM_F_SEG_PRESYN: {
             std::vector<int> v((const int *)src, (const int *)src + count);
             for (auto &x : v) x = x < 0 ? 0 : flat_enc(x, (int)K);
-            if (field == HTM_F_WINNER_CELL) return put(d.winners[q], v.data(), count, 4, (int64_t)d.k * 32);
+            if (field == HTM_F_WINNER_CELL) return put(d.winners[q], v.data(), count, 4, (int64_t)d.k * d.KP);
             if (field == HTM_F_SEG_CELL) return put(d.seg_cell, v.data(), count, 4, d.Scap);
             return put(d.presyn, v.data(), count, 4, (int64_t)d.Scap * E);
         }
         case HTM_F_SEGCOUNT:
         case HTM_F_CELL_MAX_JITTER: {
             if (count != C * K) { h->err = "htm_write: need column_dim * cell_dim elements"; return HTM_ERR_ARGUMENT; }
-            std::vector<uint32_t> tmp((size_t)C * 32, 0u);
+            std::vector<uint32_t> tmp((size_t)C * d.KP, 0u);
             const uint32_t *v = (const uint32_t *)src;
             for (int64_t col = 0; col < C; ++col)
-                for (int64_t j = 0; j < K; ++j) tmp[(size_t)col * 32 + j] = v[col * K + j];
+                for (int64_t j = 0; j < K; ++j) tmp[(size_t)col * d.KP + j] = v[col * K + j];
             return put(field == HTM_F_SEGCOUNT ? (void *)d.segcount : (void *)d.cellmax[q], tmp.data(), (int64_t)tmp.size(), 4, (int64_t)tmp.size());
         }
         default: h->err = "htm_write: field is not writable"; return HTM_ERR_ARGUMENT;
@@ -2157,7 +2162,7 @@ extern "C" int htm_import_begin(htm_handle *h, int64_t step_index) {
 
 // winner words (d.win[q], what HTM_F_WINNER_WORDS and State.winner_cell read) from the imported winner list
 __global__ __launch_bounds__(256) void k_tm_winner_words(Dev d, int q, int n) {
-    for (int c = blockIdx.x * 256 + threadIdx.x; c < d.C; c += gridDim.x * 256) d.win[q][c] = 0;
+    for (int c = blockIdx.x * 256 + threadIdx.x; c < d.C * d.WPC; c += gridDim.x * 256) d.win[q][c] = 0;
 }
 __global__ __launch_bounds__(256) void k_tm_winner_bits(Dev d, int q, int n) {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -2176,7 +2181,7 @@ extern "C" int htm_import_commit(htm_handle *h, int32_t segments, int32_t matchi
     if (rc) return rc;
     if (keep) segments = c.S;                       // (the store stays what it is)
     if (segments < 0 || segments > d.Scap || matching_segments < 0 || matching_segments > segments ||
-        winner_cells < 0 || winner_cells > d.k * 32) { h->err = "htm_import_commit: bad scalars"; return HTM_ERR_ARGUMENT; }
+        winner_cells < 0 || winner_cells > d.k * d.KP) { h->err = "htm_import_commit: bad scalars"; return HTM_ERR_ARGUMENT; }
     const int q = (int)((h->step_host + 1) & 1);
     std::vector<int> g2l;                           // column-sharded: local row of every id this rank owns, -1 otherwise
     if (h->world > 1) {
@@ -2263,7 +2268,7 @@ extern "C" int htm_import_commit(htm_handle *h, int32_t segments, int32_t matchi
         HIPCHK(h, hipMemcpy(d.match_bits[q], bits.data(), bits.size() * 4, hipMemcpyHostToDevice));
         // the other buffers (what the coming step's scan accumulates into) start clean
         HIPCHK(h, hipMemset(d.match_bits[q ^ 1], 0, bits.size() * 4));
-        HIPCHK(h, hipMemset(d.cellmax[q ^ 1], 0, (size_t)d.C * 32 * 4));
+        HIPCHK(h, hipMemset(d.cellmax[q ^ 1], 0, (size_t)d.C * d.KP * 4));
         h->imp_pot.clear(); h->imp_match_seg.clear(); h->imp_match_info.clear(); h->imp_match_jit.clear();
     }
     c.n_win[q] = winner_cells;
@@ -2277,12 +2282,12 @@ extern "C" int htm_import_commit(htm_handle *h, int32_t segments, int32_t matchi
     if (h->cfg.enable_tm) {
         // the previous step's active columns (State.active_cell / winner_cell index with them): the columns with an active cell
         {
-            std::vector<uint32_t> act((size_t)d.C);
+            std::vector<uint32_t> act((size_t)d.C * d.WPC);
             HIPCHK(h, hipMemcpy(act.data(), d.act[q], act.size() * 4, hipMemcpyDeviceToHost));
             std::vector<int> cols((size_t)d.k, 0);
             int n = 0;
             for (int col = 0; col < d.C && n < d.k; ++col)
-                if (act[(size_t)col]) cols[(size_t)n++] = col;
+                if (act[(size_t)col * d.WPC] | act[(size_t)col * d.WPC + d.WPC - 1]) cols[(size_t)n++] = col;
             HIPCHK(h, hipMemcpy(d.active_cols[q], cols.data(), cols.size() * 4, hipMemcpyHostToDevice));
         }
         // State.winner_cell / HTM_F_WINNER_WORDS read the winner words: rebuild them from the imported list

@@ -43,11 +43,11 @@ __global__ __launch_bounds__(256) void k_open_emit(Dev d, int p, int n_emit_bloc
     TraceScope ts(d, 0 + 4 * p);
     if ((int)blockIdx.x < n_emit_blocks) {
         role_emit(d, p ^ 1, 1, 1, 0, blockIdx.x, n_emit_blocks, (EmitShared *)dyn_lds);
-    } else {                                       // one active column per half-wave
-        const int idx = (((int)blockIdx.x - n_emit_blocks) * 256 + (int)threadIdx.x) >> 5;
+    } else {                                       // one active column per lane group (a half-wave; the wave where a column has 64 cell slots)
+        const int idx = ((int)blockIdx.x - n_emit_blocks) * tm_groups_per_block(d) + tm_group_of(d, threadIdx.x);
         const bool ok = idx < n_active;
         const int a = ok ? d.active_cols[p][idx] : 0;
-        tm_activate_column(d, p, 1, ok, a, idx, ok ? d.pred[p ^ 1][a] : 0u);
+        tm_activate_column(d, p, 1, ok, a, idx, tm_pred_words(d, p, ok, a));
     }
 }
 
@@ -114,8 +114,8 @@ __global__ __launch_bounds__(256, MINW) void k_scan_sel(Dev d, int p, int n_sel_
     }
     b -= n_sel_blocks;
     if (b < n_clear_blocks) {
-        const int c = b * 256 + (int)threadIdx.x, q = p ^ 1;
-        if (c < d.C) {
+        const int q = p ^ 1;
+        for (int c = b * 256 + (int)threadIdx.x; c < d.C * d.WPC; c += n_clear_blocks * 256) {
             d.act[q][c] = 0;
             d.win[q][c] = 0;
             d.pred[q][c] = 0;
@@ -141,11 +141,11 @@ __global__ __launch_bounds__(256, 8) void k_act_rows(Dev d, int p, int n_active,
                                                      int n_rows, int n_duty_blocks) {
     TraceScope ts(d, 0 + 4 * p);
     int b = blockIdx.x;
-    if (b < n_act_blocks) {                         // one active column per half-wave
-        const int idx = (b * 256 + (int)threadIdx.x) >> 5;
+    if (b < n_act_blocks) {                         // one active column per lane group (a half-wave; the wave where a column has 64 cell slots)
+        const int idx = b * tm_groups_per_block(d) + tm_group_of(d, threadIdx.x);
         const bool ok = idx < n_active;
         const int a = ok ? d.active_cols[p][idx] : 0;
-        tm_activate_column(d, p, 1, ok, a, idx, ok ? d.pred[p ^ 1][a] : 0u);
+        tm_activate_column(d, p, 1, ok, a, idx, tm_pred_words(d, p, ok, a));
         return;
     }
     b -= n_act_blocks;
@@ -165,10 +165,12 @@ __global__ __launch_bounds__(256, 8) void k_act_rows(Dev d, int p, int n_active,
     }
     // the step's dense per-column words: predictions (the scan sets bits), and the active / winner words of the columns
     // that are NOT active (the activation blocks of this launch write the others)
-    const int cc = (b - n_duty_blocks) * 256 + (int)threadIdx.x;
-    if (cc < d.C) {
-        d.pred[p][cc] = 0;
-        if (!((d.colbits[p][cc >> 5] >> (cc & 31)) & 1u)) { d.act[p][cc] = 0; d.win[p][cc] = 0; }
+    // (word w belongs to column w / WPC)
+    const int n_clear = (int)gridDim.x - n_act_blocks - n_rows - n_duty_blocks;
+    for (int w = (b - n_duty_blocks) * 256 + (int)threadIdx.x; w < d.C * d.WPC; w += n_clear * 256) {
+        const int cc = w >> (d.LK - 5);
+        d.pred[p][w] = 0;
+        if (!((d.colbits[p][cc >> 5] >> (cc & 31)) & 1u)) { d.act[p][w] = 0; d.win[p][w] = 0; }
     }
 }
 
@@ -200,14 +202,14 @@ __global__ __launch_bounds__(256) void k_mid_overlap(Dev d, int p, int n_active,
 // MINW < 6: the large-pool form: the scan streams, the grid is what is resident at once, and a block whose select finish or
 // learning items are done JOINS the scan (role_scan, DYN) instead of leaving its slot to a scan block that would have to be
 // dispatched and stage the bitmap first.  n_scan_blocks < 0: scan blocks with fixed shares and nothing joining, as before
-// (BITHTM_SCAN_DYN=0); else n_spec = the three classes' rounds in every 8 (role_scan).
+// (BITHTM_SCAN_DYN=0).
 template <int EPL, int MINW, bool TAB = false>
 __global__ __launch_bounds__(256, MINW) void k_learn_scan_emit(Dev d, int p, int n_emit_blocks, int n_learn_blocks, int n_scan_blocks, int n_spec) {
     TraceScope ts(d, 2 + 4 * p);
     constexpr bool LARGE = MINW < 6;
     const bool dyn = LARGE && n_scan_blocks > 0;
     if (n_scan_blocks < 0) n_scan_blocks = -n_scan_blocks;
-    const int join_arg = n_emit_blocks | (n_learn_blocks << 11) | (n_spec << 22);      // (dyn: n_spec = the classes' rounds, see role_scan)
+    const int join_arg = n_emit_blocks + n_learn_blocks;
     int b = blockIdx.x;
     if (b < n_emit_blocks) {
         role_emit(d, p ^ 1, 1, 1, 0, b, n_emit_blocks, (EmitShared *)dyn_lds, 1);

@@ -335,20 +335,44 @@ __global__ __launch_bounds__(256) void k_sp_count(Dev d, int sp) {
     if (threadIdx.x == 0) d.sel_blk[blockIdx.x] = total;
 }
 
-// TemporalMemory.process up to the winner cells (networks.py:95-104) for ONE active column,
-// executed by a half-wave (lane j = cell j): bursting, best-matching cell (networks.py:73-82),
-// least-used cell (:84-89).  idx = position of column a in the ascending active list.
-struct ColumnWords { uint32_t act, winner, unacc; bool burst; };
+// TemporalMemory.process up to the winner cells (networks.py:95-104) for ONE active column, executed by the KP lanes of
+// a lane group (lane j of the group = cell j): a half-wave where cell_dim <= 32 (two columns per wave), the whole wave for
+// cell_dim up to 64.  Bursting, best-matching cell (networks.py:73-82), least-used cell (:84-89).
+// idx = position of column a in the ascending active list.  The words are 64 bits wide throughout; with 32 cell slots the
+// upper halves are zero.
+struct ColumnWords { u64 act, winner, unacc; bool burst; };
 
 // what a lane (cell j of column a) reads from memory for tm_column_words: fetched for several columns at once where a
-// half-wave handles more than one (the loads of all of them in flight together)
+// lane group handles more than one (the loads of all of them in flight together)
 struct ColumnLoads { float cm; int segcount; };
 
+// op over the lanes of a group (a half-wave, or the wave when a column has 64 cell slots), the result in every lane of it
+template <typename Op>
+__device__ __forceinline__ float group_reduce(const Dev &d, float v, float ident, Op op) {
+    const float r = half_reduce(v, ident, op);
+    if (d.WPC == 1) return r;
+    const float lo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r), 0));
+    const float hi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r), 32));
+    return op(lo, hi);
+}
+// the group's share of a ballot: its 32 bits, or all 64
+__device__ __forceinline__ u64 group_ballot(const Dev &d, bool pred) {
+    const u64 b = __ballot(pred);
+    return d.WPC == 1 ? (u64)(uint32_t)(b >> (lane_id() & 32)) : b;
+}
+
+// the previous step's prediction words of column a (prev_state.cell_prediction row)
+__device__ __forceinline__ u64 tm_pred_words(const Dev &d, int p, bool col_ok, int a) {
+    if (!col_ok) return 0ull;
+    if (d.WPC == 1) return d.pred[p ^ 1][a];
+    return *(const u64 *)&d.pred[p ^ 1][2 * a];
+}
+
 __device__ __forceinline__ ColumnLoads tm_column_loads(const Dev &d, int p, bool col_ok, int a, int has_distal) {
-    const int j = lane_id() & 31;
+    const int j = lane_id() & (d.KP - 1);
     const bool valid = col_ok && j < d.K;
     ColumnLoads l;
-    const int idx = valid ? a * 32 + j : 0;          // (clamped and unconditional: a guarded load is waited for on its own)
+    const int idx = valid ? a * d.KP + j : 0;        // (clamped and unconditional: a guarded load is waited for on its own)
     const float cm = __uint_as_float(d.cellmax[p ^ 1][idx]);
     l.cm = (valid && has_distal) ? cm : -1.0f;
     l.segcount = d.segcount[idx];
@@ -356,16 +380,16 @@ __device__ __forceinline__ ColumnLoads tm_column_loads(const Dev &d, int p, bool
 }
 
 // pw = prev_state.cell_prediction row of column a (0 when !col_ok)
-__device__ __forceinline__ ColumnWords tm_column_compute(const Dev &d, int want_winner, bool col_ok, int a, uint32_t pw, const ColumnLoads &l,
+__device__ __forceinline__ ColumnWords tm_column_compute(const Dev &d, int want_winner, bool col_ok, int a, u64 pw, const ColumnLoads &l,
                                                          int has_distal, uint32_t step) {
-    const int lane = lane_id(), half = lane >> 5, j = lane & 31;
+    const int j = lane_id() & (d.KP - 1);
     const bool valid = col_ok && j < d.K;
     const bool burst = pw == 0;
-    const uint32_t act = burst ? cell_mask(d.K) : pw;        // networks.py:115
+    const u64 act = burst ? cell_mask64(d.K) : pw;           // networks.py:115
     const float cm = l.cm;
-    uint32_t winner = pw, unacc = 0;
+    u64 winner = pw, unacc = 0;
     if (want_winner) {
-        const float colmax = half_reduce(cm, -3.0e38f, [](float x, float y) { return fmaxf(x, y); });
+        const float colmax = group_reduce(d, cm, -3.0e38f, [](float x, float y) { return fmaxf(x, y); });
         const bool col_matching = has_distal && colmax >= (float)d.match_thr;      // networks.py:80
         const bool best = valid && has_distal && fabsf(cm - colmax) < d.eps;       // :81
         float jit = 3.0e38f;
@@ -373,40 +397,47 @@ __device__ __forceinline__ ColumnWords tm_column_compute(const Dev &d, int want_
             uint32_t base = htm_stream_base(d.seed, HTM_STREAM_LEAST_USED, step);
             jit = htm_jitter((float)l.segcount, htm_draw24(base, (uint32_t)(a * d.K + j), 0u));   // :86-87
         }
-        const float mn = half_reduce(jit, 3.0e38f, [](float x, float y) { return fminf(x, y); });
+        const float mn = group_reduce(d, jit, 3.0e38f, [](float x, float y) { return fminf(x, y); });
         const bool least = valid && fabsf(jit - mn) < d.eps;                       // :88
         const bool wbit = col_matching ? best : least;
-        const u64 bw = __ballot(wbit);
-        const uint32_t pick = (uint32_t)(bw >> (half * 32));
+        const u64 pick = group_ballot(d, wbit);
         if (burst) winner = pick;                                                  // :102
-        const u64 bm = __ballot(valid && has_distal && !(cm < d.eps));             // cell has a matching segment
-        unacc = has_distal ? (winner & ~(uint32_t)(bm >> (half * 32))) : 0u;       // projections.py:271
+        const u64 bm = group_ballot(d, valid && has_distal && !(cm < d.eps));      // cell has a matching segment
+        unacc = has_distal ? (winner & ~bm) : 0ull;                                // projections.py:271
     }
-    return ColumnWords{act, want_winner ? winner : 0u, unacc, burst};
+    return ColumnWords{act, want_winner ? winner : 0ull, unacc, burst};
 }
 
-__device__ __forceinline__ ColumnWords tm_column_words(const Dev &d, int p, int want_winner, bool col_ok, int a, uint32_t pw) {
+__device__ __forceinline__ ColumnWords tm_column_words(const Dev &d, int p, int want_winner, bool col_ok, int a, u64 pw) {
     const int has_distal = d.ctr->has_distal;
     const ColumnLoads l = tm_column_loads(d, p, col_ok, a, has_distal);
     return tm_column_compute(d, want_winner, col_ok, a, pw, l, has_distal, d.ctr->step[p]);
 }
 
-// store the words of active column a, the idx-th of the ascending active list
+// store the words of active column a, the idx-th of the ascending active list: lane 32 * h of the group writes word h
 __device__ __forceinline__ void tm_store_column(const Dev &d, int p, bool col_ok, int a, int idx, const ColumnWords &w) {
-    if (col_ok && (lane_id() & 31) == 0) {
-        d.act[p][a] = w.act;
-        d.win[p][a] = w.winner;
-        d.bursting[idx] = w.burst ? 1 : 0;
-        d.unacc_word[idx] = w.unacc;
-        d.winw_idx[idx] = w.winner;
-        d.actcnt[idx] = (uint8_t)__popc(w.act);
-        d.act_list[idx] = w.act;
+    const int j = lane_id() & (d.KP - 1);
+    if (col_ok && (j & 31) == 0) {
+        const int h = j >> 5, wi = a * d.WPC + h, s = idx * d.WPC + h;
+        const uint32_t act = (uint32_t)(w.act >> (32 * h)), win = (uint32_t)(w.winner >> (32 * h));
+        d.act[p][wi] = act;
+        d.win[p][wi] = win;
+        if (h == 0) d.bursting[idx] = w.burst ? 1 : 0;
+        d.actw_id[s] = wi;
+        d.unacc_word[s] = (uint32_t)(w.unacc >> (32 * h));
+        d.winw_idx[s] = win;
+        d.actcnt[s] = (uint8_t)__popc(act);
+        d.act_list[s] = act;
     }
 }
 
-__device__ __forceinline__ void tm_activate_column(const Dev &d, int p, int want_winner, bool col_ok, int a, int idx, uint32_t pw) {
+__device__ __forceinline__ void tm_activate_column(const Dev &d, int p, int want_winner, bool col_ok, int a, int idx, u64 pw) {
     tm_store_column(d, p, col_ok, a, idx, tm_column_words(d, p, want_winner, col_ok, a, pw));
 }
+
+// the active column a lane group of a 256-thread block takes: groups per block = 256 / KP, this thread's = tid / KP
+__device__ __forceinline__ int tm_group_of(const Dev &d, int tid) { return tid >> d.LK; }
+__device__ __forceinline__ int tm_groups_per_block(const Dev &d) { return 256 >> d.LK; }
 
 // ---- column sharding: the exchange record ----------------------------------------------------
 // One fixed-size record per rank and timestep (oracle/sharded.py record_nbytes): the rank's own
@@ -559,7 +590,7 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
     const bool own_col = c < d.sel_hi && c >= d.c0 && c < d.c1;
     const float my_duty = (own_col && (mode & EMIT_DUTY)) ? d.duty[c] : 0.f;
     const bool tm_here = d.act[0] && (mode & EMIT_ACTIVATE);
-    s_predw[tid] = (c < d.sel_hi && (tm_here || local)) ? d.pred[p ^ 1][c] : 0u;
+    s_predw[tid] = (c < d.sel_hi && (tm_here || local) && d.WPC == 1) ? d.pred[p ^ 1][c] : 0u;
     u64 T;
     uint32_t r;                                     // how many of the keys == T are selected
     bool second_round = false;                      // per-block counts still to be exchanged
@@ -1208,8 +1239,10 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
             atomicAdd(&s_n, 1);
         }
         if (d.act[0] && (mode & EMIT_CLEAR)) {     // Temporal Memory present
-            d.pred[p][c] = 0;
-            if (!sel || !(mode & EMIT_ACTIVATE)) { d.act[p][c] = 0; d.win[p][c] = 0; }
+            for (int h = 0; h < d.WPC; ++h) {
+                d.pred[p][c * d.WPC + h] = 0;
+                if (!sel || !(mode & EMIT_ACTIVATE)) { d.act[p][c * d.WPC + h] = 0; d.win[p][c * d.WPC + h] = 0; }
+            }
         }
     }
     if (b == 0 && tid == 0 && !d.act[0]) d.ctr->step[p ^ 1] = d.ctr->step[p] + 1;   // SP-only handle
@@ -1266,11 +1299,12 @@ __device__ __forceinline__ void role_emit(const Dev &d, int p, int want_winner, 
         }
         return;
     }
-    for (int i0 = 0; i0 < n_sel; i0 += 8) {        // 8 half-waves
-        const int i = i0 + (tid >> 5);
+    for (int i0 = 0; i0 < n_sel; i0 += tm_groups_per_block(d)) {       // a lane group per column
+        const int i = i0 + tm_group_of(d, tid);
         const bool ok = i < n_sel;
         const int a = ok ? s_col[i] : 0;
-        tm_activate_column(d, p, want_winner, ok, a, first_pos + i, ok ? s_predw[a - cbase] : 0u);
+        // (32 cell slots: the previous prediction words of the block's columns were staged with its keys)
+        tm_activate_column(d, p, want_winner, ok, a, first_pos + i, d.WPC == 1 ? (u64)(ok ? s_predw[a - cbase] : 0u) : tm_pred_words(d, p, ok, a));
     }
 }
 
@@ -1280,7 +1314,7 @@ __global__ __launch_bounds__(256) void k_sp_emit(Dev d, int p, int want_winner, 
     __shared__ EmitShared sh;
     if ((int)blockIdx.x >= n_emit_blocks) {
         const int nb = (int)gridDim.x - n_emit_blocks;
-        for (int c = ((int)blockIdx.x - n_emit_blocks) * 256 + (int)threadIdx.x; c < d.C; c += nb * 256) {
+        for (int c = ((int)blockIdx.x - n_emit_blocks) * 256 + (int)threadIdx.x; c < d.C * d.WPC; c += nb * 256) {
             d.act[p][c] = 0;
             d.win[p][c] = 0;
             d.pred[p][c] = 0;

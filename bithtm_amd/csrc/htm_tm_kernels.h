@@ -10,7 +10,7 @@
 
 // stand-alone TM: take the active columns from the caller, clear the per-step words
 __global__ __launch_bounds__(256) void k_tm_load_active(Dev d, int p, const int *cols, int n) {
-    for (int c = blockIdx.x * 256 + threadIdx.x; c < d.C; c += gridDim.x * 256) {
+    for (int c = blockIdx.x * 256 + threadIdx.x; c < d.C * d.WPC; c += gridDim.x * 256) {
         d.act[p][c] = 0;
         d.pred[p][c] = 0;
         d.win[p][c] = 0;
@@ -19,24 +19,27 @@ __global__ __launch_bounds__(256) void k_tm_load_active(Dev d, int p, const int 
     }
 }
 
-// stand-alone TM: per-column activation, one active column per half-wave
+// stand-alone TM: per-column activation, one active column per lane group
 __global__ __launch_bounds__(256) void k_tm_activate(Dev d, int p, int n_active, int want_winner) {
-    const int idx = (blockIdx.x * 256 + threadIdx.x) >> 5;
+    const int idx = blockIdx.x * tm_groups_per_block(d) + tm_group_of(d, threadIdx.x);
     const bool ok = idx < n_active;
     const int a = ok ? d.active_cols[p][idx] : 0;
-    if (ok && (threadIdx.x & 31) == 0) atomicOr(&d.colbits[p][a >> 5], 1u << (a & 31));
-    tm_activate_column(d, p, want_winner, ok, a, idx, ok ? d.pred[p ^ 1][a] : 0u);
+    if (ok && (threadIdx.x & (d.KP - 1)) == 0) atomicOr(&d.colbits[p][a >> 5], 1u << (a & 31));
+    tm_activate_column(d, p, want_winner, ok, a, idx, tm_pred_words(d, p, ok, a));
 }
 
 // PredictiveProjection.update called on its own (htm_tm_update): the learning cells come from the caller, grouped by
 // column -- pass 0 clears the step's winner words, pass 1 stores the n columns' lists and words where the middle launch
 // looks for them
+// (winw / unacc: WPC words per listed column)
 __global__ __launch_bounds__(256) void k_tm_ext_winners(Dev d, int p, const int *cols, const uint32_t *winw, const uint32_t *unacc, int n, int pass) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (pass == 0) { for (int c = i; c < d.C; c += gridDim.x * 256) d.win[p][c] = 0; return; }
-    if (i < n) {
-        d.active_cols[p][i] = cols[i];
-        d.win[p][cols[i]] = winw[i];
+    if (pass == 0) { for (int c = i; c < d.C * d.WPC; c += gridDim.x * 256) d.win[p][c] = 0; return; }
+    if (i < n * d.WPC) {
+        const int col = cols[i / d.WPC], wi = col * d.WPC + i % d.WPC;
+        if (i % d.WPC == 0) d.active_cols[p][i / d.WPC] = col;
+        d.actw_id[i] = wi;
+        d.win[p][wi] = winw[i];
         d.winw_idx[i] = winw[i];
         d.unacc_word[i] = unacc[i];
         d.actcnt[i] = 0;
@@ -45,19 +48,25 @@ __global__ __launch_bounds__(256) void k_tm_ext_winners(Dev d, int p, const int 
 
 // PredictiveProjection.process called on its own (htm_tm_scan): the active cells come from the caller as one word per
 // column; the column bitmap, the count of active cells and clean accumulators for the scan
+// (actw: WPC words per column)
 __global__ __launch_bounds__(256) void k_tm_ext_active(Dev d, int p, const uint32_t *actw) {
     for (int c0 = (blockIdx.x * 256 + (threadIdx.x & ~63)); c0 < ((d.C + 63) & ~63); c0 += gridDim.x * 256) {
         const int c = c0 + lane_id();
-        const uint32_t w = c < d.C ? actw[c] & cell_mask(d.K) : 0u;
-        if (c < d.C) { d.act[p][c] = w; d.pred[p][c] = 0; }
-        const u64 m = __ballot(w != 0);
+        uint32_t any = 0, cnt = 0;
+        for (int h = 0; h < d.WPC; ++h) {
+            const uint32_t w = c < d.C ? actw[c * d.WPC + h] & cell_mask_word(d.K, h) : 0u;
+            if (c < d.C) { d.act[p][c * d.WPC + h] = w; d.pred[p][c * d.WPC + h] = 0; }
+            any |= w;
+            cnt += (uint32_t)__popc(w);
+        }
+        const u64 m = __ballot(any != 0);
         if (lane_id() == 0) *(u64 *)&d.colbits[p][c0 >> 5] = m;
-        const uint32_t cells = wave_sum((uint32_t)__popc(w));
+        const uint32_t cells = wave_sum(cnt);
         if (lane_id() == 0 && cells) atomicAdd(&d.ctr->n_active_cells, (int)cells);
     }
 }
 
-__device__ __forceinline__ bool col_is_local(const Dev &d, int cell) { const int col = cell >> 5; return col >= d.c0 && col < d.c1; }
+__device__ __forceinline__ bool col_is_local(const Dev &d, int cell) { const int col = cell >> d.LK; return col >= d.c0 && col < d.c1; }
 
 // the global id of a local row (unsharded handles: the row IS the id)
 __device__ __forceinline__ int seg_gid_of(const Dev &d, int row) { return d.seg_gid ? d.seg_gid[row] : row; }
@@ -200,12 +209,14 @@ __device__ __forceinline__ void role_mid(const Dev &d, int p, int n_active, int 
             const uint32_t info = d.seg_info[seg];
             const int cell = d.seg_cell[seg];
             const float jit = d.seg_jit[seg];
-            const int col = cell >> 5, cb = cell & 31;
-            const bool is_winner = (d.win[p][col] >> cb) & 1u;
-            const bool unpred = !((d.pred[q][col] >> cb) & 1u);                          // :266
+            const int cw = cell >> 5, cb = cell & 31, col = cell >> d.LK;               // (the cell's word in the dense arrays; its column)
+            const bool is_winner = (d.win[p][cw] >> cb) & 1u;
+            const bool unpred = !((d.pred[q][cw] >> cb) & 1u);                           // :266
             const bool best = fabsf(jit - __uint_as_float(d.cellmax[q][cell])) < d.eps;  // :267
             learn = is_winner && ((info >> 31) || (unpred && best));                     // :268
-            punish = d.punish ? (d.punish[col] >> cb) & 1u : d.act[p][col] == 0;         // :269
+            // (a column is inactive: not on the step's column bitmap -- a column of 64 cell slots may be active with one of
+            // its two active words empty)
+            punish = d.punish ? (d.punish[cw] >> cb) & 1u : !((d.colbits[p][col >> 5] >> (col & 31)) & 1u);      // :269
         };
         if (n <= (d.cls_rows_max >= 0 ? d.cls_rows_max : 8 * n_cls * BS)) {
             // small pools: one row per thread, so that the rows of a word -- segments created together match together --
@@ -307,13 +318,16 @@ __device__ __forceinline__ void role_mid(const Dev &d, int p, int n_active, int 
     // share this launch a dependent round trip costs about 3 us)
     constexpr int LPT = 8;
     static_assert(LPT == 8, "the list pass loads 8 entries per thread");
-    for (int base = 0; base < n_active; base += LPT * BS) {
+    // (the lists are per WORD of the active columns: one per column, two where a column has 64 cell slots; a[] = the word's index
+    // in the dense arrays, so that word * 32 + bit is the cell)
+    const int n_slots = n_active * d.WPC;
+    for (int base = 0; base < n_slots; base += LPT * BS) {
         const int i0 = base + LPT * (int)threadIdx.x;
         uint32_t ww[LPT], uw[LPT];                 // (counts are recomputed from the words: the launch is capped at 64 registers)
         int a[LPT];
         uint32_t vsum = 0;
-        if (i0 < n_active) {                       // 16-byte loads (the arrays are padded by 8 entries), masked below
-            const int4 a0 = *(const int4 *)(d.active_cols[p] + i0), a1 = *(const int4 *)(d.active_cols[p] + i0 + 4);
+        if (i0 < n_slots) {                        // 16-byte loads (the arrays are padded by 8 entries), masked below
+            const int4 a0 = *(const int4 *)(d.actw_id + i0), a1 = *(const int4 *)(d.actw_id + i0 + 4);
             const uint4 w0 = *(const uint4 *)(d.winw_idx + i0), w1 = *(const uint4 *)(d.winw_idx + i0 + 4);
             const uint4 u0 = *(const uint4 *)(d.unacc_word + i0), u1 = *(const uint4 *)(d.unacc_word + i0 + 4);
             const u64 ac = *(const u64 *)(d.actcnt + i0);
@@ -322,7 +336,7 @@ __device__ __forceinline__ void role_mid(const Dev &d, int p, int n_active, int 
             uw[0] = u0.x; uw[1] = u0.y; uw[2] = u0.z; uw[3] = u0.w; uw[4] = u1.x; uw[5] = u1.y; uw[6] = u1.z; uw[7] = u1.w;
 #pragma unroll
             for (int j = 0; j < LPT; ++j) {
-                const bool ok = i0 + j < n_active;
+                const bool ok = i0 + j < n_slots;
                 if (!ok) { ww[j] = 0; uw[j] = 0; }
                 n_cells += ok ? (uint32_t)((ac >> (8 * j)) & 0xFFu) : 0u;
             }
@@ -492,7 +506,7 @@ __device__ __forceinline__ void role_learn(const Dev &d, int p, int blk, int nbl
         // launch) and reset what the coming scan accumulates
         const int n = c->has_distal ? (d.world > 1 ? c->L : c->S) : 0;
         if (c->cm_dense_step == c->step[p] + 1u) {  // the step after a state import: everything
-            for (int i = blk * BS + threadIdx.x; i < d.C * 32; i += nblk * BS) d.cellmax[p ^ 1][i] = 0u;
+            for (int i = blk * BS + threadIdx.x; i < d.C * d.KP; i += nblk * BS) d.cellmax[p ^ 1][i] = 0u;
         } else if (n <= 8 * nblk * BS) {           // small pools: one row per thread (matching rows cluster in words)
             for (int i = blk * BS + threadIdx.x; i < n; i += nblk * BS)
                 if ((d.match_bits[p ^ 1][i >> 5] >> (i & 31)) & 1u) d.cellmax[p ^ 1][d.seg_cell[i]] = 0u;
@@ -638,7 +652,7 @@ __device__ __forceinline__ void role_learn(const Dev &d, int p, int blk, int nbl
                         for (int j = 0; j < 4; ++j) {
                             const int i = b0 + j * 64 + lane;
                             const int wcell = i < n_w ? winner_at(i) : 0;
-                            pr[j] = htm_draw24(base2, gid, enc_to_flat(wcell, d.K));       // :120
+                            pr[j] = htm_draw24(base2, gid, enc_to_flat(d, wcell));         // :120
                             take[j] = i < n_w && pr[j] < T;
                         }
 #pragma unroll
@@ -825,15 +839,18 @@ __device__ __forceinline__ uint32_t select8(const uint32_t (&e)[8], int j) {
 
 // bit i: slot i of this lane (four of each of its two rows) is valid and its column is active (all valid ones without the
 // bitmap); rows are packed: slots [0, n) are the valid ones
+// (the bitmap of the step's active columns in LDS, and the bits of a cell id below its column: 5, or 6 with 64 cell slots)
+struct ColBits { const uint32_t *w; int lk; };
+
 template <bool use_lds>
-__device__ __forceinline__ uint32_t chunk_mask_all(const uint32_t *s_colbits, const uint32_t (&e)[8], int first, int l, const int (&n)[2]) {
+__device__ __forceinline__ uint32_t chunk_mask_all(const ColBits &cb, const uint32_t (&e)[8], int first, int l, const int (&n)[2]) {
     uint32_t m = 0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         uint32_t on = 1u;
         if (use_lds) {
-            const uint32_t w = s_colbits[(e[i] & SYN_CELL) >> 10];
-            on = (w >> ((e[i] >> 5) & 31)) & 1u;
+            const uint32_t w = cb.w[(e[i] & SYN_CELL) >> (cb.lk + 5)];
+            on = (w >> ((e[i] >> cb.lk) & 31)) & 1u;
         }
         m |= on << i;
     }
@@ -859,7 +876,7 @@ __device__ __forceinline__ ChunkHits chunk_read(const uint32_t *__restrict__ act
 }
 
 template <bool use_lds>
-__device__ __forceinline__ ChunkHits chunk_issue(const uint32_t *__restrict__ act, const uint32_t *s_colbits, const uint32_t (&e)[8],
+__device__ __forceinline__ ChunkHits chunk_issue(const uint32_t *__restrict__ act, const ColBits &s_colbits, const uint32_t (&e)[8],
                                                  int first, int l, const int (&n)[2]) {
     return chunk_read(act, e, chunk_mask_all<use_lds>(s_colbits, e, first, l, n));
 }
@@ -949,7 +966,7 @@ __device__ __forceinline__ ChunkHitsAll chunk_read_all(const uint32_t *__restric
 }
 
 template <bool use_lds, int NOW>
-__device__ __forceinline__ ChunkHitsAll chunk_issue_all(const uint32_t *__restrict__ act, const uint32_t *s_colbits, const uint32_t (&e)[8],
+__device__ __forceinline__ ChunkHitsAll chunk_issue_all(const uint32_t *__restrict__ act, const ColBits &s_colbits, const uint32_t (&e)[8],
                                                         int first, int l, const int (&n)[2]) {
     return chunk_read_all<NOW>(act, e, chunk_mask_all<use_lds>(s_colbits, e, first, l, n));
 }
@@ -993,15 +1010,17 @@ __device__ __forceinline__ void chunk_finish_all(const uint32_t *__restrict__ ac
 // slot instead of a divergent global read of 4 bytes in 64 different lines per instruction: a group of matching
 // segments (nearly every synapse a hit, 16 per lane over two chunks) took 6-8 us that way, the tail of the launch.
 // Every slot of the lane is looked up (no hit-by-hit passes: the reads are cheap), slots outside m count nothing.
-struct ScanTabs { const uint32_t *colbits; const uint16_t *rank; const uint32_t *actw; };
+// (lk: bits of a cell id below its column; with 64 cell slots an active column has two active words in the table, side by side)
+struct ScanTabs { const uint32_t *colbits; const uint16_t *rank; const uint32_t *actw; int lk; };
 
 __device__ __forceinline__ void chunk_count_tab(const ScanTabs &tb, const uint32_t (&e)[8], uint32_t m, uint32_t (&acc)[2]) {
     uint32_t aw[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const uint32_t col = (e[i] & SYN_CELL) >> 5, cw = col >> 5;
+        const uint32_t col = (e[i] & SYN_CELL) >> tb.lk, cw = col >> 5;
         const uint32_t w = tb.colbits[cw];
-        const uint32_t rk = (uint32_t)tb.rank[cw] + (uint32_t)__popc(w & ((1u << (col & 31)) - 1u));
+        uint32_t rk = (uint32_t)tb.rank[cw] + (uint32_t)__popc(w & ((1u << (col & 31)) - 1u));
+        if (tb.lk == 6) rk = 2u * rk + ((e[i] >> 5) & 1u);
         const uint32_t on = (m >> i) & 1u;                 // (a slot outside m may name any column: entry 0 is read for it,
         aw[i] = tb.actw[on ? rk : 0u] & (0u - on);         //  no branch -- a guarded read is waited for slot by slot)
     }
@@ -1029,27 +1048,16 @@ __device__ __forceinline__ void chunk_count_tab(const ScanTabs &tb, const uint32
 // leaves the chip half empty (2 048 blocks over 1 280 slots: the last block ended 13 us after the chip had begun to
 // drain).  Here the grid is what is resident at once and a block whose other role is done JOINS the scan (blk < 0; a barrier
 // first: its LDS is still in use by slower waves of the other role).  The groups of 16 segments are dealt in rounds: in
-// every round a wave takes one group, and a wave of class c (scan / select finish / learning role) takes part in rounds[c] of
-// every 8 rounds.  The shares are not the times the classes spend scanning: the SIMDs issue oldest wave first, and the scan
-// is bound by what it issues (eight LDS lookups and ~50 VALU operations per lane and chunk) -- measured with equal shares, a
-// wave of the select finish's blocks (dispatched first) took 1.5 us per group, one of the learning role's 1.9, one of the scan
-// blocks (dispatched last) 2.6.  (Handing the groups out on demand instead -- one
-// returning atomic per wave and group, on 64 counters a page apart -- made the launch five times LONGER: the chip completes
-// about 300 such atomics per microsecond, whatever their addresses; measured.)
+// every round each wave of the launch takes one group -- equal shares.  (Unequal ones were tried: a wave of the select finish's
+// blocks, dispatched first and therefore served first by SIMDs that issue oldest-wave-first, takes 1.5 us per group, one of
+// the scan blocks, dispatched last, 2.6 -- but shares of 6/8/7 or 5/8/6 rounds in eight for scan / select finish / learning
+// blocks all measured within a microsecond of equal ones: the launch is bound by what the chip issues and fetches in total,
+// and whoever is left runs faster once the others are done.  And handing the groups out on demand instead -- one returning
+// atomic per wave and group, on 64 counters a page apart -- made the launch five times LONGER: the chip completes about 300
+// such atomics per microsecond, whatever their addresses.)
 struct ScanRounds {
-    int n[3], rounds[3], cls, idx;                 // waves and rounds-of-8 per class (0 scan, 1 select finish, 2 learning role); this wave's class and index in it
-    __device__ __forceinline__ int group(int r) const {
-        const int q = r >> 3, m = r & 7;
-        int g = q * (rounds[0] * n[0] + rounds[1] * n[1] + rounds[2] * n[2]) + idx;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) g += min(m, rounds[c]) * n[c] + ((c < cls && m < rounds[c]) ? n[c] : 0);
-        return g;
-    }
-    __device__ __forceinline__ int first() const { return 0; }
-    __device__ __forceinline__ int next(int r) const {
-        ++r;
-        return (r & 7) >= rounds[cls] ? (r | 7) + 1 : r;
-    }
+    int n_waves, idx;                              // scanning waves of the launch (every block's), this wave's index among them
+    __device__ __forceinline__ int group(int r) const { return r * n_waves + idx; }
 };
 
 template <int BS, bool use_lds, bool LARGE, bool TAB = false, bool DYN = false>
@@ -1060,11 +1068,12 @@ __device__ __forceinline__ void role_scan(const Dev &d, int p, int blk, int nblk
     if (DYN && blk < 0) __syncthreads();
     constexpr int U = 2;                           // segments in flight per lane group
     uint32_t *s_colbits = lds + 4;
-    const int rank_q = (d.colwords * 2 + 15) / 16, actw_q = (d.k + 8 + 3) / 4;      // 16-byte units of the two tables
+    const int rank_q = (d.colwords * 2 + 15) / 16, actw_q = (d.k * d.WPC + 8 + 3) / 4;      // 16-byte units of the two tables
     uint16_t *s_rank = (uint16_t *)(s_colbits + ((d.colwords + 3) & ~3));
     uint32_t *s_actw = (uint32_t *)s_rank + rank_q * 4;
-    const ScanTabs tabs{s_colbits, s_rank, s_actw};
+    const ScanTabs tabs{s_colbits, s_rank, s_actw, d.LK};
     (void)tabs;
+    const ColBits cbits{s_colbits, d.LK};
     constexpr bool need_cell = !LARGE;
     Counters *c = d.ctr;
     const int S = d.world > 1 ? c->L : c->S;         // rows to scan (a shard scans its local rows; a free row is empty)
@@ -1085,13 +1094,8 @@ __device__ __forceinline__ void role_scan(const Dev &d, int p, int blk, int nblk
     constexpr int WPB = BS / 64;
     const int sg = LARGE ? 1 : (nblk % 256 == 0 ? 256 : nblk);
     const int gw = DYN ? 0 : LARGE ? wave : wave * sg;                                // this wave's group within the block's
-    // (DYN: nblk = scan blocks of the launch; n_spec = its select-finish blocks | learning blocks << 11 | the three classes' rounds of
-    // every 8, minus one, three bits each from bit 22; a joiner's blk = -1 - its index among the joiners, the select finish's first)
-    const int n_jemit = n_spec & 0x7FF, n_jlearn = (n_spec >> 11) & 0x7FF, jblk = -1 - blk;
-    const int my_cls = blk >= 0 ? 0 : jblk < n_jemit ? 1 : 2;
-    const ScanRounds rounds{{nblk * WPB, n_jemit * WPB, n_jlearn * WPB},
-                            {((n_spec >> 22) & 7) + 1, ((n_spec >> 25) & 7) + 1, ((n_spec >> 28) & 7) + 1}, my_cls,
-                            (blk >= 0 ? blk : my_cls == 1 ? jblk : jblk - n_jemit) * WPB + wave};
+    // (DYN: nblk = scan blocks of the launch, n_spec = the blocks that join it after another role; a joiner's blk = -1 - its index)
+    const ScanRounds rounds{(nblk + n_spec) * WPB, (blk >= 0 ? blk : nblk + (-1 - blk)) * WPB + wave};
     int round = 0;
     const int g_first = DYN ? rounds.group(0) : LARGE ? blk * WPB : (blk / sg) * (sg * WPB) + blk % sg;      // the block's first group (DYN: the wave's)
     const int gstride = nblk * WPB;
@@ -1147,7 +1151,7 @@ __device__ __forceinline__ void role_scan(const Dev &d, int p, int blk, int nblk
         // mask.  All but the rows of the patterns that are showing go that way -- their divergent cell-word reads
         // were most of a wave's instructions, and the second lines of the 35 % of rows longer than a chunk a fifth of
         // the launch's traffic.
-        uint32_t m1 = chunk_mask_all<use_lds>(s_colbits, e1, 0, l, n);
+        uint32_t m1 = chunk_mask_all<use_lds>(cbits, e1, 0, l, n);
         if (use_lds) {
             const int hits = group8_sum_all((int)(__popc(m1 & 0xFu) | (__popc(m1 >> 4) << 8)));
 #pragma unroll
@@ -1173,7 +1177,7 @@ __device__ __forceinline__ void role_scan(const Dev &d, int p, int blk, int nblk
         else if (!TAB && any_hit) g1 = chunk_read_all<2>(act, e1, m1);
         // large pools: the next iteration's rows are requested now, behind this iteration's cell-word reads (loads
         // return in issue order: requested earlier they would be waited for with those reads)
-        if (DYN) round = rounds.next(round);
+        if (DYN) ++round;
         const int b_next = DYN ? rounds.group(round) : b + gstride;
         const int cell_cur[U] = {cur.cell[0], cur.cell[1]};
         // (unconditional -- past the last batch the clamped ids fetch a row nobody uses: a branch around the loads
@@ -1186,18 +1190,18 @@ __device__ __forceinline__ void role_scan(const Dev &d, int p, int blk, int nblk
                                 (uint32_t)ps2[1].x, (uint32_t)ps2[1].y, (uint32_t)ps2[1].z, (uint32_t)ps2[1].w};
         if (TAB) {
             if (any_hit) chunk_count_tab(tabs, e1, m1, acc);
-            if (any_long) chunk_count_tab(tabs, e2, chunk_mask_all<use_lds>(s_colbits, e2, 32, l, n), acc);
+            if (any_long) chunk_count_tab(tabs, e2, chunk_mask_all<use_lds>(cbits, e2, 32, l, n), acc);
         } else if (!LARGE) {
             // small pools: the second chunk's first cell-word reads go out before the first chunk's are waited for
             // (its rows were requested before the first chunk's lookups): one round trip less on the blocks' chain
             ChunkHitsAll g2 = g1;
-            if (any_long) g2 = chunk_issue_all<use_lds, 2>(act, s_colbits, e2, 32, l, n);
+            if (any_long) g2 = chunk_issue_all<use_lds, 2>(act, cbits, e2, 32, l, n);
             if (any_hit) chunk_finish_all<2>(act, e1, g1, acc);      // (most waves have no row that can match)
             if (any_long) chunk_finish_all<2>(act, e2, g2, acc);
         } else {
             chunk_finish<false>(act, e1, h1, acc);
             if (any_long) {                          // (skipped by waves in which no row is that long)
-                const ChunkHits h2 = chunk_issue<use_lds>(act, s_colbits, e2, 32, l, n);
+                const ChunkHits h2 = chunk_issue<use_lds>(act, cbits, e2, 32, l, n);
                 chunk_finish<false>(act, e2, h2, acc);
             }
         }
@@ -1217,17 +1221,17 @@ __device__ __forceinline__ void role_scan(const Dev &d, int p, int blk, int nblk
                                     (uint32_t)pa[1].x, (uint32_t)pa[1].y, (uint32_t)pa[1].z, (uint32_t)pa[1].w};
             ChunkHits ha;
             ChunkHitsAll ga;
-            if (TAB) chunk_count_tab(tabs, ea, chunk_mask_all<use_lds>(s_colbits, ea, c * 32, l, n), acc);
-            else if (LARGE) ha = chunk_issue<use_lds>(act, s_colbits, ea, c * 32, l, n);
-            else ga = chunk_issue_all<use_lds, 2>(act, s_colbits, ea, c * 32, l, n);
+            if (TAB) chunk_count_tab(tabs, ea, chunk_mask_all<use_lds>(cbits, ea, c * 32, l, n), acc);
+            else if (LARGE) ha = chunk_issue<use_lds>(act, cbits, ea, c * 32, l, n);
+            else ga = chunk_issue_all<use_lds, 2>(act, cbits, ea, c * 32, l, n);
             if (TAB) {
                 const uint32_t eb[8] = {(uint32_t)pb[0].x, (uint32_t)pb[0].y, (uint32_t)pb[0].z, (uint32_t)pb[0].w,
                                         (uint32_t)pb[1].x, (uint32_t)pb[1].y, (uint32_t)pb[1].z, (uint32_t)pb[1].w};
-                chunk_count_tab(tabs, eb, chunk_mask_all<use_lds>(s_colbits, eb, (c + 1) * 32, l, n), acc);
+                chunk_count_tab(tabs, eb, chunk_mask_all<use_lds>(cbits, eb, (c + 1) * 32, l, n), acc);
             } else if (!LARGE) {
                 const uint32_t eb[8] = {(uint32_t)pb[0].x, (uint32_t)pb[0].y, (uint32_t)pb[0].z, (uint32_t)pb[0].w,
                                         (uint32_t)pb[1].x, (uint32_t)pb[1].y, (uint32_t)pb[1].z, (uint32_t)pb[1].w};
-                const ChunkHitsAll gb = chunk_issue_all<use_lds, 2>(act, s_colbits, eb, (c + 1) * 32, l, n);
+                const ChunkHitsAll gb = chunk_issue_all<use_lds, 2>(act, cbits, eb, (c + 1) * 32, l, n);
                 chunk_finish_all<2>(act, ea, ga, acc);
                 chunk_finish_all<2>(act, eb, gb, acc);
             } else {
@@ -1344,12 +1348,12 @@ __global__ __launch_bounds__(256) void k_tm_populate(Dev d, long long cell_begin
         if (on) {
             const uint32_t u = htm_draw24(base_p, gid, (uint32_t)lane);
             const float perm = (float)(perm_lo + (perm_hi - perm_lo) * ((double)u * (1.0 / 16777216.0)));
-            const int enc = (int)((cell / (uint32_t)d.K) * 32u + cell % (uint32_t)d.K);
+            const int enc = (int)((cell / (uint32_t)d.K) * (uint32_t)d.KP + cell % (uint32_t)d.K);
             d.presyn[(size_t)row * d.E + lane] = enc | (perm >= d.perm_thr ? (int)SYN_CONNECTED : 0);
             d.sperm[(size_t)row * d.E + lane] = perm;
         }
         if (lane == 0) {
-            const int owner = (int)((flat / d.K) * 32 + flat % d.K);
+            const int owner = (int)((flat / d.K) * d.KP + flat % d.K);
             d.seg_cell[row] = owner;
             d.seg_nsyn[row] = n_syn;
             if (d.seg_gid) { d.seg_gid[row] = (int)gid; d.g2l[gid] = row; }

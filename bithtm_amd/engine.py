@@ -32,14 +32,27 @@ def pack_bits(bits, words):
     return out.view(np.uint32)
 
 
+def words_per_column(cell_dim):
+    """32-bit words of cells per column in the device's dense cell arrays: one up to 32 cells, two up to 64."""
+    return max(1, -(-int(cell_dim) // 32))
+
+
 def words_to_bool(words, cell_dim):
-    """uint32[C] -> bool[C, K]."""
-    return ((words[:, None] >> np.arange(cell_dim, dtype=np.uint32)) & 1).astype(np.bool_)
+    """uint32[C * W] (W = words_per_column(cell_dim) words per column, side by side) -> bool[C, K]."""
+    w = words_per_column(cell_dim)
+    words = np.asarray(words, dtype=np.uint32).reshape(-1, w)
+    bits = (words[:, :, None] >> np.arange(32, dtype=np.uint32)) & 1
+    return bits.reshape(len(words), 32 * w)[:, :cell_dim].astype(np.bool_)
 
 
 def bool_to_words(mat):
+    """bool[C, K] -> uint32[C * W]."""
     mat = np.asarray(mat, dtype=np.bool_)
-    return (mat.astype(np.uint32) << np.arange(mat.shape[1], dtype=np.uint32)).sum(axis=1).astype(np.uint32)
+    C, K = mat.shape
+    w = words_per_column(K)
+    padded = np.zeros((C, 32 * w), dtype=np.uint32)
+    padded[:, :K] = mat
+    return (padded.reshape(C, w, 32) << np.arange(32, dtype=np.uint32)).sum(axis=2).astype(np.uint32).reshape(-1)
 
 
 class Engine:
@@ -52,6 +65,7 @@ class Engine:
         self.active_columns = int(active_columns)
         self.has_sp = proximal is not None
         self.has_tm = distal is not None
+        self.cell_words = self.column_dim * words_per_column(self.cell_dim)     # length of the dense cell-word fields (F_CELL_*, F_WINNER_WORDS)
         cfg = L.HtmConfig()
         cfg.struct_bytes = C.sizeof(L.HtmConfig)
         cfg.device = device
@@ -259,7 +273,7 @@ class Engine:
     def tm_scan(self, active_words):
         """PredictiveProjection.process on its own (htm_tm_scan); closes the timestep."""
         aw = np.ascontiguousarray(active_words, dtype=np.uint32)
-        assert aw.size == self.column_dim
+        assert aw.size == self.cell_words
         self._check(self.lib.htm_tm_scan(self.h, aw.ctypes.data_as(C.c_void_p)), "htm_tm_scan")
         self.steps += 1
 
@@ -413,8 +427,8 @@ class Engine:
         out = dict(
             S=np.int64(st["S"]), slots=np.int64(st["slots"]), step_index=np.int64(info.step_index),
             seg_cell=st["seg_cell"], seg_nsyn=st["seg_nsyn"], presyn=st["presyn"], perm=st["perm"], segcount=st["segcount"],
-            prev_prediction=words_to_bool(self.read(L.F_CELL_PREDICTION, np.uint32, self.column_dim), K),
-            prev_activation=words_to_bool(self.read(L.F_CELL_ACTIVATION, np.uint32, self.column_dim), K),
+            prev_prediction=words_to_bool(self.read(L.F_CELL_PREDICTION, np.uint32, self.cell_words), K),
+            prev_activation=words_to_bool(self.read(L.F_CELL_ACTIVATION, np.uint32, self.cell_words), K),
             prev_winner=self.read(L.F_WINNER_CELL, np.int32, info.winner_cells).astype(np.int64),
             has_prev_winner=np.bool_(info.has_winner_cells), has_distal=np.bool_(info.has_distal_state))
         if self.shard_world > 1:                    # rows are local: distributed.merge_shard_states puts the ranks' parts together

@@ -222,18 +222,18 @@ class TemporalMemory:
             if cols is None:
                 cols = eng.read(L.F_ACTIVE_COLUMN, np.int32, eng.active_columns).astype(np.int64)
             cols = np.asarray(cols, dtype=np.int64)             # in the CALLER's order, as the reference indexes with it
-            act = words_to_bool(eng.read(L.F_CELL_ACTIVATION, np.uint32, C), K)
+            act = words_to_bool(eng.read(L.F_CELL_ACTIVATION, np.uint32, eng.cell_words), K)
             rows, cells = np.where(act[cols])                                        # networks.py:116-117
             bursting = np.empty(len(cols), dtype=np.bool_)      # (the device keeps it by ascending column)
             bursting[np.argsort(cols, kind="stable")] = eng.read(L.F_BURSTING, np.uint8, eng.active_columns)[:len(cols)].astype(np.bool_)
             out = dict(
                 cell_activation=act,
-                cell_prediction=words_to_bool(eng.read(L.F_CELL_PREDICTION, np.uint32, C), K),
+                cell_prediction=words_to_bool(eng.read(L.F_CELL_PREDICTION, np.uint32, eng.cell_words), K),
                 active_cell=(cols[rows], cells),
                 active_column_bursting=bursting[:, None],
                 winner_cell=None)
             if info.has_winner_cells:
-                winner = words_to_bool(eng.read(L.F_WINNER_WORDS, np.uint32, C), K)
+                winner = words_to_bool(eng.read(L.F_WINNER_WORDS, np.uint32, eng.cell_words), K)
                 rows, cells = np.where(winner[cols])                                 # networks.py:103-104
                 out["winner_cell"] = (cols[rows], cells)
             d = eng.read_distal()
@@ -248,10 +248,11 @@ class TemporalMemory:
         self.distal_projection = distal_projection or PredictiveProjection(self.column_dim * self.cell_dim)     # networks.py:55
         # the device's own kind (exact type: a subclass may override the methods the fused step would skip) -- or any object
         # with the reference's PredictiveProjection interface, which is then called on the host (_process_host)
-        # (more than 32 cells per column: the device's Temporal Memory step is built on one 32-bit word of cells per column;
-        # the segment store is not -- it lives in cell space -- so such a model keeps its projection on the device and runs
-        # the per-column part of TemporalMemory.process, networks.py:95-119, on the host: correct, not fast)
-        self._own_distal = type(self.distal_projection) is PredictiveProjection and cell_dim <= 32
+        # (more than 64 cells per column: the device's Temporal Memory step is built on one or two 32-bit words of cells per
+        # column -- a lane per cell, a half-wave or a wave per column; the segment store is not -- it lives in cell space -- so
+        # such a model keeps its projection on the device and runs the per-column part of TemporalMemory.process,
+        # networks.py:95-119, on the host: correct, not fast)
+        self._own_distal = type(self.distal_projection) is PredictiveProjection and cell_dim <= 64
         if not self._own_distal:
             if isinstance(self.distal_projection, PredictiveProjection):      # a subclass of the device's: tell it the model's shape
                 self.distal_projection.cell_dim, self.distal_projection.seed = cell_dim, seed

@@ -187,7 +187,7 @@ class PredictiveProjection:
         if self._engine is None:
             from .engine import Engine
             cell_dim = int(getattr(self, "cell_dim", None) or 32)
-            if cell_dim > 32 or self.output_dim % cell_dim:
+            if cell_dim > 64 or self.output_dim % cell_dim:
                 cell_dim = 32
             C = -(-self.output_dim // cell_dim)
             self._engine = Engine(0, C, cell_dim, int(getattr(self, "active_columns", None) or C), distal=self,
@@ -222,8 +222,9 @@ class PredictiveProjection:
         eng = self._ensure_engine()
         K, C = eng.cell_dim, eng.column_dim
         flat = np.asarray(active_input, dtype=np.int64).reshape(-1)
-        words = np.zeros(C, dtype=np.uint32)
-        np.bitwise_or.at(words, flat // K, (np.uint32(1) << (flat % K).astype(np.uint32)))
+        wpc = eng.cell_words // C                    # (words per column: the cell j of a column is bit j % 32 of its word j // 32)
+        words = np.zeros(C * wpc, dtype=np.uint32)
+        np.bitwise_or.at(words, (flat // K) * wpc + (flat % K) // 32, (np.uint32(1) << ((flat % K) % 32).astype(np.uint32)))
         eng.tm_scan(words)
         eng.check_capacity()
         d = eng.read_distal()
@@ -266,8 +267,9 @@ class PredictiveProjection:
         need[unacc] = True
         learn_mask |= need                          # (a cell that gets a segment is a learning cell: :281 learns on the new segment)
         from .engine import bool_to_words
-        ww, uw = bool_to_words(learn_mask.reshape(C, K)), bool_to_words(need.reshape(C, K))
-        cols = np.flatnonzero(ww)
+        wpc = eng.cell_words // C
+        ww, uw = bool_to_words(learn_mask.reshape(C, K)).reshape(C, wpc), bool_to_words(need.reshape(C, K)).reshape(C, wpc)
+        cols = np.flatnonzero(ww.any(axis=1))
         # output_punishment=None: the mask TemporalMemory builds (networks.py:107-108,111) -- every cell of a column without a
         # learning cell -- is built by the library (htm_tm_update's punish_words == NULL)
         eng.tm_update(cols, ww[cols], uw[cols], None if output_punishment is None else

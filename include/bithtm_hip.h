@@ -45,8 +45,9 @@ typedef struct htm_config {
     int32_t device;                     /* HIP device ordinal */
     int32_t input_dim;                  /* SpatialPooler.input_dim   (networks.py:18) */
     int32_t column_dim;                 /* column_dim                (networks.py:19,52) */
-    int32_t cell_dim;                   /* TemporalMemory.cell_dim   (networks.py:53), 1..32 (a model with more cells per column keeps
-                                           its segment store on an engine of ceil(N / 32) columns of 32 cells: DESIGN.md section 7) */
+    int32_t cell_dim;                   /* TemporalMemory.cell_dim   (networks.py:53), 1..64; a column-sharded handle: 1..32 (a model with
+                                           still more cells per column keeps its segment store on an engine of ceil(N / 32) columns of
+                                           32 cells: DESIGN.md section 7) */
     int32_t active_columns;             /* k                         (networks.py:20,137) */
     int32_t enable_sp;                  /* 0: handle is a stand-alone TemporalMemory */
     int32_t enable_tm;                  /* 0: handle is a stand-alone SpatialPooler */
@@ -114,15 +115,16 @@ typedef struct htm_info {
 
 /* Device arrays readable with htm_read / writable with htm_write. Element type and count
  * (C = column_dim, k = active_columns, N = C * cell_dim, S = htm_info.segments,
- * E = segment_slots, M = htm_info.matching_segments, Wn = htm_info.winner_cells). */
+ * E = segment_slots, M = htm_info.matching_segments, Wn = htm_info.winner_cells, W = 32-bit words of cells per column:
+ * 1 for cell_dim <= 32, 2 up to 64 -- cell j of column c is bit j % 32 of word c * W + j / 32). */
 typedef enum htm_field {
     HTM_F_ACTIVE_COLUMN = 1,   /* int32[k]   State.active_column, ascending (networks.py:29) */
     HTM_F_OVERLAPS = 2,        /* int32[C]   State.overlaps (networks.py:27) */
     HTM_F_BOOSTED = 3,         /* double[C]  State.boosted_overlaps (networks.py:28) */
     HTM_F_DUTY_CYCLE = 4,      /* float[C]   ExponentialBoosting.duty_cycle (regularizations.py:13) */
-    HTM_F_CELL_ACTIVATION = 5, /* uint32[C]  State.cell_activation, packed (networks.py:118-119) */
-    HTM_F_CELL_PREDICTION = 6, /* uint32[C]  State.cell_prediction, packed (networks.py:122) */
-    HTM_F_WINNER_WORDS = 7,    /* uint32[C]  winner cells, packed (networks.py:102) */
+    HTM_F_CELL_ACTIVATION = 5, /* uint32[C*W] State.cell_activation, packed (networks.py:118-119) */
+    HTM_F_CELL_PREDICTION = 6, /* uint32[C*W] State.cell_prediction, packed (networks.py:122) */
+    HTM_F_WINNER_WORDS = 7,    /* uint32[C*W] winner cells, packed (networks.py:102) */
     HTM_F_BURSTING = 8,        /* uint8[k]   State.active_column_bursting (networks.py:97) */
     HTM_F_WINNER_CELL = 9,     /* int32[Wn]  flat winner cell ids, ascending (networks.py:103-104) */
     HTM_F_SEG_CELL = 10,       /* int32[S]   segment_bundle (projections.py:226) */
@@ -177,12 +179,13 @@ int htm_tm_step(htm_handle *h, const int32_t *active_column, int32_t n, int32_t 
 /* PredictiveProjection.update / .process (projections.py:257-293, :245-255) called on their own -- a caller that writes its
  * own TemporalMemory.process around the device's segment store (its own winner-cell rule, its own punishment mask).
  *   htm_tm_update  learning: columns[i] (distinct, at most active_columns of them) has the learning cells winner_words[i]
- *                  (bit j = cell j: `learning_output` / `output_learning`), of which unaccounted_words[i] get a new segment
- *                  (:271-281); punish_words = `output_punishment` as one word per column of the model, or NULL = every cell
+ *                  (bit j = cell j: `learning_output` / `output_learning`; cell_dim above 32: two words per listed column, side
+ *                  by side, as in the htm_field arrays), of which unaccounted_words[i] get a new segment
+ *                  (:271-281); punish_words = `output_punishment` as one word (two) per column of the model, or NULL = every cell
  *                  of a column not listed (what TemporalMemory.process passes, networks.py:107-108,111).  prev_state,
  *                  input_activation and winner_input of the reference's signature are the handle's previous step (its own
  *                  last one, or whatever was written with htm_import_begin(HTM_IMPORT_PREV_STATE) / htm_write).
- *   htm_tm_scan    the scan against the cells of active_words (one word per column of the model), which become the
+ *   htm_tm_scan    the scan against the cells of active_words (one word -- two -- per column of the model), which become the
  *                  step's cell activation; closes the timestep.  PredictiveProjection.State is read with htm_read. */
 int htm_tm_update(htm_handle *h, const int32_t *columns, const uint32_t *winner_words, const uint32_t *unaccounted_words,
                   int32_t n, const uint32_t *punish_words);

@@ -739,16 +739,102 @@ def test_default_sized_pools_grow_like_the_references_arrays():
                 fixed.engine.check_capacity()
 
 
-@pytest.mark.parametrize("K", [33, 64])
-def test_more_than_32_cells_per_column(K):
-    """networks.py:53 has no cap on cell_dim.  The device's fused Temporal Memory step is built on one 32-bit word of cells per
-    column; beyond that the segment store stays on the device (it lives in cell space: htm_tm_update / htm_tm_scan on an engine
-    laid out as words of 32 cells, flat cell ids unchanged) and the per-column part of TemporalMemory.process runs on the host.
-    Stand-alone and inside a HierarchicalTemporalMemory, against the oracle."""
+@pytest.mark.parametrize("K", [33, 48, 64])
+def test_up_to_64_cells_per_column_run_the_fused_step(K):
+    """networks.py:53 has no cap on cell_dim.  Up to 64 cells per column the device's fused step takes the model as it is: two
+    32-bit words of cells per column, a wave per active column (a half-wave up to 32).  Through process(), through run() in
+    its pipelined schedules (graph / eager, continuing calls, the four-launch schedule, the streaming scan) and as a
+    stand-alone Temporal Memory, against the oracle."""
+    import bithtm_amd as B
+    from types import SimpleNamespace
+    from hip_impl import compare_store_with_oracle, compare_with_oracle
+    from oracle import HTMOracle, TMParams, TemporalMemoryOracle, canonical_synapses
+    I, C, seed = 200, 2048, 40 + K
+    k = round(C * 0.02)
+    tmp = TMParams(segment_activation_threshold=9, segment_matching_threshold=7, segment_sampling_synapses=18, permanence_punishment=0.1)
+    kw = {f: getattr(tmp, f) for f in tmp.__dataclass_fields__}
+    np.random.seed(seed)
+    perm = np.random.randn(C, I) * 0.1
+    rng = np.random.RandomState(seed + 1)
+    bank = rng.rand(12, I) < 0.08
+
+    def make():
+        prox = B.DenseProjection(I, C)
+        prox.permanence = perm
+        tm = B.TemporalMemory(C, K, distal_projection=B.PredictiveProjection(C * K, segment_slots=64, **kw), seed=seed)
+        assert tm._own_distal
+        return B.HierarchicalTemporalMemory(I, C, K, active_columns=k, spatial_pooler=B.SpatialPooler(I, C, k, proximal_projection=prox), temporal_memory=tm)
+
+    # process(): every output of every step
+    ora = HTMOracle(I, C, K, active_columns=k, seed=seed, permanence=perm.copy(), tm_params=tmp)
+    htm = make()
+    assert htm.engine is not None
+    for t in range(100):
+        x = bank[t % 12] ^ (rng.rand(I) < 0.01)
+        learning = t % 17 != 5
+        o_sp, o_tm = ora.step(x, learning=learning)
+        h_sp, h_tm = htm.process(x, learning=learning)
+        compare_with_oracle(t, o_sp, o_tm, h_sp, h_tm, K)
+        if t % 33 == 0 or t == 99:
+            compare_store_with_oracle(t, ora, htm)
+    assert ora.temporal_memory.S > 200
+    # run(): the batched schedules against process()
+    import os
+    outs = []
+    for mode, env in (("process", {}), ("graph", {}), ("eager", {}), ("continuing", {}), ("graph", {"BITHTM_LEAN": "0"}), ("graph", {"BITHTM_SCAN_LARGE": "1"}),
+                      ("graph", {"BITHTM_SCAN_LARGE": "1", "BITHTM_LARGE_TAB": "1"}), ("graph", {"BITHTM_FUSE_TM": "0"})):
+        os.environ.update(env)
+        try:
+            htm = make()
+        finally:
+            for key in env:
+                os.environ.pop(key)
+        if mode == "process":
+            for t in range(75):
+                htm.process(bank[t % 12])
+        elif mode == "continuing":
+            for n in (1, 2, 30, 17, 25):
+                htm.run(bank, n, continuing=n != 25)
+        else:
+            htm.run(bank, 75, use_graph=mode == "graph")
+        htm.engine.check_capacity()
+        st, d = htm.engine.read_store(), htm.engine.read_distal()
+        outs.append((htm.engine.read_sp_fields()["active_column"], st["seg_cell"], st["seg_nsyn"], st["presyn"], st["perm"],
+                     htm.temporal_memory.last_state.cell_prediction, htm.temporal_memory.last_state.cell_activation, htm.engine.read_duty_cycle(),
+                     d["matching_segment"], d["max_jittered_potential"], d["segment_potential"]))
+    for o in outs[1:]:
+        for a, b in zip(outs[0], o):
+            assert np.array_equal(a, b)
+    # stand-alone Temporal Memory (htm_tm_step), learning switched off now and then
+    tm = B.TemporalMemory(C, K, distal_projection=B.PredictiveProjection(C * K, segment_slots=64, **kw), seed=seed)
+    ota = TemporalMemoryOracle(C, K, tmp, seed=seed)
+    seqs = [np.sort(rng.choice(C, k, replace=False)) for _ in range(7)]
+    for t in range(70):
+        cols = seqs[int(rng.randint(7))] if rng.rand() < 0.1 else seqs[t % 7]
+        want = ota.step(cols, learning=t % 11 != 4)
+        got = tm.process(SimpleNamespace(active_column=cols), learning=t % 11 != 4)
+        assert got.cell_prediction.shape == (C, K)
+        assert np.array_equal(got.cell_prediction, want.cell_prediction) and np.array_equal(got.cell_activation, want.cell_activation), t
+        assert np.array_equal(got.winner_cell[0] * K + got.winner_cell[1], want.winner_cell[0] * K + want.winner_cell[1]), t
+        assert np.array_equal(got.distal_state.matching_segment, want.distal_state.matching_segment), t
+        assert np.array_equal(np.asarray(got.distal_state.max_jittered_potential).view(np.int32), want.distal_state.max_jittered_potential.view(np.int32)), t
+    st = tm._engine.read_store()
+    S = ota.S
+    assert st["S"] == S > 50 and np.array_equal(st["seg_cell"], ota.seg_cell[:S]) and np.array_equal(st["seg_nsyn"], ota.seg_nsyn[:S])
+    a, b = canonical_synapses(st["seg_cell"], st["presyn"], st["perm"]), canonical_synapses(ota.seg_cell[:S], ota.presyn[:S], ota.perm[:S])
+    assert all(np.array_equal(x[1], y[1]) and np.array_equal(x[2].view(np.int32), y[2].view(np.int32)) for x, y in zip(a, b))
+
+
+@pytest.mark.parametrize("K", [65, 96])
+def test_more_than_64_cells_per_column(K):
+    """networks.py:53 has no cap on cell_dim.  The device's fused Temporal Memory step is built on one or two 32-bit words of
+    cells per column; beyond that the segment store stays on the device (it lives in cell space: htm_tm_update / htm_tm_scan on
+    an engine laid out as words of 32 cells, flat cell ids unchanged) and the per-column part of TemporalMemory.process runs on
+    the host.  Stand-alone and inside a HierarchicalTemporalMemory, against the oracle."""
     import bithtm_amd as B
     from types import SimpleNamespace
     from oracle import HTMOracle, TMParams, TemporalMemoryOracle, canonical_synapses
-    C, k, seed = 320, 10, 17                               # (320 x 33 cells: not a whole number of 32-cell words)
+    C, k, seed = 320, 10, 17                               # (320 x 65 cells: not a whole number of 32-cell words)
     tmp = TMParams(segment_activation_threshold=6, segment_matching_threshold=5, segment_sampling_synapses=12, permanence_punishment=0.1)
     tm = B.TemporalMemory(C, K, distal_projection=B.PredictiveProjection(C * K, segment_slots=64, **{f: getattr(tmp, f) for f in tmp.__dataclass_fields__}), seed=seed)
     assert not tm._own_distal

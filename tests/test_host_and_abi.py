@@ -53,7 +53,7 @@ def test_create_rejects_bad_config_without_touching_a_gpu(lib):
     assert lib.htm_create(C.byref(cfg), C.byref(h)) == -1          # struct_bytes mismatch
     assert b"size mismatch" in lib.htm_last_error(None)
     cfg.struct_bytes = C.sizeof(_lib.HtmConfig)
-    cfg.column_dim, cfg.active_columns, cfg.enable_tm, cfg.cell_dim = 64, 4, 1, 33
+    cfg.column_dim, cfg.active_columns, cfg.enable_tm, cfg.cell_dim = 64, 4, 1, 65
     cfg.segment_slots, cfg.segment_capacity, cfg.segment_sampling_synapses = 128, 16, 32
     assert lib.htm_create(C.byref(cfg), C.byref(h)) == -1
     assert b"cell_dim" in lib.htm_last_error(None)
