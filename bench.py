@@ -131,7 +131,7 @@ def role_bytes(w, k, seg_nsyn, n_work, n_match):
     }
 
 
-def recorded_traffic(kernel, files=PMC_FILES, sum_nsyn=None, section=None):
+def recorded_traffic(kernel, files=PMC_FILES, sum_nsyn=None, section=None, variant=None):
     """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r03_pmc_summary.json: rocprofv3 --pmc
     FETCH_SIZE and --pmc WRITE_SIZE in separate runs of this same command and schedule; KB units; FETCH_SIZE doubled as
     MI355X_MICROARCH.md section HBM prescribes for gfx950).  PMC counters cannot be read from inside this process, so this is a
@@ -143,7 +143,9 @@ def recorded_traffic(kernel, files=PMC_FILES, sum_nsyn=None, section=None):
             d = json.load(open(path))
             if section:                             # (a leg of the line recorded beside the headline: its own counters and state)
                 d = d[section]
-            key = next(k for k in d["FETCH_SIZE"] if kernel in k)          # template kernels: "void k_scan_sel<true, 6>"
+            # template kernels: "void k_scan_sel<true, 6>"; variant: what the instantiation's name must hold besides (the large-pool
+            # form of the last launch is k_learn_scan_emit<*, 4, *>: a run that pre-trains through the threshold launches both)
+            key = next(k for k in d["FETCH_SIZE"] if kernel in k and (variant is None or variant in k))
             f = d["FETCH_SIZE"][key]["mean_last150_KB"]
             wr = d["WRITE_SIZE"][key]["mean_last150_KB"]
             rec = d.get("state", {}).get("sum_nsyn")
@@ -474,12 +476,13 @@ def measure(w, args, device, label, reps, cpu_steps, chunk_plan, pmc_section=Non
                                       frac=round(launch_bytes[n] / (launch_us[n] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4))
                               for n in launch_us})
     sum_nsyn = int(store["seg_nsyn"].astype(np.int64).sum())
-    roofline.update(recorded_traffic(kernel_of[dominant], sum_nsyn=sum_nsyn, section=pmc_section))
+    variant = ", 4, " if "tm_scan_large+sp_emit" in dominant else ", 6, " if "tm_scan+sp_emit" in dominant else None
+    roofline.update(recorded_traffic(kernel_of[dominant], sum_nsyn=sum_nsyn, section=pmc_section, variant=variant))
     roofline["state"] = dict(step_index=int(info.step_index), segments=int(info.segments), sum_nsyn=sum_nsyn)
     try:                                               # rocprofv3's duration of the same kernel, where a pass of this command was kept
         rec = json.load(open(os.path.join(ROOT, "profiles", "r04_pipelined_kernel_us.json")))
         rec = rec[pmc_section] if pmc_section else rec
-        key = next(k2 for k2 in rec if kernel_of[dominant] in k2 and "mean_last300_us" in rec[k2])
+        key = next(k2 for k2 in rec if kernel_of[dominant] in k2 and (variant is None or variant in k2) and "mean_last300_us" in rec[k2])
         roofline["rocprofv3_us"] = round(rec[key]["mean_last300_us"], 2)
         roofline["rocprofv3_source"] = "profiles/r04_pipelined_kernel_us.json (mean of the last 300 launches, a run of its own)"
     except Exception:

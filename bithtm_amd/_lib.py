@@ -101,19 +101,23 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    # BITHTM_LIBRARY: another build of THIS library (same sources, same C ABI) -- the sanitizer build of its host code that
+    # tests/test_host_sanitizers.py links against a HIP runtime made of host memory.  Not a fallback: unset, a missing
+    # library is an error.
+    path = os.environ.get("BITHTM_LIBRARY") or LIB_PATH
+    if not os.path.exists(path):
         raise ImportError(
-            f"{LIB_PATH} is missing: the HIP extension is not built. Run `python -m bithtm_amd.build` "
+            f"{path} is missing: the HIP extension is not built. Run `python -m bithtm_amd.build` "
             "(or __graft_entry__.build()). There is no CPU fallback.")
     try:
-        lib = C.CDLL(LIB_PATH)
+        lib = C.CDLL(path)
     except OSError as e:
-        raise ImportError(f"cannot load {LIB_PATH}: {e}. There is no CPU fallback.") from e
+        raise ImportError(f"cannot load {path}: {e}. There is no CPU fallback.") from e
     for name, (restype, argtypes) in EXPORTS.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.restype = restype
         fn.argtypes = argtypes
     if lib.htm_abi_version() != ABI_VERSION:
-        raise ImportError(f"{LIB_PATH}: ABI version {lib.htm_abi_version()} != {ABI_VERSION}; rebuild")
+        raise ImportError(f"{path}: ABI version {lib.htm_abi_version()} != {ABI_VERSION}; rebuild")
     _lib = lib
     return lib

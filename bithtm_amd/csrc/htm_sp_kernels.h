@@ -1576,6 +1576,7 @@ __global__ __launch_bounds__(1024) void k_shard_select(Dev d, const unsigned cha
         d.act[p][col] = act;
         d.win[p][col] = wn;
         d.bursting[pos] = burst ? 1 : 0;
+        d.actw_id[pos] = col;                       // (a sharded handle has one cell word per column)
         d.unacc_word[pos] = un;
         d.winw_idx[pos] = wn;
         d.actcnt[pos] = (uint8_t)__popc(act);

@@ -445,8 +445,8 @@ class Engine:
         if S > self.segment_capacity:
             raise CapacityError(f"state has {S} segments, pool holds {self.segment_capacity}")
         self._check(self.lib.htm_import_begin(self.h, int(st["step_index"])), "htm_import_begin")
-        presyn = np.asarray(st["presyn"], dtype=np.int32).reshape(S, -1)
-        perm = np.asarray(st["perm"], dtype=np.float32).reshape(S, -1)
+        presyn = np.asarray(st["presyn"], dtype=np.int32).reshape(S, -1) if S else np.zeros((0, E), np.int32)      # (an empty store: a checkpoint of step 0)
+        perm = np.asarray(st["perm"], dtype=np.float32).reshape(S, -1) if S else np.zeros((0, E), np.float32)
         nsyn = (presyn >= 0).sum(axis=1).astype(np.int32)
         if nsyn.max(initial=0) > E:
             raise CapacityError(f"a segment has {nsyn.max()} synapses, segment_slots is {E}")

@@ -5,7 +5,7 @@
 # scan stress, cold phase, host-fed rate, sharded rehearsals, device-clock timelines, the stamped diagnostic builds.
 # Everything lands in gpurun_out/profile_<tag>/; copy what should be judged into profiles/.
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/profile_$TAG
 export OUT
 mkdir -p $OUT
@@ -16,6 +16,7 @@ cd /tmp && export TMPDIR=/tmp
 for ctr in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 400 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $OUT/pmc_$ctr -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-stress > $OUT/pmc_$ctr.json 2> $OUT/pmc_$ctr.log; echo "$ctr exit=$?"
   timeout -k 10 400 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $OUT/pmc_stress_$ctr -- python3 $GRAFT_REPO_ROOT/bench.py --stress-only --no-cpu-baseline > $OUT/pmc_stress_$ctr.log 2>&1; echo "$ctr (stress) exit=$?"
+  timeout -k 10 400 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $OUT/pmc_large_$ctr -- python3 $GRAFT_REPO_ROOT/bench.py --large-pool-only --steps 20 --warmup 5 --no-cpu-baseline > $OUT/pmc_large_$ctr.json 2> $OUT/pmc_large_$ctr.log; echo "$ctr (large pool) exit=$?"
 done
 python3 - <<'PY'
 import csv, glob, os, collections, json
@@ -32,6 +33,13 @@ def summarise(prefixes, tag):
         summary[ctr] = {k: {"launches": len(v), "mean_last150_KB": sum(v[-150:]) / len(v[-150:])} for k, v in d.items()}
     return summary
 s = summarise([("pmc", ""), ("pmc_stress", " [configs[4] leg]")], "")
+s["large_pool"] = summarise([("pmc_large", "")], "")     # the large_pool leg's own pass (bench.py: recorded_traffic(section="large_pool"))
+try:
+    line = json.loads(open(os.path.join(out, "pmc_large_FETCH_SIZE.json")).read().strip().splitlines()[-1])
+    s["large_pool"]["state"] = line["roofline"]["state"]
+    s["large_pool"]["command"] = "bench.py --large-pool-only --steps 20 --warmup 5 --no-cpu-baseline (under rocprofv3: eager launches)"
+except Exception as e:
+    s["large_pool"]["state_error"] = repr(e)
 try:        # the state the PMC pass saw: what bench.py compares its own with (recorded_traffic)
     line = json.loads(open(os.path.join(out, "pmc_FETCH_SIZE.json")).read().strip().splitlines()[-1])
     s["state"] = line["roofline"]["state"]
@@ -42,7 +50,7 @@ json.dump(s, open(os.path.join(out, "pmc_summary.json"), "w"), indent=1)
 PY
 find $OUT -name "*counter_collection.csv" -delete; find $OUT -name "*kernel_trace.csv" -delete
 # (the names bench.py looks for, whatever the tag of this collection)
-cp $OUT/pmc_summary.json $GRAFT_REPO_ROOT/profiles/r03_pmc_summary.json
+cp $OUT/pmc_summary.json $GRAFT_REPO_ROOT/profiles/r04_pmc_summary.json
 # ---- bench lines (they read the summary just written)
 cd $GRAFT_REPO_ROOT
 timeout -k 10 400 python bench.py --steps 20 --warmup 5 > $OUT/bench_driver_args.json 2> $OUT/bench_driver_args.log; echo "bench (driver args) exit=$?"
@@ -67,17 +75,23 @@ cd /tmp
 # rocprofv3 crashes on graph replay here), (c) the configs[4] leg alone
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $GRAFT_REPO_ROOT/bench.py --steps 500 --warmup 100 --reps 1 --no-cpu-baseline --no-stress --no-graph --no-pipeline > $OUT/stats.log 2>&1; echo "stats exit=$?"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_pipelined -- python3 $GRAFT_REPO_ROOT/bench.py --steps 500 --warmup 100 --reps 1 --no-cpu-baseline --no-stress --no-graph > $OUT/stats_pipelined.log 2>&1; echo "stats_pipelined exit=$?"
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_large -- python3 $GRAFT_REPO_ROOT/bench.py --large-pool-only --steps 300 --warmup 50 --reps 1 --no-cpu-baseline --no-graph > $OUT/stats_large.log 2>&1; echo "stats_large exit=$?"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_stress -- python3 $GRAFT_REPO_ROOT/bench.py --stress-only --no-cpu-baseline > $OUT/stats_stress.log 2>&1; echo "stats_stress exit=$?"
 python3 - <<'PY'
 import csv, glob, os, collections, json
 out = os.environ["OUT"]
 # per-kernel duration of the LAST 300 launches of the pipelined trace (steady state; the --stats file averages the whole run)
-for f in glob.glob(os.path.join(out, "stats_pipelined", "*", "*kernel_trace.csv")):
-    d = collections.defaultdict(list)
-    for r in csv.DictReader(open(f)):
-        d[r["Kernel_Name"].split("(")[0]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
-    json.dump({k: {"launches": len(v), "mean_last300_us": sum(v[-300:]) / len(v[-300:]), "mean_us": sum(v) / len(v)} for k, v in d.items()},
-              open(os.path.join(out, "pipelined_kernel_us.json"), "w"), indent=1)
+def last300(pattern):
+    res = {}
+    for f in glob.glob(os.path.join(out, pattern, "*", "*kernel_trace.csv")):
+        d = collections.defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            d[r["Kernel_Name"].split("(")[0]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+        res = {k: {"launches": len(v), "mean_last300_us": sum(v[-300:]) / len(v[-300:]), "mean_us": sum(v) / len(v)} for k, v in d.items()}
+    return res
+summary = last300("stats_pipelined")
+summary["large_pool"] = last300("stats_large")       # (bench.py reads the leg's figure from this section)
+json.dump(summary, open(os.path.join(out, "pipelined_kernel_us.json"), "w"), indent=1)
 PY
 find $OUT -name "*kernel_trace.csv" -delete
 # ---- diagnostic builds (device-clock stamps inside the roles), then the normal one again
