@@ -56,7 +56,10 @@ __global__ __launch_bounds__(256) void k_open_emit(Dev d, int p, int n_emit_bloc
 // step's duty cycle (regularizations.py:19-21, float32, two roundings).  256-thread blocks: the
 // dispatcher places them about five times faster, wave for wave, than 1024-thread ones (measured:
 // 2000 small blocks start within 1 us, 800 large ones take 7), and all of them are resident at once.
-__global__ __launch_bounds__(256, 8) void k_mid_rows(Dev d, int p, int n_active, int want_winner, int learning, int n_cls,
+#ifndef BITHTM_MID_ROWS_WAVES
+#define BITHTM_MID_ROWS_WAVES 8
+#endif
+__global__ __launch_bounds__(256, BITHTM_MID_ROWS_WAVES) void k_mid_rows(Dev d, int p, int n_active, int want_winner, int learning, int n_cls,
                                                   const uint32_t *__restrict__ bank, int n_inputs, int n_rows, int rows_ahead, int n_duty_blocks) {
     TraceScope ts(d, 1 + 4 * p);
     int b = blockIdx.x;
