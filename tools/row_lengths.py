@@ -11,18 +11,22 @@ import bench  # noqa: E402
 
 
 def main():
-    w = dict(bench.WORKLOAD)
+    large = len(sys.argv) > 1 and sys.argv[1] == "large"       # (bench.py's large_pool leg: 350 patterns)
+    w = dict(bench.LARGE_POOL if large else bench.WORKLOAD)
     noisy, perm = bench.make_inputs(w)
     htm = bench.build_htm(w, perm, 0)
     eng = htm.engine
     bank = eng.upload_bank(noisy)
-    eng.run(bank, noisy.shape[0], 10 * w["patterns"] + 1500, learning=True)
+    eng.run(bank, noisy.shape[0], 10 * w["patterns"] + (0 if large else 1500), learning=True)
     eng.sync()
     st = eng.read_store()
     n = np.asarray(st["seg_nsyn"])
     S = len(n)
     chunks = (n + 31) // 32
     print(f"S={S} mean synapses {n.mean():.1f}")
+    thr = 15                                         # a row can match whatever its first chunk holds once its later synapses alone reach the threshold
+    print(f"  rows of more than 32 synapses: {100.0 * (n > 32).mean():.1f} %; of more than {32 + thr} (their second chunk is always fetched): {100.0 * (n > 32 + thr).mean():.1f} %")
+    print("  synapses per row, deciles: " + " ".join(str(int(x)) for x in np.percentile(n, np.arange(0, 101, 10))))
     for c in range(0, 6):
         print(f"  rows with {c} chunks: {int((chunks == c).sum())} ({100.0 * (chunks == c).mean():.2f} %)")
     blocks = chunks[: S // 64 * 64].reshape(-1, 64).max(axis=1)
