@@ -75,7 +75,6 @@ struct htm_handle {
     int scan_large_above;                 // segments above which the scan takes its streaming (large-pool) form (BITHTM_SCAN_LARGE_ABOVE)
     int knob_scan_dyn;                    // ... hands its groups out on demand, every block of the launch joining in (BITHTM_SCAN_DYN)
     int lean_resident_large;              // blocks of the large-pool k_learn_scan_emit that are resident at once
-    int knob_large_tab;                   // the three-launch schedule's streaming scan looks cells up in the LDS tables (BITHTM_LARGE_TAB)
     int knob_defer_tail;                  // htm_step holds a step's last launch back for the next call's first (BITHTM_DEFER_TAIL)
     bool tail_pending;                    // ... and one is held back now: the learning role and the scan of the step of parity tail_p
     int tail_p;
@@ -198,7 +197,8 @@ static int prof_slot(htm_handle *h, const char *name) {
 
 static size_t learn_lds(int epl, int bs = RB) { return (size_t)(bs / 64) * CAND_CAP * 8 + (size_t)(bs / 64) * epl * 64 * 4 + (size_t)WIN_LDS * 4; }
 static int learn_epl(const Dev &d) { const int e = d.E / 64; return e <= 1 ? 1 : e == 2 ? 2 : e <= 4 ? 4 : 8; }
-static size_t scan_lds(const Dev &d, int use_lds) { return 16 + (use_lds ? (size_t)d.colwords * 4 : 0); }
+// (... and, behind the bitmap, the queues in which the waves of the streaming form set rows aside: 32 entries of 12 bytes per wave)
+static size_t scan_lds(const Dev &d, int use_lds) { return 16 + (use_lds ? (size_t)((d.colwords + 3) & ~3) * 4 : 0) + 4 * 32 * 12; }
 // ... with the rank of every bitmap word and the active words of the step's active columns behind the bitmap (the
 // three-launch schedule's scan looks the cells of active columns up in LDS: role_scan, TAB)
 static size_t scan_lds_tab(const Dev &d) {
@@ -404,10 +404,9 @@ static void enqueue_lean(htm_handle *h, int p, int learning, const uint32_t *ban
     const char *lse_name = scan_pool_is_large(h) ? "tm_learn+tm_scan_large+sp_emit" : "tm_learn+tm_scan+sp_emit";
 #define LAUNCH_LSE(EPL_, MINW_, TAB_) LAUNCH_ON(h, h->stream, lds, lse_name, (k_learn_scan_emit<EPL_, MINW_, TAB_>), grid, 256, d, p, n_emit, n_learn, n_scan, spec)
     if (scan_pool_is_large(h)) {
-        // (the streaming form; with the LDS tables of the step's select finish and activation where they fit: its cell-word
-        // lookups are then LDS reads, not a dependent gather per chunk)
-        if (lean_tab(d) && h->knob_large_tab) { switch (epl) { case 1: LAUNCH_LSE(1, 4, true); break; case 2: LAUNCH_LSE(2, 4, true); break; case 4: LAUNCH_LSE(4, 4, true); break; default: LAUNCH_LSE(8, 4, true); break; } }
-        else switch (epl) { case 1: LAUNCH_LSE(1, 4, false); break; case 2: LAUNCH_LSE(2, 4, false); break; case 4: LAUNCH_LSE(4, 4, false); break; default: LAUNCH_LSE(8, 4, false); break; }
+        // (the streaming form reads the cell words from memory: with the LDS tables of the small-pool form it measured 3 % slower --
+        // the LDS pipe is one of the things that bound it)
+        switch (epl) { case 1: LAUNCH_LSE(1, 4, false); break; case 2: LAUNCH_LSE(2, 4, false); break; case 4: LAUNCH_LSE(4, 4, false); break; default: LAUNCH_LSE(8, 4, false); break; }
     } else if (lean_tab(d)) {
         switch (epl) { case 1: LAUNCH_LSE(1, 6, true); break; case 2: LAUNCH_LSE(2, 6, true); break; case 4: LAUNCH_LSE(4, 6, true); break; default: LAUNCH_LSE(8, 6, true); break; }
     } else {
@@ -727,9 +726,6 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
     h->knob_tail_rows = getenv("BITHTM_TAIL_ROWS") ? atoi(getenv("BITHTM_TAIL_ROWS")) != 0 : 1;
     // (0: scan blocks with fixed shares, nothing joining; else every block of the launch joins the scan)
     h->knob_scan_dyn = getenv("BITHTM_SCAN_DYN") ? atoi(getenv("BITHTM_SCAN_DYN")) != 0 : 1;
-    // (off by default: measured on a learned pool of 1.6 M segments the tables made the launch 3 % longer -- 91 registers against 76,
-    // a block per CU fewer -- and the streaming form hides the gathers' round trip behind its prefetch anyway)
-    h->knob_large_tab = getenv("BITHTM_LARGE_TAB") ? atoi(getenv("BITHTM_LARGE_TAB")) != 0 : 0;
     h->knob_defer_tail = getenv("BITHTM_DEFER_TAIL") ? atoi(getenv("BITHTM_DEFER_TAIL")) != 0 : 1;
     h->tail_pending = false;
     h->tail_p = 0;
@@ -773,16 +769,16 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
                 h->lean_resident_large = 1 << 30;
                 const size_t lean_lds = std::max(std::max(learn_lds(learn_epl(d), 256), lean_scan_lds(d)), sizeof(EmitShared));
                 const int epl = learn_epl(d);
-#define LSE_VARIANTS(E_) {(const void *)k_learn_scan_emit<E_, 6, true>, (const void *)k_learn_scan_emit<E_, 4, true>, (const void *)k_learn_scan_emit<E_, 6, false>, (const void *)k_learn_scan_emit<E_, 4, false>}
-                const void *kerns[4][4] = {LSE_VARIANTS(1), LSE_VARIANTS(2), LSE_VARIANTS(4), LSE_VARIANTS(8)};
+#define LSE_VARIANTS(E_) {(const void *)k_learn_scan_emit<E_, 6, true>, (const void *)k_learn_scan_emit<E_, 6, false>, (const void *)k_learn_scan_emit<E_, 4, false>}
+                const void *kerns[4][3] = {LSE_VARIANTS(1), LSE_VARIANTS(2), LSE_VARIANTS(4), LSE_VARIANTS(8)};
 #undef LSE_VARIANTS
                 bool asked = cfg->enable_tm && h->emit_fits && lean_lds <= 64 * 1024;
-                for (int v = 0; asked && v < 4; ++v) {
-                    if (v < 2 && !lean_tab(d)) continue;            // (never launched without the tables)
+                for (int v = 0; asked && v < 3; ++v) {
+                    if (v == 0 && !lean_tab(d)) continue;           // (never launched without the tables)
                     int per_cu = 0;
                     asked = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kerns[epl == 1 ? 0 : epl == 2 ? 1 : epl == 4 ? 2 : 3][v], 256, lean_lds) == hipSuccess;
                     per_cu_lean = std::min(per_cu_lean, per_cu);
-                    if (asked && v == ((lean_tab(d) && h->knob_large_tab) ? 1 : 3)) h->lean_resident_large = per_cu * cus;      // (the large-pool form this handle launches)
+                    if (asked && v == 2) h->lean_resident_large = per_cu * cus;      // (the large-pool form)
                 }
                 h->emit_fits_lean = asked && c256 <= std::min(1024, per_cu_lean * cus);
                 if (h->lean_resident_large == (1 << 30)) h->lean_resident_large = 4 * cus;

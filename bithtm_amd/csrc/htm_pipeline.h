@@ -210,28 +210,24 @@ template <int EPL, int MINW, bool TAB = false>
 __global__ __launch_bounds__(256, MINW) void k_learn_scan_emit(Dev d, int p, int n_emit_blocks, int n_learn_blocks, int n_scan_blocks, int n_spec) {
     TraceScope ts(d, 2 + 4 * p);
     constexpr bool LARGE = MINW < 6;
+    static_assert(!(LARGE && TAB), "the streaming scan reads the cell words from memory");
     const bool dyn = LARGE && n_scan_blocks > 0;
     if (n_scan_blocks < 0) n_scan_blocks = -n_scan_blocks;
-    const int join_arg = n_emit_blocks + n_learn_blocks;
-    int b = blockIdx.x;
+    int b = blockIdx.x, scan_blk;
     if (b < n_emit_blocks) {
         role_emit(d, p ^ 1, 1, 1, 0, b, n_emit_blocks, (EmitShared *)dyn_lds, 1);
-        if (LARGE) { if (dyn) role_scan<256, true, LARGE, TAB, LARGE>(d, p, -1 - b, n_scan_blocks, join_arg, (uint32_t *)dyn_lds); }
-        return;
-    }
-    b -= n_emit_blocks;
-    if (b < n_learn_blocks) {
-        role_learn<EPL, 256, true>(d, p, b, n_learn_blocks, (LearnShared<EPL, 256> *)dyn_lds);
-        if (LARGE) { if (dyn) role_scan<256, true, LARGE, TAB, LARGE>(d, p, -1 - (n_emit_blocks + b), n_scan_blocks, join_arg, (uint32_t *)dyn_lds); }
-        return;
-    }
-    b -= n_learn_blocks;
-    if (LARGE) {
-        if (dyn) role_scan<256, true, LARGE, TAB, LARGE>(d, p, b, n_scan_blocks, join_arg, (uint32_t *)dyn_lds);
-        else role_scan<256, true, LARGE, TAB, false>(d, p, b, n_scan_blocks, n_spec, (uint32_t *)dyn_lds);
+        if (!dyn) return;
+        scan_blk = -1 - b;                           // (joins the scan)
+    } else if (b < n_emit_blocks + n_learn_blocks) {
+        role_learn<EPL, 256, true>(d, p, b - n_emit_blocks, n_learn_blocks, (LearnShared<EPL, 256> *)dyn_lds);
+        if (!dyn) return;
+        scan_blk = -1 - b;
     } else {
-        role_scan<256, true, false, TAB>(d, p, b, n_scan_blocks, n_spec, (uint32_t *)dyn_lds);
+        scan_blk = b - n_emit_blocks - n_learn_blocks;
     }
+    // (one call site: the role is the launch's largest piece of code, and four inlined copies of it spilled)
+    if (LARGE) role_scan<256, true, true, false, true>(d, p, scan_blk, n_scan_blocks, dyn ? n_emit_blocks + n_learn_blocks : 0, (uint32_t *)dyn_lds);
+    else role_scan<256, true, false, TAB>(d, p, scan_blk, n_scan_blocks, n_spec, (uint32_t *)dyn_lds);
 }
 
 // The last launch of a step run role by role (enqueue_tm): the learning role, the scan, and a streaming role behind them --

@@ -1064,9 +1064,19 @@ template <int BS, bool use_lds, bool LARGE, bool TAB = false, bool DYN = false>
 __device__ __forceinline__ void role_scan(const Dev &d, int p, int blk, int nblk, int n_spec, uint32_t *lds) {
     static_assert(BS % 64 == 0, "whole waves of 16 segments");
     static_assert(!TAB || use_lds, "the tables go with the LDS bitmap");
-    static_assert(!DYN || LARGE, "on-demand groups belong to the streaming form");
+    static_assert(!DYN || LARGE, "joining blocks belong to the streaming form");
+    static_assert(!(LARGE && TAB), "the streaming form reads the cell words from memory");
     if (DYN && blk < 0) __syncthreads();
     constexpr int U = 2;                           // segments in flight per lane group
+    // QUEUE (the streaming form in 256-thread blocks): rows that need more than their first chunk are set aside and counted
+    // sixteen at a time.  A learned pool is not the pre-populated one: 46 % of the 350-pattern pool's rows hold 33-64 synapses,
+    // 7 % more than 47 (which can match whatever their first chunk says), and about one row in ten goes on to its second
+    // chunk -- one such row among a wave's sixteen, four waves in five, and the WHOLE wave masked, looked up and gathered a
+    // second chunk: the scan's VALU and LDS work nearly doubled (56 us for 1.57 M learned rows against 38 for as many
+    // one-chunk rows).  Now such a row leaves its first chunk's counts in a queue of the wave (LDS, 32 entries), and when
+    // sixteen are waiting the wave counts their further chunks in one dense pass (and the rest when it runs out of rows).
+    constexpr bool QUEUE = LARGE && BS == 256;
+    constexpr int QCAP = 32;
     uint32_t *s_colbits = lds + 4;
     const int rank_q = (d.colwords * 2 + 15) / 16, actw_q = (d.k * d.WPC + 8 + 3) / 4;      // 16-byte units of the two tables
     uint16_t *s_rank = (uint16_t *)(s_colbits + ((d.colwords + 3) & ~3));
@@ -1074,6 +1084,8 @@ __device__ __forceinline__ void role_scan(const Dev &d, int p, int blk, int nblk
     const ScanTabs tabs{s_colbits, s_rank, s_actw, d.LK};
     (void)tabs;
     const ColBits cbits{s_colbits, d.LK};
+    uint32_t *s_queue = lds + 4 + (use_lds ? ((d.colwords + 3) & ~3) : 0) + (threadIdx.x >> 6) * (QCAP * 3);      // (this wave's: row, synapses, counts so far)
+    int qn = 0;                                      // rows waiting in it (wave-uniform)
     constexpr bool need_cell = !LARGE;
     Counters *c = d.ctr;
     const int S = d.world > 1 ? c->L : c->S;         // rows to scan (a shard scans its local rows; a free row is empty)
@@ -1133,6 +1145,63 @@ __device__ __forceinline__ void role_scan(const Dev &d, int p, int blk, int nblk
     }
     __syncthreads();                                 // the only barrier: from here on the waves share nothing
     SCAN_STAMP(1);
+    // QUEUE: the last `count` (<= 16) rows waiting in the wave's queue, their further chunks and their publication
+    auto flush = [&](int count) __attribute__((always_inline)) {
+        const int qbase = qn - count;
+        int qs[U], qlen[U];
+        uint32_t qacc[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int r = u * 8 + gi;
+            const bool ok = r < count;
+            const uint32_t *ent = s_queue + (qbase + (ok ? r : 0)) * 3;
+            qs[u] = ok ? (int)ent[0] : S;
+            qlen[u] = ok ? (int)ent[1] : 0;
+            qacc[u] = (ok && l == 0) ? ent[2] : 0u;      // (the first chunk's counts, already summed over the row's lanes)
+        }
+        for (int cc = 1; __any(qlen[0] > cc * 32 || qlen[1] > cc * 32); ++cc) {
+            int4 pa[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                pa[u] = qlen[u] > cc * 32 ? *(const int4 *)(d.presyn + (size_t)qs[u] * d.E + cc * 32 + l * 4) : make_int4(0, 0, 0, 0);
+            const uint32_t ea[8] = {(uint32_t)pa[0].x, (uint32_t)pa[0].y, (uint32_t)pa[0].z, (uint32_t)pa[0].w,
+                                    (uint32_t)pa[1].x, (uint32_t)pa[1].y, (uint32_t)pa[1].z, (uint32_t)pa[1].w};
+            const ChunkHits ha = chunk_issue<use_lds>(act, cbits, ea, cc * 32, l, qlen);
+            chunk_finish<false>(act, ea, ha, qacc);
+        }
+        bool mt[U];
+        int qpot[U], qconn[U], qcell[U];
+        float qjit[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t sum = (uint32_t)group8_sum_first((int)qacc[u]);
+            qpot[u] = (int)(sum & 0xFFFFu);
+            qconn[u] = (int)(sum >> 16);
+            mt[u] = l == 0 && qs[u] < S && qpot[u] >= d.match_thr;                  // :247
+            qjit[u] = 0.f;
+            qcell[u] = 0;
+        }
+        if (__any(mt[0] || mt[1])) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t gid = mt[u] ? (uint32_t)seg_gid_of(d, qs[u]) : 0u;
+                qcell[u] = mt[u] ? d.seg_cell[qs[u]] : 0;
+                qjit[u] = htm_jitter((float)qpot[u], htm_draw24(base3, gid, 0u));   // :234-235
+            }
+            asm volatile("" : "+v"(qjit[0]), "+v"(qjit[1]), "+v"(qcell[0]), "+v"(qcell[1]) : : "memory");
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (mt[u]) {
+                    const bool active = qconn[u] >= d.act_thr;                       // :250
+                    atomicMax(&d.cellmax[p][qcell[u]], __float_as_uint(qjit[u]));   // :237
+                    if (active) atomicOr(&d.pred[p][qcell[u] >> 5], 1u << (qcell[u] & 31));
+                    d.seg_info[qs[u]] = (uint32_t)qpot[u] | ((uint32_t)qconn[u] << 12) | 0x40000000u | (active ? 0x80000000u : 0u);
+                    d.seg_jit[qs[u]] = qjit[u];
+                    atomicOr(&d.match_bits[p][qs[u] >> 5], 1u << (qs[u] & 31));
+                }
+        }
+        qn -= count;
+    };
     for (int b = g_first; b * 16 < S; b += gstride) {    // b = the block's first group of this iteration
         int seg[U], n[U];
 #pragma unroll
@@ -1161,6 +1230,9 @@ __device__ __forceinline__ void role_scan(const Dev &d, int p, int blk, int nblk
                     m1 &= ~(0xFu << (4 * u));
                 }
         }
+        // QUEUE: a row that goes on past its first chunk (it can match, and is longer) is set aside below; here it ends at 32
+        const int n_full[U] = {n[0], n[1]};
+        if (QUEUE) { n[0] = min(n[0], 32); n[1] = min(n[1], 32); }
         // round trip 2 (only rows longer than one chunk): second chunk, in flight during the lookups of the first
         int4 ps2[U];
 #pragma unroll
@@ -1251,9 +1323,24 @@ __device__ __forceinline__ void role_scan(const Dev &d, int p, int blk, int nblk
             const uint32_t sum = (uint32_t)group8_sum_first((int)acc[u]);     // (valid in the segment's first lane only)
             pot[u] = (int)(sum & 0xFFFFu);
             conn[u] = (int)(sum >> 16);
-            matching[u] = l == 0 && seg[u] < S && pot[u] >= d.match_thr;              // :247
+            matching[u] = l == 0 && seg[u] < S && pot[u] >= d.match_thr && !(QUEUE && n_full[u] > 32);      // :247 (a row set aside is not done)
             jit[u] = 0.f;
             cell_of[u] = 0;
+        }
+        if (QUEUE) {                                 // rows that go on past their first chunk: into the wave's queue
+            const bool q0 = l == 0 && n_full[0] > 32, q1 = l == 0 && n_full[1] > 32;
+            const u64 d0 = __ballot(q0), d1 = __ballot(q1);
+            if (d0 | d1) {                           // (wave-uniform)
+                if (qn > QCAP - 16) flush(16);
+                const int pos = qn + (q0 ? __popcll(d0 & lanemask_lt()) : __popcll(d0) + __popcll(d1 & lanemask_lt()));
+                if (q0) { s_queue[pos * 3] = (uint32_t)seg[0]; s_queue[pos * 3 + 1] = (uint32_t)n_full[0]; s_queue[pos * 3 + 2] = (uint32_t)pot[0] | ((uint32_t)conn[0] << 16); }
+                if (q1) {
+                    const int pos1 = qn + __popcll(d0) + __popcll(d1 & lanemask_lt());
+                    s_queue[pos1 * 3] = (uint32_t)seg[1]; s_queue[pos1 * 3 + 1] = (uint32_t)n_full[1]; s_queue[pos1 * 3 + 2] = (uint32_t)pot[1] | ((uint32_t)conn[1] << 16);
+                }
+                (void)pos;
+                qn += __popcll(d0) + __popcll(d1);
+            }
         }
         if (__any(matching[0] || matching[1])) {     // (few waves: the streaming forms must not pay for the arithmetic)
 #pragma unroll
@@ -1294,6 +1381,8 @@ __device__ __forceinline__ void role_scan(const Dev &d, int p, int blk, int nblk
         SCAN_STAMP(1);
 #endif
     }
+    if (QUEUE)
+        while (qn > 0) flush(min(qn, 16));           // the rows still waiting
 #ifdef BITHTM_SCAN_STAMPS                            // when the wave left, and how many groups it took
     if (d.trace && blk < 2048 && BS == 256 && (threadIdx.x & 63) == 0) {
         d.trace[(size_t)(blk * 4 + wave) * 8 + 6] = wall_clock64();

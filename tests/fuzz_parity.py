@@ -21,7 +21,7 @@ from bithtm_amd.engine import CapacityError  # noqa: E402
 
 
 def draw_config(rng):
-    K = int(rng.choice([1, 2, 4, 7, 8, 16, 31, 32]))
+    K = int(rng.choice([1, 2, 4, 7, 8, 16, 31, 32, 33, 40, 48, 63, 64]))       # (above 32: two cell words per column, a wave per active column)
     C = int(rng.choice([64, 96, 256, 512, 1000, 2048, 4096, 6000]))
     I = int(rng.choice([17, 32, 64, 100, 257, 512, 1000]))
     k = max(1, int(round(C * rng.choice([0.01, 0.02, 0.05, 0.1]))))

@@ -27,6 +27,19 @@ def main():
     thr = 15                                         # a row can match whatever its first chunk holds once its later synapses alone reach the threshold
     print(f"  rows of more than 32 synapses: {100.0 * (n > 32).mean():.1f} %; of more than {32 + thr} (their second chunk is always fetched): {100.0 * (n > 32 + thr).mean():.1f} %")
     print("  synapses per row, deciles: " + " ".join(str(int(x)) for x in np.percentile(n, np.arange(0, 101, 10))))
+    # what the scan's first-chunk test lets through against the last step's active columns: a row goes on to its second chunk
+    # if its synapses on active columns among the first 32 plus all its later synapses reach the matching threshold
+    from bithtm_amd import _lib as L
+    K, C = w["cell_dim"], w["column_dim"]
+    active = np.zeros(C, bool)
+    active[eng.read(L.F_ACTIVE_COLUMN, np.int32, htm.active_columns)] = True
+    presyn = np.asarray(st["presyn"])[:, :32]
+    hits = (active[np.clip(presyn, 0, None) // K] & (presyn >= 0)).sum(axis=1)
+    can = hits + np.maximum(n - 32, 0) >= thr
+    print(f"  first-chunk hits on active columns: mean {hits.mean():.2f}, deciles " + " ".join(str(int(x)) for x in np.percentile(hits, np.arange(0, 101, 10))))
+    print(f"  rows that go on past the bitmap test (cell words looked up): {100.0 * can.mean():.1f} %; of them longer than 32 (second chunk fetched): {100.0 * (can & (n > 32)).mean():.1f} % of all rows")
+    per_wave = (can & (n > 32))[: S // 16 * 16].reshape(-1, 16).any(axis=1)
+    print(f"  16-row groups with at least one such row: {100.0 * per_wave.mean():.1f} %")
     for c in range(0, 6):
         print(f"  rows with {c} chunks: {int((chunks == c).sum())} ({100.0 * (chunks == c).mean():.2f} %)")
     blocks = chunks[: S // 64 * 64].reshape(-1, 64).max(axis=1)
