@@ -142,13 +142,14 @@ def test_temporal_memory_epsilon_matches_oracle():
         tm.process(SimpleNamespace(active_column=cols), epsilon=2.0)
 
 
-def test_temporal_memory_prev_state_matches_oracle():
+@pytest.mark.parametrize("K", [8, 40])
+def test_temporal_memory_prev_state_matches_oracle(K):
     """TemporalMemory.process(sp_state, prev_state=X) (networks.py:91-93) with X an earlier State of the same object,
     or the empty state (a sequence reset): X's fields become the device's previous step.  Against the oracle, which the
     CPU suite pins against the reference run with the same prev_state schedule."""
     import bithtm_amd as B
     from types import SimpleNamespace
-    C, K, k = 1024, 8, 24
+    C, k = 1024, 24
     tm = B.TemporalMemory(C, K, seed=11)
     ora = TemporalMemoryOracle(C, K, seed=11)
     rng = np.random.RandomState(12)
@@ -576,17 +577,19 @@ def test_example_harness_swaps_in_the_users_reference_temporal_memory(monkeypatc
         example.main(args + ["--use_reference_implementation"], out=io.StringIO())
 
 
-def test_checkpoint_and_resume(tmp_path):
-    """save() after 90 steps, then a fresh object load()s and continues exactly like the original."""
+@pytest.mark.parametrize("K", [8, 40])
+def test_checkpoint_and_resume(tmp_path, K):
+    """save() after 90 steps, then a fresh object load()s and continues exactly like the original (one and two cell words
+    per column)."""
     import bithtm_amd as B
     rng = np.random.RandomState(41)
     bank = rng.rand(30, 160) < 0.1
     np.random.seed(42)
-    a = B.HierarchicalTemporalMemory(160, 2048, 8, seed=9)
+    a = B.HierarchicalTemporalMemory(160, 2048, K, seed=9)
     a.run(bank, 90)
     a.save(tmp_path / "ckpt.npz")
     np.random.seed(43)                                   # different initial permanences on purpose
-    b = B.HierarchicalTemporalMemory(160, 2048, 8, seed=9)
+    b = B.HierarchicalTemporalMemory(160, 2048, K, seed=9)
     b.load(tmp_path / "ckpt.npz")
     for t in range(90, 150):
         sa, ma = a.process(bank[t % 30])
