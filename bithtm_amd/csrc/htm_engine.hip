@@ -73,7 +73,7 @@ struct htm_handle {
     bool emit_fits_lean;                  // ... and in k_learn_scan_emit
     int knob_lean, knob_fuse_tm, knob_shard_window, knob_scan_large, knob_step_window, knob_tail_rows;
     int scan_large_above;                 // segments above which the scan takes its streaming (large-pool) form (BITHTM_SCAN_LARGE_ABOVE)
-    int knob_scan_dyn;                    // ... hands its groups out on demand, every block of the launch joining in (BITHTM_SCAN_DYN)
+    int knob_scan_dyn;                    // the large-pool form of the last launch: every block joins the streaming scan when its own role is done (BITHTM_SCAN_DYN)
     int lean_resident_large;              // blocks of the large-pool k_learn_scan_emit that are resident at once
     int knob_defer_tail;                  // htm_step holds a step's last launch back for the next call's first (BITHTM_DEFER_TAIL)
     bool tail_pending;                    // ... and one is held back now: the learning role and the scan of the step of parity tail_p
