@@ -387,12 +387,11 @@ static void enqueue_lean(htm_handle *h, int p, int learning, const uint32_t *ban
               bank, n_inputs, h->G, n_ov);
     const int epl = learn_epl(d), n_emit = plan.next_sp ? h->c256_blocks : 0;
     const size_t lds = std::max(std::max(learn_lds(epl, 256), lean_scan_lds(d)), sizeof(EmitShared));
-    // (a large pool streams: more scan blocks than are resident at once -- as the select finish's and the learning role's blocks
-    // leave, the dispatcher fills their slots with scan blocks; 768 resident-at-once blocks left the launch 13 % longer)
-    // DYN (the default for a large pool): the grid is what is resident at once and every block ends up scanning (role_scan); the
-    // kernel is told by the sign of its n_scan argument.  More
-    // learning blocks than a small pool gets: a wave per work item (a large learned pool has ~2 800 a step), so that no block
-    // joins late because its waves had second items.
+    // A large pool streams.  DYN (the default): the grid is what is resident at once and every block ends up scanning
+    // (role_scan); the kernel is told by the sign of its n_scan argument.  More learning blocks than a small pool gets: a wave
+    // per work item (a large learned pool has ~2 800 a step), so that no block joins late because its waves had second items.
+    // BITHTM_SCAN_DYN=0: scan blocks with fixed shares -- more of them than are resident at once (as the select finish's and the
+    // learning role's blocks leave, the dispatcher fills their slots; the 768 of the small-pool form left the launch 13 % longer).
     const bool large = scan_pool_is_large(h), dyn = large && h->knob_scan_dyn > 0;
     const int n_learn = dyn ? h->lean_learn_blocks_large : h->lean_learn_blocks;
     int n_scan = large ? h->lean_scan_blocks_large : h->lean_scan_blocks;
