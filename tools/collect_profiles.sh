@@ -56,6 +56,10 @@ cd $GRAFT_REPO_ROOT
 timeout -k 10 400 python bench.py --steps 20 --warmup 5 > $OUT/bench_driver_args.json 2> $OUT/bench_driver_args.log; echo "bench (driver args) exit=$?"
 timeout -k 10 400 python bench.py --no-stress > $OUT/bench.json 2> $OUT/bench.log; echo "bench exit=$?"
 timeout -k 10 200 python tools/step_timeline.py > $OUT/step_timeline.txt 2>&1
+# the large_pool leg's state: timeline of its step, row lengths and what passes the first-chunk test, how the pool grows
+TIMELINE_WORKLOAD=large TIMELINE_WARMUP=3500 timeout -k 10 200 python tools/step_timeline.py > $OUT/timeline_large.txt 2>&1
+timeout -k 10 200 python tools/row_lengths.py large > $OUT/row_lengths_large.txt 2>&1
+timeout -k 10 200 python tools/pool_growth.py 350 12 > $OUT/pool_growth.txt 2>&1
 timeout -k 10 300 python tools/step_spans.py 16 > $OUT/step_spans.txt 2>&1
 timeout -k 10 200 python tools/soak.py > $OUT/soak.txt 2>&1
 # the four-launch schedule, for comparison
@@ -65,10 +69,12 @@ timeout -k 10 200 python bench.py --no-cpu-baseline --no-stress --no-large-pool 
 timeout -k 10 200 python tools/pcie_rate.py > $OUT/pcie_rate.txt 2>&1
 timeout -k 10 200 python tools/hostfed_profile.py >> $OUT/pcie_rate.txt 2>&1
 for w in 2 4 8; do timeout -k 10 200 python tools/shard_rehearsal.py --world $w; done > $OUT/shard_rehearsal.jsonl 2>&1
+for w in 2 4 8; do timeout -k 10 250 python tools/shard_rehearsal.py --large --world $w; done > $OUT/shard_rehearsal_large.jsonl 2>&1
 # bench.py --gpus 2 as two processes on this one GPU, records staged through the host over gloo (the multi-process flow of
 # bench_sharded.py; the RCCL path needs one GPU per rank)
 BITHTM_DIST_BACKEND=gloo BITHTM_SINGLE_DEVICE=1 timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 2 --steps 20 --warmup 5 > $OUT/bench_2ranks_one_gpu_gloo.json 2> $OUT/bench_2ranks_one_gpu_gloo.log; echo "2-rank rehearsal exit=$?"
 timeout -k 10 600 python tools/scan_stress.py --segments 250000 1000000 4000000 16000000 --slots 64 > $OUT/scan_stress.jsonl 2> $OUT/scan_stress.log
+for sl in 64 128 256; do timeout -k 10 170 python tools/scan_stress.py --segments 1572864 --slots $sl; done > $OUT/scan_stride.jsonl 2>> $OUT/scan_stress.log
 timeout -k 10 300 python tools/scan_stress.py --columns 262144 --cells 16 --segments 4000000 16000000 --slots 64 >> $OUT/scan_stress.jsonl 2>> $OUT/scan_stress.log
 cd /tmp
 # ---- rocprofv3 kernel stats: (a) one role per launch, (b) the pipelined schedule bench.py times (eager instead of hipGraph:
