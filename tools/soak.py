@@ -2,24 +2,33 @@
 check every 50 000 steps; prints the segment count, the number of select fallbacks and a digest of the final
 segment store and duty cycles (the two runs must agree: the path is deterministic).
 
-    python tools/soak.py
+    python tools/soak.py            # the headline workload (50 patterns)
+    python tools/soak.py large      # bench.py's large_pool workload (350 patterns): 40 000 steps, twice as the library
+                                    # schedules them and once each with fixed scan shares and in the four-launch schedule --
+                                    # four digests that must all agree (different kernels, one result)
 """
 import os, sys, time, hashlib
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
-w = dict(bench.WORKLOAD)
+large = len(sys.argv) > 1 and sys.argv[1] == "large"
+w = dict(bench.LARGE_POOL, segment_capacity=3 << 20) if large else dict(bench.WORKLOAD)
+chunks, per_chunk = (8, 5000) if large else (6, 50000)
+variants = [{}, {}, {"BITHTM_SCAN_DYN": "0"}, {"BITHTM_LEAN": "0"}] if large else [{}, {}]
 noisy, perm = bench.make_inputs(w)
 digests = []
-for rep in range(2):
-    htm = bench.build_htm(w, perm, 0)
+for rep, env in enumerate(variants):
+    os.environ.update(env)
+    htm = bench.build_htm(w, perm, 0)              # (the knobs are read when the handle is created)
+    for key in env:
+        os.environ.pop(key)
     eng = htm.engine
     bank = eng.upload_bank(noisy)
     t0 = time.perf_counter()
-    for chunk in range(6):
-        eng.run(bank, noisy.shape[0], 50000, learning=True, use_graph=True)
+    for chunk in range(chunks):
+        eng.run(bank, noisy.shape[0], per_chunk, learning=True, use_graph=True)
         info = eng.check_capacity()
-        print(f"rep {rep} after {info.step_index} steps: S={info.segments} fallbacks={info.select_fallbacks} ({time.perf_counter() - t0:.1f}s)", flush=True)
+        print(f"rep {rep} {env or ''} after {info.step_index} steps: S={info.segments} fallbacks={info.select_fallbacks} ({time.perf_counter() - t0:.1f}s) {eng.run_plan(per_chunk)}", flush=True)
     st = eng.read_store()
     hsh = hashlib.sha256()
     for key in ("seg_cell", "seg_nsyn", "presyn", "perm", "segcount"):
@@ -28,4 +37,4 @@ for rep in range(2):
     digests.append(hsh.hexdigest())
     print("digest", digests[-1][:16], flush=True)
     del htm, eng
-print("deterministic" if digests[0] == digests[1] else "DIFFERENT")
+print("deterministic" if len(set(digests)) == 1 else "DIFFERENT")
