@@ -85,6 +85,11 @@ LEAN_KERNEL = {"tm_activate+sp_learn": "k_act_rows", "tm_mid+sp_overlap": "k_mid
                "tm_learn+tm_scan_large+sp_emit": "k_learn_scan_emit"}
 LEAN_ROLES = {"tm_activate+sp_learn": ("tm_activate", "sp_rows", "tm_clear"), "tm_mid+sp_overlap": ("tm_mid", "sp_overlap"),
               "tm_learn+tm_scan+sp_emit": ("tm_learn", "tm_scan", "sp_emit"), "tm_learn+tm_scan_large+sp_emit": ("tm_learn", "tm_scan", "sp_emit")}
+# ... two (BITHTM_LEAN=2: the first two in one, the middle role behind an in-launch fan-in) ...
+LEAN2_KERNEL = {"tm_activate+tm_mid+sp_learn+sp_overlap": "k_act_mid_rows", "tm_learn+tm_scan+sp_emit": "k_learn_scan_emit",
+                "tm_learn+tm_scan_large+sp_emit": "k_learn_scan_emit"}
+LEAN2_ROLES = {"tm_activate+tm_mid+sp_learn+sp_overlap": ("tm_activate", "sp_rows", "tm_clear", "tm_mid", "sp_overlap"),
+               "tm_learn+tm_scan+sp_emit": ("tm_learn", "tm_scan", "sp_emit"), "tm_learn+tm_scan_large+sp_emit": ("tm_learn", "tm_scan", "sp_emit")}
 # ... or four (BITHTM_LEAN=0)
 LAUNCH_KERNEL = {"tm_activate+sp_emit": "k_open_emit", "tm_mid+sp_learn": "k_mid_rows",
                  "tm_learn+sp_overlap": "k_learn_overlap", "tm_scan+sp_select": "k_scan_sel", "tm_scan_large+sp_select": "k_scan_sel"}
@@ -447,9 +452,9 @@ def measure(w, args, device, label, reps, cpu_steps, chunk_plan, pmc_section=Non
     role_us = {n: 1e3 * ms / cnt for n, (ms, cnt) in prof_roles.items() if cnt}
     log(f"[bench] {label}: one role per launch, average launch (us): " +
         ", ".join(f"{n}={v:.1f}" for n, v in sorted(role_us.items(), key=lambda kv: -kv[1])))
-    lean, four = launches_seen(prof_timed, LEAN_KERNEL), launches_seen(prof_timed, LAUNCH_KERNEL)
-    if pipeline and (lean or four):
-        ran, roles_of, kernel_of = (lean, LEAN_ROLES, LEAN_KERNEL) if lean else (four, LAUNCH_ROLES, LAUNCH_KERNEL)
+    lean, four, two = launches_seen(prof_timed, LEAN_KERNEL), launches_seen(prof_timed, LAUNCH_KERNEL), launches_seen(prof_timed, LEAN2_KERNEL)
+    if pipeline and (lean or four or two):
+        ran, roles_of, kernel_of = (two, LEAN2_ROLES, LEAN2_KERNEL) if two else (lean, LEAN_ROLES, LEAN_KERNEL) if lean else (four, LAUNCH_ROLES, LAUNCH_KERNEL)
         launch_us = {n: 1e3 * ms / cnt for n, (ms, cnt) in ran.items()}
         launch_bytes = {n: sum(rb[r] for r in roles_of[n]) for n in ran}
     else:                                             # --no-pipeline (or a grid too large to pipeline): the roles ARE the launches

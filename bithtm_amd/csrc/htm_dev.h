@@ -14,6 +14,8 @@ typedef unsigned long long u64;
 #define COARSE_REP 16         // to a few hot runs: block b to copy b % COARSE_REP): the windowed select picks the run first, then the bin
                               // inside it -- two reads of a few kilobytes instead of one of 64 KB by every block of the select's finish
 #define COARSE_STRIDE 1024    // words between two coarse copies (a page each: the copies' atomics go to different memory channels)
+#define FAN_COUNTERS 16       // the in-launch fan-in of the two-launch schedule (k_act_mid_rows): producer block b adds to counter b % 16,
+#define FAN_STRIDE 32         // the counters 128 bytes apart (tools/fanin.hip: 1.1-1.5 us from the last producer's bytes to the consumers)
 #define HIST0_FINE (HIST_REP * SEL_BINS)
 #define HIST0_PAR (HIST0_FINE + COARSE_REP * COARSE_STRIDE)      // words per step parity: fine copies, then coarse copies
 #define RB 512                // threads per block of the role kernels (overlap, select, learn, scan)
@@ -162,6 +164,7 @@ struct Dev {
     uint32_t *act_list;       // [k * WPC] active word (same as act[p][actw_id[s]])
     uint16_t *col_rank[2];    // [colwords] active columns below each 32-column word of colbits[p] (written by the select's finish)
     uint32_t *unacc_word;     // [k * WPC]
+    uint32_t *fan;            // [2][FAN_COUNTERS * FAN_STRIDE] activation blocks done, per step parity (two-launch schedule: the middle role waits for them)
     int *unacc_list;          // [k * KP] winners without a matching segment, ascending
     int *seg_cell;            // [Scap] owning cell (enc)
     int *seg_nsyn;            // [Scap] valid synapses; rows are packed: slots [0, nsyn) are valid

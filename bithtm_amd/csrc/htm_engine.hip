@@ -83,7 +83,7 @@ struct htm_handle {
     int sel_passes_fused, sel_passes_full; // launched select digits with / without the in-kernel finish
     int seg_hint;                         // a lower bound of the segment count (see scan_spec_blocks)
     int *seg_pinned;                      // pinned word the end of each htm_run copies the count into
-    int sp_blocks, sel_blocks, c256_blocks, s1024_blocks, scan_blocks, zero_blocks, lean_learn_blocks, lean_learn_blocks_large, lean_scan_blocks, lean_scan_blocks_large, lean_overlap_blocks, cus;
+    int sp_blocks, sel_blocks, c256_blocks, s1024_blocks, scan_blocks, zero_blocks, lean_learn_blocks, lean_learn_blocks_large, lean_scan_blocks, lean_scan_blocks_large, lean_overlap_blocks, lean2_classify_blocks, lean2_order, cus;
     const uint32_t *ahead_bank;           // htm_run ended with HTM_RUN_CONTINUE on this bank: the SP has done the next step
     int ahead_n_inputs, ahead_learning;   //   and the front of the one after it
     bool ahead_lean;                      //   ... in the three-launch schedule (else the four-launch one)
@@ -381,10 +381,18 @@ static bool can_lean(const htm_handle *h) {
 static void enqueue_lean(htm_handle *h, int p, int learning, const uint32_t *bank, int n_inputs, StepPlan plan) {
     Dev &d = h->d;
     const int n_act = (d.k * d.KP + 255) / 256, n_rows = learning ? d.k : 0;
-    LAUNCH(h, "tm_activate+sp_learn", k_act_rows, n_act + n_rows + (1 + d.WPC) * h->c256_blocks, 256, d, p, d.k, n_act, bank, n_inputs, n_rows, h->c256_blocks);
     const int n_cls = learning ? kClassifyBlocks : 0, n_ov = plan.next_sp ? h->lean_overlap_blocks : 0;
-    LAUNCH_ON(h, h->stream, (size_t)SEL_BINS * 4, "tm_mid+sp_overlap", k_mid_overlap, 1 + n_cls + n_ov + h->zero_blocks, 256, d, p, d.k, 1, learning, n_cls,
-              bank, n_inputs, h->G, n_ov);
+    if (h->knob_lean == 2) {                        // the two-launch schedule: both of these in one (htm_pipeline.h)
+        const int n_cls2 = learning ? h->lean2_classify_blocks : 0;
+        const int n_duty = n_ov ? 0 : h->c256_blocks, n_clear = d.WPC * h->c256_blocks;
+        LAUNCH_ON(h, h->stream, (size_t)SEL_BINS * 4, "tm_activate+tm_mid+sp_learn+sp_overlap", k_act_mid_rows,
+                  n_act + 1 + n_cls2 + n_rows + n_ov + n_duty + n_clear + h->zero_blocks, 256, d, p, d.k, n_act, learning, n_cls2, bank, n_inputs, n_rows, h->G, n_ov,
+                  n_duty, n_clear, h->lean2_order);
+    } else {
+        LAUNCH(h, "tm_activate+sp_learn", k_act_rows, n_act + n_rows + (1 + d.WPC) * h->c256_blocks, 256, d, p, d.k, n_act, bank, n_inputs, n_rows, h->c256_blocks);
+        LAUNCH_ON(h, h->stream, (size_t)SEL_BINS * 4, "tm_mid+sp_overlap", k_mid_overlap, 1 + n_cls + n_ov + h->zero_blocks, 256, d, p, d.k, 1, learning, n_cls,
+                  bank, n_inputs, h->G, n_ov);
+    }
     const int epl = learn_epl(d), n_emit = plan.next_sp ? h->c256_blocks : 0;
     const size_t lds = std::max(std::max(learn_lds(epl, 256), lean_scan_lds(d)), sizeof(EmitShared));
     // A large pool streams.  DYN (the default): the grid is what is resident at once and every block ends up scanning
@@ -660,6 +668,7 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
         rc |= dalloc(h, &d.col_rank[0], colwords_padded);
         rc |= dalloc(h, &d.col_rank[1], colwords_padded);
         rc |= dalloc(h, &d.unacc_word, k * WPC + 8);
+        rc |= dalloc(h, &d.fan, (size_t)2 * FAN_COUNTERS * FAN_STRIDE);
         rc |= dalloc(h, &d.unacc_list, k * KP);
         rc |= dalloc(h, &d.seg_cell, S);
         rc |= dalloc(h, &d.seg_nsyn, S);
@@ -715,7 +724,16 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
     h->zero_blocks = std::max(1, std::min((d.Lcap / 128 + 4095) / 4096, 1024));     // k_mid_rows: 16 stores of 16 bytes per thread at most
     // the three-launch schedule: waves of one 256-thread block per work item in the steady state; the scan's waves take
     // two groups of segments each, so that emit + learn + scan are all resident at once (tuning knobs)
-    h->knob_lean = getenv("BITHTM_LEAN") ? atoi(getenv("BITHTM_LEAN")) != 0 : 1;
+    // launches per step of htm_run's pipelined schedule -- 2 (the default): two (k_act_mid_rows + k_learn_scan_emit); 1: three; 0: four
+    h->knob_lean = getenv("BITHTM_LEAN") ? std::max(0, std::min(2, atoi(getenv("BITHTM_LEAN")))) : 2;
+    h->lean2_classify_blocks = getenv("BITHTM_LEAN2_CLASSIFY") ? std::max(1, atoi(getenv("BITHTM_LEAN2_CLASSIFY"))) : kClassifyBlocks;
+    {   // the grid order of k_act_mid_rows' roles (hex digits: 0 activation, 1 middle, 2 rows, 3 overlap); a permutation with 0 before 1
+        // (measured at the bench shape, 8 waves per SIMD: 0312 42.4 k timesteps/s, 0321 41.9, 0123 41.2, 3201 40.2)
+        const int o = getenv("BITHTM_LEAN2_ORDER") ? (int)strtol(getenv("BITHTM_LEAN2_ORDER"), nullptr, 16) : 0x0312;
+        int seen = 0, pos[4] = {-1, -1, -1, -1};
+        for (int i = 0; i < 4; ++i) { const int r = (o >> (4 * (3 - i))) & 15; if (r < 4) { seen |= 1 << r; pos[r] = i; } }
+        h->lean2_order = (o >= 0 && o <= 0x3333 && seen == 15 && pos[0] < pos[1]) ? o : 0x0312;
+    }
     h->knob_fuse_tm = getenv("BITHTM_FUSE_TM") ? atoi(getenv("BITHTM_FUSE_TM")) != 0 : 1;
     h->knob_shard_window = getenv("BITHTM_SHARD_WINDOW") ? atoi(getenv("BITHTM_SHARD_WINDOW")) != 0 : 1;
     h->knob_scan_large = getenv("BITHTM_SCAN_LARGE") ? atoi(getenv("BITHTM_SCAN_LARGE")) : -1;
@@ -786,6 +804,23 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
                 h->emit_fits = h->emit_fits_open = h->emit_fits_lean = false;
                 h->lean_resident_large = 1024;
             }
+        }
+        if (!getenv("BITHTM_LEAN2_CLASSIFY")) {
+            // the two-launch schedule's first launch: as many classification blocks as are resident BESIDE the activation, the
+            // overlap and the winner rows -- a block that waits for a slot starts a round late, and the middle role's blocks wait for
+            // the activation whenever they start (bench shape: 164 + 512 + 1 311 + 1 of 2 048 slots leave 60; small models get 384)
+            hipDeviceProp_t prop;
+            int per_cu = 0, resident = 1536;
+            if (hipGetDeviceProperties(&prop, h->device) == hipSuccess &&
+                hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_act_mid_rows, 256, (size_t)SEL_BINS * 4) == hipSuccess)
+                resident = per_cu * prop.multiProcessorCount;
+            else
+                (void)hipGetLastError();
+            const int others = (d.k * d.KP + 255) / 256 + h->lean_overlap_blocks + d.k + 1;
+            // (... but no more than 32 where they leave fewer than 128: measured at the bench shape, 60 free slots -- 32 blocks 42.4 k
+            // timesteps/s, 40: 41.9, 56: 41.6)
+            const int room = (resident - others) & ~7;
+            h->lean2_classify_blocks = room >= 128 ? std::min(kClassifyBlocks, room) : 32;
         }
         h->sel_passes_full = d.sel_passes;
         h->sel_passes_fused = std::min(d.sel_passes, 2);
@@ -1875,7 +1910,8 @@ extern "C" int htm_get_info(htm_handle *h, htm_info *out) {
         h->err = std::string("capacity exhausted:") + ((c.error & 1) ? " segment pool (segment_capacity)" : "") +
                  ((c.error & 2) ? " synapse slots (segment_slots)" : "") + ((c.error & 4) ? " work list / growth staging" : "") +
                  ((c.error & 8) ? " dead-segment report (DEAD_CAP)" : "") +
-                 ((c.error & 16) ? " (internal) block hand-off timed out in k_sp_emit" : "");
+                 ((c.error & 16) ? " (internal) block hand-off timed out in k_sp_emit" : "") +
+                 ((c.error & 32) ? " (internal) the middle role's wait for the activation blocks timed out in k_act_mid_rows" : "");
         return HTM_ERR_CAPACITY;          // *out is filled in all the same
     }
     return HTM_OK;

@@ -197,6 +197,114 @@ __global__ __launch_bounds__(256) void k_mid_overlap(Dev d, int p, int n_active,
     for (int i = b * 256 + (int)threadIdx.x; i < words4; i += nz * 256) mb[i] = make_uint4(0u, 0u, 0u, 0u);
 }
 
+// ---- the two-launch schedule (BITHTM_LEAN=2) ---------------------------------------------------------------------
+// k_act_rows and k_mid_overlap in ONE launch; the last launch stays k_learn_scan_emit:
+//
+//   k_act_mid_rows(t)     activate(t) -> fan-in -> mid(t), clears, match-bit zeroing
+//                         | rows(t) + each winner column's own overlap(t+1)  | overlap(t+1) of the other columns + duty(t)
+//   k_learn_scan_emit(t)  learn(t) + scan(t)                                 | emit(t+1)
+//
+// Two dependencies used to need the boundary between the two launches.  (1) overlap(t+1) reads the permanence masks rows(t)
+// rewrites: only the k winner rows change, and their blocks hold the new mask words in registers -- they count them against
+// the coming input themselves (role_sp_row OWN), the overlap role passes over the winners (role_overlap fold = 2) and takes
+// the duty-cycle update along (a column's duty cycle is read and written by the one block that finishes the column).
+// (2) mid(t) reads what activate(t) writes: the activation blocks store through to memory, wait for the acknowledgement and
+// count themselves done on one of 16 counters; the middle role's blocks -- behind them in the grid, so every activation
+// block has been dispatched before any of them can spin -- poll the counters' sum (tools/fanin.hip: 1.1-1.5 us from the last
+// producer's bytes to the consumers, against 1.2-1.7 us of idle device plus a ramp for a launch boundary).
+// The launch's blocks are not all resident at once (activation 164 + middle 385 + rows 1 311 + overlap 512 at the bench shape,
+// for 1 536 slots): nothing but the middle role waits for another block, so the order of the grid is only a matter of speed.
+__device__ __forceinline__ void fan_signal(const Dev &d, int p, int b) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // (the write-through stores are acknowledged)
+    __syncthreads();
+    if (threadIdx.x == 0)
+        __hip_atomic_fetch_add(d.fan + (size_t)(p * FAN_COUNTERS + (b & (FAN_COUNTERS - 1))) * FAN_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ void fan_wait(const Dev &d, int p, uint32_t target) {
+    if (threadIdx.x < 64) {
+        for (int looks = 0;; ++looks) {
+            uint32_t v = threadIdx.x < FAN_COUNTERS
+                             ? __hip_atomic_load(d.fan + (size_t)(p * FAN_COUNTERS + (int)threadIdx.x) * FAN_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            v = wave_sum(v);
+            if (v >= target) break;
+            if (looks >= (1 << 18)) {                                // (every wave leaves: an activation block never arrived)
+                if (threadIdx.x == 0) atomicOr(&d.ctr->error, 32);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(4);
+        }
+    }
+    __syncthreads();                                                // (what the activation wrote is read with agent-scope loads: role_mid, same_launch)
+}
+
+// grid: [activation][middle role: block 0, classification][winner rows][overlap | duty cycle][dense-word clears][match-bit zeroing]
+// n_overlap_blocks > 0: the coming step's overlap rides along (a steady-state step); else the duty cycle has blocks of its own
+// and the rows are plain (the last step of a call)
+#ifndef BITHTM_LEAN2_WAVES
+#define BITHTM_LEAN2_WAVES 8
+#endif
+__global__ __launch_bounds__(256, BITHTM_LEAN2_WAVES) void k_act_mid_rows(Dev d, int p, int n_active, int n_act_blocks, int learning, int n_cls,
+                                                      const uint32_t *__restrict__ bank, int n_inputs, int n_rows, int G, int n_overlap_blocks,
+                                                      int n_duty_blocks, int n_clear_blocks, int order) {
+    TraceScope ts(d, 0 + 4 * p);
+    int b = blockIdx.x;
+    // the four big roles in the order the host asks for (hex digits, first role first: 0 activation, 1 middle, 2 rows, 3 overlap;
+    // the activation before the middle role, which waits for it)
+    int role = 4;
+#pragma unroll
+    for (int i = 3; i >= 0 && role == 4; --i) {
+        const int r = (order >> (4 * i)) & 15;
+        const int n = r == 0 ? n_act_blocks : r == 1 ? 1 + n_cls : r == 2 ? n_rows : n_overlap_blocks;
+        if (b < n) role = r; else b -= n;
+    }
+    if (role == 0) {
+        const int idx = b * tm_groups_per_block(d) + tm_group_of(d, threadIdx.x);
+        const bool ok = idx < n_active;
+        const int a = ok ? d.active_cols[p][idx] : 0;
+        tm_activate_column<true>(d, p, 1, ok, a, idx, tm_pred_words(d, p, ok, a));
+        fan_signal(d, p, b);
+        return;
+    }
+    if (role == 1) {
+        fan_wait(d, p, (uint32_t)n_act_blocks);
+        role_mid<256>(d, p, n_active, 1, learning, b, n_cls, 1);
+        return;
+    }
+    if (role == 2) {
+        if (n_overlap_blocks > 0) role_sp_row<256, true>(d, p, bank, n_inputs, 0, b, threadIdx.x);
+        else role_sp_row<256>(d, p, bank, n_inputs, 0, b, threadIdx.x);
+        return;
+    }
+    if (role == 3) {
+        role_overlap<256>(d, bank, n_inputs, G, p, p ^ 1, 1, b, n_overlap_blocks, (uint32_t *)dyn_lds, 1, n_rows > 0 ? 2 : 1);
+        return;
+    }
+    if (b < n_duty_blocks) {
+        const int c = b * 256 + (int)threadIdx.x;
+        if (c < d.C) {
+            float dc = d.duty[c] * d.mom;
+            if ((d.colbits[p][c >> 5] >> (c & 31)) & 1u) dc = dc + d.dinc;
+            d.duty[c] = dc;
+        }
+        return;
+    }
+    b -= n_duty_blocks;
+    if (b < n_clear_blocks) {                          // (see k_act_rows)
+        for (int w = b * 256 + (int)threadIdx.x; w < d.C * d.WPC; w += n_clear_blocks * 256) {
+            const int cc = w >> (d.LK - 5);
+            d.pred[p][w] = 0;
+            if (!((d.colbits[p][cc >> 5] >> (cc & 31)) & 1u)) { d.act[p][w] = 0; d.win[p][w] = 0; }
+        }
+        return;
+    }
+    b -= n_clear_blocks;
+    const int nz = (int)gridDim.x - n_act_blocks - 1 - n_cls - n_rows - n_overlap_blocks - n_duty_blocks - n_clear_blocks;      // (see k_mid_rows)
+    const int words4 = (d.ctr->S + 127) >> 7;
+    uint4 *mb = (uint4 *)d.match_bits[p];
+    for (int i = b * 256 + (int)threadIdx.x; i < words4; i += nz * 256) mb[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+
 // the emit blocks wait for each other's records: they come first in the grid (all resident whatever the others do);
 // then the learning role, whose items are the longest chains; then the scan
 // TAB: the scan looks active cells up in the LDS tables of the step's select finish and activation (role_scan) -- the
@@ -213,6 +321,9 @@ __global__ __launch_bounds__(256, MINW) void k_learn_scan_emit(Dev d, int p, int
     static_assert(!(LARGE && TAB), "the streaming scan reads the cell words from memory");
     const bool dyn = LARGE && n_scan_blocks > 0;
     if (n_scan_blocks < 0) n_scan_blocks = -n_scan_blocks;
+    // (the fan-in counters of the step's first launch, k_act_mid_rows, are this launch's to reset: it always follows that one, whatever
+    // schedule the steps before and after take)
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x < FAN_COUNTERS) d.fan[(size_t)(p * FAN_COUNTERS + (int)threadIdx.x) * FAN_STRIDE] = 0u;
     int b = blockIdx.x, scan_blk;
     if (b < n_emit_blocks) {
         role_emit(d, p ^ 1, 1, 1, 0, b, n_emit_blocks, (EmitShared *)dyn_lds, 1);

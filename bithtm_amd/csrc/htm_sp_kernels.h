@@ -38,8 +38,12 @@ __global__ __launch_bounds__(256) void k_sp_build_mask(Dev d, int row_begin, int
 #endif
 template <int BS>
 // wmode: the histogram of the windowed select (win_bin) instead of the top key digit
+// fold (two-launch schedule, k_act_mid_rows: the overlap of step p's successor in the launch that updates step p's permanence
+// rows): the role also applies step p's duty-cycle update (regularizations.py:19-21) to every column it finishes -- 1: all of
+// them; 2: not the winners of step p (colbits[p]), whose rows are being rewritten in this very launch: their row blocks count
+// the new row against the coming input themselves (role_sp_row, OWN) and leave key, bin and duty cycle
 __device__ __forceinline__ void role_overlap(const Dev &d, const uint32_t *__restrict__ bank, int n_inputs, int G,
-                                             int p, int sp, int step_offset, int blk, int nblk, uint32_t *h, int wmode = 0) {
+                                             int p, int sp, int step_offset, int blk, int nblk, uint32_t *h, int wmode = 0, int fold = 0) {
     const int gtid = blk * BS + threadIdx.x;
     const int nthreads = nblk * BS;
     uint32_t *ghist = d.hist + sp * SEL_MAX_PASSES * SEL_BINS;
@@ -60,23 +64,20 @@ __device__ __forceinline__ void role_overlap(const Dev &d, const uint32_t *__res
     const bool spread = G == 8;
     const int first_row0 = d.c0 + wave * rpw * U;
     // the first rows' masks and duty cycles are asked for before anything else: the LDS histogram is zeroed while they travel
-    uint4 m_first[U];
-    float dty_first[U];
+    uint4 m[U];                                    // (the first row group's first chunk; the loop below loads every other into it)
+    float dty_first = 0.f;                         // (a lane that finishes ONE row -- spread -- asks for its duty cycle here; the
+                                                   // first lane of a wider group asks for its four when the counts are in)
+    uint32_t cbw_first = 0u;                       // (fold: the word of step p's column bitmap that holds the row's bit -- asked for
+                                                   // with the duty cycle where a lane finishes ONE row; else when the row is finished)
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const int row = first_row0 + u * rpw + sub;
-        m_first[u] = (row < d.c1 && l < d.W4) ? mask4[(size_t)row * d.W4 + l] : make_uint4(0, 0, 0, 0);
-        dty_first[u] = 0.f;
+        m[u] = (row < d.c1 && l < d.W4) ? mask4[(size_t)row * d.W4 + l] : make_uint4(0, 0, 0, 0);
     }
     if (spread) {
         const int row = first_row0 + (l & 3) * rpw + sub;
-        dty_first[0] = (l < U && row < d.c1) ? d.duty[row] : 0.f;
-    } else {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int row = first_row0 + u * rpw + sub;
-            dty_first[u] = (l == 0 && row < d.c1) ? d.duty[row] : 0.f;
-        }
+        dty_first = (l < U && row < d.c1) ? d.duty[row] : 0.f;
+        if (fold) cbw_first = (l < U && row < d.c1) ? d.colbits[p][row >> 5] : 0u;
     }
     for (int i = gtid; i < (d.sel_passes - 1) * SEL_BINS; i += nthreads) ghist[SEL_BINS + i] = 0;
     for (int i = threadIdx.x; i < SEL_BINS; i += BS) h[i] = 0;
@@ -90,8 +91,16 @@ __device__ __forceinline__ void role_overlap(const Dev &d, const uint32_t *__res
     static_assert(WIN_BINS <= SEL_BINS - SEL_COARSE, "the runs' sums live behind the window's bins in the LDS histogram");
     uint32_t *hc = h + SEL_BINS - SEL_COARSE;       // (window mode only)
     // one row's share of the step: overlap (projections.py:18-21), boosted overlap (regularizations.py:15-17), key, bin
-    auto finish_row = [&](bool owner, int row, int cn, float duty) {
+    auto finish_row = [&](bool owner, int row, int cn, float duty, uint32_t cbw) {
         u64 key = 0;
+        if (owner && fold) {                       // step p's duty cycle first: float32, two separately rounded operations
+            duty = duty * d.mom;
+            if ((cbw >> (row & 31)) & 1u) {
+                if (fold == 2) owner = false;
+                else duty = duty + d.dinc;
+            }
+            if (owner) d.duty[row] = duty;
+        }
         if (owner) {
             d.overlap[sp][row] = cn;
             const float f = htm_exp_f32(d.coef * duty);                // float32 product, documented exp
@@ -113,30 +122,22 @@ __device__ __forceinline__ void role_overlap(const Dev &d, const uint32_t *__res
     for (int row0 = first_row0; row0 < d.c1; row0 += nwaves * rpw * U) {
         const bool first = row0 == first_row0;
         int cnt[U];
-        float dty[U];                              // fetched with the mask rows, not after the reduction
+        float dty = dty_first;                     // (spread: fetched with the mask rows, not after the reduction)
+        uint32_t cbw = cbw_first;
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            cnt[u] = 0;
-            dty[u] = dty_first[u];
+        for (int u = 0; u < U; ++u) cnt[u] = 0;
+        if (!first && spread) {
+            const int row = row0 + (l & 3) * rpw + sub;
+            dty = (l < U && row < d.c1) ? d.duty[row] : 0.f;
+            if (fold) cbw = (l < U && row < d.c1) ? d.colbits[p][row >> 5] : 0u;
         }
-        if (!first) {
-            if (spread) {
-                const int row = row0 + (l & 3) * rpw + sub;
-                dty[0] = (l < U && row < d.c1) ? d.duty[row] : 0.f;
-            } else {
+        for (int j = l; j < d.W4; j += G) {
+            if (!(first && j == l)) {              // the mask rows first: they do not wait for the step counter
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const int row = row0 + u * rpw + sub;
-                    dty[u] = (l == 0 && row < d.c1) ? d.duty[row] : 0.f;
+                    m[u] = row < d.c1 ? mask4[(size_t)row * d.W4 + j] : make_uint4(0, 0, 0, 0);
                 }
-            }
-        }
-        for (int j = l; j < d.W4; j += G) {
-            uint4 m[U];                            // the mask rows first: they do not wait for the step counter
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int row = row0 + u * rpw + sub;
-                m[u] = (first && j == l) ? m_first[u] : (row < d.c1 ? mask4[(size_t)row * d.W4 + j] : make_uint4(0, 0, 0, 0));
             }
             const uint4 x = in4[j];
 #pragma unroll
@@ -152,14 +153,15 @@ __device__ __forceinline__ void role_overlap(const Dev &d, const uint32_t *__res
                 if (l == u) mine = cn;
             }
             const int row = row0 + (l & 3) * rpw + sub;
-            finish_row(l < U && row < d.c1, row, mine, dty[0]);
+            finish_row(l < U && row < d.c1, row, mine, dty, cbw);
         } else {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 int cn = cnt[u];
                 for (int o = G >> 1; o > 0; o >>= 1) cn += __shfl_xor(cn, o);
                 const int row = row0 + u * rpw + sub;
-                finish_row(l == 0 && row < d.c1, row, cn, dty[u]);
+                const bool mine = l == 0 && row < d.c1;
+                finish_row(mine, row, cn, mine ? d.duty[row] : 0.f, (fold && mine) ? d.colbits[p][row >> 5] : 0u);
             }
         }
     }
@@ -415,24 +417,33 @@ __device__ __forceinline__ ColumnWords tm_column_words(const Dev &d, int p, int 
 }
 
 // store the words of active column a, the idx-th of the ascending active list: lane 32 * h of the group writes word h
+// WT: the stores go through to memory (agent scope) -- the two-launch schedule, whose middle role reads them in the SAME
+// launch, from whichever XCD its blocks run on (k_act_mid_rows)
+template <bool WT = false, typename T>
+__device__ __forceinline__ void tm_put(T *ptr, T v) {
+    if (WT) __hip_atomic_store(ptr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *ptr = v;
+}
+template <bool WT = false>
 __device__ __forceinline__ void tm_store_column(const Dev &d, int p, bool col_ok, int a, int idx, const ColumnWords &w) {
     const int j = lane_id() & (d.KP - 1);
     if (col_ok && (j & 31) == 0) {
         const int h = j >> 5, wi = a * d.WPC + h, s = idx * d.WPC + h;
         const uint32_t act = (uint32_t)(w.act >> (32 * h)), win = (uint32_t)(w.winner >> (32 * h));
-        d.act[p][wi] = act;
-        d.win[p][wi] = win;
-        if (h == 0) d.bursting[idx] = w.burst ? 1 : 0;
-        d.actw_id[s] = wi;
-        d.unacc_word[s] = (uint32_t)(w.unacc >> (32 * h));
-        d.winw_idx[s] = win;
-        d.actcnt[s] = (uint8_t)__popc(act);
-        d.act_list[s] = act;
+        tm_put<WT>(&d.act[p][wi], act);
+        tm_put<WT>(&d.win[p][wi], win);
+        if (h == 0) tm_put<WT>(&d.bursting[idx], (uint8_t)(w.burst ? 1 : 0));
+        tm_put<WT>(&d.actw_id[s], wi);
+        tm_put<WT>(&d.unacc_word[s], (uint32_t)(w.unacc >> (32 * h)));
+        tm_put<WT>(&d.winw_idx[s], win);
+        tm_put<WT>(&d.actcnt[s], (uint8_t)__popc(act));
+        tm_put<WT>(&d.act_list[s], act);
     }
 }
 
+template <bool WT = false>
 __device__ __forceinline__ void tm_activate_column(const Dev &d, int p, int want_winner, bool col_ok, int a, int idx, u64 pw) {
-    tm_store_column(d, p, col_ok, a, idx, tm_column_words(d, p, want_winner, col_ok, a, pw));
+    tm_store_column<WT>(d, p, col_ok, a, idx, tm_column_words(d, p, want_winner, col_ok, a, pw));
 }
 
 // the active column a lane group of a 256-thread block takes: groups per block = 256 / KP, this thread's = tid / KP

@@ -141,18 +141,31 @@ __device__ __forceinline__ void shard_bind(const Dev &d, int p, int gid, int cel
 #else
 #define ROW_STAMP(i) do { } while (0)
 #endif
-template <int TPR>
 // p: parity of the step the rows belong to; ahead = 1 when that step's index is not published yet
 // (the row update runs beside the previous step's scan): it is step[p ^ 1] + 1 then
+// OWN (two-launch schedule, k_act_mid_rows; unsharded, the windowed select): the block also does, for its column, what the
+// overlap role of the same launch does for the columns that did not win (role_overlap, fold = 2) -- step p's duty-cycle update
+// (regularizations.py:19-21: this column won), the overlap of the NEW connected bits with the coming step's input
+// (projections.py:18-21), boosted overlap and key (regularizations.py:15-17), the key's bin of the select histogram.  The new
+// mask words are in the ballots of the pass: no other block has to wait for them.
+template <int TPR, bool OWN = false>
 __device__ __forceinline__ void role_sp_row(const Dev &d, int p, const uint32_t *__restrict__ bank, int n_inputs, int ahead, int ri, int t) {
     ROW_STAMP(0);
     const uint32_t step = ahead ? d.ctr->step[p ^ 1] + 1u : d.ctr->step[p];
     const uint32_t *in = bank + (size_t)(step % (uint32_t)n_inputs) * d.W;
+    const uint32_t *in_next = bank + (size_t)((step + 1u) % (uint32_t)n_inputs) * d.W;
     const int row = d.active_cols[p][ri];
     if (row < d.c0 || row >= d.c1) return;          // another rank's column
     ROW_STAMP(1);
     double *prow = d.perm + (size_t)row * d.Ipad;
     uint32_t *mrow = d.mask + (size_t)row * d.W;
+    float duty0 = 0.f;                              // (asked for now, used when the row is done)
+    uint32_t wbase = 0u;
+    if (OWN && t == 0) {
+        duty0 = d.duty[row];
+        wbase = d.ctr->sel_win[p ^ 1];
+    }
+    int own_cn = 0;
     for (int i0 = 0; i0 < d.Ipad; i0 += 2 * TPR) {
         const int e0 = i0 + 2 * t;                   // Ipad is a multiple of 128: e0 + 1 < Ipad whenever e0 < Ipad
         bool c0 = false, c1 = false;
@@ -177,10 +190,41 @@ __device__ __forceinline__ void role_sp_row(const Dev &d, int p, const uint32_t 
         const int base = i0 + 2 * (t & ~63);
         if (lane_id() == 0 && base < d.Ipad) {
             u64 *mw = (u64 *)&mrow[base >> 5];
-            mw[0] = spread32((uint32_t)b0) | (spread32((uint32_t)b1) << 1);
-            mw[1] = spread32((uint32_t)(b0 >> 32)) | (spread32((uint32_t)(b1 >> 32)) << 1);
+            const u64 m0 = spread32((uint32_t)b0) | (spread32((uint32_t)b1) << 1);
+            const u64 m1 = spread32((uint32_t)(b0 >> 32)) | (spread32((uint32_t)(b1 >> 32)) << 1);
+            mw[0] = m0;
+            mw[1] = m1;
+            if (OWN) {
+                const u64 *nx = (const u64 *)&in_next[base >> 5];
+                own_cn += __popcll(m0 & nx[0]) + __popcll(m1 & nx[1]);
+            }
         }
         if (i0 == 0) ROW_STAMP(3); else ROW_STAMP(5);
+    }
+    if (OWN) {
+        __shared__ int s_own[TPR / 64];
+        if (lane_id() == 0) s_own[t >> 6] = own_cn;
+        __syncthreads();
+        if (t == 0) {
+            int cn = 0;
+#pragma unroll
+            for (int wv = 0; wv < TPR / 64; ++wv) cn += s_own[wv];
+            const int sp = p ^ 1;
+            float dc = duty0 * d.mom;               // float32, two separately rounded operations
+            dc = dc + d.dinc;
+            d.duty[row] = dc;
+            d.overlap[sp][row] = cn;
+            const float f = htm_exp_f32(d.coef * dc);
+            const double bo = (double)f * (double)cn;
+            d.boosted[sp][row] = bo;
+            const u64 key = select_key(bo);
+            d.key[sp][row] = key;
+            const uint32_t bin = win_bin(key, wbase);
+            if (bin != 0u) {                        // (as role_overlap's flush, straight to the copies)
+                atomicAdd(d.hist0 + (size_t)sp * HIST0_PAR + (size_t)(ri & (HIST_REP - 1)) * SEL_BINS + bin, 1u);
+                atomicAdd(d.hist0 + (size_t)sp * HIST0_PAR + HIST0_FINE + (size_t)(ri & (COARSE_REP - 1)) * COARSE_STRIDE + (bin >> 6), 1u);
+            }
+        }
     }
 }
 
@@ -195,8 +239,16 @@ __device__ __forceinline__ void role_sp_row(const Dev &d, int p, const uint32_t 
 //                fused with the rebuild of that row's connected mask: independent of the TM work and
 //                bandwidth-bound, it rides along with the latency-bound block 0
 // block 0 and the classify blocks 1..n_cls of the middle launch (below)
+// same_launch: the activation ran in THIS launch (k_act_mid_rows, behind its fan-in) and so do the clears of the dense words of
+// inactive columns -- a winner bit counts only on a column of the step's bitmap (what the cleared words say everywhere else),
+// and what the activation wrote is read with agent-scope loads: past this XCD's L2, which may hold the lines as they were.
+// (An acquire fence instead -- buffer_inv sc1 by each of the role's 1 540 waves -- took the launch from 11 to 26 us.)
+template <typename T>
+__device__ __forceinline__ T ld_agent(const T *ptr, int same_launch) {
+    return same_launch ? __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *ptr;
+}
 template <int BS>
-__device__ __forceinline__ void role_mid(const Dev &d, int p, int n_active, int want_winner, int learning, int blk, int n_cls) {
+__device__ __forceinline__ void role_mid(const Dev &d, int p, int n_active, int want_winner, int learning, int blk, int n_cls, int same_launch = 0) {
     Counters *c = d.ctr;
     if (blk > 0) {
         // Which of the previous matching segments learn, which are punished.  The scan left one bit per row; the
@@ -210,15 +262,18 @@ __device__ __forceinline__ void role_mid(const Dev &d, int p, int n_active, int 
             const int cell = d.seg_cell[seg];
             const float jit = d.seg_jit[seg];
             const int cw = cell >> 5, cb = cell & 31, col = cell >> d.LK;               // (the cell's word in the dense arrays; its column)
-            const bool is_winner = (d.win[p][cw] >> cb) & 1u;
+            const bool on_col = (d.colbits[p][col >> 5] >> (col & 31)) & 1u;
+            const bool is_winner = ((ld_agent(&d.win[p][cw], same_launch) >> cb) & 1u) && (on_col || !same_launch);
             const bool unpred = !((d.pred[q][cw] >> cb) & 1u);                           // :266
             const bool best = fabsf(jit - __uint_as_float(d.cellmax[q][cell])) < d.eps;  // :267
             learn = is_winner && ((info >> 31) || (unpred && best));                     // :268
             // (a column is inactive: not on the step's column bitmap -- a column of 64 cell slots may be active with one of
             // its two active words empty)
-            punish = d.punish ? (d.punish[cw] >> cb) & 1u : !((d.colbits[p][col >> 5] >> (col & 31)) & 1u);      // :269
+            punish = d.punish ? (d.punish[cw] >> cb) & 1u : !on_col;      // :269
         };
-        if (n <= (d.cls_rows_max >= 0 ? d.cls_rows_max : 8 * n_cls * BS)) {
+        // (... up to 8 rows per thread; 2 where the role's blocks wait for the activation of their own launch: few blocks, whatever they
+        // do after the wait is at the end of the launch's longest chain)
+        if (n <= (d.cls_rows_max >= 0 ? d.cls_rows_max : (same_launch ? 2 : 8) * n_cls * BS)) {
             // small pools: one row per thread, so that the rows of a word -- segments created together match together --
             // are classified side by side, not one after the other
             for (int i0 = (blk - 1) * BS; i0 < n; i0 += n_cls * BS) {
@@ -326,14 +381,28 @@ __device__ __forceinline__ void role_mid(const Dev &d, int p, int n_active, int 
         uint32_t ww[LPT], uw[LPT];                 // (counts are recomputed from the words: the launch is capped at 64 registers)
         int a[LPT];
         uint32_t vsum = 0;
-        if (i0 < n_slots) {                        // 16-byte loads (the arrays are padded by 8 entries), masked below
+        u64 ac = 0;
+        if (i0 < n_slots && same_launch) {         // (agent-scope loads, 8 bytes each: the arrays are padded by 8 entries)
+#pragma unroll
+            for (int j = 0; j < LPT; j += 2) {
+                const u64 av = __hip_atomic_load((const u64 *)(d.actw_id + i0 + j), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const u64 wv = __hip_atomic_load((const u64 *)(d.winw_idx + i0 + j), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const u64 uv = __hip_atomic_load((const u64 *)(d.unacc_word + i0 + j), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                a[j] = (int)(uint32_t)av; a[j + 1] = (int)(uint32_t)(av >> 32);
+                ww[j] = (uint32_t)wv; ww[j + 1] = (uint32_t)(wv >> 32);
+                uw[j] = (uint32_t)uv; uw[j + 1] = (uint32_t)(uv >> 32);
+            }
+            ac = __hip_atomic_load((const u64 *)(d.actcnt + i0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (i0 < n_slots) {                 // 16-byte loads (the arrays are padded by 8 entries), masked below
             const int4 a0 = *(const int4 *)(d.actw_id + i0), a1 = *(const int4 *)(d.actw_id + i0 + 4);
             const uint4 w0 = *(const uint4 *)(d.winw_idx + i0), w1 = *(const uint4 *)(d.winw_idx + i0 + 4);
             const uint4 u0 = *(const uint4 *)(d.unacc_word + i0), u1 = *(const uint4 *)(d.unacc_word + i0 + 4);
-            const u64 ac = *(const u64 *)(d.actcnt + i0);
+            ac = *(const u64 *)(d.actcnt + i0);
             a[0] = a0.x; a[1] = a0.y; a[2] = a0.z; a[3] = a0.w; a[4] = a1.x; a[5] = a1.y; a[6] = a1.z; a[7] = a1.w;
             ww[0] = w0.x; ww[1] = w0.y; ww[2] = w0.z; ww[3] = w0.w; ww[4] = w1.x; ww[5] = w1.y; ww[6] = w1.z; ww[7] = w1.w;
             uw[0] = u0.x; uw[1] = u0.y; uw[2] = u0.z; uw[3] = u0.w; uw[4] = u1.x; uw[5] = u1.y; uw[6] = u1.z; uw[7] = u1.w;
+        }
+        if (i0 < n_slots) {
 #pragma unroll
             for (int j = 0; j < LPT; ++j) {
                 const bool ok = i0 + j < n_slots;

@@ -264,16 +264,17 @@ def large_pool_oracle():
     return dict(w=w, noisy=noisy, ora=ora, o_sp=o_sp, o_tm=o_tm, n=n)
 
 
-@pytest.mark.parametrize("lean", [True, False], ids=["three-launches", "four-launches"])
-def test_full_size_pool_outgrows_the_resident_scan_in_mid_run(large_pool_oracle, lean, monkeypatch):
+@pytest.mark.parametrize("launches", [2, 3, 4], ids=["two-launches", "three-launches", "four-launches"])
+def test_full_size_pool_outgrows_the_resident_scan_in_mid_run(large_pool_oracle, launches, monkeypatch):
     """The headline shape fed 350 patterns instead of 50: the pool crosses the large-pool threshold in the middle of a
     stream of htm.run calls (graph keys change, the last launch becomes k_learn_scan_emit<E, 4, false>: the streaming scan
     beside the learning role and the select finish -- or k_scan_sel<*, 1> in the four-launch schedule).  From scratch
     against the from-scratch oracle: last step's outputs, every potential, the per-cell maxima, the whole state."""
     import bench
     from hip_impl import compare_store_with_oracle, step_outputs
-    if not lean:
-        monkeypatch.setenv("BITHTM_LEAN", "0")
+    lean = launches < 4
+    if launches != 2:                              # (two is the default)
+        monkeypatch.setenv("BITHTM_LEAN", "1" if launches == 3 else "0")
     f = large_pool_oracle
     w, noisy, ora, n = f["w"], f["noisy"], f["ora"], f["n"]
     K = w["cell_dim"]
@@ -293,6 +294,7 @@ def test_full_size_pool_outgrows_the_resident_scan_in_mid_run(large_pool_oracle,
     names = set(eng.profile_read())
     eng.profile(False)
     assert ("tm_learn+tm_scan_large+sp_emit" if lean else "tm_scan_large+sp_select") in names, names
+    assert ("tm_activate+tm_mid+sp_learn+sp_overlap" in names) == (launches == 2) and ("tm_mid+sp_overlap" in names) == (launches == 3), names
     assert not ({"tm_learn+tm_scan+sp_emit", "tm_scan+sp_select", "tm_scan"} & names), names
     info = eng.check_capacity()
     assert info.step_index == n and info.segments == ora.temporal_memory.S

@@ -330,11 +330,21 @@ def test_batched_run_equals_step_by_step(eager_below, monkeypatch):
                                  # the large-pool form of the learn / punish classification (32-row words listed per block)
                                  {"BITHTM_CLASSIFY_WORDS_ABOVE": "0"}, {"BITHTM_CLASSIFY_WORDS_ABOVE": "0", "BITHTM_SCAN_LARGE": "1"},
                                  # the library's default call policy (conftest.py asks for graphs whatever the call's length)
-                                 {"BITHTM_EAGER_BELOW": "64"}, {"BITHTM_EAGER_BELOW": "64", "BITHTM_LEAN": "0"}],
+                                 {"BITHTM_EAGER_BELOW": "64"}, {"BITHTM_EAGER_BELOW": "64", "BITHTM_LEAN": "0"},
+                                 # The default is two launches per step (k_act_mid_rows: the middle role behind an in-launch fan-in of the
+                                 # activation blocks, winner rows that count their own new bits against the coming input): everything above
+                                 # without a BITHTM_LEAN runs it; here with grids of a few blocks and every grid order of its roles ...
+                                 {"BITHTM_LEAN_OVERLAP": "3", "BITHTM_LEAN2_CLASSIFY": "2", "BITHTM_LEAN_SCAN": "3", "BITHTM_LEAN_LEARN": "2"},
+                                 {"BITHTM_LEAN2_ORDER": "0123"}, {"BITHTM_LEAN2_ORDER": "3201", "BITHTM_LEAN2_CLASSIFY": "5"}, {"BITHTM_LEAN2_ORDER": "2031", "BITHTM_LEAN2_CLASSIFY": "300"},
+                                 # ... and the three-launch schedule (k_act_rows, k_mid_overlap): alone, with a window that always misses, with
+                                 # grids of a few blocks, with both forms of the classification and of the scan, under the default call policy
+                                 {"BITHTM_LEAN": "1"}, {"BITHTM_LEAN": "1", "BITHTM_SEL_WINDOW_OFFSET": "4000"}, {"BITHTM_LEAN": "1", "BITHTM_EAGER_BELOW": "64"},
+                                 {"BITHTM_LEAN": "1", "BITHTM_LEAN_OVERLAP": "3", "BITHTM_LEAN_SCAN": "3", "BITHTM_LEAN_LEARN": "2"},
+                                 {"BITHTM_LEAN": "1", "BITHTM_CLASSIFY_WORDS_ABOVE": "0", "BITHTM_SCAN_LARGE": "1"}, {"BITHTM_LEAN": "1", "BITHTM_SCAN_LARGE_ABOVE": "1500"}],
                          ids=lambda e: ",".join(f"{k[7:]}={v}" for k, v in e.items()) or "default")
 def test_pipelined_schedules_and_select_paths_equal_step_by_step(env, monkeypatch):
-    """htm.run in its pipelined schedules -- three launches per step (the learning role scanning its own rows beside the
-    scan, the one-pass windowed select) and the four-launch one -- against process(), with the select forced down every
+    """htm.run in its pipelined schedules -- two launches per step (the default), three (the learning role scanning its own rows
+    beside the scan, the one-pass windowed select; both share their last launch) and the four-launch one -- against process(), with the select forced down every
     path: a window that always misses (exact fallback each step), records that overflow (slots 0 / 1), the tie merge
     (pairwise 0; others 0 = radix refinement only; SPECULATE 0 = without the shortcut "the k-th key is the heaviest key"), the
     cut to the k-th key's sub-bin that a crowded bin gets before it is ranked (ZOOM 0: every merge; 3: some), and grids of a
@@ -371,7 +381,8 @@ def test_pipelined_schedules_and_select_paths_equal_step_by_step(env, monkeypatc
             assert np.array_equal(a, b)
 
 
-@pytest.mark.parametrize("env", [{}, {"BITHTM_SCAN_LARGE": "1"}, {"BITHTM_SCAN_LARGE_ABOVE": "600"}, {"BITHTM_EAGER_BELOW": "64"}],
+@pytest.mark.parametrize("env", [{}, {"BITHTM_SCAN_LARGE": "1"}, {"BITHTM_SCAN_LARGE_ABOVE": "600"}, {"BITHTM_EAGER_BELOW": "64"}, {"BITHTM_LEAN": "1"},
+                                 {"BITHTM_LEAN": "1", "BITHTM_EAGER_BELOW": "64"}],
                          ids=lambda e: ",".join(f"{k[7:]}={v}" for k, v in e.items()) or "default")
 def test_random_call_patterns_equal_step_by_step(env, monkeypatch):
     """Seeded random sequences of htm.run (graph / eager, continuing or not, learning on or off, run lengths on either
@@ -784,7 +795,8 @@ def test_up_to_64_cells_per_column_run_the_fused_step(K):
     import os
     outs = []
     for mode, env in (("process", {}), ("graph", {}), ("eager", {}), ("continuing", {}), ("graph", {"BITHTM_LEAN": "0"}), ("graph", {"BITHTM_SCAN_LARGE": "1"}),
-                      ("graph", {"BITHTM_SCAN_LARGE": "1", "BITHTM_SCAN_DYN": "0"}), ("graph", {"BITHTM_FUSE_TM": "0"})):
+                      ("graph", {"BITHTM_SCAN_LARGE": "1", "BITHTM_SCAN_DYN": "0"}), ("graph", {"BITHTM_FUSE_TM": "0"}), ("graph", {"BITHTM_LEAN": "1"}),
+                      ("eager", {"BITHTM_LEAN": "1"})):
         os.environ.update(env)
         try:
             htm = make()

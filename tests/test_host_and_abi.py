@@ -43,6 +43,10 @@ def test_the_three_launches_keep_their_register_budget():
         assert r["scratch_bytes_per_lane"] == 0, (name, r)
     for name, r in timed.items():
         assert r["vgprs"] <= 80 and r["occupancy"] >= 6, (name, r)
+    # ... and the first launch of the default, two-launch schedule to 8 blocks per CU (every block of the bench shape resident at once)
+    # with no more scratch than it was measured with (24 bytes per lane, all of them the middle role's: the same role costs k_mid_rows 20)
+    first = [v for k, v in res.items() if "k_act_mid_rows" in k]
+    assert len(first) == 1 and first[0]["occupancy"] >= 8 and first[0]["scratch_bytes_per_lane"] <= 24, first
 
 
 def test_create_rejects_bad_config_without_touching_a_gpu(lib):

@@ -2,10 +2,11 @@
 check every 50 000 steps; prints the segment count, the number of select fallbacks and a digest of the final
 segment store and duty cycles (the two runs must agree: the path is deterministic).
 
-    python tools/soak.py            # the headline workload (50 patterns)
+    python tools/soak.py            # the headline workload (50 patterns): twice as the library schedules it (two launches per step)
+                                    # and once in the three-launch schedule -- three digests that must agree
     python tools/soak.py large      # bench.py's large_pool workload (350 patterns): 40 000 steps, twice as the library
-                                    # schedules them and once each with fixed scan shares and in the four-launch schedule --
-                                    # four digests that must all agree (different kernels, one result)
+                                    # schedules them and once each with fixed scan shares, in the three-launch and in the
+                                    # four-launch schedule -- five digests that must all agree (different kernels, one result)
 """
 import os, sys, time, hashlib
 import numpy as np
@@ -14,7 +15,7 @@ import bench
 large = len(sys.argv) > 1 and sys.argv[1] == "large"
 w = dict(bench.LARGE_POOL, segment_capacity=3 << 20) if large else dict(bench.WORKLOAD)
 chunks, per_chunk = (8, 5000) if large else (6, 50000)
-variants = [{}, {}, {"BITHTM_SCAN_DYN": "0"}, {"BITHTM_LEAN": "0"}] if large else [{}, {}]
+variants = [{}, {}, {"BITHTM_SCAN_DYN": "0"}, {"BITHTM_LEAN": "1"}, {"BITHTM_LEAN": "0"}] if large else [{}, {}, {"BITHTM_LEAN": "1"}]
 noisy, perm = bench.make_inputs(w)
 digests = []
 for rep, env in enumerate(variants):

@@ -21,8 +21,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 
 LAUNCHES = ("tm_activate+sp_emit", "tm_mid+sp_learn", "tm_learn+sp_overlap", "tm_scan+sp_select")
-LEAN = ("tm_activate+sp_learn", "tm_mid+sp_overlap", "tm_learn+tm_scan+sp_emit", "-")
-LEAN_ON = os.environ.get("BITHTM_LEAN", "1") != "0"
+TWO = os.environ.get("BITHTM_LEAN", "2") == "2"          # the default schedule: two launches per step
+LEAN = ("tm_activate+tm_mid+sp_learn+sp_overlap" if TWO else "tm_activate+sp_learn", "tm_mid+sp_overlap", "tm_learn+tm_scan+sp_emit", "-")
+LEAN_ON = os.environ.get("BITHTM_LEAN", "2") != "0"
 
 
 def roles(launch, k, C):
@@ -31,6 +32,15 @@ def roles(launch, k, C):
     if LEAN_ON:                                      # the three-launch schedule (htm_pipeline.h); block counts as htm_create sets them
         n_act, n_learn = (k * 32 + 255) // 256, int(os.environ.get("BITHTM_LEAN_LEARN", 768 if os.environ.get("TIMELINE_WORKLOAD") == "large" else 512))
         n_ov = int(os.environ.get("BITHTM_LEAN_OVERLAP", 512))
+        if launch == 0 and TWO:      # two launches per step: k_act_mid_rows, its roles in the grid's order
+            m = int(os.environ.get("BITHTM_LEAN2_CLASSIFY", 32))
+            sizes = {"0": (("tm_activate", n_act),), "1": (("tm_mid block 0", 1), ("tm_mid classify", m)), "2": (("sp rows", k),), "3": (("sp_overlap", n_ov),)}
+            out, at = [], 0
+            for digit in os.environ.get("BITHTM_LEAN2_ORDER", "0312"):
+                for name, n in sizes[digit]:
+                    out.append((at, at + n, name))
+                    at += n
+            return tuple(out) + ((at, at + c256, "clear"), (at + c256, 4096, "zero match bits"))
         if launch == 0:
             return ((0, n_act, "tm_activate"), (n_act, n_act + k, "sp rows"), (n_act + k, n_act + k + c256, "sp duty"), (n_act + k + c256, 4096, "clear"))
         if launch == 1:
