@@ -267,8 +267,7 @@ __global__ __launch_bounds__(256, BITHTM_LEAN2_WAVES) void k_act_mid_rows(Dev d,
         return;
     }
     if (role == 1) {
-        fan_wait(d, p, (uint32_t)n_act_blocks);
-        role_mid<256>(d, p, n_active, 1, learning, b, n_cls, 1);
+        role_mid<256>(d, p, n_active, 1, learning, b, n_cls, 1, [&]() { fan_wait(d, p, (uint32_t)n_act_blocks); });
         return;
     }
     if (role == 2) {

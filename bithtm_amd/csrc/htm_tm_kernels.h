@@ -247,8 +247,14 @@ template <typename T>
 __device__ __forceinline__ T ld_agent(const T *ptr, int same_launch) {
     return same_launch ? __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *ptr;
 }
-template <int BS>
-__device__ __forceinline__ void role_mid(const Dev &d, int p, int n_active, int want_winner, int learning, int blk, int n_cls, int same_launch = 0) {
+// wait: called once by the whole block, right before the first read of anything the activation wrote -- k_act_mid_rows passes its
+// fan-in there; everything the role can fetch and decide WITHOUT the activation's output is done before (a classification
+// block: the match words, its first rows' owner cells, jitter, prediction bits and per-cell maxima -- three round trips that
+// now run under the activation instead of behind it)
+struct NoWait { __device__ __forceinline__ void operator()() const {} };
+template <int BS, typename Wait = NoWait>
+__device__ __forceinline__ void role_mid(const Dev &d, int p, int n_active, int want_winner, int learning, int blk, int n_cls, int same_launch = 0,
+                                         Wait wait = Wait()) {
     Counters *c = d.ctr;
     if (blk > 0) {
         // Which of the previous matching segments learn, which are punished.  The scan left one bit per row; the
@@ -256,20 +262,25 @@ __device__ __forceinline__ void role_mid(const Dev &d, int p, int n_active, int 
         if (!learning || !c->has_distal) return;
         const int q = p ^ 1;
         const int n = d.world > 1 ? c->L : c->S;     // rows at or above the count of the last scan are not matching
-        // classification of one matching row
-        auto classify = [&](int seg, bool &learn, bool &punish) {
+        // classification of one matching row, in two halves: what does not need the step's winner cells (cand: the row
+        // learns if its cell is a winner), then the winner bit
+        bool waited = false;
+        auto wait_once = [&]() { if (!waited) { wait(); waited = true; } };           // (block-uniform call sites)
+        auto gather = [&](int seg, bool &cand, bool &punish, int &cell) {
             const uint32_t info = d.seg_info[seg];
-            const int cell = d.seg_cell[seg];
+            cell = d.seg_cell[seg];
             const float jit = d.seg_jit[seg];
             const int cw = cell >> 5, cb = cell & 31, col = cell >> d.LK;               // (the cell's word in the dense arrays; its column)
             const bool on_col = (d.colbits[p][col >> 5] >> (col & 31)) & 1u;
-            const bool is_winner = ((ld_agent(&d.win[p][cw], same_launch) >> cb) & 1u) && (on_col || !same_launch);
             const bool unpred = !((d.pred[q][cw] >> cb) & 1u);                           // :266
             const bool best = fabsf(jit - __uint_as_float(d.cellmax[q][cell])) < d.eps;  // :267
-            learn = is_winner && ((info >> 31) || (unpred && best));                     // :268
+            cand = ((info >> 31) || (unpred && best)) && (on_col || !same_launch);       // :268, but for the winner bit
             // (a column is inactive: not on the step's column bitmap -- a column of 64 cell slots may be active with one of
             // its two active words empty)
             punish = d.punish ? (d.punish[cw] >> cb) & 1u : !on_col;      // :269
+        };
+        auto decide = [&](bool cand, int cell) {                                          // :268
+            return cand && ((ld_agent(&d.win[p][cell >> 5], same_launch) >> (cell & 31)) & 1u);
         };
         // (... up to 8 rows per thread; 2 where the role's blocks wait for the activation of their own launch: few blocks, whatever they
         // do after the wait is at the end of the launch's longest chain)
@@ -278,8 +289,11 @@ __device__ __forceinline__ void role_mid(const Dev &d, int p, int n_active, int 
             // are classified side by side, not one after the other
             for (int i0 = (blk - 1) * BS; i0 < n; i0 += n_cls * BS) {
                 const int seg = i0 + (int)threadIdx.x;
-                bool learn = false, punish = false;
-                if (seg < n && ((d.match_bits[q][seg >> 5] >> (seg & 31)) & 1u)) classify(seg, learn, punish);
+                bool cand = false, punish = false;
+                int cell = 0;
+                if (seg < n && ((d.match_bits[q][seg >> 5] >> (seg & 31)) & 1u)) gather(seg, cand, punish, cell);
+                wait_once();
+                const bool learn = decide(cand, cell);
                 if (learn || punish) d.seg_nsyn[seg] |= (int)SEG_BUSY;
                 const u64 ml = __ballot(learn), mp = __ballot(punish);
                 const int n_l = __popcll(ml), n_p = __popcll(mp);
@@ -338,8 +352,11 @@ __device__ __forceinline__ void role_mid(const Dev &d, int p, int n_active, int 
                 const int i = i0 + ((int)threadIdx.x >> 5);
                 const bool on = i < listed && ((s_bits[min(i, BS - 1)] >> (threadIdx.x & 31)) & 1u);
                 const int seg = on ? s_words[i] * 32 + (int)(threadIdx.x & 31) : 0;
-                bool learn = false, punish = false;
-                if (on) classify(seg, learn, punish);
+                bool cand = false, punish = false;
+                int cell = 0;
+                if (on) gather(seg, cand, punish, cell);
+                wait_once();
+                const bool learn = decide(cand, cell);
                 if (learn || punish) d.seg_nsyn[seg] |= (int)SEG_BUSY;
                 const u64 ml = __ballot(learn), mp = __ballot(punish);
                 const int n_l = __popcll(ml), n_p = __popcll(mp);
@@ -376,6 +393,7 @@ __device__ __forceinline__ void role_mid(const Dev &d, int p, int n_active, int 
     // (the lists are per WORD of the active columns: one per column, two where a column has 64 cell slots; a[] = the word's index
     // in the dense arrays, so that word * 32 + bit is the cell)
     const int n_slots = n_active * d.WPC;
+    wait();
     for (int base = 0; base < n_slots; base += LPT * BS) {
         const int i0 = base + LPT * (int)threadIdx.x;
         uint32_t ww[LPT], uw[LPT];                 // (counts are recomputed from the words: the launch is capped at 64 registers)
