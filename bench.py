@@ -78,14 +78,14 @@ def build_htm(w, perm, device, column_range=None):
     return B.HierarchicalTemporalMemory(I, C, K, active_columns=k, spatial_pooler=sp, temporal_memory=tm, device=device)
 
 
-# the launches of the pipelined schedules (htm_pipeline.h) and the roles each holds: three per timestep (the default) ...
+# the launches of the pipelined schedules (htm_pipeline.h) and the roles each holds: three per timestep (BITHTM_LEAN=1) ...
 # (the last launch's name says which form of the scan it holds: small pools are scanned by blocks that are all resident at
 # once, pools of more than ~295 k segments by the streaming form -- htm_engine.hip: scan_pool_is_large)
 LEAN_KERNEL = {"tm_activate+sp_learn": "k_act_rows", "tm_mid+sp_overlap": "k_mid_overlap", "tm_learn+tm_scan+sp_emit": "k_learn_scan_emit",
                "tm_learn+tm_scan_large+sp_emit": "k_learn_scan_emit"}
 LEAN_ROLES = {"tm_activate+sp_learn": ("tm_activate", "sp_rows", "tm_clear"), "tm_mid+sp_overlap": ("tm_mid", "sp_overlap"),
               "tm_learn+tm_scan+sp_emit": ("tm_learn", "tm_scan", "sp_emit"), "tm_learn+tm_scan_large+sp_emit": ("tm_learn", "tm_scan", "sp_emit")}
-# ... two (BITHTM_LEAN=2: the first two in one, the middle role behind an in-launch fan-in) ...
+# ... two (the default: the first two in one, the middle role behind an in-launch fan-in of the activation blocks) ...
 LEAN2_KERNEL = {"tm_activate+tm_mid+sp_learn+sp_overlap": "k_act_mid_rows", "tm_learn+tm_scan+sp_emit": "k_learn_scan_emit",
                 "tm_learn+tm_scan_large+sp_emit": "k_learn_scan_emit"}
 LEAN2_ROLES = {"tm_activate+tm_mid+sp_learn+sp_overlap": ("tm_activate", "sp_rows", "tm_clear", "tm_mid", "sp_overlap"),

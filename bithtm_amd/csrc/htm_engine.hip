@@ -84,6 +84,7 @@ struct htm_handle {
     int seg_hint;                         // a lower bound of the segment count (see scan_spec_blocks)
     int *seg_pinned;                      // pinned word the end of each htm_run copies the count into
     int sp_blocks, sel_blocks, c256_blocks, s1024_blocks, scan_blocks, zero_blocks, lean_learn_blocks, lean_learn_blocks_large, lean_scan_blocks, lean_scan_blocks_large, lean_overlap_blocks, lean2_classify_blocks, lean2_order, cus;
+    bool lean2_classify_set;               // BITHTM_LEAN2_CLASSIFY given: that many classification blocks whatever the pool's size
     const uint32_t *ahead_bank;           // htm_run ended with HTM_RUN_CONTINUE on this bank: the SP has done the next step
     int ahead_n_inputs, ahead_learning;   //   and the front of the one after it
     bool ahead_lean;                      //   ... in the three-launch schedule (else the four-launch one)
@@ -383,7 +384,10 @@ static void enqueue_lean(htm_handle *h, int p, int learning, const uint32_t *ban
     const int n_act = (d.k * d.KP + 255) / 256, n_rows = learning ? d.k : 0;
     const int n_cls = learning ? kClassifyBlocks : 0, n_ov = plan.next_sp ? h->lean_overlap_blocks : 0;
     if (h->knob_lean == 2) {                        // the two-launch schedule: both of these in one (htm_pipeline.h)
-        const int n_cls2 = learning ? h->lean2_classify_blocks : 0;
+        // (a large pool has a classification block read ~250 match words and classify tens of them: more blocks there, though they
+        // are not all resident from the start -- 350-pattern pool of the bench, 1.6 M segments: 32 blocks 11.7 k timesteps/s, 128: 13.3, 256: 13.3,
+        // 384: 13.1; three launches: 12.8)
+        const int n_cls2 = !learning ? 0 : (scan_pool_is_large(h) && !h->lean2_classify_set) ? std::max(h->lean2_classify_blocks, 192) : h->lean2_classify_blocks;
         const int n_duty = n_ov ? 0 : h->c256_blocks, n_clear = d.WPC * h->c256_blocks;
         LAUNCH_ON(h, h->stream, (size_t)SEL_BINS * 4, "tm_activate+tm_mid+sp_learn+sp_overlap", k_act_mid_rows,
                   n_act + 1 + n_cls2 + n_rows + n_ov + n_duty + n_clear + h->zero_blocks, 256, d, p, d.k, n_act, learning, n_cls2, bank, n_inputs, n_rows, h->G, n_ov,
@@ -727,6 +731,7 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
     // launches per step of htm_run's pipelined schedule -- 2 (the default): two (k_act_mid_rows + k_learn_scan_emit); 1: three; 0: four
     h->knob_lean = getenv("BITHTM_LEAN") ? std::max(0, std::min(2, atoi(getenv("BITHTM_LEAN")))) : 2;
     h->lean2_classify_blocks = getenv("BITHTM_LEAN2_CLASSIFY") ? std::max(1, atoi(getenv("BITHTM_LEAN2_CLASSIFY"))) : kClassifyBlocks;
+    h->lean2_classify_set = getenv("BITHTM_LEAN2_CLASSIFY") != nullptr;
     {   // the grid order of k_act_mid_rows' roles (hex digits: 0 activation, 1 middle, 2 rows, 3 overlap); a permutation with 0 before 1
         // (measured at the bench shape, 8 waves per SIMD: 0312 42.4 k timesteps/s, 0321 41.9, 0123 41.2, 3201 40.2)
         const int o = getenv("BITHTM_LEAN2_ORDER") ? (int)strtol(getenv("BITHTM_LEAN2_ORDER"), nullptr, 16) : 0x0312;

@@ -64,6 +64,9 @@ timeout -k 10 300 python tools/step_spans.py 16 > $OUT/step_spans.txt 2>&1
 timeout -k 10 200 python tools/soak.py > $OUT/soak.txt 2>&1
 # the four-launch schedule, for comparison
 BITHTM_LEAN=0 timeout -k 10 300 python bench.py --no-cpu-baseline --no-stress --no-large-pool > $OUT/bench_four_launches.json 2> $OUT/bench_four_launches.log; echo "bench (four launches) exit=$?"
+# ... and the three-launch one (the default of rounds 3 and 4 until the two-launch schedule)
+BITHTM_LEAN=1 timeout -k 10 300 python bench.py --no-cpu-baseline --no-stress --no-large-pool > $OUT/bench_three_launches.json 2> $OUT/bench_three_launches.log; echo "bench (three launches) exit=$?"
+BITHTM_LEAN=1 timeout -k 10 200 python tools/step_timeline.py > $OUT/step_timeline_three_launches.txt 2>&1
 # from scratch: the first 250 steps (every column bursting at first, ~1 300 new segments per step)
 timeout -k 10 200 python bench.py --no-cpu-baseline --no-stress --no-large-pool --pretrain 0 --steps 250 --warmup 0 --reps 1 > $OUT/bench_cold_250.json 2> $OUT/bench_cold_250.log; echo "bench (cold) exit=$?"
 timeout -k 10 200 python tools/pcie_rate.py > $OUT/pcie_rate.txt 2>&1
