@@ -217,7 +217,7 @@ int htm_sp_phase(htm_handle *h, int32_t phase, const void *data, int64_t count);
  * example.py:48-53 runs, with the input bank resident in HBM.  use_graph bit 0: replay captured
  * hipGraphs (one per step, or per 16 steady-state steps) instead of issuing the launches one by one;
  * bit 1: do NOT pipeline.  By default the Spatial Pooler works ahead of the Temporal Memory inside the
- * call -- the next step's overlaps and winner list are computed in the three launches of the current TM step
+ * call -- the next step's overlaps and winner list are computed in the two launches of the current TM step
  * (its permanence and duty-cycle updates are not ahead; in the four-launch schedule a handle falls back to when the
  * scan's column bitmap does not fit the LDS they are) --; it never looks past n_steps, so the state a call leaves
  * behind is exactly that of n_steps htm_step calls. */
@@ -247,7 +247,7 @@ int htm_prepare(htm_handle *h, const uint32_t *device_inputs, int32_t n_inputs, 
  *   HTM_PLAN_GRAPH      the steady-state steps replay hipGraphs (use_graph bit 0 AND n_steps at or above the eager limit,
  *                       64 unless BITHTM_EAGER_BELOW says otherwise, AND no htm_profile collection in progress)
  *   HTM_PLAN_PIPELINED  the Spatial Pooler works ahead of the Temporal Memory (heterogeneous launches)
- *   HTM_PLAN_LEAN       ... in the three-launch schedule (else four launches per step)
+ *   HTM_PLAN_LEAN       ... in the two-launch schedule (three under BITHTM_LEAN=1; else four launches per step)
  *   HTM_PLAN_SCAN_LARGE the segment scan runs in its streaming (large-pool) form
  * Negative: an error status. */
 #define HTM_PLAN_GRAPH 1
