@@ -1,5 +1,6 @@
-// The fused launches of htm_run's pipelined schedules -- three per timestep (below: k_act_rows, k_mid_overlap,
-// k_learn_scan_emit), or four where the scan's column bitmap does not fit the LDS -- and the device-clock trace.
+// The fused launches of htm_run's pipelined schedules -- two per timestep (below: k_act_mid_rows, k_learn_scan_emit), three
+// (BITHTM_LEAN=1: k_act_rows, k_mid_overlap, k_learn_scan_emit), or four where the scan's column bitmap does not fit the LDS
+// -- and the device-clock trace.
 // Part of the single translation unit htm_engine.hip (included there, in this order:
 // htm_dev.h, htm_sp_kernels.h, htm_tm_kernels.h, htm_pipeline.h).
 #ifndef BITHTM_HTM_PIPELINE_H
