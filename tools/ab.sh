@@ -1,3 +1,8 @@
+# A/B helpers for one gpurun call (source this on the GPU box, from the repo root; results under gpurun_out/ab_<name>.*):
+#     source tools/ab.sh && run base && run three BITHTM_LEAN=1 && runlarge large_c128 BITHTM_LEAN2_CLASSIFY=128
+# run: the headline at the default arguments, 3 repetitions, no legs; runlarge: the large_pool leg alone.  Each prints the median
+# rate and the per-launch times of the timed schedule.  Variants are environment knobs or another build of the
+# library (BITHTM_LIBRARY=$PWD/bithtm_amd/<other>.so); join the calls with && so that nothing follows a run that was killed.
 set -e
 run() { # name, env...
   name=$1; shift
