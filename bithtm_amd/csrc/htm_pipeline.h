@@ -233,7 +233,10 @@ __device__ __forceinline__ void fan_wait(const Dev &d, int p, uint32_t target) {
                 if (threadIdx.x == 0) atomicOr(&d.ctr->error, 32);
                 break;
             }
-            __builtin_amdgcn_s_sleep(4);
+#ifndef BITHTM_FAN_SLEEP
+#define BITHTM_FAN_SLEEP 4
+#endif
+            __builtin_amdgcn_s_sleep(BITHTM_FAN_SLEEP);
         }
     }
     __syncthreads();                                                // (what the activation wrote is read with agent-scope loads: role_mid, same_launch)

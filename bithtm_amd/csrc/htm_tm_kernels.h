@@ -453,7 +453,7 @@ __device__ __forceinline__ void role_mid(const Dev &d, int p, int n_active, int 
     }
     n_cells = wave_sum(n_cells);
     if (lane_id() == 0) atomicAdd(&s_cells, n_cells);
-    __syncthreads();
+    lds_barrier();                                  // (LDS only: the winner lists' stores need not be acknowledged for the count to be read)
     const int n_un = (learning && c->has_distal) ? (int)carry_u : 0;
     if (threadIdx.x == 0) {
         c->n_win[p] = want_winner ? (int)carry_w : 0;
