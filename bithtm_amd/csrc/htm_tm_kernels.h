@@ -172,7 +172,8 @@ __device__ __forceinline__ void role_sp_row(const Dev &d, int p, const uint32_t 
         if (e0 < d.Ipad) {
             // (one pass at a time on purpose: with the second pass's loads in flight beside the first's the first pass waits
             // 2.9 us instead of 1.8 and the launch is a microsecond longer -- 1 311 scattered 8-KB rows read at 3-3.7 TB/s
-            // whatever is asked at once: tools/rows_phases.py)
+            // whatever is asked at once: tools/rows_phases.py; again in the two-launch schedule's first launch: 43.65 against 43.85 k
+            // timesteps/s, twice)
             double2 v = *(double2 *)(prow + e0);
             const uint32_t bits = in[e0 >> 5] >> (e0 & 31);
             // (OWN: the coming input's bits of the thread's two elements, asked for with the row -- the lane that stores the mask
