@@ -14,3 +14,8 @@ runlarge() { # name, env...
   env "$@" timeout -k 10 250 python bench.py --large-pool-only --steps 500 --warmup 100 --no-cpu-baseline > gpurun_out/ab_$name.json 2> gpurun_out/ab_$name.err
   echo "$name: $(grep -o 'median [0-9]* timesteps/s' gpurun_out/ab_$name.err | head -1) | $(grep -o 'launches of the timed schedule.*' gpurun_out/ab_$name.err | head -1 | cut -c1-200)"
 }
+rundriver() { # name, env...: the driver's arguments (20 timed steps per call), 15 repetitions, no legs
+  name=$1; shift
+  env "$@" timeout -k 10 150 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-stress --no-large-pool > gpurun_out/ab_$name.json 2> gpurun_out/ab_$name.err
+  echo "$name: $(grep -o 'median [0-9]* timesteps/s (min [0-9]*, max [0-9]*)' gpurun_out/ab_$name.err | head -1)"
+}
