@@ -258,6 +258,10 @@ template <int BS, typename Wait = NoWait>
 __device__ __forceinline__ void role_mid(const Dev &d, int p, int n_active, int want_winner, int learning, int blk, int n_cls, int same_launch = 0,
                                          Wait wait = Wait()) {
     Counters *c = d.ctr;
+    // (the classification blocks' list of non-zero match words; block 0 keeps the 1 024-blocks it recycles from in s_words)
+    __shared__ int s_words[BS];
+    __shared__ uint32_t s_bits[BS];
+    __shared__ int s_nwords;
     if (blk > 0) {
         // Which of the previous matching segments learn, which are punished.  The scan left one bit per row; the
         // items of a wave are appended with one reservation (same-address atomics are slow: ~88 per us).
@@ -323,9 +327,6 @@ __device__ __forceinline__ void role_mid(const Dev &d, int p, int n_active, int 
         // blocks of ONE residue mod 8 -- blocks are dealt round-robin to the 8 XCDs, so a line is fetched into one L2, not
         // eight (a pool of 134 M rows has 17 MB of match bits).  With u = the index of a word among those of the lines
         // L = x mod 8: block 8 * (u mod G8) + x takes it as its (u / G8)-th word.
-        __shared__ int s_words[BS];
-        __shared__ uint32_t s_bits[BS];
-        __shared__ int s_nwords;
         const int nwords = (n + 31) >> 5;
         const bool by_xcd = n_cls % 8 == 0 && n_cls >= 256;
         const int G8 = by_xcd ? n_cls / 8 : 1, x = (blk - 1) & 7, g = (blk - 1) >> 3;
@@ -395,6 +396,11 @@ __device__ __forceinline__ void role_mid(const Dev &d, int p, int n_active, int 
     // (the lists are per WORD of the active columns: one per column, two where a column has 64 cell slots; a[] = the word's index
     // in the dense arrays, so that word * 32 + bit is the cell)
     const int n_slots = n_active * d.WPC;
+    // what the allocation below needs of the PREVIOUS step and of the pool, asked for before the wait: the counts of recyclable
+    // segments per 2^20 ids (their first 256), whether and how many winners the last step had
+    const int nb2 = (nb + 1023) >> 10;
+    const int cnt2_first = ((int)threadIdx.x < 256 && (int)threadIdx.x < nb2) ? d.recyc_cnt2[threadIdx.x] : 0;
+    const int prev_has_winner = c->has_winner[p ^ 1], prev_n_win = c->n_win[p ^ 1];
     wait();
     for (int base = 0; base < n_slots; base += LPT * BS) {
         const int i0 = base + LPT * (int)threadIdx.x;
@@ -467,30 +473,38 @@ __device__ __forceinline__ void role_mid(const Dev &d, int p, int n_active, int 
     uint32_t carry = 0;                       // recyclable segments seen so far
     // the counts per 2^20 ids first (one load): ranges without a recyclable segment are passed over -- a pool of 134 M
     // segments has 130 k per-1024 counts, and walking them 256 at a time took this block 0.3 ms per step
+    // (the barriers of this part order LDS traffic only -- lds_barrier: none of them waits for the acknowledgement of the stores
+    // before it; under the row traffic of the launch each such wait was a microsecond of this block's chain)
     __shared__ int s_cnt2[256];
-    const int nb2 = (nb + 1023) >> 10;
+    constexpr int NEED_LDS = BS / 2;               // needed 1 024-blocks kept in LDS (s_words, as pairs); more go through d.recyc_need
     for (int r0 = 0; r0 < nb2 && carry < (uint32_t)n_un; r0 += 256) {
-        __syncthreads();
-        s_cnt2[threadIdx.x & 255] = ((int)threadIdx.x < 256 && r0 + (int)threadIdx.x < nb2) ? d.recyc_cnt2[r0 + threadIdx.x] : 0;
-        __syncthreads();
+        lds_barrier();
+        s_cnt2[threadIdx.x & 255] = r0 == 0 ? cnt2_first : (((int)threadIdx.x < 256 && r0 + (int)threadIdx.x < nb2) ? d.recyc_cnt2[r0 + threadIdx.x] : 0);
+        lds_barrier();
         for (int r = r0; r < min(r0 + 256, nb2) && carry < (uint32_t)n_un; ++r) {
             if (s_cnt2[r - r0] == 0) continue;
             for (int base = r << 10; base < min(nb, (r + 1) << 10); base += BS) {
                 const int b = base + threadIdx.x;
                 const uint32_t v = base == 0 ? recyc_first : ((b < nb && b < ((r + 1) << 10)) ? (uint32_t)d.recyc_cnt[b] : 0u);
                 uint32_t total;
-                const uint32_t ex = block_excl_scan<BS>(v, s_wave, total);
+                const uint32_t ex = block_excl_scan<BS, true>(v, s_wave, total);
                 if (v > 0 && carry + ex < (uint32_t)n_un) {
                     const int slot = atomicAdd(&s_nneed, 1);
-                    d.recyc_need[2 * slot] = b;
-                    d.recyc_need[2 * slot + 1] = (int)(carry + ex);
+                    if (slot < NEED_LDS) {
+                        s_words[2 * slot] = b;
+                        s_words[2 * slot + 1] = (int)(carry + ex);
+                    } else {
+                        d.recyc_need[2 * slot] = b;
+                        d.recyc_need[2 * slot + 1] = (int)(carry + ex);
+                    }
                 }
                 carry += total;
                 if (carry >= (uint32_t)n_un) break;
             }
         }
     }
-    __syncthreads();
+    lds_barrier();
+    if (s_nneed > NEED_LDS) __syncthreads();       // (entries that went through memory: their stores acknowledged)
     const int n_r = min(n_un, (int)carry);
     int n_new = n_un - n_r;
     if (S + n_new > d.Scap) {
@@ -500,13 +514,13 @@ __device__ __forceinline__ void role_mid(const Dev &d, int p, int n_active, int 
     // the bound segments are queued from the back of the work array (no reservation to wait for);
     // sharded: only the binds to own cells are queued, each with its own reservation at the front
     const bool whole = d.world == 1;
-    __syncthreads();
+    __syncthreads();                                // (this one for memory: the list of winners without a segment, stored by the list pass, is read below)
     const int wbase = d.work_cap - (n_r + n_new);
-    const int n_w = c->has_winner[p ^ 1] ? c->n_win[p ^ 1] : -1;
+    const int n_w = prev_has_winner ? prev_n_win : -1;
     const int grown = n_w > 0 ? min(d.sample, n_w) : 0;
     const int n_need = s_nneed;
     for (int i = 0; i < n_need; ++i) {          // each needed 1024-block: rank its recyclable segments
-        const int b = d.recyc_need[2 * i], off = d.recyc_need[2 * i + 1];
+        const int b = i < NEED_LDS ? s_words[2 * i] : d.recyc_need[2 * i], off = i < NEED_LDS ? s_words[2 * i + 1] : d.recyc_need[2 * i + 1];
         constexpr int IPT = 1024 / BS;             // consecutive segments per thread
         uint32_t fl[IPT], cnt = 0;
 #pragma unroll

@@ -33,7 +33,7 @@ def roles(launch, k, C):
         n_act, n_learn = (k * 32 + 255) // 256, int(os.environ.get("BITHTM_LEAN_LEARN", 768 if os.environ.get("TIMELINE_WORKLOAD") == "large" else 512))
         n_ov = int(os.environ.get("BITHTM_LEAN_OVERLAP", 512))
         if launch == 0 and TWO:      # two launches per step: k_act_mid_rows, its roles in the grid's order
-            m = int(os.environ.get("BITHTM_LEAN2_CLASSIFY", 32))
+            m = int(os.environ.get("BITHTM_LEAN2_CLASSIFY", 192 if os.environ.get("TIMELINE_WORKLOAD") == "large" else 32))
             sizes = {"0": (("tm_activate", n_act),), "1": (("tm_mid block 0", 1), ("tm_mid classify", m)), "2": (("sp rows", k),), "3": (("sp_overlap", n_ov),)}
             out, at = [], 0
             for digit in os.environ.get("BITHTM_LEAN2_ORDER", "0312"):
