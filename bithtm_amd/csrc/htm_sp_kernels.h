@@ -72,7 +72,7 @@ __device__ __forceinline__ void role_overlap(const Dev &d, const uint32_t *__res
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const int row = first_row0 + u * rpw + sub;
-        m[u] = (row < d.c1 && l < d.W4) ? mask4[(size_t)row * d.W4 + l] : make_uint4(0, 0, 0, 0);
+        m[u] = (row < d.c1 && l < d.W4) ? mask4[(uint32_t)row * (uint32_t)d.W4 + (uint32_t)l] : make_uint4(0, 0, 0, 0);
     }
     if (spread) {
         const int row = first_row0 + (l & 3) * rpw + sub;
@@ -136,7 +136,7 @@ __device__ __forceinline__ void role_overlap(const Dev &d, const uint32_t *__res
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const int row = row0 + u * rpw + sub;
-                    m[u] = row < d.c1 ? mask4[(size_t)row * d.W4 + j] : make_uint4(0, 0, 0, 0);
+                    m[u] = row < d.c1 ? mask4[(uint32_t)row * (uint32_t)d.W4 + (uint32_t)j] : make_uint4(0, 0, 0, 0);
                 }
             }
             const uint4 x = in4[j];
