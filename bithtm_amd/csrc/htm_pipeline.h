@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256) void k_mid_overlap(Dev d, int p, int n_active,
     for (int i = b * 256 + (int)threadIdx.x; i < words4; i += nz * 256) mb[i] = make_uint4(0u, 0u, 0u, 0u);
 }
 
-// ---- the two-launch schedule (BITHTM_LEAN=2) ---------------------------------------------------------------------
+// ---- the two-launch schedule (the default; BITHTM_LEAN=2) -----------------------------------------------------------
 // k_act_rows and k_mid_overlap in ONE launch; the last launch stays k_learn_scan_emit:
 //
 //   k_act_mid_rows(t)     activate(t) -> fan-in -> mid(t), clears, match-bit zeroing
@@ -206,15 +206,19 @@ __global__ __launch_bounds__(256) void k_mid_overlap(Dev d, int p, int n_active,
 //   k_learn_scan_emit(t)  learn(t) + scan(t)                                 | emit(t+1)
 //
 // Two dependencies used to need the boundary between the two launches.  (1) overlap(t+1) reads the permanence masks rows(t)
-// rewrites: only the k winner rows change, and their blocks hold the new mask words in registers -- they count them against
+// rewrites: only the k winner rows change, and their blocks hold the new connected bits in registers -- they count them against
 // the coming input themselves (role_sp_row OWN), the overlap role passes over the winners (role_overlap fold = 2) and takes
 // the duty-cycle update along (a column's duty cycle is read and written by the one block that finishes the column).
 // (2) mid(t) reads what activate(t) writes: the activation blocks store through to memory, wait for the acknowledgement and
 // count themselves done on one of 16 counters; the middle role's blocks -- behind them in the grid, so every activation
-// block has been dispatched before any of them can spin -- poll the counters' sum (tools/fanin.hip: 1.1-1.5 us from the last
-// producer's bytes to the consumers, against 1.2-1.7 us of idle device plus a ramp for a launch boundary).
-// The launch's blocks are not all resident at once (activation 164 + middle 385 + rows 1 311 + overlap 512 at the bench shape,
-// for 1 536 slots): nothing but the middle role waits for another block, so the order of the grid is only a matter of speed.
+// block has been dispatched before any of them can spin -- poll the counters' sum and read the activation's output with
+// agent-scope loads (NOT behind an acquire fence: buffer_inv sc1 by every wave of the role took the launch from 11 to 26 us).
+// In place the hand-off costs about 2 us (acknowledgement, atomic, poll: three trips to memory under the launch's traffic;
+// tools/fanin.hip measured 1.1-1.5 us on an idle device) -- what a launch boundary costs: the gain of the schedule is that the
+// winner rows and the overlap now stream UNDER the chain activate -> mid instead of before and after it.
+// All of the launch's blocks are resident at once at the bench shape (activation 164 + overlap 512 + middle 33 + rows 1 311 =
+// 2 020 of the 2 048 slots 64 registers leave); nothing but the middle role waits for another block, so the order of the grid
+// is only a matter of speed.  The counters are reset by k_learn_scan_emit, which always follows.
 __device__ __forceinline__ void fan_signal(const Dev &d, int p, int b) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // (the write-through stores are acknowledged)
     __syncthreads();
