@@ -30,7 +30,7 @@ def _stale():
 def _kernel_resources(log):
     """The compiler's per-kernel remarks -> {mangled name: {"vgprs", "agprs", "sgprs", "scratch_bytes_per_lane", "occupancy",
     "lds_bytes"}}.  k_learn_scan_emit lives at 80 VGPRs (6 waves per SIMD) with NO scratch: a single spilled register slows
-    every role of that launch by microseconds -- tests/test_host_and_abi.py holds the build to it."""
+    every role of that launch by microseconds (LABNOTES.md) -- tests/test_host_and_abi.py holds the build to it."""
     fields = {"VGPRs": "vgprs", "AGPRs": "agprs", "SGPRs": "sgprs", "ScratchSize [bytes/lane]": "scratch_bytes_per_lane",
               "Occupancy [waves/SIMD]": "occupancy", "LDS Size [bytes/block]": "lds_bytes"}
     out, cur = {}, None

@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol(lib):
 def test_the_three_launches_keep_their_register_budget():
     """k_learn_scan_emit is three roles in one launch, all resident at once at 6 waves per SIMD: 80 VGPRs and NO scratch.
     One spilled register costs every role of the launch microseconds (measured: 32 bytes of scratch per lane, the scan's
-    last block 7.8 -> 10.5 us, 37 -> 32.5 k timesteps/s).  The compiler's own report of the build."""
+    last block 7.8 -> 10.5 us, 37 -> 32.5 k timesteps/s; LABNOTES.md).  The compiler's own report of the build."""
     from bithtm_amd.build import kernel_resources
     res = kernel_resources()
     if res is None:
