@@ -381,6 +381,34 @@ def test_pipelined_schedules_and_select_paths_equal_step_by_step(env, monkeypatc
             assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("lean, per_step", [(None, 2), ("1", 3), ("0", 4)], ids=["default", "LEAN=1", "LEAN=0"])
+def test_launches_per_timestep_of_the_batched_run(lean, per_step, monkeypatch):
+    """htm.run issues two launches per steady-state timestep by default (k_act_mid_rows + k_learn_scan_emit), three under
+    BITHTM_LEAN=1, four under BITHTM_LEAN=0 -- counted from the library's own per-launch profile of an eager call (the first
+    step of a call selects its winners on its own, the last steps look ahead less: the count is taken over the steps between)."""
+    import bithtm_amd as B
+    if lean is not None:
+        monkeypatch.setenv("BITHTM_LEAN", lean)
+    np.random.seed(3)
+    htm = B.HierarchicalTemporalMemory(300, 4096, 8)
+    bank = np.random.RandomState(4).rand(20, 300) < 0.06
+    htm.run(bank, 10)
+    counts = []
+    for n in (10, 30):
+        htm.engine.profile(True)
+        htm.run(bank, n)
+        counts.append(sum(cnt for _, cnt in htm.engine.profile_read().values()))
+        htm.engine.profile(False)
+    assert counts[1] - counts[0] == 20 * per_step, counts          # 20 more steady-state steps
+    names = set()
+    htm.engine.profile(True)
+    htm.run(bank, 5)
+    names = {n for n, (_, cnt) in htm.engine.profile_read().items() if cnt}
+    htm.engine.profile(False)
+    assert ("tm_activate+tm_mid+sp_learn+sp_overlap" in names) == (per_step == 2), names
+    assert ("tm_mid+sp_overlap" in names) == (per_step == 3) and ("tm_scan+sp_select" in names) == (per_step == 4), names
+
+
 @pytest.mark.parametrize("env", [{}, {"BITHTM_SCAN_LARGE": "1"}, {"BITHTM_SCAN_LARGE_ABOVE": "600"}, {"BITHTM_EAGER_BELOW": "64"}, {"BITHTM_LEAN": "1"},
                                  {"BITHTM_LEAN": "1", "BITHTM_EAGER_BELOW": "64"}],
                          ids=lambda e: ",".join(f"{k[7:]}={v}" for k, v in e.items()) or "default")
