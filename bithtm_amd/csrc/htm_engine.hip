@@ -71,7 +71,7 @@ struct htm_handle {
     int eager_below;                      // calls of fewer steps than this launch eagerly (BITHTM_EAGER_BELOW)
     bool emit_fused, emit_fused_open;     // the emit grid is resident at once in k_sp_emit / in k_open_emit (refreshed per call)
     bool emit_fits_lean;                  // ... and in k_learn_scan_emit
-    int knob_lean, knob_fuse_tm, knob_shard_window, knob_scan_large, knob_step_window, knob_tail_rows;
+    int knob_lean, knob_fuse_tm, knob_shard_window, knob_scan_large, knob_step_window, knob_tail_rows, knob_step_split;
     int scan_large_above;                 // segments above which the scan takes its streaming (large-pool) form (BITHTM_SCAN_LARGE_ABOVE)
     int knob_scan_dyn;                    // the large-pool form of the last launch: every block joins the streaming scan when its own role is done (BITHTM_SCAN_DYN)
     int lean_resident_large;              // blocks of the large-pool k_learn_scan_emit that are resident at once
@@ -732,6 +732,9 @@ extern "C" int htm_create(const htm_config *cfg, htm_handle **out) {
     h->knob_lean = getenv("BITHTM_LEAN") ? std::max(0, std::min(2, atoi(getenv("BITHTM_LEAN")))) : 2;
     h->lean2_classify_blocks = getenv("BITHTM_LEAN2_CLASSIFY") ? std::max(1, atoi(getenv("BITHTM_LEAN2_CLASSIFY"))) : kClassifyBlocks;
     h->lean2_classify_set = getenv("BITHTM_LEAN2_CLASSIFY") != nullptr;
+    // the host-fed step (htm_step): select finish alone + k_act_mid_rows, instead of select finish with the activation in its blocks +
+    // k_mid_rows (BITHTM_STEP_SPLIT=0: as before)
+    h->knob_step_split = getenv("BITHTM_STEP_SPLIT") ? atoi(getenv("BITHTM_STEP_SPLIT")) != 0 : 1;
     {   // the grid order of k_act_mid_rows' roles (hex digits: 0 activation, 1 middle, 2 rows, 3 overlap); a permutation with 0 before 1
         // (measured at the bench shape, 8 waves per SIMD: 0312 42.4 k timesteps/s, 0321 41.9, 0123 41.2, 3201 40.2)
         const int o = getenv("BITHTM_LEAN2_ORDER") ? (int)strtol(getenv("BITHTM_LEAN2_ORDER"), nullptr, 16) : 0x0312;
@@ -993,8 +996,24 @@ extern "C" int htm_step(htm_handle *h, const uint32_t *packed_input, int32_t lea
         } else {
             enqueue_sp_front(h, d.input_stage, 1, p, wmode, packed_input);
         }
-        enqueue_sp_back(h, d.input_stage, 1, p, 1, EMIT_ALL, false, wmode);
-        enqueue_tm(h, d.k, learning ? 1 : 0, 1, p, d.input_stage, 1, true, -1, true);
+        if (h->knob_step_split) {
+            // the select finish on its own (winner list and column bitmap, nothing else), then the two-launch schedule's first launch
+            // in the form its last step takes: activation -> fan-in -> middle role beside the winner rows, the duty cycle and the
+            // clears (k_act_mid_rows without an overlap role).  The activation no longer waits at the end of the select finish's
+            // blocks with nothing beside it, and the rows stream under the Temporal Memory's chain (measured: DESIGN.md section 4)
+            enqueue_sp_back(h, d.input_stage, 1, p, 1, 0, false, wmode);
+            const int lrn = learning ? 1 : 0;
+            const int n_act = (d.k * d.KP + 255) / 256, n_rows = lrn ? d.k : 0;
+            const int n_cls2 = !lrn ? 0 : (scan_pool_is_large(h) && !h->lean2_classify_set) ? std::max(h->lean2_classify_blocks, 192) : h->lean2_classify_blocks;
+            const int n_duty = h->c256_blocks, n_clear = d.WPC * h->c256_blocks;
+            LAUNCH_ON(h, h->stream, 0, "tm_activate+tm_mid+sp_learn", k_act_mid_rows, n_act + 1 + n_cls2 + n_rows + n_duty + n_clear + h->zero_blocks, 256,
+                      d, p, d.k, n_act, lrn, n_cls2, d.input_stage, 1, n_rows, h->G, 0, n_duty, n_clear, h->lean2_order);
+            h->tail_pending = true;
+            h->tail_p = p;
+        } else {
+            enqueue_sp_back(h, d.input_stage, 1, p, 1, EMIT_ALL, false, wmode);
+            enqueue_tm(h, d.k, learning ? 1 : 0, 1, p, d.input_stage, 1, true, -1, true);
+        }
         h->step_host += 1;
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { h->err = std::string("kernel launch: ") + hipGetErrorString(e); return HTM_ERR_HIP; }

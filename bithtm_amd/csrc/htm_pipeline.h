@@ -357,6 +357,7 @@ template <int EPL>
 __global__ __launch_bounds__(256, 6) void k_learn_scan_tail(Dev d, int p, int n_learn_blocks, int n_scan_blocks, int n_spec,
                                                             const uint32_t *__restrict__ bank, int n_inputs, int G, int wmode, int n_rows) {
     int b = blockIdx.x;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x < FAN_COUNTERS) d.fan[(size_t)(p * FAN_COUNTERS + (int)threadIdx.x) * FAN_STRIDE] = 0u;     // (as k_learn_scan_emit)
     if (b < n_learn_blocks) {
         role_learn<EPL, 256, true>(d, p, b, n_learn_blocks, (LearnShared<EPL, 256> *)dyn_lds);
         return;
@@ -378,6 +379,8 @@ template <int EPL>
 __global__ __launch_bounds__(256, 6) void k_learn_scan_front(Dev d, int p_prev, int n_learn_blocks, int n_scan_blocks, int n_spec,
                                                              PackedInputArg in, int G, int p, int wmode) {
     int b = blockIdx.x;
+    // (the fan-in counters of the held-back step's k_act_mid_rows: see k_learn_scan_emit)
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x < FAN_COUNTERS) d.fan[(size_t)(p_prev * FAN_COUNTERS + (int)threadIdx.x) * FAN_STRIDE] = 0u;
     if (b < n_learn_blocks) {
         role_learn<EPL, 256, true>(d, p_prev, b, n_learn_blocks, (LearnShared<EPL, 256> *)dyn_lds);
         return;

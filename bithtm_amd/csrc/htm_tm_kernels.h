@@ -896,6 +896,8 @@ extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
 
 template <int EPL>
 __global__ __launch_bounds__(RB) void k_tm_learn(Dev d, int p) {
+    // (every form of a step's learning launch resets the fan-in counters its k_act_mid_rows may have used: htm_pipeline.h)
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x < FAN_COUNTERS) d.fan[(size_t)(p * FAN_COUNTERS + (int)threadIdx.x) * FAN_STRIDE] = 0u;
     role_learn<EPL, RB>(d, p, blockIdx.x, gridDim.x, (LearnShared<EPL, RB> *)dyn_lds);
 }
 
