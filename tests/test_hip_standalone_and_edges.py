@@ -336,6 +336,9 @@ def test_batched_run_equals_step_by_step(eager_below, monkeypatch):
                                  # without a BITHTM_LEAN runs it; here with grids of a few blocks and every grid order of its roles ...
                                  {"BITHTM_LEAN_OVERLAP": "3", "BITHTM_LEAN2_CLASSIFY": "2", "BITHTM_LEAN_SCAN": "3", "BITHTM_LEAN_LEARN": "2"},
                                  {"BITHTM_LEAN2_ORDER": "0123"}, {"BITHTM_LEAN2_ORDER": "3201", "BITHTM_LEAN2_CLASSIFY": "5"}, {"BITHTM_LEAN2_ORDER": "2031", "BITHTM_LEAN2_CLASSIFY": "300"},
+                                 # (process() -- the side every mode is compared with -- steps through the same launch without an overlap role;
+                                 # here as it was before: the activation in the select finish's blocks, the rows beside the middle role)
+                                 {"BITHTM_STEP_SPLIT": "0"}, {"BITHTM_STEP_SPLIT": "0", "BITHTM_DEFER_TAIL": "0"},
                                  # ... and the three-launch schedule (k_act_rows, k_mid_overlap): alone, with a window that always misses, with
                                  # grids of a few blocks, with both forms of the classification and of the scan, under the default call policy
                                  {"BITHTM_LEAN": "1"}, {"BITHTM_LEAN": "1", "BITHTM_SEL_WINDOW_OFFSET": "4000"}, {"BITHTM_LEAN": "1", "BITHTM_EAGER_BELOW": "64"},
