@@ -377,27 +377,11 @@ static bool can_lean(const htm_handle *h) {
     return h->knob_lean && can_pipeline(h) && scan_lds(h->d, 1) <= 64 * 1024 && h->emit_fits_lean;
 }
 
-// sp_done: the winner list of this step exists (the previous step's last launch, or the cold start).  next_sp: select
-// the next step's winners beside this step's Temporal Memory.
-static void enqueue_lean(htm_handle *h, int p, int learning, const uint32_t *bank, int n_inputs, StepPlan plan) {
+// the last launch of a step in the two- and three-launch schedules: learn(p) + scan(p) beside the select finish + winner list of the
+// step of the other parity (n_emit blocks of it, or none)
+static void launch_learn_scan_emit(htm_handle *h, int p, int n_emit) {
     Dev &d = h->d;
-    const int n_act = (d.k * d.KP + 255) / 256, n_rows = learning ? d.k : 0;
-    const int n_cls = learning ? kClassifyBlocks : 0, n_ov = plan.next_sp ? h->lean_overlap_blocks : 0;
-    if (h->knob_lean == 2) {                        // the two-launch schedule: both of these in one (htm_pipeline.h)
-        // (a large pool has a classification block read ~250 match words and classify tens of them: more blocks there, though they
-        // are not all resident from the start -- 350-pattern pool of the bench, 1.6 M segments: 32 blocks 11.7 k timesteps/s, 128: 13.3, 256: 13.3,
-        // 384: 13.1; three launches: 12.8)
-        const int n_cls2 = !learning ? 0 : (scan_pool_is_large(h) && !h->lean2_classify_set) ? std::max(h->lean2_classify_blocks, 192) : h->lean2_classify_blocks;
-        const int n_duty = n_ov ? 0 : h->c256_blocks, n_clear = d.WPC * h->c256_blocks;
-        LAUNCH_ON(h, h->stream, (size_t)SEL_BINS * 4, "tm_activate+tm_mid+sp_learn+sp_overlap", k_act_mid_rows,
-                  n_act + 1 + n_cls2 + n_rows + n_ov + n_duty + n_clear + h->zero_blocks, 256, d, p, d.k, n_act, learning, n_cls2, bank, n_inputs, n_rows, h->G, n_ov,
-                  n_duty, n_clear, h->lean2_order);
-    } else {
-        LAUNCH(h, "tm_activate+sp_learn", k_act_rows, n_act + n_rows + (1 + d.WPC) * h->c256_blocks, 256, d, p, d.k, n_act, bank, n_inputs, n_rows, h->c256_blocks);
-        LAUNCH_ON(h, h->stream, (size_t)SEL_BINS * 4, "tm_mid+sp_overlap", k_mid_overlap, 1 + n_cls + n_ov + h->zero_blocks, 256, d, p, d.k, 1, learning, n_cls,
-                  bank, n_inputs, h->G, n_ov);
-    }
-    const int epl = learn_epl(d), n_emit = plan.next_sp ? h->c256_blocks : 0;
+    const int epl = learn_epl(d);
     const size_t lds = std::max(std::max(learn_lds(epl, 256), lean_scan_lds(d)), sizeof(EmitShared));
     // A large pool streams.  DYN (the default): the grid is what is resident at once and every block ends up scanning
     // (role_scan); the kernel is told by the sign of its n_scan argument.  More learning blocks than a small pool gets: a wave
@@ -424,6 +408,29 @@ static void enqueue_lean(htm_handle *h, int p, int learning, const uint32_t *ban
         switch (epl) { case 1: LAUNCH_LSE(1, 6, false); break; case 2: LAUNCH_LSE(2, 6, false); break; case 4: LAUNCH_LSE(4, 6, false); break; default: LAUNCH_LSE(8, 6, false); break; }
     }
 #undef LAUNCH_LSE
+}
+
+// sp_done: the winner list of this step exists (the previous step's last launch, or the cold start).  next_sp: select
+// the next step's winners beside this step's Temporal Memory.
+static void enqueue_lean(htm_handle *h, int p, int learning, const uint32_t *bank, int n_inputs, StepPlan plan) {
+    Dev &d = h->d;
+    const int n_act = (d.k * d.KP + 255) / 256, n_rows = learning ? d.k : 0;
+    const int n_cls = learning ? kClassifyBlocks : 0, n_ov = plan.next_sp ? h->lean_overlap_blocks : 0;
+    if (h->knob_lean == 2) {                        // the two-launch schedule: both of these in one (htm_pipeline.h)
+        // (a large pool has a classification block read ~250 match words and classify tens of them: more blocks there, though they
+        // are not all resident from the start -- 350-pattern pool of the bench, 1.6 M segments: 32 blocks 11.7 k timesteps/s, 128: 13.3, 256: 13.3,
+        // 384: 13.1; three launches: 12.8)
+        const int n_cls2 = !learning ? 0 : (scan_pool_is_large(h) && !h->lean2_classify_set) ? std::max(h->lean2_classify_blocks, 192) : h->lean2_classify_blocks;
+        const int n_duty = n_ov ? 0 : h->c256_blocks, n_clear = d.WPC * h->c256_blocks;
+        LAUNCH_ON(h, h->stream, (size_t)SEL_BINS * 4, "tm_activate+tm_mid+sp_learn+sp_overlap", k_act_mid_rows,
+                  n_act + 1 + n_cls2 + n_rows + n_ov + n_duty + n_clear + h->zero_blocks, 256, d, p, d.k, n_act, learning, n_cls2, bank, n_inputs, n_rows, h->G, n_ov,
+                  n_duty, n_clear, h->lean2_order);
+    } else {
+        LAUNCH(h, "tm_activate+sp_learn", k_act_rows, n_act + n_rows + (1 + d.WPC) * h->c256_blocks, 256, d, p, d.k, n_act, bank, n_inputs, n_rows, h->c256_blocks);
+        LAUNCH_ON(h, h->stream, (size_t)SEL_BINS * 4, "tm_mid+sp_overlap", k_mid_overlap, 1 + n_cls + n_ov + h->zero_blocks, 256, d, p, d.k, 1, learning, n_cls,
+                  bank, n_inputs, h->G, n_ov);
+    }
+    launch_learn_scan_emit(h, p, plan.next_sp ? h->c256_blocks : 0);
 }
 
 // the four launches of a pipelined step (see the kernels): step p's Temporal Memory beside SP work of
@@ -980,7 +987,19 @@ extern "C" int htm_step(htm_handle *h, const uint32_t *packed_input, int32_t lea
     Dev &d = h->d;
     if (h->knob_defer_tail && d.W <= ARG_INPUT_WORDS && tm_tail_fused(h) && !h->profile) {
         const int p = (int)(h->step_host & 1), wmode = step_wmode(h);
-        if (h->tail_pending) {
+        // the held-back learning role and scan of the step before ride beside THIS step's select finish (k_learn_scan_emit, the last
+        // launch of htm_run's schedules) where that launch is available: the overlap then has the first launch to itself (4.5 us), and the
+        // select finish -- 7 us of a chain on 256 blocks -- no longer has the GPU to itself.  (The activation, which reads the
+        // predictions that scan leaves, has moved behind it: k_act_mid_rows.)
+        const bool ride_emit = h->knob_step_split && h->tail_pending && wmode && h->emit_fused && can_lean(h);
+        bool emitted = false;
+        if (ride_emit) {
+            enqueue_sp_front(h, d.input_stage, 1, p, wmode, packed_input);
+            h->tail_pending = false;
+            launch_learn_scan_emit(h, h->tail_p, h->c256_blocks);
+            h->window_known = true;
+            emitted = true;
+        } else if (h->tail_pending) {
             PackedInputArg in;
             memset(&in, 0, sizeof(in));
             memcpy(in.w, packed_input, (size_t)((d.I + 31) / 32) * 4);
@@ -1001,7 +1020,7 @@ extern "C" int htm_step(htm_handle *h, const uint32_t *packed_input, int32_t lea
             // in the form its last step takes: activation -> fan-in -> middle role beside the winner rows, the duty cycle and the
             // clears (k_act_mid_rows without an overlap role).  The activation no longer waits at the end of the select finish's
             // blocks with nothing beside it, and the rows stream under the Temporal Memory's chain (measured: DESIGN.md section 4)
-            enqueue_sp_back(h, d.input_stage, 1, p, 1, 0, false, wmode);
+            if (!emitted) enqueue_sp_back(h, d.input_stage, 1, p, 1, 0, false, wmode);
             const int lrn = learning ? 1 : 0;
             const int n_act = (d.k * d.KP + 255) / 256, n_rows = lrn ? d.k : 0;
             const int n_cls2 = !lrn ? 0 : (scan_pool_is_large(h) && !h->lean2_classify_set) ? std::max(h->lean2_classify_blocks, 192) : h->lean2_classify_blocks;
