@@ -168,8 +168,8 @@ int htm_sp_get_permanence(htm_handle *h, double *rows, int32_t row_begin, int32_
  *   htm_tm_step  TemporalMemory.process(sp_state, learning=, return_winner_cell=)
  *                (networks.py:91-128) for a stand-alone TM: active_column is a host array of n
  *                distinct column ids (any order; processed in ascending order).
- * htm_step may hold the step's last launch (learning + segment scan) back so that it rides in the next htm_step's first
- * launch; every other entry point lets it go before doing anything else (htm_sync included), so the only way to observe
+ * htm_step may hold the step's last launch (learning + segment scan) back so that it rides in one of the next htm_step's
+ * launches (beside its select finish, or beside its overlap); every other entry point lets it go before doing anything else (htm_sync included), so the only way to observe
  * it is to synchronise the STREAM yourself between two htm_step calls -- call htm_sync instead. */
 int htm_step(htm_handle *h, const uint32_t *packed_input, int32_t learning);
 int htm_sp_step(htm_handle *h, const uint32_t *packed_input, int32_t learning);
