@@ -524,6 +524,30 @@ def large_pool_leg(args, device):
     return out
 
 
+def host_fed_leg(w, device, steps=3000):
+    """The loop the reference's example.py runs, unchanged but for the import: one `htm.process(x)` per timestep with a host
+    input (bit-packing, one ctypes call, 128 bytes host -> device in the launch's arguments, the State objects of the
+    reference's API; nothing read back), on the headline shape in its learned state.  A PCIe-inclusive rate: reported beside
+    the line, never its `value` (the boundary's device-resident rate is)."""
+    noisy, perm = make_inputs(w)
+    htm = build_htm(w, perm, device)
+    eng = htm.engine
+    bank = eng.upload_bank(noisy)
+    eng.run(bank, noisy.shape[0], 10 * w["patterns"], learning=True)        # untimed: the learned state, as the headline's
+    for t in range(200):                                                      # warm-up of the host-fed path itself
+        htm.process(noisy[t % len(noisy)])
+    eng.sync()
+    t0 = time.perf_counter()
+    for t in range(steps):
+        htm.process(noisy[t % len(noisy)])
+    eng.sync()
+    dt = time.perf_counter() - t0
+    info = eng.check_capacity()
+    return dict(value=round(steps / dt, 1), unit="timesteps/s", us_per_step=round(1e6 * dt / steps, 2), steps=steps,
+                what="htm.process(x) per timestep from host memory (example.py's loop): three launches per step, no read-back",
+                segments=int(info.segments))
+
+
 def run_single(args):
     w = dict(WORKLOAD)
     if args.columns:
@@ -542,6 +566,15 @@ def run_single(args):
         except Exception as e:                          # a report beside the headline: never a reason to lose the line
             log(f"[bench] large_pool leg failed: {e!r}")
             large = dict(error=repr(e))
+        gc.collect()
+    host_fed = None
+    if not args.no_host_fed and not args.columns:
+        try:
+            host_fed = host_fed_leg(w, device)
+            log(f"[bench] host-fed loop (htm.process per step): {host_fed['value']:.0f} timesteps/s")
+        except Exception as e:
+            log(f"[bench] host-fed leg failed: {e!r}")
+            host_fed = dict(error=repr(e))
         gc.collect()
     stress = None
     if not args.no_stress and not args.columns:
@@ -565,7 +598,7 @@ def run_single(args):
                     hip_graph=m["plan"]["hip_graph"], hip_graph_requested=not args.no_graph, pipelined=m["plan"]["pipelined"],
                     launches_per_step=m["launches_per_step"], repetitions=reps, streamed_calls=m["streamed"]),
         repetitions=[round(r, 1) for r in m["rates"]],
-        roofline=m["roofline"], cpu_baseline=m["cpu"], large_pool=large, stress=stress,
+        roofline=m["roofline"], cpu_baseline=m["cpu"], large_pool=large, host_fed=host_fed, stress=stress,
         role_us_one_per_launch={n: round(v, 2) for n, v in m["role_us"].items()},
         role_bytes={n: int(v) for n, v in m["role_bytes"].items()})
 
@@ -584,6 +617,7 @@ def main():
     ap.add_argument("--large-pool-only", action="store_true", help="run only the large_pool leg and print its object (profiling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stress", action="store_true", help="skip the configs[4] leg (one rank's pre-populated shard)")
+    ap.add_argument("--no-host-fed", action="store_true", help="skip the host-fed leg (example.py's loop: htm.process(x) per timestep)")
     ap.add_argument("--stress-only", action="store_true", help="run only the configs[4] leg and print its object (profiling)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="one role per launch (what the profiled replay always does)")

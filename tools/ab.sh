@@ -6,7 +6,7 @@
 set -e
 run() { # name, env...
   name=$1; shift
-  env "$@" timeout -k 10 150 python bench.py --steps 2000 --warmup 500 --reps 3 --no-cpu-baseline --no-stress --no-large-pool > gpurun_out/ab_$name.json 2> gpurun_out/ab_$name.err
+  env "$@" timeout -k 10 150 python bench.py --steps 2000 --warmup 500 --reps 3 --no-cpu-baseline --no-stress --no-large-pool --no-host-fed > gpurun_out/ab_$name.json 2> gpurun_out/ab_$name.err
   echo "$name: $(grep -o 'median [0-9]* timesteps/s' gpurun_out/ab_$name.err | head -1) | $(grep -o 'launches of the timed schedule.*' gpurun_out/ab_$name.err | head -1 | cut -c1-200)"
 }
 runlarge() { # name, env...
@@ -16,6 +16,6 @@ runlarge() { # name, env...
 }
 rundriver() { # name, env...: the driver's arguments (20 timed steps per call), 15 repetitions, no legs
   name=$1; shift
-  env "$@" timeout -k 10 150 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-stress --no-large-pool > gpurun_out/ab_$name.json 2> gpurun_out/ab_$name.err
+  env "$@" timeout -k 10 150 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-stress --no-large-pool --no-host-fed > gpurun_out/ab_$name.json 2> gpurun_out/ab_$name.err
   echo "$name: $(grep -o 'median [0-9]* timesteps/s (min [0-9]*, max [0-9]*)' gpurun_out/ab_$name.err | head -1)"
 }

@@ -14,7 +14,7 @@ cd /tmp && export TMPDIR=/tmp
 # same schedule under the profiler) and the configs[4] leg.  (The sharded launches -- all eight ranks in one process,
 # tools/shard_rehearsal.py -- crash under rocprofv3 on this image, eager launches included: no PMC pass of them.)
 for ctr in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 400 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $OUT/pmc_$ctr -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-stress --no-large-pool > $OUT/pmc_$ctr.json 2> $OUT/pmc_$ctr.log; echo "$ctr exit=$?"
+  timeout -k 10 400 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $OUT/pmc_$ctr -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-stress --no-large-pool --no-host-fed > $OUT/pmc_$ctr.json 2> $OUT/pmc_$ctr.log; echo "$ctr exit=$?"
   timeout -k 10 400 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $OUT/pmc_stress_$ctr -- python3 $GRAFT_REPO_ROOT/bench.py --stress-only --no-cpu-baseline > $OUT/pmc_stress_$ctr.log 2>&1; echo "$ctr (stress) exit=$?"
   timeout -k 10 400 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $OUT/pmc_large_$ctr -- python3 $GRAFT_REPO_ROOT/bench.py --large-pool-only --steps 20 --warmup 5 --no-cpu-baseline > $OUT/pmc_large_$ctr.json 2> $OUT/pmc_large_$ctr.log; echo "$ctr (large pool) exit=$?"
 done
@@ -43,7 +43,7 @@ except Exception as e:
 try:        # the state the PMC pass saw: what bench.py compares its own with (recorded_traffic)
     line = json.loads(open(os.path.join(out, "pmc_FETCH_SIZE.json")).read().strip().splitlines()[-1])
     s["state"] = line["roofline"]["state"]
-    s["command"] = "bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-stress --no-large-pool (under rocprofv3: eager launches)"
+    s["command"] = "bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-stress --no-large-pool --no-host-fed (under rocprofv3: eager launches)"
 except Exception as e:
     s["state_error"] = repr(e)
 json.dump(s, open(os.path.join(out, "pmc_summary.json"), "w"), indent=1)
@@ -63,12 +63,12 @@ timeout -k 10 200 python tools/pool_growth.py 350 12 > $OUT/pool_growth.txt 2>&1
 timeout -k 10 300 python tools/step_spans.py 16 > $OUT/step_spans.txt 2>&1
 timeout -k 10 200 python tools/soak.py > $OUT/soak.txt 2>&1
 # the four-launch schedule, for comparison
-BITHTM_LEAN=0 timeout -k 10 300 python bench.py --no-cpu-baseline --no-stress --no-large-pool > $OUT/bench_four_launches.json 2> $OUT/bench_four_launches.log; echo "bench (four launches) exit=$?"
+BITHTM_LEAN=0 timeout -k 10 300 python bench.py --no-cpu-baseline --no-stress --no-large-pool --no-host-fed > $OUT/bench_four_launches.json 2> $OUT/bench_four_launches.log; echo "bench (four launches) exit=$?"
 # ... and the three-launch one (the default of rounds 3 and 4 until the two-launch schedule)
-BITHTM_LEAN=1 timeout -k 10 300 python bench.py --no-cpu-baseline --no-stress --no-large-pool > $OUT/bench_three_launches.json 2> $OUT/bench_three_launches.log; echo "bench (three launches) exit=$?"
+BITHTM_LEAN=1 timeout -k 10 300 python bench.py --no-cpu-baseline --no-stress --no-large-pool --no-host-fed > $OUT/bench_three_launches.json 2> $OUT/bench_three_launches.log; echo "bench (three launches) exit=$?"
 BITHTM_LEAN=1 timeout -k 10 200 python tools/step_timeline.py > $OUT/step_timeline_three_launches.txt 2>&1
 # from scratch: the first 250 steps (every column bursting at first, ~1 300 new segments per step)
-timeout -k 10 200 python bench.py --no-cpu-baseline --no-stress --no-large-pool --pretrain 0 --steps 250 --warmup 0 --reps 1 > $OUT/bench_cold_250.json 2> $OUT/bench_cold_250.log; echo "bench (cold) exit=$?"
+timeout -k 10 200 python bench.py --no-cpu-baseline --no-stress --no-large-pool --no-host-fed --pretrain 0 --steps 250 --warmup 0 --reps 1 > $OUT/bench_cold_250.json 2> $OUT/bench_cold_250.log; echo "bench (cold) exit=$?"
 timeout -k 10 200 python tools/pcie_rate.py > $OUT/pcie_rate.txt 2>&1
 timeout -k 10 200 python tools/hostfed_profile.py >> $OUT/pcie_rate.txt 2>&1
 for w in 2 4 8; do timeout -k 10 200 python tools/shard_rehearsal.py --world $w; done > $OUT/shard_rehearsal.jsonl 2>&1
@@ -82,8 +82,8 @@ timeout -k 10 300 python tools/scan_stress.py --columns 262144 --cells 16 --segm
 cd /tmp
 # ---- rocprofv3 kernel stats: (a) one role per launch, (b) the pipelined schedule bench.py times (eager instead of hipGraph:
 # rocprofv3 crashes on graph replay here), (c) the configs[4] leg alone
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $GRAFT_REPO_ROOT/bench.py --steps 500 --warmup 100 --reps 1 --no-cpu-baseline --no-stress --no-large-pool --no-graph --no-pipeline > $OUT/stats.log 2>&1; echo "stats exit=$?"
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_pipelined -- python3 $GRAFT_REPO_ROOT/bench.py --steps 500 --warmup 100 --reps 1 --no-cpu-baseline --no-stress --no-large-pool --no-graph > $OUT/stats_pipelined.log 2>&1; echo "stats_pipelined exit=$?"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $GRAFT_REPO_ROOT/bench.py --steps 500 --warmup 100 --reps 1 --no-cpu-baseline --no-stress --no-large-pool --no-host-fed --no-graph --no-pipeline > $OUT/stats.log 2>&1; echo "stats exit=$?"
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_pipelined -- python3 $GRAFT_REPO_ROOT/bench.py --steps 500 --warmup 100 --reps 1 --no-cpu-baseline --no-stress --no-large-pool --no-host-fed --no-graph > $OUT/stats_pipelined.log 2>&1; echo "stats_pipelined exit=$?"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_large -- python3 $GRAFT_REPO_ROOT/bench.py --large-pool-only --steps 300 --warmup 50 --reps 1 --no-cpu-baseline --no-graph > $OUT/stats_large.log 2>&1; echo "stats_large exit=$?"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_stress -- python3 $GRAFT_REPO_ROOT/bench.py --stress-only --no-cpu-baseline > $OUT/stats_stress.log 2>&1; echo "stats_stress exit=$?"
 python3 - <<'PY'
