@@ -1968,9 +1968,21 @@ static inline int flat_enc(int flat, int K) { return (flat / K) * (K > 32 ? 64 :
 extern "C" int64_t htm_read(htm_handle *h, int32_t field, void *dst, int64_t count) {
     if (!h || !dst) return HTM_ERR_ARGUMENT;
     if (h) flush_tail(h);
+    // the fields whose length the handle's shape gives need no counters: the stream is waited for, nothing else (a State of the
+    // reference's API is a dozen reads, and the counters' copy was half of each small one)
+    const bool fixed_size = field == HTM_F_ACTIVE_COLUMN || field == HTM_F_OVERLAPS || field == HTM_F_BOOSTED || field == HTM_F_DUTY_CYCLE ||
+                            field == HTM_F_CELL_ACTIVATION || field == HTM_F_CELL_PREDICTION || field == HTM_F_WINNER_WORDS ||
+                            field == HTM_F_BURSTING || field == HTM_F_SEGCOUNT || field == HTM_F_CELL_MAX_JITTER;
     Counters c;
-    int rc = read_counters(h, &c);
-    if (rc) return rc;
+    memset(&c, 0, sizeof(c));
+    int rc = 0;
+    if (fixed_size) {
+        HIPCHK(h, hipSetDevice(h->device));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    } else {
+        rc = read_counters(h, &c);
+        if (rc) return rc;
+    }
     Dev &d = h->d;
     const int q = (int)((h->step_host + 1) & 1);
     const int qs = h->phase_open ? (int)(h->step_host & 1) : q;      // Spatial Pooler fields while a step is run phase by phase
